@@ -1,0 +1,24 @@
+# Builds the gfx950 C-ABI library (product) and the CPU oracle (test infrastructure).
+HIPCC ?= hipcc
+ARCH ?= gfx950
+HIPFLAGS ?= -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Wall -Wno-unused-result -Wno-unused-function -ffp-contract=fast
+CSRC := small_gicp_amd/csrc
+OBJDIR := build/obj
+SRCS := $(wildcard $(CSRC)/*.hip)
+OBJS := $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(SRCS))
+LIB := small_gicp_amd/lib/libsmall_gicp_amd.so
+
+all: lib oracle
+lib: $(LIB)
+$(OBJDIR)/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.hpp) include/small_gicp_amd.h
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+$(LIB): $(OBJS)
+	@mkdir -p small_gicp_amd/lib
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+oracle:
+	$(MAKE) -C oracle
+clean:
+	rm -rf build $(LIB)
+	$(MAKE) -C oracle clean
+.PHONY: all lib oracle clean

@@ -1,0 +1,181 @@
+/*
+ * small_gicp_amd — C-ABI of the MI355X-native registration hot path.
+ *
+ * Drop-in boundary for koide3/small_gicp's per-iteration linearization (reference tree /root/reference, v1.0.1).
+ * Every entry point names the reference interface it replaces (file:line relative to /root/reference).
+ * Plain C: opaque handles, caller-owned host buffers, int status codes, no exceptions, no torch types.
+ *
+ * Conventions
+ *   - 4x4 transforms are column-major double[16] (Eigen::Isometry3d::matrix().data()).
+ *   - 6x6 H is row-major double[36] (symmetric), b is double[6]; twist order is [rx ry rz tx ty tz] (util/lie.hpp:73-77).
+ *   - Symmetric 3x3 matrices ("cov6", "mahalanobis6") are packed xx,xy,xz,yy,yz,zz.
+ *   - All device work of a context is serialised on ONE HIP stream; blocking calls synchronise that stream only.
+ *   - A context is bound to one GPU; multi-GPU = one process (or context) per GPU with the source cloud sharded and
+ *     the 30-double accumulator all-reduced between sga_linearize_async() and the host read-back.
+ */
+#ifndef SMALL_GICP_AMD_H
+#define SMALL_GICP_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sga_context sga_context; /* one GPU + one stream */
+typedef struct sga_cloud sga_cloud;     /* device-resident point cloud: points [+ normals] [+ covariances]          (points/point_cloud.hpp:15-71) */
+typedef struct sga_index sga_index;     /* nearest-neighbour search target: uniform-grid index (replaces ann/kdtree.hpp KdTree) or GaussianVoxelMap */
+typedef struct sga_problem sga_problem; /* a (target index, source cloud) pairing + per-source-point factor state (registration.hpp:41 std::vector<PointFactor>) */
+
+enum sga_status {
+  SGA_OK = 0,
+  SGA_ERR_INVALID = 1,     /* bad argument */
+  SGA_ERR_HIP = 2,         /* a HIP runtime call failed; see sga_last_error() */
+  SGA_ERR_NO_DEVICE = 3,   /* no usable gfx950 device: the product path NEVER falls back to the CPU */
+  SGA_ERR_UNSUPPORTED = 4, /* combination not available (e.g. PLANE_ICP against a voxel map) */
+  SGA_ERR_CALLBACK = 5     /* a user callback returned non-zero */
+};
+
+/* registration_helper.hpp:38 RegistrationSetting::RegistrationType (VGICP = GICP factor against a GaussianVoxelMap index) */
+enum sga_factor_kind { SGA_ICP = 0, SGA_PLANE_ICP = 1, SGA_GICP = 2 };
+/* factors/robust_kernel.hpp:11-59 */
+enum sga_robust_kind { SGA_ROBUST_NONE = 0, SGA_ROBUST_HUBER = 1, SGA_ROBUST_CAUCHY = 2 };
+enum sga_optimizer_kind { SGA_LEVENBERG_MARQUARDT = 0, SGA_GAUSS_NEWTON = 1 };
+enum sga_math_mode { SGA_MATH_FP32 = 0, SGA_MATH_FP64 = 1 }; /* per-pair arithmetic; data in HBM is fp32 either way, sums are fp64 */
+
+/* Thread-local description of the last failure on the calling thread. Never NULL. */
+const char* sga_last_error(void);
+/* Library version string. */
+const char* sga_version(void);
+/* Number of visible HIP devices (0 when there is no GPU / no driver). */
+int sga_device_count(void);
+
+/* ---- context -------------------------------------------------------------------------------------------------- */
+int sga_context_create(int device, sga_context** out);
+/* Borrow an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) instead of creating one. */
+int sga_context_create_on_stream(int device, void* hip_stream, sga_context** out);
+int sga_context_destroy(sga_context* ctx);
+int sga_context_synchronize(sga_context* ctx);
+void* sga_context_stream(sga_context* ctx); /* the hipStream_t */
+
+/* ---- clouds (points/traits.hpp:15-78 accessor protocol: size / point / normal / cov) --------------------------------- */
+/* fp32 input: xyz n*3, normals n*3 or NULL, cov6 n*6 or NULL */
+int sga_cloud_create_f32(sga_context* ctx, const float* xyz, const float* normals, const float* cov6, size_t n, sga_cloud** out);
+/* Reference PointCloud layout (points/point_cloud.hpp:69-71): xyzw n*4 doubles, normals n*4 doubles or NULL, covs n*16 doubles (4x4) or NULL */
+int sga_cloud_create_f64(sga_context* ctx, const double* xyzw, const double* normals4, const double* cov4x4, size_t n, sga_cloud** out);
+int sga_cloud_destroy(sga_cloud* cloud);
+int sga_cloud_size(const sga_cloud* cloud, size_t* n);
+int sga_cloud_has(const sga_cloud* cloud, int* has_normals, int* has_covs);
+/* Any of xyz / normals / cov6 may be NULL. */
+int sga_cloud_download(sga_context* ctx, const sga_cloud* cloud, float* xyz, float* normals, float* cov6);
+
+/* ---- preprocessing (registration_helper.cpp:22-34 preprocess_points) ----------------------------------------------- */
+/* util/downsampling.hpp:23-78 voxelgrid_sampling: centroid per occupied voxel, output in ascending packed-key order. */
+int sga_voxelgrid_sampling(sga_context* ctx, const sga_cloud* in, double leaf_size, sga_cloud** out);
+/* util/normal_estimation.hpp:65-92 estimate_local_features: kNN(k, incl. self) -> mean/cov -> eigvecs -> normal / covariance.
+ * index must be a grid index built over `cloud`.  flags: bit0 = normals, bit1 = covariances. */
+int sga_estimate_normals_covariances(sga_context* ctx, sga_cloud* cloud, const sga_index* index, int num_neighbors, int flags);
+
+/* ---- search indices --------------------------------------------------------------------------------------------- */
+typedef struct sga_grid_params {
+  double cell_size;        /* <= 0: choose automatically from the point density */
+  double search_radius;    /* hint: the largest correspondence distance that will be queried (sizes the automatic cell); <= 0: 1.0 */
+  double points_per_cell;  /* target mean occupancy of non-empty cells for the automatic choice; <= 0: 2.0 */
+  uint64_t max_cells;      /* cap on the dense cell table; 0: max(2^16, 64 * n) */
+} sga_grid_params;
+/* Replaces KdTree<PointCloud>(points) (ann/kdtree.hpp:250-252): exact nearest neighbour / kNN over `target`.
+ * The index keeps its own cell-sorted copy of the target's points / normals / covariances. params may be NULL. */
+int sga_index_build_grid(sga_context* ctx, const sga_cloud* target, const sga_grid_params* params, sga_index** out);
+/* Replaces create_gaussian_voxelmap (registration_helper.cpp:50-54; ann/incremental_voxelmap.hpp:55-92, gaussian_voxelmap.hpp:32-53):
+ * one-shot insert of a cloud WITH covariances; voxel ids follow first-insertion order like the reference. */
+int sga_index_build_gaussian_voxelmap(sga_context* ctx, const sga_cloud* points_with_covs, double leaf_size, sga_index** out);
+int sga_index_destroy(sga_index* index);
+/* Number of target points (grid) or voxels (voxel map): traits::size(target). */
+int sga_index_size(const sga_index* index, size_t* n);
+/* Voxel map contents in voxel-id order: coords n*3 int32, means n*3, cov6 n*6, counts n (any may be NULL). */
+int sga_index_voxelmap_download(sga_context* ctx, const sga_index* index, int32_t* coords, float* means, float* cov6, uint32_t* counts);
+/* traits::knn_search / nearest_neighbor_search (ann/traits.hpp:22-57) for m host queries (m*3 floats):
+ * idx m*k int64 (original target indices, -1 = none), sq_dist m*k floats ascending (inf = none).
+ * max_sq_dist < 0 means unbounded.  Voxel maps support k = 1 only (own voxel, incremental_voxelmap.hpp:99-119). */
+int sga_index_knn(sga_context* ctx, const sga_index* index, const float* queries, size_t m, int k, double max_sq_dist, int64_t* idx, float* sq_dist);
+
+/* ---- the hot path: Reduction::linearize / Reduction::error (registration/reduction_omp.hpp:24-70) ------------------------- */
+typedef struct sga_factor_params {
+  int factor_kind;    /* sga_factor_kind */
+  int robust_kind;    /* sga_robust_kind */
+  double robust_c;    /* robust kernel width (robust_kernel.hpp:16,42) */
+  double max_dist_sq; /* DistanceRejector::max_dist_sq (rejector.hpp:19-28); < 0 = NullRejector */
+  int math_mode;      /* sga_math_mode */
+} sga_factor_params;
+void sga_factor_params_default(sga_factor_params* p);
+
+/* Pair a target index with a source cloud.  The problem keeps a spatially sorted copy of the source (sorted by the target-grid
+ * cell of init_T * p) and the per-point factor state (target index + cached mahalanobis), i.e. registration.hpp:41. */
+int sga_problem_create(sga_context* ctx, const sga_index* target, const sga_cloud* source, const double init_T[16], sga_problem** out);
+int sga_problem_destroy(sga_problem* problem);
+/* Sum_i (H_i, b_i, e_i) at T over all source points with a correspondence; refreshes the factor state. */
+int sga_linearize(sga_context* ctx, sga_problem* problem, const sga_factor_params* params, const double T[16], double H[36], double b[6], double* e, uint64_t* num_inliers);
+/* Sum_i e_i at T with the correspondences and mahalanobis cached by the last sga_linearize (gicp_factor.hpp:80-89). */
+int sga_error(sga_context* ctx, sga_problem* problem, const sga_factor_params* params, const double T[16], double* e);
+/* Enqueue-only forms for multi-GPU: results stay in device memory so they can be all-reduced (RCCL) on the same stream before
+ * the host reads them.  d_out30: [0..20] upper triangle of H row-wise, [21..26] b, [27] e, [28] num_inliers (as double), [29] 0.
+ * d_out1: e.  Both must be device pointers valid on the context's device; no host synchronisation is performed. */
+#define SGA_ACCUM_DOUBLES 30
+int sga_linearize_async(sga_context* ctx, sga_problem* problem, const sga_factor_params* params, const double T[16], double* d_out30);
+int sga_error_async(sga_context* ctx, sga_problem* problem, const sga_factor_params* params, const double T[16], double* d_out1);
+/* Expand a 30-double accumulator (host memory) into H[36], b[6], e, num_inliers. */
+void sga_unpack_accumulator(const double acc30[SGA_ACCUM_DOUBLES], double H[36], double b[6], double* e, uint64_t* num_inliers);
+/* Factor state in the caller's source order: target_index n int64 (-1 = outlier; voxel id for voxel maps), mahalanobis6 n*6 floats (GICP only). */
+int sga_problem_get_factors(sga_context* ctx, const sga_problem* problem, int64_t* target_index, float* mahalanobis6);
+/* Average device time (ms) of the last linearize / error kernel chains measured with HIP events on the context's stream (0 if profiling off). */
+int sga_context_set_profiling(sga_context* ctx, int enabled);
+int sga_context_get_kernel_ms(sga_context* ctx, double* linearize_ms, uint64_t* linearize_calls, double* error_ms, uint64_t* error_calls);
+
+/* ---- the driver: Registration<>::align + optimizers (registration/registration.hpp:33-54, optimizer.hpp:24-149) -------- */
+typedef struct sga_registration_setting {
+  sga_factor_params factor;  /* PointFactor + CorrespondenceRejector */
+  int optimizer;             /* sga_optimizer_kind */
+  int max_iterations;        /* optimizer.hpp: 20 */
+  int max_inner_iterations;  /* LM: 10 */
+  double init_lambda;        /* LM: 1e-3 */
+  double lambda_factor;      /* LM: 10 */
+  double gn_lambda;          /* GN: 1e-6 */
+  double translation_eps;    /* termination_criteria.hpp: 1e-3 */
+  double rotation_eps;       /* 0.1 deg in rad */
+  int verbose;
+  /* general_factor.hpp:41-75 RestrictDoFFactor: if restrict_dof_lambda > 0, H += lambda * diag(|mask - 1|) */
+  double restrict_dof_lambda;
+  double restrict_dof_mask[6];
+} sga_registration_setting;
+void sga_registration_setting_default(sga_registration_setting* s);
+
+/* registration_result.hpp:11-30, field for field */
+typedef struct sga_result {
+  double T_target_source[16];
+  int converged;
+  uint64_t iterations;
+  uint64_t num_inliers;
+  double H[36];
+  double b[6];
+  double error;
+} sga_result;
+
+/* Registration<Factor, ParallelReductionHIP>::align(target, source, target_tree, init_T): everything device-resident, LM/GN on the host. */
+int sga_align(sga_context* ctx, const sga_index* target, const sga_cloud* source, const double init_T[16], const sga_registration_setting* setting, sga_result* out);
+/* Same, on an existing problem (re-uses the sorted source and the factor buffers). */
+int sga_align_problem(sga_context* ctx, sga_problem* problem, const double init_T[16], const sga_registration_setting* setting, sga_result* out);
+
+/* The optimizer alone, over user reductions (the reference's Optimizer::optimize with a pluggable Reduction, optimizer.hpp:27-36):
+ * used for sharded multi-GPU runs where linearize = local kernels + all-reduce.  Callbacks return 0 on success. */
+typedef int (*sga_linearize_fn)(void* user, const double T[16], double H[36], double b[6], double* e, uint64_t* num_inliers);
+typedef int (*sga_error_fn)(void* user, const double T[16], double* e);
+int sga_optimize(const sga_registration_setting* setting, const double init_T[16], sga_linearize_fn linearize, sga_error_fn error, void* user, sga_result* out);
+
+/* util/lie.hpp:77-96 se3_exp (host). */
+void sga_se3_exp(const double twist[6], double T[16]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMALL_GICP_AMD_H */

@@ -1,0 +1,468 @@
+"""Python host layer over the C-ABI, mirroring the reference's Python module surface
+(src/python/{pointcloud,kdtree,voxelmap,preprocess,align,result}.cpp of /root/reference): PointCloud, KdTree,
+GaussianVoxelMap, voxelgrid_sampling, estimate_*, preprocess_points, align, RegistrationResult.
+All compute happens in the HIP library; numpy only carries host buffers in and out.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import GICP, ICP, PLANE_ICP, FactorParams, GridParams, RegistrationSettingC, ResultC, check, load
+
+_FACTOR_BY_NAME = {"ICP": ICP, "PLANE_ICP": PLANE_ICP, "GICP": GICP, "VGICP": GICP}
+
+
+def _fp(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _T16(T):
+    T = np.eye(4) if T is None else np.asarray(T, dtype=np.float64).reshape(4, 4)
+    return np.ascontiguousarray(T.T).reshape(16)  # column-major
+
+
+class Context:
+    """One GPU + one HIP stream (sga_context)."""
+
+    def __init__(self, device=0, stream=None):
+        self.h = C.c_void_p()
+        L = load()
+        if stream is None:
+            check(L.sga_context_create(int(device), C.byref(self.h)))
+        else:
+            check(L.sga_context_create_on_stream(int(device), C.c_void_p(int(stream)), C.byref(self.h)))
+        self.device = device
+
+    def __del__(self):
+        if getattr(self, "h", None) and self.h.value:
+            load().sga_context_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def synchronize(self):
+        check(load().sga_context_synchronize(self.h))
+
+    def set_profiling(self, enabled=True):
+        check(load().sga_context_set_profiling(self.h, int(enabled)))
+
+    def kernel_ms(self):
+        lm, em = C.c_double(), C.c_double()
+        lc, ec = C.c_uint64(), C.c_uint64()
+        check(load().sga_context_get_kernel_ms(self.h, C.byref(lm), C.byref(lc), C.byref(em), C.byref(ec)))
+        return {"linearize_ms": lm.value, "linearize_calls": lc.value, "error_ms": em.value, "error_calls": ec.value}
+
+
+_DEFAULT_CTX = None
+
+
+def default_context():
+    global _DEFAULT_CTX
+    if _DEFAULT_CTX is None:
+        _DEFAULT_CTX = Context(0)
+    return _DEFAULT_CTX
+
+
+def sym6_from_mats(covs):
+    """(N,3,3) or (N,4,4) symmetric -> (N,6) xx,xy,xz,yy,yz,zz"""
+    c = np.asarray(covs)
+    return np.stack([c[:, 0, 0], c[:, 0, 1], c[:, 0, 2], c[:, 1, 1], c[:, 1, 2], c[:, 2, 2]], axis=1)
+
+
+def mats_from_sym6(c6):
+    c6 = np.asarray(c6)
+    m = np.empty((len(c6), 3, 3), dtype=c6.dtype)
+    m[:, 0, 0], m[:, 0, 1], m[:, 0, 2] = c6[:, 0], c6[:, 1], c6[:, 2]
+    m[:, 1, 0], m[:, 1, 1], m[:, 1, 2] = c6[:, 1], c6[:, 3], c6[:, 4]
+    m[:, 2, 0], m[:, 2, 1], m[:, 2, 2] = c6[:, 2], c6[:, 4], c6[:, 5]
+    return m
+
+
+class PointCloud:
+    """Device-resident point cloud (points [+ normals] [+ covariances]); mirrors small_gicp.PointCloud."""
+
+    def __init__(self, points=None, normals=None, covs=None, ctx=None, _handle=None):
+        self.ctx = ctx or default_context()
+        if _handle is not None:
+            self.h = _handle
+            return
+        pts = np.zeros((0, 3), np.float32) if points is None else np.asarray(points)
+        if pts.ndim != 2 or pts.shape[1] not in (3, 4):
+            raise ValueError("points must be (N,3) or (N,4)")
+        xyz = np.ascontiguousarray(pts[:, :3], dtype=np.float32)
+        nrm = None if normals is None else np.ascontiguousarray(np.asarray(normals)[:, :3], dtype=np.float32)
+        c6 = None
+        if covs is not None:
+            covs = np.asarray(covs)
+            c6 = covs if covs.ndim == 2 and covs.shape[1] == 6 else sym6_from_mats(covs)
+            c6 = np.ascontiguousarray(c6, dtype=np.float32)
+        self.h = C.c_void_p()
+        check(load().sga_cloud_create_f32(self.ctx.h, _fp(xyz), _fp(nrm), _fp(c6), len(xyz), C.byref(self.h)))
+
+    def __del__(self):
+        if getattr(self, "h", None) and self.h.value:
+            load().sga_cloud_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def size(self):
+        n = C.c_size_t()
+        check(load().sga_cloud_size(self.h, C.byref(n)))
+        return n.value
+
+    __len__ = size
+
+    def empty(self):
+        return self.size() == 0
+
+    def _has(self):
+        a, b = C.c_int(), C.c_int()
+        check(load().sga_cloud_has(self.h, C.byref(a), C.byref(b)))
+        return bool(a.value), bool(b.value)
+
+    def points(self):
+        """(N,4) float64 homogeneous points, like the reference binding."""
+        n = self.size()
+        xyz = np.empty((n, 3), np.float32)
+        check(load().sga_cloud_download(self.ctx.h, self.h, _fp(xyz), None, None))
+        return np.concatenate([xyz.astype(np.float64), np.ones((n, 1))], axis=1)
+
+    def xyz(self):
+        n = self.size()
+        xyz = np.empty((n, 3), np.float32)
+        check(load().sga_cloud_download(self.ctx.h, self.h, _fp(xyz), None, None))
+        return xyz
+
+    def normals(self):
+        n = self.size()
+        if not self._has()[0]:
+            return np.zeros((n, 4))
+        nr = np.empty((n, 3), np.float32)
+        check(load().sga_cloud_download(self.ctx.h, self.h, None, _fp(nr), None))
+        return np.concatenate([nr.astype(np.float64), np.zeros((n, 1))], axis=1)
+
+    def covs(self):
+        """(N,4,4) float64 with zero padding, like the reference binding."""
+        n = self.size()
+        out = np.zeros((n, 4, 4))
+        if self._has()[1]:
+            c6 = np.empty((n, 6), np.float32)
+            check(load().sga_cloud_download(self.ctx.h, self.h, None, None, _fp(c6)))
+            out[:, :3, :3] = mats_from_sym6(c6.astype(np.float64))
+        return out
+
+
+class KdTree:
+    """Exact nearest-neighbour index over a PointCloud.  The name mirrors small_gicp.KdTree; the structure is a
+    cell-sorted uniform grid built on the GPU (sga_index_build_grid)."""
+
+    def __init__(self, points, cell_size=0.0, search_radius=1.0, points_per_cell=0.0, max_cells=0, num_threads=1):
+        if not isinstance(points, PointCloud):
+            points = PointCloud(points)
+        self.cloud = points
+        self.ctx = points.ctx
+        gp = GridParams(float(cell_size), float(search_radius), float(points_per_cell), int(max_cells))
+        self.h = C.c_void_p()
+        check(load().sga_index_build_grid(self.ctx.h, points.h, C.byref(gp), C.byref(self.h)))
+
+    def __del__(self):
+        if getattr(self, "h", None) and self.h.value:
+            load().sga_index_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def size(self):
+        n = C.c_size_t()
+        check(load().sga_index_size(self.h, C.byref(n)))
+        return n.value
+
+    def batch_knn_search(self, pts, k, max_sq_dist=-1.0, num_threads=1):
+        q = np.ascontiguousarray(np.asarray(pts)[:, :3], dtype=np.float32)
+        idx = np.empty((len(q), k), np.int64)
+        d2 = np.empty((len(q), k), np.float32)
+        check(load().sga_index_knn(self.ctx.h, self.h, _fp(q), len(q), int(k), float(max_sq_dist), idx.ctypes.data_as(C.POINTER(C.c_int64)), _fp(d2)))
+        return idx, d2
+
+    def batch_nearest_neighbor_search(self, pts, num_threads=1):
+        idx, d2 = self.batch_knn_search(pts, 1)
+        return idx[:, 0], d2[:, 0]
+
+    def knn_search(self, pt, k):
+        idx, d2 = self.batch_knn_search(np.asarray(pt, dtype=np.float64).reshape(1, -1), k)
+        return idx[0], d2[0]
+
+    def nearest_neighbor_search(self, pt):
+        idx, d2 = self.knn_search(pt, 1)
+        return (1 if idx[0] >= 0 else 0), int(idx[0]), float(d2[0])
+
+
+class GaussianVoxelMap:
+    """small_gicp.GaussianVoxelMap: `GaussianVoxelMap(leaf); insert(cloud_with_covs)` (one-shot)."""
+
+    def __init__(self, leaf_size, ctx=None):
+        self.leaf = float(leaf_size)
+        self.ctx = ctx or default_context()
+        self.h = C.c_void_p()
+
+    def __del__(self):
+        if getattr(self, "h", None) and self.h.value:
+            load().sga_index_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def insert(self, cloud, T=None):
+        if T is not None and not np.allclose(np.asarray(T), np.eye(4)):
+            raise NotImplementedError("insert() with a transform")
+        if self.h.value:
+            raise NotImplementedError("incremental insertion is out of scope (SURVEY.md §8f row 3); build one map per target")
+        self.ctx = cloud.ctx
+        check(load().sga_index_build_gaussian_voxelmap(self.ctx.h, cloud.h, self.leaf, C.byref(self.h)))
+
+    def size(self):
+        if not self.h.value:
+            return 0
+        n = C.c_size_t()
+        check(load().sga_index_size(self.h, C.byref(n)))
+        return n.value
+
+    def download(self):
+        n = self.size()
+        coords = np.empty((n, 3), np.int32)
+        means = np.empty((n, 3), np.float32)
+        c6 = np.empty((n, 6), np.float32)
+        counts = np.empty(n, np.uint32)
+        check(load().sga_index_voxelmap_download(self.ctx.h, self.h, coords.ctypes.data_as(C.POINTER(C.c_int32)), _fp(means), _fp(c6), counts.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return coords, means, c6, counts
+
+    def voxel_points(self):
+        m = self.download()[1].astype(np.float64)
+        return np.concatenate([m, np.ones((len(m), 1))], axis=1)
+
+    def voxel_covs(self):
+        c6 = self.download()[2].astype(np.float64)
+        out = np.zeros((len(c6), 4, 4))
+        out[:, :3, :3] = mats_from_sym6(c6)
+        return out
+
+
+class RegistrationResult:
+    """registration_result.hpp:11-30, field for field."""
+
+    def __init__(self, rc=None):
+        if rc is None:
+            self.T_target_source = np.eye(4)
+            self.converged, self.iterations, self.num_inliers = False, 0, 0
+            self.H, self.b, self.error = np.zeros((6, 6)), np.zeros(6), 0.0
+        else:
+            self.T_target_source = np.array(rc.T_target_source).reshape(4, 4).T.copy()
+            self.converged = bool(rc.converged)
+            self.iterations = int(rc.iterations)
+            self.num_inliers = int(rc.num_inliers)
+            self.H = np.array(rc.H).reshape(6, 6)
+            self.b = np.array(rc.b)
+            self.error = float(rc.error)
+
+    def __repr__(self):
+        return f"RegistrationResult(converged={self.converged}, iterations={self.iterations}, num_inliers={self.num_inliers}, error={self.error:.6g})"
+
+
+def make_setting(
+    registration_type="GICP",
+    max_correspondence_distance=1.0,
+    max_iterations=20,
+    rotation_eps=0.1 * np.pi / 180.0,
+    translation_eps=1e-3,
+    robust_kernel=None,
+    robust_c=1.0,
+    optimizer="LM",
+    math_mode="fp32",
+    verbose=False,
+    max_inner_iterations=10,
+    init_lambda=1e-3,
+    lambda_factor=10.0,
+    gn_lambda=1e-6,
+    restrict_dof_lambda=0.0,
+    restrict_dof_mask=None,
+):
+    s = RegistrationSettingC()
+    load().sga_registration_setting_default(C.byref(s))
+    s.factor.factor_kind = _FACTOR_BY_NAME[registration_type] if isinstance(registration_type, str) else int(registration_type)
+    s.factor.max_dist_sq = -1.0 if max_correspondence_distance is None else float(max_correspondence_distance) ** 2
+    s.factor.robust_kind = {None: 0, "NONE": 0, "HUBER": 1, "CAUCHY": 2}[robust_kernel if robust_kernel is None else robust_kernel.upper()]
+    s.factor.robust_c = float(robust_c)
+    s.factor.math_mode = {"fp32": 0, "fp64": 1}[math_mode]
+    s.optimizer = {"LM": 0, "GN": 1}[optimizer]
+    s.max_iterations = int(max_iterations)
+    s.max_inner_iterations = int(max_inner_iterations)
+    s.init_lambda, s.lambda_factor, s.gn_lambda = float(init_lambda), float(lambda_factor), float(gn_lambda)
+    s.rotation_eps, s.translation_eps = float(rotation_eps), float(translation_eps)
+    s.verbose = int(verbose)
+    s.restrict_dof_lambda = float(restrict_dof_lambda)
+    if restrict_dof_mask is not None:
+        for i in range(6):
+            s.restrict_dof_mask[i] = float(restrict_dof_mask[i])
+    return s
+
+
+class Problem:
+    """(target index, source cloud) pairing with device-resident factor state: the Reduction slot of Registration<>."""
+
+    def __init__(self, target, source, init_T=None):
+        self.target, self.source = target, source
+        self.ctx = source.ctx
+        self.h = C.c_void_p()
+        t16 = _T16(init_T)
+        check(load().sga_problem_create(self.ctx.h, target.h, source.h, _dp(t16), C.byref(self.h)))
+
+    def __del__(self):
+        if getattr(self, "h", None) and self.h.value:
+            load().sga_problem_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def linearize(self, factor_params, T):
+        H, b = np.empty(36), np.empty(6)
+        e, ninl = C.c_double(), C.c_uint64()
+        t16 = _T16(T)
+        check(load().sga_linearize(self.ctx.h, self.h, C.byref(factor_params), _dp(t16), _dp(H), _dp(b), C.byref(e), C.byref(ninl)))
+        return H.reshape(6, 6), b, e.value, ninl.value
+
+    def error(self, factor_params, T):
+        e = C.c_double()
+        t16 = _T16(T)
+        check(load().sga_error(self.ctx.h, self.h, C.byref(factor_params), _dp(t16), C.byref(e)))
+        return e.value
+
+    def linearize_async(self, factor_params, T, d_out_ptr):
+        t16 = _T16(T)
+        check(load().sga_linearize_async(self.ctx.h, self.h, C.byref(factor_params), _dp(t16), C.c_void_p(int(d_out_ptr))))
+
+    def error_async(self, factor_params, T, d_out_ptr):
+        t16 = _T16(T)
+        check(load().sga_error_async(self.ctx.h, self.h, C.byref(factor_params), _dp(t16), C.c_void_p(int(d_out_ptr))))
+
+    def factors(self):
+        n = self.source.size()
+        ti = np.empty(n, np.int64)
+        m6 = np.empty((n, 6), np.float32)
+        check(load().sga_problem_get_factors(self.ctx.h, self.h, ti.ctypes.data_as(C.POINTER(C.c_int64)), _fp(m6)))
+        return ti, m6
+
+    def align(self, setting, init_T=None):
+        res = ResultC()
+        t16 = _T16(init_T)
+        check(load().sga_align_problem(self.ctx.h, self.h, _dp(t16), C.byref(setting), C.byref(res)))
+        return RegistrationResult(res)
+
+
+def unpack_accumulator(acc30):
+    a = np.ascontiguousarray(acc30, dtype=np.float64)
+    H, b = np.empty(36), np.empty(6)
+    e, n = C.c_double(), C.c_uint64()
+    load().sga_unpack_accumulator(_dp(a), _dp(H), _dp(b), C.byref(e), C.byref(n))
+    return H.reshape(6, 6), b, e.value, n.value
+
+
+def optimize(setting, init_T, linearize, error):
+    """sga_optimize: the host LM/GN over python callbacks linearize(T)->(H,b,e,num_inliers), error(T)->e.  T is 4x4 row-major numpy."""
+
+    def _lin(user, T, H, b, e, n):
+        try:
+            Tm = np.ctypeslib.as_array(T, shape=(16,)).reshape(4, 4).T
+            h, bb, ee, nn = linearize(Tm.copy())
+            np.ctypeslib.as_array(H, shape=(36,))[:] = np.asarray(h, dtype=np.float64).reshape(36)
+            np.ctypeslib.as_array(b, shape=(6,))[:] = np.asarray(bb, dtype=np.float64).reshape(6)
+            e[0] = float(ee)
+            n[0] = int(nn)
+            return 0
+        except Exception as ex:  # noqa: BLE001
+            _lin.exc = ex
+            return 1
+
+    def _err(user, T, e):
+        try:
+            Tm = np.ctypeslib.as_array(T, shape=(16,)).reshape(4, 4).T
+            e[0] = float(error(Tm.copy()))
+            return 0
+        except Exception as ex:  # noqa: BLE001
+            _lin.exc = ex
+            return 1
+
+    _lin.exc = None
+    res = ResultC()
+    t16 = _T16(init_T)
+    rc = load().sga_optimize(C.byref(setting), _dp(t16), _lib.LINEARIZE_FN(_lin), _lib.ERROR_FN(_err), None, C.byref(res))
+    if _lin.exc is not None:
+        raise _lin.exc
+    check(rc)
+    return RegistrationResult(res)
+
+
+# ---- preprocessing (src/python/preprocess.cpp) -----------------------------------------------------------------------------
+def voxelgrid_sampling(points, downsampling_resolution, num_threads=1):
+    cloud = points if isinstance(points, PointCloud) else PointCloud(points)
+    out = C.c_void_p()
+    check(load().sga_voxelgrid_sampling(cloud.ctx.h, cloud.h, float(downsampling_resolution), C.byref(out)))
+    return PointCloud(ctx=cloud.ctx, _handle=out)
+
+
+def _estimate(cloud, tree, num_neighbors, flags):
+    check(load().sga_estimate_normals_covariances(cloud.ctx.h, cloud.h, tree.h if tree is not None else None, int(num_neighbors), flags))
+
+
+def estimate_normals(points, tree=None, num_neighbors=20, num_threads=1):
+    _estimate(points, tree, num_neighbors, 1)
+
+
+def estimate_covariances(points, tree=None, num_neighbors=20, num_threads=1):
+    _estimate(points, tree, num_neighbors, 2)
+
+
+def estimate_normals_covariances(points, tree=None, num_neighbors=20, num_threads=1):
+    _estimate(points, tree, num_neighbors, 3)
+
+
+def preprocess_points(points, downsampling_resolution=0.25, num_neighbors=10, num_threads=1):
+    """registration_helper.cpp:22-34: downsample -> index -> normals + covariances.  Returns (PointCloud, KdTree)."""
+    cloud = points if isinstance(points, PointCloud) else PointCloud(points)
+    down = voxelgrid_sampling(cloud, downsampling_resolution)
+    estimate_normals_covariances(down, None, num_neighbors)
+    tree = KdTree(down)
+    return down, tree
+
+
+def align(
+    target,
+    source,
+    target_tree=None,
+    init_T_target_source=None,
+    registration_type="GICP",
+    voxel_resolution=1.0,
+    downsampling_resolution=0.25,
+    max_correspondence_distance=1.0,
+    num_threads=1,
+    max_iterations=20,
+    verbose=False,
+    **kw,
+):
+    """small_gicp.align (src/python/align.cpp:22-295), three call forms:
+    align(target_numpy, source_numpy, ...)            -> preprocess both, then register          (registration_helper.cpp:57-69)
+    align(target_cloud, source_cloud, target_tree)    -> ICP / PLANE_ICP / GICP                    (registration_helper.cpp:81-122)
+    align(target_voxelmap, source_cloud)              -> VGICP                                      (registration_helper.cpp:125-137)
+    """
+    if isinstance(target, GaussianVoxelMap):
+        setting = make_setting("GICP", max_correspondence_distance, max_iterations, verbose=verbose, **kw)
+        return Problem(target, source, init_T_target_source).align(setting, init_T_target_source)
+    if not isinstance(target, PointCloud):
+        tgt, tree = preprocess_points(np.asarray(target), downsampling_resolution, 10)
+        src, _ = preprocess_points(np.asarray(source), downsampling_resolution, 10)
+        if registration_type == "VGICP":
+            vm = GaussianVoxelMap(voxel_resolution, ctx=tgt.ctx)
+            vm.insert(tgt)
+            # registration_helper.cpp:130-136 leaves the rejector at its default 1.0 m^2 for VGICP
+            setting = make_setting("GICP", 1.0, max_iterations, verbose=verbose, **kw)
+            return Problem(vm, src, init_T_target_source).align(setting, init_T_target_source)
+        target, source, target_tree = tgt, src, tree
+    if target_tree is None:
+        target_tree = KdTree(target, search_radius=max_correspondence_distance or 1.0)
+    setting = make_setting(registration_type, max_correspondence_distance, max_iterations, verbose=verbose, **kw)
+    return Problem(target_tree, source, init_T_target_source).align(setting, init_T_target_source)

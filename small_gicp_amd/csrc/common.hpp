@@ -1,0 +1,142 @@
+// Internal definitions shared by the HIP translation units of libsmall_gicp_amd.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/small_gicp_amd.h"
+
+namespace sga {
+
+// ---- error plumbing --------------------------------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int fail(int code, const char* fmt, ...);
+
+#define SGA_HIP(expr)                                                                                             \
+  do {                                                                                                            \
+    hipError_t _e = (expr);                                                                                       \
+    if (_e != hipSuccess) return ::sga::fail(SGA_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+  } while (0)
+#define SGA_TRY(expr)           \
+  do {                          \
+    int _rc = (expr);           \
+    if (_rc != SGA_OK) return _rc; \
+  } while (0)
+
+// ---- device buffer -----------------------------------------------------------------------------------------------------
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  int alloc(size_t count) {
+    release();
+    if (count == 0) return SGA_OK;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+    if (e != hipSuccess) {
+      p = nullptr;
+      return fail(SGA_ERR_HIP, "hipMalloc(%zu bytes) -> %s", count * sizeof(T), hipGetErrorString(e));
+    }
+    n = count;
+    return SGA_OK;
+  }
+  // grow-only
+  int reserve(size_t count) { return (count <= n) ? SGA_OK : alloc(count); }
+};
+
+// ---- packed records (HBM layout) ---------------------------------------------------------------------------------------
+// pts4 : float4 {x, y, z, bitcast(u32 original index)}           16 B, one dwordx4 gather
+// nrm4 : float4 {nx, ny, nz, 0}                                   16 B
+// cov8 : 2 x float4 {xx, xy, xz, yy | yz, zz, 0, 0}               32 B, two dwordx4 gathers
+struct alignas(16) Cov8 {
+  float xx, xy, xz, yy, yz, zz, pad0, pad1;
+};
+
+}  // namespace sga
+
+// ---- opaque handles ------------------------------------------------------------------------------------------------------
+struct sga_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool owns_stream = false;
+  // scratch
+  sga::DevBuf<double> d_accum;    // SGA_ACCUM_DOUBLES
+  double* h_accum = nullptr;      // pinned, SGA_ACCUM_DOUBLES
+  sga::DevBuf<uint8_t> d_temp;    // rocPRIM temp storage (grow-only)
+  // profiling
+  bool profiling = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double lin_ms = 0.0, err_ms = 0.0;
+  uint64_t lin_calls = 0, err_calls = 0;
+  int num_cus = 256;
+};
+
+struct sga_cloud {
+  int device = 0;
+  size_t n = 0;
+  bool has_normals = false, has_covs = false;
+  sga::DevBuf<float4> pts;   // w = bitcast(original index)
+  sga::DevBuf<float4> nrm;
+  sga::DevBuf<sga::Cov8> cov;
+};
+
+enum { SGA_INDEX_GRID = 0, SGA_INDEX_VOXELMAP = 1 };
+
+struct GridDesc {
+  float origin[3];   // lower corner of cell (0,0,0)
+  float inv_cell;    // 1 / h
+  float cell;        // h
+  int dims[3];       // nx, ny, nz
+  // linear cell id = (z * ny + y) * nx + x  (x fastest: the cells of one (y,z) row are contiguous in the sorted target)
+};
+
+struct sga_index {
+  int kind = SGA_INDEX_GRID;
+  int device = 0;
+  size_t n = 0;  // points (grid) or voxels (voxelmap)
+  bool has_normals = false, has_covs = false;
+  // grid
+  GridDesc grid{};
+  sga::DevBuf<float4> pts;          // cell-sorted; w = original index bits
+  sga::DevBuf<float4> nrm;          // cell-sorted
+  sga::DevBuf<sga::Cov8> cov;       // cell-sorted
+  sga::DevBuf<uint32_t> cell_start; // ncells + 1
+  uint64_t ncells = 0;
+  // voxel map
+  double leaf = 0.0;
+  sga::DevBuf<unsigned long long> hkeys;  // open addressing, EMPTY = ~0ull
+  sga::DevBuf<uint32_t> hvals;            // voxel id
+  uint32_t hmask = 0;
+  sga::DevBuf<int> vcoords;               // n*3
+  sga::DevBuf<uint32_t> vcounts;          // n
+  // (means live in pts, mean covariances in cov)
+};
+
+struct sga_problem {
+  int device = 0;
+  const sga_index* target = nullptr;
+  size_t n = 0;  // source points
+  bool has_normals = false, has_covs = false;
+  sga::DevBuf<float4> pts;       // spatially sorted copy of the source; w = original index bits
+  sga::DevBuf<sga::Cov8> cov;
+  // factor state
+  sga::DevBuf<int> corr;         // sorted-target position (grid) / voxel id (voxelmap); -1 = outlier
+  sga::DevBuf<float> maha;       // n*6 (fp32 mode) — fused mahalanobis of the last linearize
+  sga::DevBuf<double> maha64;    // n*6 (fp64 mode, allocated on first use)
+  // reduction scratch
+  sga::DevBuf<double> partials;  // nblocks * 32
+  int max_blocks = 0;
+};

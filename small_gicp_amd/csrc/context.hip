@@ -1,0 +1,264 @@
+// Context (one GPU + one stream), error plumbing and device-resident clouds.
+#include "common.hpp"
+
+namespace sga {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+__global__ void pack_cloud_f32_kernel(const float* __restrict__ xyz, const float* __restrict__ nrm, const float* __restrict__ cov6, size_t n, float4* __restrict__ pts, float4* __restrict__ onrm, Cov8* __restrict__ ocov) {
+  const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
+  if (i >= n) return;
+  pts[i] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], __uint_as_float(static_cast<uint32_t>(i)));
+  if (nrm) onrm[i] = make_float4(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2], 0.f);
+  if (cov6) {
+    Cov8 c;
+    c.xx = cov6[6 * i];
+    c.xy = cov6[6 * i + 1];
+    c.xz = cov6[6 * i + 2];
+    c.yy = cov6[6 * i + 3];
+    c.yz = cov6[6 * i + 4];
+    c.zz = cov6[6 * i + 5];
+    c.pad0 = c.pad1 = 0.f;
+    ocov[i] = c;
+  }
+}
+
+__global__ void unpack_cloud_kernel(const float4* __restrict__ pts, const float4* __restrict__ nrm, const Cov8* __restrict__ cov, size_t n, float* __restrict__ xyz, float* __restrict__ onrm, float* __restrict__ cov6) {
+  const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
+  if (i >= n) return;
+  if (xyz) {
+    const float4 p = pts[i];
+    xyz[3 * i] = p.x;
+    xyz[3 * i + 1] = p.y;
+    xyz[3 * i + 2] = p.z;
+  }
+  if (onrm) {
+    const float4 q = nrm[i];
+    onrm[3 * i] = q.x;
+    onrm[3 * i + 1] = q.y;
+    onrm[3 * i + 2] = q.z;
+  }
+  if (cov6) {
+    const Cov8 c = cov[i];
+    cov6[6 * i] = c.xx;
+    cov6[6 * i + 1] = c.xy;
+    cov6[6 * i + 2] = c.xz;
+    cov6[6 * i + 3] = c.yy;
+    cov6[6 * i + 4] = c.yz;
+    cov6[6 * i + 5] = c.zz;
+  }
+}
+
+int ensure_temp(sga_context* ctx, size_t bytes) { return ctx->d_temp.reserve(bytes); }
+
+}  // namespace sga
+
+using namespace sga;
+
+extern "C" {
+
+const char* sga_last_error(void) { return g_err; }
+const char* sga_version(void) { return "small_gicp_amd 0.1.0 (gfx950)"; }
+
+int sga_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+static int context_create_impl(int device, void* stream, bool borrow, sga_context** out) {
+  if (!out) return fail(SGA_ERR_INVALID, "null out");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) return fail(SGA_ERR_NO_DEVICE, "no HIP device available (%s): small_gicp_amd has no CPU fallback", e == hipSuccess ? "count=0" : hipGetErrorString(e));
+  if (device < 0 || device >= n) return fail(SGA_ERR_INVALID, "device %d out of range [0,%d)", device, n);
+  SGA_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  SGA_HIP(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(SGA_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+  auto* ctx = new sga_context;
+  ctx->device = device;
+  ctx->num_cus = prop.multiProcessorCount;
+  if (borrow) {
+    ctx->stream = static_cast<hipStream_t>(stream);
+    ctx->owns_stream = false;
+  } else {
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+      delete ctx;
+      return fail(SGA_ERR_HIP, "hipStreamCreate failed");
+    }
+    ctx->owns_stream = true;
+  }
+  int rc = ctx->d_accum.alloc(64);
+  if (rc == SGA_OK && hipHostMalloc(reinterpret_cast<void**>(&ctx->h_accum), 64 * sizeof(double), hipHostMallocDefault) != hipSuccess) rc = fail(SGA_ERR_HIP, "hipHostMalloc failed");
+  if (rc == SGA_OK && (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess)) rc = fail(SGA_ERR_HIP, "hipEventCreate failed");
+  if (rc != SGA_OK) {
+    sga_context_destroy(ctx);
+    return rc;
+  }
+  *out = ctx;
+  return SGA_OK;
+}
+
+int sga_context_create(int device, sga_context** out) { return context_create_impl(device, nullptr, false, out); }
+int sga_context_create_on_stream(int device, void* hip_stream, sga_context** out) { return context_create_impl(device, hip_stream, true, out); }
+
+int sga_context_destroy(sga_context* ctx) {
+  if (!ctx) return SGA_OK;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->h_accum) (void)hipHostFree(ctx->h_accum);
+  if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return SGA_OK;
+}
+
+int sga_context_synchronize(sga_context* ctx) {
+  if (!ctx) return fail(SGA_ERR_INVALID, "null context");
+  SGA_HIP(hipStreamSynchronize(ctx->stream));
+  return SGA_OK;
+}
+
+void* sga_context_stream(sga_context* ctx) { return ctx ? static_cast<void*>(ctx->stream) : nullptr; }
+
+int sga_context_set_profiling(sga_context* ctx, int enabled) {
+  if (!ctx) return fail(SGA_ERR_INVALID, "null context");
+  ctx->profiling = enabled != 0;
+  ctx->lin_ms = ctx->err_ms = 0.0;
+  ctx->lin_calls = ctx->err_calls = 0;
+  return SGA_OK;
+}
+
+int sga_context_get_kernel_ms(sga_context* ctx, double* lin_ms, uint64_t* lin_calls, double* err_ms, uint64_t* err_calls) {
+  if (!ctx) return fail(SGA_ERR_INVALID, "null context");
+  if (lin_ms) *lin_ms = ctx->lin_calls ? ctx->lin_ms / ctx->lin_calls : 0.0;
+  if (lin_calls) *lin_calls = ctx->lin_calls;
+  if (err_ms) *err_ms = ctx->err_calls ? ctx->err_ms / ctx->err_calls : 0.0;
+  if (err_calls) *err_calls = ctx->err_calls;
+  return SGA_OK;
+}
+
+int sga_cloud_create_f32(sga_context* ctx, const float* xyz, const float* normals, const float* cov6, size_t n, sga_cloud** out) {
+  if (!ctx || !out || (n > 0 && !xyz)) return fail(SGA_ERR_INVALID, "null argument");
+  if (n >= (1ull << 31)) return fail(SGA_ERR_INVALID, "cloud too large (%zu points; limit 2^31-1)", n);
+  *out = nullptr;
+  SGA_HIP(hipSetDevice(ctx->device));
+  auto* c = new sga_cloud;
+  c->device = ctx->device;
+  c->n = n;
+  c->has_normals = normals != nullptr;
+  c->has_covs = cov6 != nullptr;
+  DevBuf<float> sx, sn, sc;
+  int rc = c->pts.alloc(n);
+  if (rc == SGA_OK && normals) rc = c->nrm.alloc(n);
+  if (rc == SGA_OK && cov6) rc = c->cov.alloc(n);
+  if (rc == SGA_OK) rc = sx.alloc(n * 3);
+  if (rc == SGA_OK && normals) rc = sn.alloc(n * 3);
+  if (rc == SGA_OK && cov6) rc = sc.alloc(n * 6);
+  if (rc != SGA_OK) {
+    delete c;
+    return rc;
+  }
+  if (n > 0) {
+    hipError_t e = hipMemcpyAsync(sx.p, xyz, n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && normals) e = hipMemcpyAsync(sn.p, normals, n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && cov6) e = hipMemcpyAsync(sc.p, cov6, n * 6 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(pack_cloud_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, sx.p, sn.p, sc.p, n, c->pts.p, c->nrm.p, c->cov.p);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+      delete c;
+      return fail(SGA_ERR_HIP, "cloud upload failed: %s", hipGetErrorString(e));
+    }
+  }
+  *out = c;
+  return SGA_OK;
+}
+
+int sga_cloud_create_f64(sga_context* ctx, const double* xyzw, const double* normals4, const double* cov4x4, size_t n, sga_cloud** out) {
+  if (!ctx || !out || (n > 0 && !xyzw)) return fail(SGA_ERR_INVALID, "null argument");
+  std::vector<float> xyz(n * 3), nrm, cov;
+  for (size_t i = 0; i < n; i++)
+    for (int k = 0; k < 3; k++) xyz[3 * i + k] = static_cast<float>(xyzw[4 * i + k]);
+  if (normals4) {
+    nrm.resize(n * 3);
+    for (size_t i = 0; i < n; i++)
+      for (int k = 0; k < 3; k++) nrm[3 * i + k] = static_cast<float>(normals4[4 * i + k]);
+  }
+  if (cov4x4) {
+    cov.resize(n * 6);
+    for (size_t i = 0; i < n; i++) {
+      const double* m = cov4x4 + 16 * i;  // symmetric: storage order irrelevant
+      cov[6 * i + 0] = static_cast<float>(m[0]);
+      cov[6 * i + 1] = static_cast<float>(m[1]);
+      cov[6 * i + 2] = static_cast<float>(m[2]);
+      cov[6 * i + 3] = static_cast<float>(m[5]);
+      cov[6 * i + 4] = static_cast<float>(m[6]);
+      cov[6 * i + 5] = static_cast<float>(m[10]);
+    }
+  }
+  return sga_cloud_create_f32(ctx, xyz.data(), normals4 ? nrm.data() : nullptr, cov4x4 ? cov.data() : nullptr, n, out);
+}
+
+int sga_cloud_destroy(sga_cloud* cloud) {
+  if (cloud) {
+    (void)hipSetDevice(cloud->device);
+    delete cloud;
+  }
+  return SGA_OK;
+}
+
+int sga_cloud_size(const sga_cloud* cloud, size_t* n) {
+  if (!cloud || !n) return fail(SGA_ERR_INVALID, "null argument");
+  *n = cloud->n;
+  return SGA_OK;
+}
+
+int sga_cloud_has(const sga_cloud* cloud, int* has_normals, int* has_covs) {
+  if (!cloud) return fail(SGA_ERR_INVALID, "null argument");
+  if (has_normals) *has_normals = cloud->has_normals;
+  if (has_covs) *has_covs = cloud->has_covs;
+  return SGA_OK;
+}
+
+int sga_cloud_download(sga_context* ctx, const sga_cloud* cloud, float* xyz, float* normals, float* cov6) {
+  if (!ctx || !cloud) return fail(SGA_ERR_INVALID, "null argument");
+  if (normals && !cloud->has_normals) return fail(SGA_ERR_INVALID, "cloud has no normals");
+  if (cov6 && !cloud->has_covs) return fail(SGA_ERR_INVALID, "cloud has no covariances");
+  const size_t n = cloud->n;
+  if (n == 0) return SGA_OK;
+  SGA_HIP(hipSetDevice(ctx->device));
+  DevBuf<float> sx, sn, sc;
+  if (xyz) SGA_TRY(sx.alloc(n * 3));
+  if (normals) SGA_TRY(sn.alloc(n * 3));
+  if (cov6) SGA_TRY(sc.alloc(n * 6));
+  hipLaunchKernelGGL(unpack_cloud_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, cloud->pts.p, cloud->nrm.p, cloud->cov.p, n, sx.p, sn.p, sc.p);
+  SGA_HIP(hipGetLastError());
+  if (xyz) SGA_HIP(hipMemcpyAsync(xyz, sx.p, n * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  if (normals) SGA_HIP(hipMemcpyAsync(normals, sn.p, n * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  if (cov6) SGA_HIP(hipMemcpyAsync(cov6, sc.p, n * 6 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  SGA_HIP(hipStreamSynchronize(ctx->stream));
+  return SGA_OK;
+}
+
+}  // extern "C"

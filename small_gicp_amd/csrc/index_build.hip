@@ -1,0 +1,471 @@
+// Search-index construction on the GPU: the cell-sorted uniform grid that replaces KdTreeBuilder::build_tree
+// (ann/kdtree.hpp:80-126, reference tree /root/reference) and the one-shot GaussianVoxelMap that replaces
+// IncrementalVoxelMap::insert + GaussianVoxel::add/finalize (ann/incremental_voxelmap.hpp:55-92,
+// ann/gaussian_voxelmap.hpp:32-53).  Build time is outside the per-iteration hot loop; sorts use rocPRIM.
+#include <algorithm>
+#include <cmath>
+
+#include "common.hpp"
+
+#include <memory>
+#include <rocprim/rocprim.hpp>
+#include "nn_search.hpp"
+
+namespace sga {
+
+int ensure_temp(sga_context* ctx, size_t bytes);
+
+// ---- bounding box --------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bbox_kernel(const float4* __restrict__ pts, size_t n, float* __restrict__ out6 /* min xyz (init +inf), max xyz (init -inf) as ordered ints */) {
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n; i += static_cast<size_t>(gridDim.x) * blockDim.x) {
+    const float4 p = pts[i];
+    lo[0] = fminf(lo[0], p.x);
+    lo[1] = fminf(lo[1], p.y);
+    lo[2] = fminf(lo[2], p.z);
+    hi[0] = fmaxf(hi[0], p.x);
+    hi[1] = fmaxf(hi[1], p.y);
+    hi[2] = fmaxf(hi[2], p.z);
+  }
+  for (int k = 0; k < 3; k++) {
+    for (int off = 32; off > 0; off >>= 1) {
+      lo[k] = fminf(lo[k], __shfl_xor(lo[k], off));
+      hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
+    }
+  }
+  if ((threadIdx.x & 63) == 0) {
+    // float atomics via the order-preserving int mapping
+    auto enc = [](float f) {
+      int i = __float_as_int(f);
+      return i >= 0 ? i : i ^ 0x7fffffff;
+    };
+    int* o = reinterpret_cast<int*>(out6);
+    for (int k = 0; k < 3; k++) {
+      atomicMin(&o[k], enc(lo[k]));
+      atomicMax(&o[3 + k], enc(hi[k]));
+    }
+  }
+}
+
+static inline float dec_ordered(int i) {
+  int j = i >= 0 ? i : i ^ 0x7fffffff;
+  float f;
+  memcpy(&f, &j, 4);
+  return f;
+}
+
+__device__ __forceinline__ uint32_t point_cell(const float4 p, float ox, float oy, float oz, float inv, int nx, int ny, int nz) {
+  const int cx = min(max(cell_coord(p.x, ox, inv), 0), nx - 1);
+  const int cy = min(max(cell_coord(p.y, oy, inv), 0), ny - 1);
+  const int cz = min(max(cell_coord(p.z, oz, inv), 0), nz - 1);
+  return (static_cast<uint32_t>(cz) * ny + cy) * nx + cx;
+}
+
+__global__ void cell_keys_kernel(const float4* __restrict__ pts, size_t n, float ox, float oy, float oz, float inv, int nx, int ny, int nz, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ counts) {
+  const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t c = point_cell(pts[i], ox, oy, oz, inv, nx, ny, nz);
+  if (keys) keys[i] = c;
+  if (vals) vals[i] = static_cast<uint32_t>(i);
+  atomicAdd(&counts[c], 1u);
+}
+
+__global__ void count_nonzero_kernel(const uint32_t* __restrict__ counts, size_t n, unsigned long long* __restrict__ out) {
+  unsigned int local = 0;
+  for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n; i += static_cast<size_t>(gridDim.x) * blockDim.x) local += counts[i] != 0;
+  for (int off = 32; off > 0; off >>= 1) local += __shfl_xor(local, off);
+  if ((threadIdx.x & 63) == 0 && local) atomicAdd(out, static_cast<unsigned long long>(local));
+}
+
+__global__ void gather_sorted_kernel(
+  const uint32_t* __restrict__ order, size_t n, const float4* __restrict__ pts, const float4* __restrict__ nrm, const Cov8* __restrict__ cov, float4* __restrict__ opts, float4* __restrict__ onrm, Cov8* __restrict__ ocov) {
+  const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t s = order[i];
+  opts[i] = pts[s];  // w keeps the original index bits
+  if (nrm) onrm[i] = nrm[s];
+  if (cov) ocov[i] = cov[s];
+}
+
+static void grid_dims(const float lo[3], const float hi[3], double h, int dims[3]) {
+  for (int k = 0; k < 3; k++) {
+    const double ext = std::max(0.0, static_cast<double>(hi[k]) - lo[k]);
+    const double d = std::floor(ext / h) + 1.0;
+    dims[k] = static_cast<int>(std::min(d, 2.0e9));
+  }
+}
+static double grid_cells(const int dims[3]) { return static_cast<double>(dims[0]) * dims[1] * dims[2]; }
+
+struct GridScratch {
+  DevBuf<uint32_t> counts;
+  DevBuf<unsigned long long> occ;
+};
+
+// number of occupied cells at cell size h (dense count table)
+static int count_occupied(sga_context* ctx, const sga_cloud* cloud, const float lo[3], double h, const int dims[3], GridScratch& sc, uint64_t* occupied) {
+  const size_t ncells = static_cast<size_t>(grid_cells(dims));
+  SGA_TRY(sc.counts.reserve(ncells + 1));
+  if (!sc.occ.p) SGA_TRY(sc.occ.alloc(1));
+  SGA_HIP(hipMemsetAsync(sc.counts.p, 0, (ncells + 1) * sizeof(uint32_t), ctx->stream));
+  SGA_HIP(hipMemsetAsync(sc.occ.p, 0, sizeof(unsigned long long), ctx->stream));
+  hipLaunchKernelGGL(cell_keys_kernel, dim3((cloud->n + 255) / 256), dim3(256), 0, ctx->stream, cloud->pts.p, cloud->n, lo[0], lo[1], lo[2], static_cast<float>(1.0 / h), dims[0], dims[1], dims[2], nullptr, nullptr, sc.counts.p);
+  hipLaunchKernelGGL(count_nonzero_kernel, dim3(1024), dim3(256), 0, ctx->stream, sc.counts.p, ncells, sc.occ.p);
+  SGA_HIP(hipGetLastError());
+  unsigned long long occ = 0;
+  SGA_HIP(hipMemcpyAsync(&occ, sc.occ.p, sizeof(occ), hipMemcpyDeviceToHost, ctx->stream));
+  SGA_HIP(hipStreamSynchronize(ctx->stream));
+  *occupied = occ;
+  return SGA_OK;
+}
+
+// ---- voxel map kernels -------------------------------------------------------------------------------------------------------
+__global__ void voxel_keys_kernel(const float4* __restrict__ pts, size_t n, double inv_leaf, unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = pts[i];
+  const int cx = fast_floor_d(static_cast<double>(p.x) * inv_leaf), cy = fast_floor_d(static_cast<double>(p.y) * inv_leaf), cz = fast_floor_d(static_cast<double>(p.z) * inv_leaf);
+  const bool bad = abs(cx) >= (1 << 20) || abs(cy) >= (1 << 20) || abs(cz) >= (1 << 20);
+  keys[i] = bad ? SGA_HASH_EMPTY : voxel_key(cx, cy, cz);  // out-of-range points sort last and are dropped
+  vals[i] = static_cast<uint32_t>(i);
+}
+
+__global__ void segment_heads_kernel(const unsigned long long* __restrict__ keys, size_t n, uint32_t* __restrict__ flags) {
+  const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long k = keys[i];
+  flags[i] = (k != SGA_HASH_EMPTY && (i == 0 || keys[i - 1] != k)) ? 1u : 0u;
+}
+
+__global__ void segment_starts_kernel(const uint32_t* __restrict__ flags, const uint32_t* __restrict__ seg_id, const uint32_t* __restrict__ order, size_t n, uint32_t* __restrict__ seg_start, uint32_t* __restrict__ seg_first_idx, uint32_t* __restrict__ seg_ids) {
+  const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
+  if (i >= n) return;
+  if (flags[i]) {
+    const uint32_t s = seg_id[i];
+    seg_start[s] = static_cast<uint32_t>(i);
+    seg_first_idx[s] = order[i];  // stable sort: the first entry of a segment is the earliest inserted point
+    seg_ids[s] = s;
+  }
+}
+
+// One thread per voxel (in voxel-id order): mean of points and mean of covariances, summed in insertion order in fp64.
+__global__ void voxel_finalize_kernel(
+  const uint32_t* __restrict__ seg_by_rank, uint32_t nvox, const uint32_t* __restrict__ seg_start, uint32_t n_valid, const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ order,
+  const float4* __restrict__ pts, const Cov8* __restrict__ cov, float4* __restrict__ means, Cov8* __restrict__ mcov, int* __restrict__ coords, uint32_t* __restrict__ counts,
+  unsigned long long* __restrict__ hkeys, uint32_t* __restrict__ hvals, uint32_t hmask) {
+  const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nvox) return;
+  const uint32_t seg = seg_by_rank[v];
+  const uint32_t s = seg_start[seg];
+  const unsigned long long key = keys[s];
+  double m[3] = {0, 0, 0}, c[6] = {0, 0, 0, 0, 0, 0};
+  uint32_t cnt = 0;
+  for (uint32_t i = s; i < n_valid && keys[i] == key; ++i) {
+    const uint32_t src = order[i];
+    const float4 p = pts[src];
+    const Cov8 q = cov[src];
+    m[0] += p.x;
+    m[1] += p.y;
+    m[2] += p.z;
+    c[0] += q.xx;
+    c[1] += q.xy;
+    c[2] += q.xz;
+    c[3] += q.yy;
+    c[4] += q.yz;
+    c[5] += q.zz;
+    cnt++;
+  }
+  const double inv = 1.0 / cnt;
+  means[v] = make_float4(static_cast<float>(m[0] * inv), static_cast<float>(m[1] * inv), static_cast<float>(m[2] * inv), __uint_as_float(v));
+  Cov8 o;
+  o.xx = static_cast<float>(c[0] * inv);
+  o.xy = static_cast<float>(c[1] * inv);
+  o.xz = static_cast<float>(c[2] * inv);
+  o.yy = static_cast<float>(c[3] * inv);
+  o.yz = static_cast<float>(c[4] * inv);
+  o.zz = static_cast<float>(c[5] * inv);
+  o.pad0 = o.pad1 = 0.f;
+  mcov[v] = o;
+  coords[3 * v + 0] = static_cast<int>(key & 0x1fffffu) - (1 << 20);
+  coords[3 * v + 1] = static_cast<int>((key >> 21) & 0x1fffffu) - (1 << 20);
+  coords[3 * v + 2] = static_cast<int>((key >> 42) & 0x1fffffu) - (1 << 20);
+  counts[v] = cnt;
+  uint32_t slot = voxel_hash(key) & hmask;
+  for (;;) {
+    const unsigned long long prev = atomicCAS(&hkeys[slot], SGA_HASH_EMPTY, key);
+    if (prev == SGA_HASH_EMPTY) {
+      hvals[slot] = v;
+      break;
+    }
+    slot = (slot + 1) & hmask;
+  }
+}
+
+__global__ void count_valid_keys_kernel(const unsigned long long* __restrict__ keys, size_t n, unsigned long long* __restrict__ out) {
+  unsigned int local = 0;
+  for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n; i += static_cast<size_t>(gridDim.x) * blockDim.x) local += keys[i] != SGA_HASH_EMPTY;
+  for (int off = 32; off > 0; off >>= 1) local += __shfl_xor(local, off);
+  if ((threadIdx.x & 63) == 0 && local) atomicAdd(out, static_cast<unsigned long long>(local));
+}
+
+}  // namespace sga
+
+using namespace sga;
+
+extern "C" {
+
+int sga_index_build_grid(sga_context* ctx, const sga_cloud* target, const sga_grid_params* params, sga_index** out) {
+  if (!ctx || !target || !out) return fail(SGA_ERR_INVALID, "null argument");
+  if (target->device != ctx->device) return fail(SGA_ERR_INVALID, "cloud lives on another device");
+  *out = nullptr;
+  SGA_HIP(hipSetDevice(ctx->device));
+  sga_grid_params gp{};
+  if (params) gp = *params;
+  const size_t n = target->n;
+  const double radius = gp.search_radius > 0 ? gp.search_radius : 1.0;
+  const double ppc_target = gp.points_per_cell > 0 ? gp.points_per_cell : 2.0;
+  uint64_t max_cells = gp.max_cells ? gp.max_cells : std::max<uint64_t>(1ull << 16, 64ull * n);
+  max_cells = std::min<uint64_t>(max_cells, 1ull << 30);
+
+  std::unique_ptr<sga_index> idx(new sga_index);
+  idx->kind = SGA_INDEX_GRID;
+  idx->device = ctx->device;
+  idx->n = n;
+  idx->has_normals = target->has_normals;
+  idx->has_covs = target->has_covs;
+
+  float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+  if (n > 0) {
+    DevBuf<float> d_bbox;
+    SGA_TRY(d_bbox.alloc(6));
+    const int init[6] = {0x7f800000, 0x7f800000, 0x7f800000, static_cast<int>(0xff800000u) ^ 0x7fffffff, static_cast<int>(0xff800000u) ^ 0x7fffffff, static_cast<int>(0xff800000u) ^ 0x7fffffff};
+    SGA_HIP(hipMemcpyAsync(d_bbox.p, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(bbox_kernel, dim3(std::min<size_t>(1024, (n + 255) / 256)), dim3(256), 0, ctx->stream, target->pts.p, n, d_bbox.p);
+    SGA_HIP(hipGetLastError());
+    int h_bbox[6];
+    SGA_HIP(hipMemcpyAsync(h_bbox, d_bbox.p, sizeof(h_bbox), hipMemcpyDeviceToHost, ctx->stream));
+    SGA_HIP(hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < 3; k++) {
+      lo[k] = dec_ordered(h_bbox[k]);
+      hi[k] = dec_ordered(h_bbox[3 + k]);
+      if (!std::isfinite(lo[k]) || !std::isfinite(hi[k])) return fail(SGA_ERR_INVALID, "target cloud contains non-finite coordinates");
+    }
+  }
+
+  // ---- cell size ----
+  const double ext_max = std::max({static_cast<double>(hi[0]) - lo[0], static_cast<double>(hi[1]) - lo[1], static_cast<double>(hi[2]) - lo[2], 1e-6});
+  auto cap_h = [&](double h) {
+    int d[3];
+    grid_dims(lo, hi, h, d);
+    while (grid_cells(d) > static_cast<double>(max_cells)) {
+      h *= 1.2599210498948732;  // 2^(1/3): halves the cell count
+      grid_dims(lo, hi, h, d);
+    }
+    return h;
+  };
+  double h;
+  GridScratch sc;
+  if (gp.cell_size > 0) {
+    h = cap_h(gp.cell_size);
+  } else if (n == 0) {
+    h = radius;
+  } else {
+    const double h_hi = std::min(radius, ext_max);
+    const double h_lo = h_hi / 64.0;
+    h = cap_h(h_hi);
+    double h_prev = 0, ppc_prev = 0;
+    for (int it = 0; it < 4; it++) {
+      int d[3];
+      grid_dims(lo, hi, h, d);
+      uint64_t occ = 0;
+      SGA_TRY(count_occupied(ctx, target, lo, h, d, sc, &occ));
+      const double ppc = static_cast<double>(n) / std::max<uint64_t>(occ, 1);
+      if (ppc <= ppc_target * 1.3 || it == 3) break;  // cells never get larger than the search radius
+      double expo = 2.0;  // surface-like clouds: occupancy ~ h^2
+      if (it > 0 && h_prev != h && ppc_prev > 0) expo = std::min(3.0, std::max(1.0, std::log(ppc / ppc_prev) / std::log(h / h_prev)));
+      h_prev = h;
+      ppc_prev = ppc;
+      double h_new = h * std::pow(ppc_target / ppc, 1.0 / expo);
+      h_new = cap_h(std::max(h_lo, std::min(h_hi, h_new)));
+      if (std::abs(h_new - h) < 1e-3 * h) break;
+      h = h_new;
+    }
+  }
+  int dims[3];
+  grid_dims(lo, hi, h, dims);
+  const size_t ncells = static_cast<size_t>(grid_cells(dims));
+  idx->grid.origin[0] = lo[0];
+  idx->grid.origin[1] = lo[1];
+  idx->grid.origin[2] = lo[2];
+  idx->grid.cell = static_cast<float>(h);
+  idx->grid.inv_cell = static_cast<float>(1.0 / h);
+  idx->grid.dims[0] = dims[0];
+  idx->grid.dims[1] = dims[1];
+  idx->grid.dims[2] = dims[2];
+  idx->ncells = ncells;
+
+  // ---- keys, histogram, scan, stable sort, gather ----
+  SGA_TRY(idx->cell_start.alloc(ncells + 1));
+  SGA_HIP(hipMemsetAsync(idx->cell_start.p, 0, (ncells + 1) * sizeof(uint32_t), ctx->stream));
+  if (n > 0) {
+    DevBuf<uint32_t> keys, keys_sorted, vals, vals_sorted;
+    SGA_TRY(keys.alloc(n));
+    SGA_TRY(keys_sorted.alloc(n));
+    SGA_TRY(vals.alloc(n));
+    SGA_TRY(vals_sorted.alloc(n));
+    hipLaunchKernelGGL(cell_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, target->pts.p, n, lo[0], lo[1], lo[2], idx->grid.inv_cell, dims[0], dims[1], dims[2], keys.p, vals.p, idx->cell_start.p);
+    SGA_HIP(hipGetLastError());
+    size_t tb = 0;
+    SGA_HIP(rocprim::exclusive_scan(nullptr, tb, idx->cell_start.p, idx->cell_start.p, 0u, ncells + 1, rocprim::plus<uint32_t>(), ctx->stream));
+    SGA_TRY(ensure_temp(ctx, tb));
+    SGA_HIP(rocprim::exclusive_scan(ctx->d_temp.p, tb, idx->cell_start.p, idx->cell_start.p, 0u, ncells + 1, rocprim::plus<uint32_t>(), ctx->stream));
+    unsigned end_bit = 1;
+    while (end_bit < 32 && (1ull << end_bit) < ncells) end_bit++;
+    size_t tb2 = 0;
+    SGA_HIP(rocprim::radix_sort_pairs(nullptr, tb2, keys.p, keys_sorted.p, vals.p, vals_sorted.p, n, 0, end_bit, ctx->stream));
+    SGA_TRY(ensure_temp(ctx, tb2));
+    SGA_HIP(rocprim::radix_sort_pairs(ctx->d_temp.p, tb2, keys.p, keys_sorted.p, vals.p, vals_sorted.p, n, 0, end_bit, ctx->stream));
+    SGA_TRY(idx->pts.alloc(n));
+    if (target->has_normals) SGA_TRY(idx->nrm.alloc(n));
+    if (target->has_covs) SGA_TRY(idx->cov.alloc(n));
+    hipLaunchKernelGGL(gather_sorted_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, vals_sorted.p, n, target->pts.p, target->nrm.p, target->cov.p, idx->pts.p, idx->nrm.p, idx->cov.p);
+    SGA_HIP(hipGetLastError());
+    SGA_HIP(hipStreamSynchronize(ctx->stream));
+  } else {
+    SGA_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  *out = idx.release();
+  return SGA_OK;
+}
+
+int sga_index_build_gaussian_voxelmap(sga_context* ctx, const sga_cloud* cloud, double leaf, sga_index** out) {
+  if (!ctx || !cloud || !out) return fail(SGA_ERR_INVALID, "null argument");
+  if (!(leaf > 0)) return fail(SGA_ERR_INVALID, "leaf size must be positive");
+  if (!cloud->has_covs) return fail(SGA_ERR_INVALID, "GaussianVoxelMap needs point covariances");
+  if (cloud->device != ctx->device) return fail(SGA_ERR_INVALID, "cloud lives on another device");
+  *out = nullptr;
+  SGA_HIP(hipSetDevice(ctx->device));
+  const size_t n = cloud->n;
+  std::unique_ptr<sga_index> idx(new sga_index);
+  idx->kind = SGA_INDEX_VOXELMAP;
+  idx->device = ctx->device;
+  idx->leaf = leaf;
+  idx->has_covs = true;
+  idx->has_normals = false;
+  uint32_t nvox = 0;
+  DevBuf<unsigned long long> keys, keys_sorted;
+  DevBuf<uint32_t> vals, order, flags, seg_id, seg_start, seg_first, seg_ids, seg_first_sorted, seg_by_rank;
+  DevBuf<unsigned long long> d_count;
+  unsigned long long n_valid = 0;
+  if (n > 0) {
+    SGA_TRY(keys.alloc(n));
+    SGA_TRY(keys_sorted.alloc(n));
+    SGA_TRY(vals.alloc(n));
+    SGA_TRY(order.alloc(n));
+    SGA_TRY(flags.alloc(n));
+    SGA_TRY(seg_id.alloc(n));
+    SGA_TRY(d_count.alloc(1));
+    hipLaunchKernelGGL(voxel_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, cloud->pts.p, n, 1.0 / leaf, keys.p, vals.p);
+    size_t tb = 0;
+    SGA_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys.p, keys_sorted.p, vals.p, order.p, n, 0, 64, ctx->stream));
+    SGA_TRY(ensure_temp(ctx, tb));
+    SGA_HIP(rocprim::radix_sort_pairs(ctx->d_temp.p, tb, keys.p, keys_sorted.p, vals.p, order.p, n, 0, 64, ctx->stream));
+    hipLaunchKernelGGL(segment_heads_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, keys_sorted.p, n, flags.p);
+    size_t tb2 = 0;
+    SGA_HIP(rocprim::exclusive_scan(nullptr, tb2, flags.p, seg_id.p, 0u, n, rocprim::plus<uint32_t>(), ctx->stream));
+    SGA_TRY(ensure_temp(ctx, tb2));
+    SGA_HIP(rocprim::exclusive_scan(ctx->d_temp.p, tb2, flags.p, seg_id.p, 0u, n, rocprim::plus<uint32_t>(), ctx->stream));
+    SGA_HIP(hipMemsetAsync(d_count.p, 0, sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL(count_valid_keys_kernel, dim3(256), dim3(256), 0, ctx->stream, keys_sorted.p, n, d_count.p);
+    uint32_t last_flag = 0, last_seg = 0;
+    SGA_HIP(hipMemcpyAsync(&last_flag, flags.p + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+    SGA_HIP(hipMemcpyAsync(&last_seg, seg_id.p + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+    SGA_HIP(hipMemcpyAsync(&n_valid, d_count.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SGA_HIP(hipStreamSynchronize(ctx->stream));
+    nvox = last_seg + last_flag;
+  }
+  idx->n = nvox;
+  uint32_t hsize = 16;
+  while (hsize < 2 * static_cast<uint64_t>(nvox)) hsize <<= 1;
+  idx->hmask = hsize - 1;
+  SGA_TRY(idx->hkeys.alloc(hsize));
+  SGA_TRY(idx->hvals.alloc(hsize));
+  SGA_HIP(hipMemsetAsync(idx->hkeys.p, 0xff, hsize * sizeof(unsigned long long), ctx->stream));
+  SGA_HIP(hipMemsetAsync(idx->hvals.p, 0, hsize * sizeof(uint32_t), ctx->stream));
+  if (nvox > 0) {
+    SGA_TRY(seg_start.alloc(nvox));
+    SGA_TRY(seg_first.alloc(nvox));
+    SGA_TRY(seg_ids.alloc(nvox));
+    SGA_TRY(seg_first_sorted.alloc(nvox));
+    SGA_TRY(seg_by_rank.alloc(nvox));
+    hipLaunchKernelGGL(segment_starts_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, flags.p, seg_id.p, order.p, n, seg_start.p, seg_first.p, seg_ids.p);
+    // voxel id = rank of the voxel's first inserted point (incremental_voxelmap.hpp:63-69: flat_voxels grows in first-touch order)
+    size_t tb = 0;
+    SGA_HIP(rocprim::radix_sort_pairs(nullptr, tb, seg_first.p, seg_first_sorted.p, seg_ids.p, seg_by_rank.p, nvox, 0, 32, ctx->stream));
+    SGA_TRY(ensure_temp(ctx, tb));
+    SGA_HIP(rocprim::radix_sort_pairs(ctx->d_temp.p, tb, seg_first.p, seg_first_sorted.p, seg_ids.p, seg_by_rank.p, nvox, 0, 32, ctx->stream));
+    SGA_TRY(idx->pts.alloc(nvox));
+    SGA_TRY(idx->cov.alloc(nvox));
+    SGA_TRY(idx->vcoords.alloc(static_cast<size_t>(nvox) * 3));
+    SGA_TRY(idx->vcounts.alloc(nvox));
+    hipLaunchKernelGGL(
+      voxel_finalize_kernel, dim3((nvox + 127) / 128), dim3(128), 0, ctx->stream, seg_by_rank.p, nvox, seg_start.p, static_cast<uint32_t>(n_valid), keys_sorted.p, order.p, cloud->pts.p, cloud->cov.p, idx->pts.p, idx->cov.p,
+      idx->vcoords.p, idx->vcounts.p, idx->hkeys.p, idx->hvals.p, idx->hmask);
+    SGA_HIP(hipGetLastError());
+  }
+  SGA_HIP(hipStreamSynchronize(ctx->stream));
+  *out = idx.release();
+  return SGA_OK;
+}
+
+int sga_index_destroy(sga_index* index) {
+  if (index) {
+    (void)hipSetDevice(index->device);
+    delete index;
+  }
+  return SGA_OK;
+}
+
+int sga_index_size(const sga_index* index, size_t* n) {
+  if (!index || !n) return fail(SGA_ERR_INVALID, "null argument");
+  *n = index->n;
+  return SGA_OK;
+}
+
+int sga_index_voxelmap_download(sga_context* ctx, const sga_index* index, int32_t* coords, float* means, float* cov6, uint32_t* counts) {
+  if (!ctx || !index) return fail(SGA_ERR_INVALID, "null argument");
+  if (index->kind != SGA_INDEX_VOXELMAP) return fail(SGA_ERR_INVALID, "not a voxel map");
+  const size_t n = index->n;
+  if (n == 0) return SGA_OK;
+  SGA_HIP(hipSetDevice(ctx->device));
+  std::vector<float4> hp;
+  std::vector<Cov8> hc;
+  if (means) {
+    hp.resize(n);
+    SGA_HIP(hipMemcpyAsync(hp.data(), index->pts.p, n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  if (cov6) {
+    hc.resize(n);
+    SGA_HIP(hipMemcpyAsync(hc.data(), index->cov.p, n * sizeof(Cov8), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  if (coords) SGA_HIP(hipMemcpyAsync(coords, index->vcoords.p, n * 3 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  if (counts) SGA_HIP(hipMemcpyAsync(counts, index->vcounts.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  SGA_HIP(hipStreamSynchronize(ctx->stream));
+  for (size_t i = 0; i < n; i++) {
+    if (means) {
+      means[3 * i] = hp[i].x;
+      means[3 * i + 1] = hp[i].y;
+      means[3 * i + 2] = hp[i].z;
+    }
+    if (cov6) {
+      cov6[6 * i] = hc[i].xx;
+      cov6[6 * i + 1] = hc[i].xy;
+      cov6[6 * i + 2] = hc[i].xz;
+      cov6[6 * i + 3] = hc[i].yy;
+      cov6[6 * i + 4] = hc[i].yz;
+      cov6[6 * i + 5] = hc[i].zz;
+    }
+  }
+  return SGA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,421 @@
+// K1 (linearize) and K2 (error): the per-iteration hot loop of Registration<>::align on gfx950.
+//
+// Replaces ParallelReductionOMP::linearize / ::error (registration/reduction_omp.hpp:24-70) fused with
+// {GICP,PointToPlaneICP,ICP}Factor::linearize / ::error (factors/*.hpp), RobustFactor (robust_kernel.hpp:70-98),
+// DistanceRejector (rejector.hpp:19-28) and the nearest-neighbour search (ann/kdtree.hpp:193-233 or
+// ann/incremental_voxelmap.hpp:99-119).  One lane per source point; tiles of 256 points; per-pair values reduced with
+// DPP inside a wave (fp32), accumulated per wave in fp64 in LDS, one 32-double partial row per workgroup, then a single
+// deterministic fp64 tree over the partial rows.  The 6x6 solve stays on the host (optimizer.cpp).
+#include "common.hpp"
+#include "device_math.hpp"
+#include "nn_search.hpp"
+
+namespace sga {
+
+constexpr int kTile = 256;           // threads per workgroup = source points per tile
+constexpr int kRow = 32;             // doubles per partial row (28 used + inliers)
+constexpr int kMaxBlocks = 1024;     // 4 workgroups per CU on 256 CUs: the whole grid is resident
+
+template <typename Real>
+struct LinParams {
+  const float4* __restrict__ src_pts;
+  const Cov8* __restrict__ src_cov;
+  int n;
+  int num_tiles;
+  const float4* __restrict__ tgt_pts;
+  const float4* __restrict__ tgt_nrm;
+  const Cov8* __restrict__ tgt_cov;
+  GridView grid;
+  VoxelView vox;
+  int* __restrict__ corr;
+  Real* __restrict__ maha;  // n*6
+  Rigid<Real> T;
+  float max_sq;  // INFINITY = no rejector
+  int robust_kind;
+  Real robust_c;
+  double* __restrict__ partials;
+};
+
+// XCD-aware tile schedule: workgroup b runs on XCD b % 8 (observed placement; used for L2 affinity only).  Each XCD
+// gets one contiguous 1/8th of the (spatially sorted) tiles so that neighbouring tiles share an L2.
+__device__ __forceinline__ void tile_schedule(int num_tiles, int& first, int& stride, int& end) {
+  const int nblocks = gridDim.x;
+  if (nblocks % 8 == 0 && num_tiles >= nblocks) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd_blocks = nblocks >> 3;
+    const int t0 = static_cast<int>((static_cast<long long>(num_tiles) * xcd) >> 3);
+    const int t1 = static_cast<int>((static_cast<long long>(num_tiles) * (xcd + 1)) >> 3);
+    first = t0 + slot;
+    stride = per_xcd_blocks;
+    end = t1;
+  } else {
+    first = blockIdx.x;
+    stride = nblocks;
+    end = num_tiles;
+  }
+}
+
+template <typename Real>
+__device__ __forceinline__ Sym3<Real> load_sym(const Cov8* __restrict__ c, int i) {
+  const float4 a = reinterpret_cast<const float4*>(c)[2 * i];
+  const float4 b = reinterpret_cast<const float4*>(c)[2 * i + 1];
+  return {Real(a.x), Real(a.y), Real(a.z), Real(a.w), Real(b.x), Real(b.y)};
+}
+
+template <typename Real, int FACTOR, bool VOXELMAP>
+__global__ __launch_bounds__(kTile) void linearize_kernel(const LinParams<Real> p) {
+  __shared__ double sh_acc[kTile / 64][kRow];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane < kRow) sh_acc[wave][lane] = 0.0;  // each wave owns its row: no workgroup barrier needed until the end
+
+  int tile, stride, tile_end;
+  tile_schedule(p.num_tiles, tile, stride, tile_end);
+  for (; tile < tile_end; tile += stride) {
+    const int i = tile * kTile + threadIdx.x;
+    Real vals[28];
+#pragma unroll
+    for (int k = 0; k < 28; k++) vals[k] = Real(0);
+    bool inlier = false;
+    if (i < p.n) {
+      const float4 ps4 = p.src_pts[i];
+      const Real px = ps4.x, py = ps4.y, pz = ps4.z;
+      Real qx, qy, qz;
+      transform_point(p.T, px, py, pz, qx, qy, qz);
+      int j = -1;
+      Real tx = 0, ty = 0, tz = 0;
+      if constexpr (VOXELMAP) {
+        j = voxel_lookup(p.vox, static_cast<float>(qx), static_cast<float>(qy), static_cast<float>(qz));
+        if (j >= 0) {
+          const float4 m = p.tgt_pts[j];
+          tx = m.x;
+          ty = m.y;
+          tz = m.z;
+        }
+      } else {
+        const NNBest nb = grid_nearest(p.grid, static_cast<float>(qx), static_cast<float>(qy), static_cast<float>(qz), p.max_sq);
+        j = nb.idx;
+        tx = nb.x;
+        ty = nb.y;
+        tz = nb.z;
+      }
+      const Real rx = tx - qx, ry = ty - qy, rz = tz - qz;
+      const Real d2 = rx * rx + ry * ry + rz * rz;
+      inlier = (j >= 0) && !(d2 > static_cast<Real>(p.max_sq));
+      if (inlier) {
+        Sym3<Real> M;
+        if constexpr (FACTOR == SGA_GICP) {
+          const Sym3<Real> Cs = load_sym<Real>(p.src_cov, i);
+          const Sym3<Real> Ct = load_sym<Real>(p.tgt_cov, j);
+          const Sym3<Real> RCR = rotate_sym(p.T.r, Cs);
+          M = inverse_sym<Real>({Ct.xx + RCR.xx, Ct.xy + RCR.xy, Ct.xz + RCR.xz, Ct.yy + RCR.yy, Ct.yz + RCR.yz, Ct.zz + RCR.zz});
+          Real* m = p.maha + static_cast<size_t>(i) * 6;
+          m[0] = M.xx;
+          m[1] = M.xy;
+          m[2] = M.xz;
+          m[3] = M.yy;
+          m[4] = M.yz;
+          m[5] = M.zz;
+        } else if constexpr (FACTOR == SGA_PLANE_ICP) {
+          const float4 nn = p.tgt_nrm[j];
+          M = {Real(nn.x) * Real(nn.x), Real(0), Real(0), Real(nn.y) * Real(nn.y), Real(0), Real(nn.z) * Real(nn.z)};
+        } else {
+          M = {Real(1), Real(0), Real(0), Real(1), Real(0), Real(1)};
+        }
+        Real w = Real(1);
+        if (p.robust_kind != SGA_ROBUST_NONE) {
+          const Real vx = M.xx * rx + M.xy * ry + M.xz * rz, vy = M.xy * rx + M.yy * ry + M.yz * rz, vz = M.xz * rx + M.yz * ry + M.zz * rz;
+          w = robust_weight<Real>(p.robust_kind, p.robust_c, Real(0.5) * (rx * vx + ry * vy + rz * vz));
+        }
+        pair_system<Real>(p.T.r, px, py, pz, rx, ry, rz, M, w, vals);
+      }
+      p.corr[i] = inlier ? j : -1;
+    }
+    // ---- wave reduction of this tile ----
+    const unsigned long long inl_mask = __ballot(inlier);
+    if (inl_mask != 0ull) {  // wave-uniform
+      if constexpr (sizeof(Real) == 4) {
+#pragma unroll
+        for (int k = 0; k < 27; k++) {
+          const float s = wave_sum_to_lane63(vals[k]);
+          if (lane == 63) sh_acc[wave][k] += static_cast<double>(s);
+        }
+        const double e = wave_sum_f64(static_cast<double>(vals[27]));
+        if (lane == 63) sh_acc[wave][27] += e;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 28; k++) {
+          const double s = wave_sum_f64(vals[k]);
+          if (lane == 63) sh_acc[wave][k] += s;
+        }
+      }
+      if (lane == 63) sh_acc[wave][28] += static_cast<double>(__popcll(inl_mask));
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < kRow) {
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < kTile / 64; w++) s += sh_acc[w][threadIdx.x];
+    p.partials[static_cast<size_t>(blockIdx.x) * kRow + threadIdx.x] = s;
+  }
+}
+
+template <typename Real>
+struct ErrParams {
+  const float4* __restrict__ src_pts;
+  int n;
+  int num_tiles;
+  const float4* __restrict__ tgt_pts;
+  const float4* __restrict__ tgt_nrm;
+  const int* __restrict__ corr;
+  const Real* __restrict__ maha;
+  Rigid<Real> T;
+  int robust_kind;
+  Real robust_c;
+  double* __restrict__ partials;
+};
+
+template <typename Real, int FACTOR>
+__global__ __launch_bounds__(kTile) void error_kernel(const ErrParams<Real> p) {
+  __shared__ double sh_e[kTile / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double acc = 0.0;
+  int tile, stride, tile_end;
+  tile_schedule(p.num_tiles, tile, stride, tile_end);
+  for (; tile < tile_end; tile += stride) {
+    const int i = tile * kTile + threadIdx.x;
+    Real e = Real(0);
+    if (i < p.n) {
+      const int j = p.corr[i];
+      if (j >= 0) {
+        const float4 ps4 = p.src_pts[i];
+        Real qx, qy, qz;
+        transform_point<Real>(p.T, ps4.x, ps4.y, ps4.z, qx, qy, qz);
+        const float4 t4 = p.tgt_pts[j];
+        const Real rx = Real(t4.x) - qx, ry = Real(t4.y) - qy, rz = Real(t4.z) - qz;
+        if constexpr (FACTOR == SGA_GICP) {
+          const Real* m = p.maha + static_cast<size_t>(i) * 6;
+          const Real vx = m[0] * rx + m[1] * ry + m[2] * rz, vy = m[1] * rx + m[3] * ry + m[4] * rz, vz = m[2] * rx + m[4] * ry + m[5] * rz;
+          e = Real(0.5) * (rx * vx + ry * vy + rz * vz);
+        } else if constexpr (FACTOR == SGA_PLANE_ICP) {
+          const float4 nn = p.tgt_nrm[j];
+          const Real ex = Real(nn.x) * rx, ey = Real(nn.y) * ry, ez = Real(nn.z) * rz;
+          // same association as pair_system's 1/2 r^T diag(n^2) r
+          e = Real(0.5) * (rx * (Real(nn.x) * Real(nn.x) * rx) + ry * (Real(nn.y) * Real(nn.y) * ry) + rz * (Real(nn.z) * Real(nn.z) * rz));
+          (void)ex;
+          (void)ey;
+          (void)ez;
+        } else {
+          e = Real(0.5) * (rx * rx + ry * ry + rz * rz);
+        }
+        if (p.robust_kind != SGA_ROBUST_NONE) e *= robust_weight<Real>(p.robust_kind, p.robust_c, e);
+      }
+    }
+    acc += wave_sum_f64(static_cast<double>(e));
+  }
+  if (lane == 0) sh_e[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int w = 0; w < kTile / 64; w++) s += sh_e[w];
+    p.partials[blockIdx.x] = s;
+  }
+}
+
+// Deterministic fp64 sum of `nrows` partial rows of `ncols` (<= 32) doubles -> out[ncols] (+ zero padding up to out_n).
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const double* __restrict__ partials, int nrows, int ncols, int row_stride, double* __restrict__ out, int out_n) {
+  __shared__ double sh[8][32];
+  const int c = threadIdx.x & 31, s = threadIdx.x >> 5;
+  double acc = 0.0;
+  if (c < ncols)
+    for (int r = s; r < nrows; r += 8) acc += partials[static_cast<size_t>(r) * row_stride + c];
+  sh[s][c] = acc;
+  __syncthreads();
+  if (threadIdx.x < out_n) {
+    double t = 0.0;
+    if (threadIdx.x < ncols)
+      for (int k = 0; k < 8; k++) t += sh[k][threadIdx.x];
+    out[threadIdx.x] = t;
+  }
+}
+
+static int grid_blocks(int num_tiles) { return num_tiles < kMaxBlocks ? (num_tiles < 1 ? 1 : num_tiles) : kMaxBlocks; }
+
+template <typename Real, int FACTOR, bool VOXELMAP>
+static void launch_linearize(hipStream_t st, const LinParams<Real>& p, int blocks) {
+  hipLaunchKernelGGL((linearize_kernel<Real, FACTOR, VOXELMAP>), dim3(blocks), dim3(kTile), 0, st, p);
+}
+
+template <typename Real>
+static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, const double T[16], double* d_out30) {
+  const sga_index* idx = pb->target;
+  const bool voxel = idx->kind == SGA_INDEX_VOXELMAP;
+  if (fp->factor_kind == SGA_GICP && (!pb->has_covs || !idx->has_covs)) return fail(SGA_ERR_INVALID, "GICP needs covariances on both source and target");
+  if (fp->factor_kind == SGA_PLANE_ICP && (voxel || !idx->has_normals)) return fail(SGA_ERR_UNSUPPORTED, "PLANE_ICP needs a grid index over a target with normals");
+  if (fp->factor_kind < 0 || fp->factor_kind > 2) return fail(SGA_ERR_INVALID, "invalid factor_kind %d", fp->factor_kind);
+
+  LinParams<Real> p{};
+  p.src_pts = pb->pts.p;
+  p.src_cov = pb->cov.p;
+  p.n = static_cast<int>(pb->n);
+  p.num_tiles = (p.n + kTile - 1) / kTile;
+  p.tgt_pts = idx->pts.p;
+  p.tgt_nrm = idx->nrm.p;
+  p.tgt_cov = idx->cov.p;
+  if (voxel) {
+    p.vox.hkeys = idx->hkeys.p;
+    p.vox.hvals = idx->hvals.p;
+    p.vox.hmask = idx->hmask;
+    p.vox.inv_leaf = 1.0 / idx->leaf;
+  } else {
+    p.grid = make_grid_view(idx);
+  }
+  p.corr = pb->corr.p;
+  if constexpr (sizeof(Real) == 4) {
+    p.maha = pb->maha.p;
+  } else {
+    if (pb->maha64.n < pb->n * 6) SGA_TRY(pb->maha64.alloc(pb->n * 6));
+    p.maha = pb->maha64.p;
+  }
+  p.T = rigid_from_colmajor<Real>(T);
+  p.max_sq = fp->max_dist_sq < 0 ? INFINITY : static_cast<float>(fp->max_dist_sq);
+  p.robust_kind = fp->robust_kind;
+  p.robust_c = static_cast<Real>(fp->robust_c);
+  p.partials = pb->partials.p;
+  const int blocks = grid_blocks(p.num_tiles);
+
+  if (ctx->profiling) (void)hipEventRecord(ctx->ev0, ctx->stream);
+  if (p.n > 0) {
+    if (voxel) {
+      if (fp->factor_kind == SGA_GICP)
+        launch_linearize<Real, SGA_GICP, true>(ctx->stream, p, blocks);
+      else
+        launch_linearize<Real, SGA_ICP, true>(ctx->stream, p, blocks);
+    } else {
+      switch (fp->factor_kind) {
+        case SGA_GICP: launch_linearize<Real, SGA_GICP, false>(ctx->stream, p, blocks); break;
+        case SGA_PLANE_ICP: launch_linearize<Real, SGA_PLANE_ICP, false>(ctx->stream, p, blocks); break;
+        default: launch_linearize<Real, SGA_ICP, false>(ctx->stream, p, blocks); break;
+      }
+    }
+  }
+  if (ctx->profiling) (void)hipEventRecord(ctx->ev1, ctx->stream);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, ctx->stream, pb->partials.p, p.n > 0 ? blocks : 0, 29, kRow, d_out30, SGA_ACCUM_DOUBLES);
+  SGA_HIP(hipGetLastError());
+  return SGA_OK;
+}
+
+template <typename Real>
+static int error_dispatch(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, const double T[16], double* d_out1) {
+  const sga_index* idx = pb->target;
+  ErrParams<Real> p{};
+  p.src_pts = pb->pts.p;
+  p.n = static_cast<int>(pb->n);
+  p.num_tiles = (p.n + kTile - 1) / kTile;
+  p.tgt_pts = idx->pts.p;
+  p.tgt_nrm = idx->nrm.p;
+  p.corr = pb->corr.p;
+  if constexpr (sizeof(Real) == 4) {
+    p.maha = pb->maha.p;
+  } else {
+    if (pb->maha64.n < pb->n * 6) return fail(SGA_ERR_INVALID, "sga_error(fp64) before sga_linearize(fp64)");
+    p.maha = pb->maha64.p;
+  }
+  p.T = rigid_from_colmajor<Real>(T);
+  p.robust_kind = fp->robust_kind;
+  p.robust_c = static_cast<Real>(fp->robust_c);
+  p.partials = pb->partials.p;
+  const int blocks = grid_blocks(p.num_tiles);
+  if (fp->factor_kind == SGA_PLANE_ICP && !idx->has_normals) return fail(SGA_ERR_UNSUPPORTED, "PLANE_ICP needs target normals");
+  if (ctx->profiling) (void)hipEventRecord(ctx->ev0, ctx->stream);
+  if (p.n > 0) {
+    switch (fp->factor_kind) {
+      case SGA_GICP: hipLaunchKernelGGL((error_kernel<Real, SGA_GICP>), dim3(blocks), dim3(kTile), 0, ctx->stream, p); break;
+      case SGA_PLANE_ICP: hipLaunchKernelGGL((error_kernel<Real, SGA_PLANE_ICP>), dim3(blocks), dim3(kTile), 0, ctx->stream, p); break;
+      case SGA_ICP: hipLaunchKernelGGL((error_kernel<Real, SGA_ICP>), dim3(blocks), dim3(kTile), 0, ctx->stream, p); break;
+      default: return fail(SGA_ERR_INVALID, "invalid factor_kind %d", fp->factor_kind);
+    }
+  }
+  if (ctx->profiling) (void)hipEventRecord(ctx->ev1, ctx->stream);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, ctx->stream, pb->partials.p, p.n > 0 ? blocks : 0, 1, 1, d_out1, 1);
+  SGA_HIP(hipGetLastError());
+  return SGA_OK;
+}
+
+int problem_partials_rows() { return kMaxBlocks; }
+
+static int check_args(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, const double* T) {
+  if (!ctx || !pb || !fp || !T) return fail(SGA_ERR_INVALID, "null argument");
+  if (pb->device != ctx->device) return fail(SGA_ERR_INVALID, "problem lives on device %d, context on %d", pb->device, ctx->device);
+  return SGA_OK;
+}
+
+static void profile_collect(sga_context* ctx, bool lin) {
+  if (!ctx->profiling) return;
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) {
+    if (lin) {
+      ctx->lin_ms += ms;
+      ctx->lin_calls++;
+    } else {
+      ctx->err_ms += ms;
+      ctx->err_calls++;
+    }
+  }
+}
+
+}  // namespace sga
+
+using namespace sga;
+
+extern "C" {
+
+void sga_unpack_accumulator(const double acc[SGA_ACCUM_DOUBLES], double H[36], double b[6], double* e, uint64_t* num_inliers) {
+  int k = 0;
+  for (int i = 0; i < 6; i++)
+    for (int j = i; j < 6; j++) {
+      H[6 * i + j] = acc[k];
+      H[6 * j + i] = acc[k];
+      k++;
+    }
+  for (int i = 0; i < 6; i++) b[i] = acc[21 + i];
+  if (e) *e = acc[27];
+  if (num_inliers) *num_inliers = static_cast<uint64_t>(acc[28] + 0.5);
+}
+
+int sga_linearize_async(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, const double T[16], double* d_out30) {
+  SGA_TRY(check_args(ctx, pb, fp, T));
+  if (!d_out30) return fail(SGA_ERR_INVALID, "null output");
+  SGA_HIP(hipSetDevice(ctx->device));
+  return fp->math_mode == SGA_MATH_FP64 ? linearize_dispatch<double>(ctx, pb, fp, T, d_out30) : linearize_dispatch<float>(ctx, pb, fp, T, d_out30);
+}
+
+int sga_error_async(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, const double T[16], double* d_out1) {
+  SGA_TRY(check_args(ctx, pb, fp, T));
+  if (!d_out1) return fail(SGA_ERR_INVALID, "null output");
+  SGA_HIP(hipSetDevice(ctx->device));
+  return fp->math_mode == SGA_MATH_FP64 ? error_dispatch<double>(ctx, pb, fp, T, d_out1) : error_dispatch<float>(ctx, pb, fp, T, d_out1);
+}
+
+int sga_linearize(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, const double T[16], double H[36], double b[6], double* e, uint64_t* num_inliers) {
+  SGA_TRY(check_args(ctx, pb, fp, T));
+  if (!H || !b || !e) return fail(SGA_ERR_INVALID, "null output");
+  SGA_TRY(sga_linearize_async(ctx, pb, fp, T, ctx->d_accum.p));
+  SGA_HIP(hipMemcpyAsync(ctx->h_accum, ctx->d_accum.p, sizeof(double) * SGA_ACCUM_DOUBLES, hipMemcpyDeviceToHost, ctx->stream));
+  SGA_HIP(hipStreamSynchronize(ctx->stream));
+  profile_collect(ctx, true);
+  sga_unpack_accumulator(ctx->h_accum, H, b, e, num_inliers);
+  return SGA_OK;
+}
+
+int sga_error(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, const double T[16], double* e) {
+  SGA_TRY(check_args(ctx, pb, fp, T));
+  if (!e) return fail(SGA_ERR_INVALID, "null output");
+  SGA_TRY(sga_error_async(ctx, pb, fp, T, ctx->d_accum.p));
+  SGA_HIP(hipMemcpyAsync(ctx->h_accum, ctx->d_accum.p, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  SGA_HIP(hipStreamSynchronize(ctx->stream));
+  profile_collect(ctx, false);
+  *e = ctx->h_accum[0];
+  return SGA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,281 @@
+// sga_problem: the (target index, source cloud) pairing that Registration<>::align creates per call
+// (registration/registration.hpp:41 `std::vector<PointFactor> factors(size(source))`), device resident.
+// The source is copied once in a spatially coherent order (sorted by the target-grid cell of init_T * p, Morton order
+// over cells) so that the 64 lanes of a wave query neighbouring cells and share cache lines of the target.
+#include <memory>
+
+#include "common.hpp"
+
+#include <memory>
+#include <rocprim/rocprim.hpp>
+#include "device_math.hpp"
+#include "nn_search.hpp"
+
+namespace sga {
+
+int ensure_temp(sga_context* ctx, size_t bytes);
+int problem_partials_rows();
+
+__device__ __forceinline__ unsigned long long spread3(unsigned long long v) {
+  v &= 0x1fffffull;
+  v = (v | (v << 32)) & 0x1f00000000ffffull;
+  v = (v | (v << 16)) & 0x1f0000ff0000ffull;
+  v = (v | (v << 8)) & 0x100f00f00f00f00full;
+  v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
+  v = (v | (v << 2)) & 0x1249249249249249ull;
+  return v;
+}
+
+__global__ void source_keys_kernel(const float4* __restrict__ pts, size_t n, Rigid<float> T, float ox, float oy, float oz, float inv, unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = pts[i];
+  float qx, qy, qz;
+  transform_point<float>(T, p.x, p.y, p.z, qx, qy, qz);
+  // cell coordinates relative to the target grid, biased so that sources sticking out of the grid stay ordered
+  const long long bias = 1 << 20;
+  long long cx = static_cast<long long>(floorf((qx - ox) * inv)) + bias, cy = static_cast<long long>(floorf((qy - oy) * inv)) + bias, cz = static_cast<long long>(floorf((qz - oz) * inv)) + bias;
+  cx = min(max(cx, 0ll), (1ll << 21) - 1);
+  cy = min(max(cy, 0ll), (1ll << 21) - 1);
+  cz = min(max(cz, 0ll), (1ll << 21) - 1);
+  keys[i] = spread3(cx) | (spread3(cy) << 1) | (spread3(cz) << 2);
+  vals[i] = static_cast<uint32_t>(i);
+}
+
+__global__ void gather_source_kernel(const uint32_t* __restrict__ order, size_t n, const float4* __restrict__ pts, const Cov8* __restrict__ cov, float4* __restrict__ opts, Cov8* __restrict__ ocov) {
+  const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t s = order[i];
+  opts[i] = pts[s];
+  if (cov) ocov[i] = cov[s];
+}
+
+// Factor state back in the caller's source order with original target indices.
+template <typename Real>
+__global__ void export_factors_kernel(const float4* __restrict__ src_pts, const int* __restrict__ corr, const Real* __restrict__ maha, size_t n, const float4* __restrict__ tgt_pts, long long* __restrict__ out_idx, float* __restrict__ out_m) {
+  const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t orig = __float_as_uint(src_pts[i].w);
+  const int j = corr[i];
+  if (out_idx) out_idx[orig] = j < 0 ? -1ll : static_cast<long long>(__float_as_uint(tgt_pts[j].w));
+  if (out_m) {
+    for (int k = 0; k < 6; k++) out_m[6 * static_cast<size_t>(orig) + k] = (j >= 0 && maha) ? static_cast<float>(maha[6 * i + k]) : 0.f;
+  }
+}
+
+// ---- standalone kNN over the grid (traits::knn_search).  One lane per query, k-best kept in LDS as [k][64]. ----------------
+constexpr int kKnnBlock = 64;
+
+__global__ __launch_bounds__(kKnnBlock) void knn_kernel(const GridView g, const float* __restrict__ queries, size_t m, int k, float max_sq, long long* __restrict__ out_idx, float* __restrict__ out_d2) {
+  extern __shared__ float sh[];  // k*64 distances then k*64 indices
+  float* sd = sh;
+  int* si = reinterpret_cast<int*>(sh + static_cast<size_t>(k) * kKnnBlock);
+  const int lane = threadIdx.x;
+  const size_t qi = blockIdx.x * static_cast<size_t>(kKnnBlock) + lane;
+  for (int j = 0; j < k; j++) {
+    sd[j * kKnnBlock + lane] = INFINITY;
+    si[j * kKnnBlock + lane] = -1;
+  }
+  if (qi >= m) return;
+  const float qx = queries[3 * qi], qy = queries[3 * qi + 1], qz = queries[3 * qi + 2];
+  const int cx = cell_coord(qx, g.ox, g.inv_cell), cy = cell_coord(qy, g.oy, g.inv_cell), cz = cell_coord(qz, g.oz, g.inv_cell);
+  int r_all = max(max(max(cx, g.nx - 1 - cx), max(cy, g.ny - 1 - cy)), max(cz, g.nz - 1 - cz));
+  r_all = max(r_all, 0);
+  const float h = g.cell * 0.9999f;
+  float worst = INFINITY;  // k-th best so far
+  auto push_run = [&](uint32_t s, uint32_t e) {
+    for (uint32_t j = s; j < e; ++j) {
+      const float4 p = g.pts[j];
+      const float dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
+      const float d2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+      if (d2 >= worst) continue;  // knn_result.hpp:81-83: ties do not displace
+      int loc = k - 1;
+      for (; loc > 0 && d2 < sd[(loc - 1) * kKnnBlock + lane]; loc--) {
+        sd[loc * kKnnBlock + lane] = sd[(loc - 1) * kKnnBlock + lane];
+        si[loc * kKnnBlock + lane] = si[(loc - 1) * kKnnBlock + lane];
+      }
+      sd[loc * kKnnBlock + lane] = d2;
+      si[loc * kKnnBlock + lane] = static_cast<int>(j);
+      worst = sd[(k - 1) * kKnnBlock + lane];
+    }
+  };
+  for (int r = 0;; ++r) {
+    const int zlo = max(cz - r, 0), zhi = min(cz + r, g.nz - 1);
+    const int ylo = max(cy - r, 0), yhi = min(cy + r, g.ny - 1);
+    for (int z = zlo; z <= zhi; ++z) {
+      const int adz = abs(z - cz);
+      const float ddz = (z == cz) ? 0.f : (z > cz ? (g.oz + z * g.cell) - qz : qz - (g.oz + (z + 1) * g.cell));
+      for (int y = ylo; y <= yhi; ++y) {
+        const int ady = abs(y - cy);
+        const float ddy = (y == cy) ? 0.f : (y > cy ? (g.oy + y * g.cell) - qy : qy - (g.oy + (y + 1) * g.cell));
+        const float row_d2 = fmaxf(ddy, 0.f) * fmaxf(ddy, 0.f) + fmaxf(ddz, 0.f) * fmaxf(ddz, 0.f);
+        if (row_d2 * 0.9999f >= worst || row_d2 * 0.9999f > max_sq) continue;
+        const uint32_t row = (static_cast<uint32_t>(z) * g.ny + y) * g.nx;
+        if (max(ady, adz) == r) {
+          const int x0 = max(cx - r, 0), x1 = min(cx + r, g.nx - 1);
+          if (x0 <= x1) push_run(g.cell_start[row + x0], g.cell_start[row + x1 + 1]);
+        } else {
+          const int xa = cx - r, xb = cx + r;
+          if (xa >= 0 && xa < g.nx) push_run(g.cell_start[row + xa], g.cell_start[row + xa + 1]);
+          if (xb >= 0 && xb < g.nx) push_run(g.cell_start[row + xb], g.cell_start[row + xb + 1]);
+        }
+      }
+    }
+    const float reach = r * h;
+    const float reach2 = reach * reach;
+    if (worst <= reach2 || reach2 >= max_sq || r >= r_all) break;
+  }
+  for (int j = 0; j < k; j++) {
+    const float d2 = sd[j * kKnnBlock + lane];
+    const int id = si[j * kKnnBlock + lane];
+    const bool ok = id >= 0 && !(d2 > max_sq);
+    out_idx[qi * k + j] = ok ? static_cast<long long>(__float_as_uint(g.pts[id].w)) : -1ll;
+    out_d2[qi * k + j] = ok ? d2 : INFINITY;
+  }
+}
+
+__global__ void voxel_nn_kernel(const VoxelView v, const float4* __restrict__ means, const float* __restrict__ queries, size_t m, float max_sq, long long* __restrict__ out_idx, float* __restrict__ out_d2) {
+  const size_t qi = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
+  if (qi >= m) return;
+  const float qx = queries[3 * qi], qy = queries[3 * qi + 1], qz = queries[3 * qi + 2];
+  const int j = voxel_lookup(v, qx, qy, qz);
+  long long id = -1;
+  float d2 = INFINITY;
+  if (j >= 0) {
+    const float4 c = means[j];
+    const float dx = c.x - qx, dy = c.y - qy, dz = c.z - qz;
+    const float d = dx * dx + dy * dy + dz * dz;
+    if (!(d > max_sq)) {
+      id = j;
+      d2 = d;
+    }
+  }
+  out_idx[qi] = id;
+  out_d2[qi] = d2;
+}
+
+}  // namespace sga
+
+using namespace sga;
+
+extern "C" {
+
+void sga_factor_params_default(sga_factor_params* p) {
+  if (!p) return;
+  p->factor_kind = SGA_GICP;
+  p->robust_kind = SGA_ROBUST_NONE;
+  p->robust_c = 1.0;
+  p->max_dist_sq = 1.0;
+  p->math_mode = SGA_MATH_FP32;
+}
+
+int sga_problem_create(sga_context* ctx, const sga_index* target, const sga_cloud* source, const double init_T[16], sga_problem** out) {
+  if (!ctx || !target || !source || !out) return fail(SGA_ERR_INVALID, "null argument");
+  if (target->device != ctx->device || source->device != ctx->device) return fail(SGA_ERR_INVALID, "target/source live on another device");
+  *out = nullptr;
+  SGA_HIP(hipSetDevice(ctx->device));
+  static const double I16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  const double* T = init_T ? init_T : I16;
+  std::unique_ptr<sga_problem> pb(new sga_problem);
+  pb->device = ctx->device;
+  pb->target = target;
+  pb->n = source->n;
+  pb->has_normals = source->has_normals;
+  pb->has_covs = source->has_covs;
+  const size_t n = source->n;
+  pb->max_blocks = problem_partials_rows();
+  SGA_TRY(pb->partials.alloc(static_cast<size_t>(pb->max_blocks) * 32));
+  if (n > 0) {
+    SGA_TRY(pb->pts.alloc(n));
+    if (source->has_covs) SGA_TRY(pb->cov.alloc(n));
+    SGA_TRY(pb->corr.alloc(n));
+    SGA_TRY(pb->maha.alloc(n * 6));
+    SGA_HIP(hipMemsetAsync(pb->corr.p, 0xff, n * sizeof(int), ctx->stream));
+    SGA_HIP(hipMemsetAsync(pb->maha.p, 0, n * 6 * sizeof(float), ctx->stream));
+    DevBuf<unsigned long long> keys, keys_sorted;
+    DevBuf<uint32_t> vals, order;
+    SGA_TRY(keys.alloc(n));
+    SGA_TRY(keys_sorted.alloc(n));
+    SGA_TRY(vals.alloc(n));
+    SGA_TRY(order.alloc(n));
+    float ox = 0, oy = 0, oz = 0, inv = 1.f;
+    if (target->kind == SGA_INDEX_GRID) {
+      ox = target->grid.origin[0];
+      oy = target->grid.origin[1];
+      oz = target->grid.origin[2];
+      inv = target->grid.inv_cell;
+    } else {
+      inv = static_cast<float>(4.0 / target->leaf);  // quarter-voxel cells: neighbouring lanes probe the same voxel
+    }
+    hipLaunchKernelGGL(source_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, source->pts.p, n, rigid_from_colmajor<float>(T), ox, oy, oz, inv, keys.p, vals.p);
+    SGA_HIP(hipGetLastError());
+    size_t tb = 0;
+    SGA_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys.p, keys_sorted.p, vals.p, order.p, n, 0, 63, ctx->stream));
+    SGA_TRY(ensure_temp(ctx, tb));
+    SGA_HIP(rocprim::radix_sort_pairs(ctx->d_temp.p, tb, keys.p, keys_sorted.p, vals.p, order.p, n, 0, 63, ctx->stream));
+    hipLaunchKernelGGL(gather_source_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, order.p, n, source->pts.p, source->cov.p, pb->pts.p, pb->cov.p);
+    SGA_HIP(hipGetLastError());
+    SGA_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  *out = pb.release();
+  return SGA_OK;
+}
+
+int sga_problem_destroy(sga_problem* problem) {
+  if (problem) {
+    (void)hipSetDevice(problem->device);
+    delete problem;
+  }
+  return SGA_OK;
+}
+
+int sga_problem_get_factors(sga_context* ctx, const sga_problem* pb, int64_t* target_index, float* mahalanobis6) {
+  if (!ctx || !pb) return fail(SGA_ERR_INVALID, "null argument");
+  const size_t n = pb->n;
+  if (n == 0) return SGA_OK;
+  SGA_HIP(hipSetDevice(ctx->device));
+  DevBuf<long long> d_idx;
+  DevBuf<float> d_m;
+  if (target_index) SGA_TRY(d_idx.alloc(n));
+  if (mahalanobis6) SGA_TRY(d_m.alloc(n * 6));
+  hipLaunchKernelGGL((export_factors_kernel<float>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, pb->pts.p, pb->corr.p, pb->maha.p, n, pb->target->pts.p, d_idx.p, d_m.p);
+  SGA_HIP(hipGetLastError());
+  if (target_index) SGA_HIP(hipMemcpyAsync(target_index, d_idx.p, n * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+  if (mahalanobis6) SGA_HIP(hipMemcpyAsync(mahalanobis6, d_m.p, n * 6 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  SGA_HIP(hipStreamSynchronize(ctx->stream));
+  return SGA_OK;
+}
+
+int sga_index_knn(sga_context* ctx, const sga_index* index, const float* queries, size_t m, int k, double max_sq_dist, int64_t* idx, float* sq_dist) {
+  if (!ctx || !index || (m > 0 && (!queries || !idx || !sq_dist))) return fail(SGA_ERR_INVALID, "null argument");
+  if (k < 1 || k > 128) return fail(SGA_ERR_INVALID, "k must be in [1,128]");
+  if (index->kind == SGA_INDEX_VOXELMAP && k != 1) return fail(SGA_ERR_UNSUPPORTED, "voxel maps answer k = 1 only");
+  if (m == 0) return SGA_OK;
+  SGA_HIP(hipSetDevice(ctx->device));
+  DevBuf<float> d_q, d_d;
+  DevBuf<long long> d_i;
+  SGA_TRY(d_q.alloc(m * 3));
+  SGA_TRY(d_d.alloc(m * k));
+  SGA_TRY(d_i.alloc(m * k));
+  SGA_HIP(hipMemcpyAsync(d_q.p, queries, m * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  const float max_sq = max_sq_dist < 0 ? INFINITY : static_cast<float>(max_sq_dist);
+  if (index->kind == SGA_INDEX_VOXELMAP) {
+    VoxelView v{index->hkeys.p, index->hvals.p, index->hmask, 1.0 / index->leaf};
+    hipLaunchKernelGGL(voxel_nn_kernel, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, v, index->pts.p, d_q.p, m, max_sq, d_i.p, d_d.p);
+  } else if (index->n == 0) {
+    SGA_HIP(hipMemsetAsync(d_i.p, 0xff, m * k * sizeof(long long), ctx->stream));
+    std::vector<float> inf(m * k, INFINITY);
+    SGA_HIP(hipMemcpyAsync(d_d.p, inf.data(), m * k * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    SGA_HIP(hipStreamSynchronize(ctx->stream));
+  } else {
+    const size_t shmem = static_cast<size_t>(k) * kKnnBlock * 8;
+    hipLaunchKernelGGL(knn_kernel, dim3((m + kKnnBlock - 1) / kKnnBlock), dim3(kKnnBlock), shmem, ctx->stream, make_grid_view(index), d_q.p, m, k, max_sq, d_i.p, d_d.p);
+  }
+  SGA_HIP(hipGetLastError());
+  SGA_HIP(hipMemcpyAsync(idx, d_i.p, m * k * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+  SGA_HIP(hipMemcpyAsync(sq_dist, d_d.p, m * k * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  SGA_HIP(hipStreamSynchronize(ctx->stream));
+  return SGA_OK;
+}
+
+}  // extern "C"
