@@ -90,6 +90,9 @@ int sga_index_build_grid(sga_context* ctx, const sga_cloud* target, const sga_gr
 /* Replaces create_gaussian_voxelmap (registration_helper.cpp:50-54; ann/incremental_voxelmap.hpp:55-92, gaussian_voxelmap.hpp:32-53):
  * one-shot insert of a cloud WITH covariances; voxel ids follow first-insertion order like the reference. */
 int sga_index_build_gaussian_voxelmap(sga_context* ctx, const sga_cloud* points_with_covs, double leaf_size, sga_index** out);
+/* Re-copy normals / covariances from `cloud` (the cloud the grid was built over) into the index's cell-sorted arrays, e.g. after
+ * attributes were estimated or set once the index already existed (reference flow: KdTree first, estimate_covariances second). */
+int sga_index_refresh_attributes(sga_context* ctx, sga_index* index, const sga_cloud* cloud);
 int sga_index_destroy(sga_index* index);
 /* Number of target points (grid) or voxels (voxel map): traits::size(target). */
 int sga_index_size(const sga_index* index, size_t* n);

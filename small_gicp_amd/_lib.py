@@ -83,6 +83,7 @@ SYMBOLS = [
     ("sga_estimate_normals_covariances", C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int]),
     ("sga_index_build_grid", C.c_int, [_vp, _vp, C.POINTER(GridParams), _pvp]),
     ("sga_index_build_gaussian_voxelmap", C.c_int, [_vp, _vp, C.c_double, _pvp]),
+    ("sga_index_refresh_attributes", C.c_int, [_vp, _vp, _vp]),
     ("sga_index_destroy", C.c_int, [_vp]),
     ("sga_index_size", C.c_int, [_vp, C.POINTER(C.c_size_t)]),
     ("sga_index_voxelmap_download", C.c_int, [_vp, _vp, C.POINTER(C.c_int32), _fp, _fp, C.POINTER(C.c_uint32)]),

@@ -177,6 +177,10 @@ class KdTree:
         check(load().sga_index_size(self.h, C.byref(n)))
         return n.value
 
+    def refresh_attributes(self):
+        """Pull the cloud's current normals / covariances into the index (needed when they were set after the index was built)."""
+        check(load().sga_index_refresh_attributes(self.ctx.h, self.h, self.cloud.h))
+
     def batch_knn_search(self, pts, k, max_sq_dist=-1.0, num_threads=1):
         q = np.ascontiguousarray(np.asarray(pts)[:, :3], dtype=np.float32)
         idx = np.empty((len(q), k), np.int64)
@@ -464,5 +468,6 @@ def align(
         target, source, target_tree = tgt, src, tree
     if target_tree is None:
         target_tree = KdTree(target, search_radius=max_correspondence_distance or 1.0)
+    target_tree.refresh_attributes()
     setting = make_setting(registration_type, max_correspondence_distance, max_iterations, verbose=verbose, **kw)
     return Problem(target_tree, source, init_T_target_source).align(setting, init_T_target_source)

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -78,6 +79,7 @@ struct sga_context {
   sga::DevBuf<uint8_t> d_temp;    // rocPRIM temp storage (grow-only)
   // profiling
   bool profiling = false;
+  int pending = 0;  // 1 = a linearize event pair awaits collection, 2 = an error pair
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double lin_ms = 0.0, err_ms = 0.0;
   uint64_t lin_calls = 0, err_calls = 0;
@@ -110,11 +112,15 @@ struct sga_index {
   bool has_normals = false, has_covs = false;
   // grid
   GridDesc grid{};
-  sga::DevBuf<float4> pts;          // cell-sorted; w = original index bits
-  sga::DevBuf<float4> nrm;          // cell-sorted
-  sga::DevBuf<sga::Cov8> cov;       // cell-sorted
+  sga::DevBuf<float4> pts;          // cell-sorted (kNN / preprocessing walks); w = original index bits.  Voxel maps: means in voxel-id order
+  sga::DevBuf<float4> nrm;          // kd order, like kd_pts
+  sga::DevBuf<sga::Cov8> cov;       // kd order.  Voxel maps: mean covariances in voxel-id order
   sga::DevBuf<uint32_t> cell_start; // ncells + 1
   uint64_t ncells = 0;
+  // implicit balanced kd-tree over the target (registration hot path, kd_search.hpp): points in kd order + {threshold, axis} heap
+  sga::DevBuf<float4> kd_pts;       // kd order; w = original index bits
+  sga::DevBuf<float2> kd_nodes;     // 2^kd_depth entries (index 0 unused)
+  int kd_depth = 0;
   // voxel map
   double leaf = 0.0;
   sga::DevBuf<unsigned long long> hkeys;  // open addressing, EMPTY = ~0ull
@@ -133,7 +139,8 @@ struct sga_problem {
   sga::DevBuf<float4> pts;       // spatially sorted copy of the source; w = original index bits
   sga::DevBuf<sga::Cov8> cov;
   // factor state
-  sga::DevBuf<int> corr;         // sorted-target position (grid) / voxel id (voxelmap); -1 = outlier
+  sga::DevBuf<int> corr;         // kd position of the matched target point / voxel id (voxelmap); -1 = outlier
+  sga::DevBuf<int> hint;         // last nearest neighbour found per source point, rejected or not (search start of the next iteration)
   sga::DevBuf<float> maha;       // n*6 (fp32 mode) — fused mahalanobis of the last linearize
   sga::DevBuf<double> maha64;    // n*6 (fp64 mode, allocated on first use)
   // reduction scratch

@@ -68,6 +68,8 @@ int ensure_temp(sga_context* ctx, size_t bytes) { return ctx->d_temp.reserve(byt
 
 }  // namespace sga
 
+void sga_profile_collect_pending(sga_context* ctx);
+
 using namespace sga;
 
 extern "C" {
@@ -144,11 +146,13 @@ int sga_context_set_profiling(sga_context* ctx, int enabled) {
   ctx->profiling = enabled != 0;
   ctx->lin_ms = ctx->err_ms = 0.0;
   ctx->lin_calls = ctx->err_calls = 0;
+  ctx->pending = 0;
   return SGA_OK;
 }
 
 int sga_context_get_kernel_ms(sga_context* ctx, double* lin_ms, uint64_t* lin_calls, double* err_ms, uint64_t* err_calls) {
   if (!ctx) return fail(SGA_ERR_INVALID, "null context");
+  sga_profile_collect_pending(ctx);
   if (lin_ms) *lin_ms = ctx->lin_calls ? ctx->lin_ms / ctx->lin_calls : 0.0;
   if (lin_calls) *lin_calls = ctx->lin_calls;
   if (err_ms) *err_ms = ctx->err_calls ? ctx->err_ms / ctx->err_calls : 0.0;

@@ -87,6 +87,157 @@ __global__ void gather_sorted_kernel(
   if (cov) ocov[i] = cov[s];
 }
 
+
+// ---- implicit balanced kd-tree (see kd_search.hpp for the layout) ----------------------------------------------------------------
+// Built top-down, one level per pass: per-segment bounding box -> split axis = longest extent -> sort by (segment, coordinate)
+// -> threshold = coordinate of the first point of the right half.  (The reference picks the axis of largest sampled
+// variance, projection.hpp:31-50; any axis gives an exact search.)
+__device__ __forceinline__ uint32_t kd_bound_d(uint32_t n, int d, uint32_t k) { return static_cast<uint32_t>((static_cast<unsigned long long>(k) * n) >> d); }
+
+__device__ __forceinline__ uint32_t kd_segment_of(uint32_t i, uint32_t n, int d) {
+  uint32_t k = static_cast<uint32_t>((static_cast<unsigned long long>(i) << d) / n);
+  while (kd_bound_d(n, d, k + 1) <= i) k++;
+  while (kd_bound_d(n, d, k) > i) k--;
+  return k;
+}
+
+__device__ __forceinline__ int ordered_from_float(float f) {
+  const int i = __float_as_int(f);
+  return i >= 0 ? i : i ^ 0x7fffffff;
+}
+
+// seg_box: 6 ints per segment (min xyz, max xyz) in the order-preserving int encoding
+__global__ __launch_bounds__(256) void kd_segment_box_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ perm, uint32_t n, int d, int* __restrict__ seg_box) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = i < n;
+  const uint32_t seg = valid ? kd_segment_of(i, n, d) : 0xffffffffu;
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  if (valid) {
+    const float4 p = pts[perm[i]];
+    lo[0] = hi[0] = p.x;
+    lo[1] = hi[1] = p.y;
+    lo[2] = hi[2] = p.z;
+  }
+  const uint32_t seg0 = __shfl(seg, 0);
+  if (__all(seg == seg0)) {  // the whole wave sits in one segment: reduce first, six atomics per wave
+    for (int k = 0; k < 3; k++)
+      for (int off = 32; off > 0; off >>= 1) {
+        lo[k] = fminf(lo[k], __shfl_xor(lo[k], off));
+        hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
+      }
+    if ((threadIdx.x & 63) == 0 && valid) {
+      for (int k = 0; k < 3; k++) {
+        atomicMin(&seg_box[6 * seg + k], ordered_from_float(lo[k]));
+        atomicMax(&seg_box[6 * seg + 3 + k], ordered_from_float(hi[k]));
+      }
+    }
+  } else if (valid) {
+    for (int k = 0; k < 3; k++) {
+      atomicMin(&seg_box[6 * seg + k], ordered_from_float(lo[k]));
+      atomicMax(&seg_box[6 * seg + 3 + k], ordered_from_float(hi[k]));
+    }
+  }
+}
+
+__global__ void kd_init_box_kernel(int* __restrict__ seg_box, uint32_t nseg) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nseg) return;
+  for (int k = 0; k < 3; k++) {
+    seg_box[6 * s + k] = 0x7f800000;                                // +inf
+    seg_box[6 * s + 3 + k] = static_cast<int>(0xff800000u) ^ 0x7fffffff;  // -inf
+  }
+}
+
+__device__ __forceinline__ float float_from_ordered(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
+
+__global__ void kd_keys_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ perm, uint32_t n, int d, const int* __restrict__ seg_box, unsigned long long* __restrict__ keys) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t seg = kd_segment_of(i, n, d);
+  const float ex = float_from_ordered(seg_box[6 * seg + 3]) - float_from_ordered(seg_box[6 * seg + 0]);
+  const float ey = float_from_ordered(seg_box[6 * seg + 4]) - float_from_ordered(seg_box[6 * seg + 1]);
+  const float ez = float_from_ordered(seg_box[6 * seg + 5]) - float_from_ordered(seg_box[6 * seg + 2]);
+  const int axis = ex >= ey ? (ex >= ez ? 0 : 2) : (ey >= ez ? 1 : 2);
+  const float4 p = pts[perm[i]];
+  const float c = axis == 0 ? p.x : (axis == 1 ? p.y : p.z);
+  const uint32_t oc = static_cast<uint32_t>(ordered_from_float(c)) ^ 0x80000000u;  // unsigned order
+  keys[i] = (static_cast<unsigned long long>(seg) << 32) | oc;
+}
+
+__global__ void kd_nodes_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ perm, uint32_t n, int d, const int* __restrict__ seg_box, float2* __restrict__ nodes) {
+  const uint32_t seg = blockIdx.x * blockDim.x + threadIdx.x;
+  if (seg >= (1u << d)) return;
+  const float ex = float_from_ordered(seg_box[6 * seg + 3]) - float_from_ordered(seg_box[6 * seg + 0]);
+  const float ey = float_from_ordered(seg_box[6 * seg + 4]) - float_from_ordered(seg_box[6 * seg + 1]);
+  const float ez = float_from_ordered(seg_box[6 * seg + 5]) - float_from_ordered(seg_box[6 * seg + 2]);
+  const int axis = ex >= ey ? (ex >= ez ? 0 : 2) : (ey >= ez ? 1 : 2);
+  const uint32_t first = kd_bound_d(n, d, seg), end = kd_bound_d(n, d, seg + 1);
+  const uint32_t m = kd_bound_d(n, d + 1, 2 * seg + 1);  // first point of the right child
+  float thr = 0.f;
+  if (first < end) {
+    const float4 p = pts[perm[min(m, end - 1)]];
+    thr = axis == 0 ? p.x : (axis == 1 ? p.y : p.z);
+  }
+  nodes[(1u << d) + seg] = make_float2(thr, __int_as_float(axis));
+}
+
+__global__ void iota_kernel(uint32_t* __restrict__ v, size_t n) {
+  const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
+  if (i < n) v[i] = static_cast<uint32_t>(i);
+}
+
+__global__ void gather_attr_kernel(const float4* __restrict__ sorted_pts, size_t n, const float4* __restrict__ nrm, const Cov8* __restrict__ cov, float4* __restrict__ onrm, Cov8* __restrict__ ocov) {
+  const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t s = __float_as_uint(sorted_pts[i].w);
+  if (nrm) onrm[i] = nrm[s];
+  if (cov) ocov[i] = cov[s];
+}
+
+static int build_kdtree(sga_context* ctx, const sga_cloud* cloud, sga_index* idx) {
+  const size_t n = cloud->n;
+  idx->kd_depth = 0;
+  if (n == 0) return SGA_OK;
+  int D = 0;
+  while ((n >> D) > 8 || (((n + (1ull << D) - 1) >> D) > 8)) D++;  // ceil(n / 2^D) <= 8
+  if (D > 24) return fail(SGA_ERR_INVALID, "target too large for the kd-tree (%zu points)", n);
+  idx->kd_depth = D;
+  DevBuf<uint32_t> perm, perm2;
+  DevBuf<unsigned long long> keys, keys2;
+  DevBuf<int> seg_box;
+  SGA_TRY(perm.alloc(n));
+  SGA_TRY(perm2.alloc(n));
+  SGA_TRY(keys.alloc(n));
+  SGA_TRY(keys2.alloc(n));
+  SGA_TRY(seg_box.alloc(6ull << (D > 0 ? D - 1 : 0)));
+  SGA_TRY(idx->kd_nodes.alloc(1ull << D));
+  const dim3 grid((n + 255) / 256), block(256);
+  hipLaunchKernelGGL(iota_kernel, grid, block, 0, ctx->stream, perm.p, n);
+  uint32_t* cur = perm.p;
+  uint32_t* nxt = perm2.p;
+  size_t tb = 0;
+  SGA_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys.p, keys2.p, cur, nxt, n, 0, 64, ctx->stream));
+  SGA_TRY(ensure_temp(ctx, tb));
+  for (int d = 0; d < D; d++) {
+    const uint32_t nseg = 1u << d;
+    hipLaunchKernelGGL(kd_init_box_kernel, dim3((nseg + 255) / 256), block, 0, ctx->stream, seg_box.p, nseg);
+    hipLaunchKernelGGL(kd_segment_box_kernel, grid, block, 0, ctx->stream, cloud->pts.p, cur, static_cast<uint32_t>(n), d, seg_box.p);
+    hipLaunchKernelGGL(kd_keys_kernel, grid, block, 0, ctx->stream, cloud->pts.p, cur, static_cast<uint32_t>(n), d, seg_box.p, keys.p);
+    const unsigned end_bit = 32 + (d > 0 ? d : 1);
+    SGA_HIP(rocprim::radix_sort_pairs(ctx->d_temp.p, tb, keys.p, keys2.p, cur, nxt, n, 0, end_bit, ctx->stream));
+    std::swap(cur, nxt);
+    hipLaunchKernelGGL(kd_nodes_kernel, dim3((nseg + 255) / 256), block, 0, ctx->stream, cloud->pts.p, cur, static_cast<uint32_t>(n), d, seg_box.p, idx->kd_nodes.p);
+  }
+  SGA_HIP(hipGetLastError());
+  SGA_TRY(idx->kd_pts.alloc(n));
+  if (cloud->has_normals) SGA_TRY(idx->nrm.alloc(n));
+  if (cloud->has_covs) SGA_TRY(idx->cov.alloc(n));
+  hipLaunchKernelGGL(gather_sorted_kernel, grid, block, 0, ctx->stream, cur, n, cloud->pts.p, cloud->has_normals ? cloud->nrm.p : nullptr, cloud->has_covs ? cloud->cov.p : nullptr, idx->kd_pts.p, idx->nrm.p, idx->cov.p);
+  SGA_HIP(hipGetLastError());
+  SGA_HIP(hipStreamSynchronize(ctx->stream));
+  return SGA_OK;
+}
+
 static void grid_dims(const float lo[3], const float hi[3], double h, int dims[3]) {
   for (int k = 0; k < 3; k++) {
     const double ext = std::max(0.0, static_cast<double>(hi[k]) - lo[k]);
@@ -325,11 +476,10 @@ int sga_index_build_grid(sga_context* ctx, const sga_cloud* target, const sga_gr
     SGA_TRY(ensure_temp(ctx, tb2));
     SGA_HIP(rocprim::radix_sort_pairs(ctx->d_temp.p, tb2, keys.p, keys_sorted.p, vals.p, vals_sorted.p, n, 0, end_bit, ctx->stream));
     SGA_TRY(idx->pts.alloc(n));
-    if (target->has_normals) SGA_TRY(idx->nrm.alloc(n));
-    if (target->has_covs) SGA_TRY(idx->cov.alloc(n));
-    hipLaunchKernelGGL(gather_sorted_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, vals_sorted.p, n, target->pts.p, target->nrm.p, target->cov.p, idx->pts.p, idx->nrm.p, idx->cov.p);
+    hipLaunchKernelGGL(gather_sorted_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, vals_sorted.p, n, target->pts.p, static_cast<const float4*>(nullptr), static_cast<const Cov8*>(nullptr), idx->pts.p, static_cast<float4*>(nullptr), static_cast<Cov8*>(nullptr));
     SGA_HIP(hipGetLastError());
     SGA_HIP(hipStreamSynchronize(ctx->stream));
+    SGA_TRY(build_kdtree(ctx, target, idx.get()));
   } else {
     SGA_HIP(hipStreamSynchronize(ctx->stream));
   }

@@ -6,15 +6,20 @@
 // ann/incremental_voxelmap.hpp:99-119).  One lane per source point; tiles of 256 points; per-pair values reduced with
 // DPP inside a wave (fp32), accumulated per wave in fp64 in LDS, one 32-double partial row per workgroup, then a single
 // deterministic fp64 tree over the partial rows.  The 6x6 solve stays on the host (optimizer.cpp).
+#include <chrono>
+
 #include "common.hpp"
 #include "device_math.hpp"
+#include "kd_search.hpp"
 #include "nn_search.hpp"
+
+void sga_profile_collect_pending(sga_context* ctx);
 
 namespace sga {
 
 constexpr int kTile = 256;           // threads per workgroup = source points per tile
 constexpr int kRow = 32;             // doubles per partial row (28 used + inliers)
-constexpr int kMaxBlocks = 1024;     // 4 workgroups per CU on 256 CUs: the whole grid is resident
+constexpr int kMaxBlocks = 1536;     // 6 workgroups per CU (24 KB of traversal stack each) on 256 CUs: the whole grid is resident
 
 template <typename Real>
 struct LinParams {
@@ -25,9 +30,11 @@ struct LinParams {
   const float4* __restrict__ tgt_pts;
   const float4* __restrict__ tgt_nrm;
   const Cov8* __restrict__ tgt_cov;
-  GridView grid;
+  KdView kd;
   VoxelView vox;
   int* __restrict__ corr;
+  int* __restrict__ hint;   // last nearest neighbour found for each source point (kd position) or -1
+  int use_hints;            // SGA_KD_HINTS=1: start the search bottom-up from the previous neighbour
   Real* __restrict__ maha;  // n*6
   Rigid<Real> T;
   float max_sq;  // INFINITY = no rejector
@@ -75,14 +82,19 @@ __global__ __launch_bounds__(kTile) void linearize_kernel(const LinParams<Real> 
 #pragma unroll
     for (int k = 0; k < 28; k++) vals[k] = Real(0);
     bool inlier = false;
-    if (i < p.n) {
+    const bool active = i < p.n;
+    Real px = 0, py = 0, pz = 0, qx = 0, qy = 0, qz = 0;
+    if (active) {
       const float4 ps4 = p.src_pts[i];
-      const Real px = ps4.x, py = ps4.y, pz = ps4.z;
-      Real qx, qy, qz;
+      px = ps4.x;
+      py = ps4.y;
+      pz = ps4.z;
       transform_point(p.T, px, py, pz, qx, qy, qz);
-      int j = -1;
-      Real tx = 0, ty = 0, tz = 0;
-      if constexpr (VOXELMAP) {
+    }
+    int j = -1;
+    Real tx = 0, ty = 0, tz = 0;
+    if constexpr (VOXELMAP) {
+      if (active) {
         j = voxel_lookup(p.vox, static_cast<float>(qx), static_cast<float>(qy), static_cast<float>(qz));
         if (j >= 0) {
           const float4 m = p.tgt_pts[j];
@@ -90,13 +102,19 @@ __global__ __launch_bounds__(kTile) void linearize_kernel(const LinParams<Real> 
           ty = m.y;
           tz = m.z;
         }
-      } else {
-        const NNBest nb = grid_nearest(p.grid, static_cast<float>(qx), static_cast<float>(qy), static_cast<float>(qz), p.max_sq);
-        j = nb.idx;
-        tx = nb.x;
-        ty = nb.y;
-        tz = nb.z;
       }
+    } else {
+      __shared__ uint32_t kd_stack[kKdMaxDepth * kTile];
+      // d2 == max_sq must still be found (the rejector is a strict '>'): search bound one ulp above
+      const float bound2 = p.max_sq < 3.0e38f ? p.max_sq * 1.0000002f : INFINITY;
+      const KdBest nb = kd_nearest<kTile>(p.kd, static_cast<float>(qx), static_cast<float>(qy), static_cast<float>(qz), bound2, p.use_hints && active ? p.hint[i] : -1, kd_stack, threadIdx.x, active);
+      if (active) p.hint[i] = nb.idx;  // also kept for rejected pairs: next iteration's search starts from here
+      j = nb.idx;
+      tx = nb.x;
+      ty = nb.y;
+      tz = nb.z;
+    }
+    if (active) {
       const Real rx = tx - qx, ry = ty - qy, rz = tz - qz;
       const Real d2 = rx * rx + ry * ry + rz * rz;
       inlier = (j >= 0) && !(d2 > static_cast<Real>(p.max_sq));
@@ -198,12 +216,8 @@ __global__ __launch_bounds__(kTile) void error_kernel(const ErrParams<Real> p) {
           e = Real(0.5) * (rx * vx + ry * vy + rz * vz);
         } else if constexpr (FACTOR == SGA_PLANE_ICP) {
           const float4 nn = p.tgt_nrm[j];
-          const Real ex = Real(nn.x) * rx, ey = Real(nn.y) * ry, ez = Real(nn.z) * rz;
           // same association as pair_system's 1/2 r^T diag(n^2) r
           e = Real(0.5) * (rx * (Real(nn.x) * Real(nn.x) * rx) + ry * (Real(nn.y) * Real(nn.y) * ry) + rz * (Real(nn.z) * Real(nn.z) * rz));
-          (void)ex;
-          (void)ey;
-          (void)ez;
         } else {
           e = Real(0.5) * (rx * rx + ry * ry + rz * rz);
         }
@@ -249,8 +263,8 @@ template <typename Real>
 static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, const double T[16], double* d_out30) {
   const sga_index* idx = pb->target;
   const bool voxel = idx->kind == SGA_INDEX_VOXELMAP;
-  if (fp->factor_kind == SGA_GICP && (!pb->has_covs || !idx->has_covs)) return fail(SGA_ERR_INVALID, "GICP needs covariances on both source and target");
-  if (fp->factor_kind == SGA_PLANE_ICP && (voxel || !idx->has_normals)) return fail(SGA_ERR_UNSUPPORTED, "PLANE_ICP needs a grid index over a target with normals");
+  if (fp->factor_kind == SGA_GICP && ((pb->n > 0 && !pb->has_covs) || (idx->n > 0 && !idx->has_covs))) return fail(SGA_ERR_INVALID, "GICP needs covariances on both source and target");
+  if (fp->factor_kind == SGA_PLANE_ICP && (voxel || (idx->n > 0 && !idx->has_normals))) return fail(SGA_ERR_UNSUPPORTED, "PLANE_ICP needs a grid index over a target with normals");
   if (fp->factor_kind < 0 || fp->factor_kind > 2) return fail(SGA_ERR_INVALID, "invalid factor_kind %d", fp->factor_kind);
 
   LinParams<Real> p{};
@@ -258,7 +272,7 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
   p.src_cov = pb->cov.p;
   p.n = static_cast<int>(pb->n);
   p.num_tiles = (p.n + kTile - 1) / kTile;
-  p.tgt_pts = idx->pts.p;
+  p.tgt_pts = voxel ? idx->pts.p : idx->kd_pts.p;
   p.tgt_nrm = idx->nrm.p;
   p.tgt_cov = idx->cov.p;
   if (voxel) {
@@ -267,9 +281,14 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
     p.vox.hmask = idx->hmask;
     p.vox.inv_leaf = 1.0 / idx->leaf;
   } else {
-    p.grid = make_grid_view(idx);
+    p.kd = make_kd_view(idx);
   }
   p.corr = pb->corr.p;
+  p.hint = pb->hint.p;
+  {
+    static const int use_hints = getenv("SGA_KD_HINTS") ? atoi(getenv("SGA_KD_HINTS")) : 0;
+    p.use_hints = use_hints;
+  }
   if constexpr (sizeof(Real) == 4) {
     p.maha = pb->maha.p;
   } else {
@@ -283,7 +302,17 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
   p.partials = pb->partials.p;
   const int blocks = grid_blocks(p.num_tiles);
 
-  if (ctx->profiling) (void)hipEventRecord(ctx->ev0, ctx->stream);
+  static const bool dbg_time = getenv("SGA_DEBUG_STATS") != nullptr;
+  std::chrono::steady_clock::time_point dbg_t0;
+  if (dbg_time) {
+    (void)hipStreamSynchronize(ctx->stream);
+    dbg_t0 = std::chrono::steady_clock::now();
+  }
+  if (ctx->profiling) {
+    sga_profile_collect_pending(ctx);
+    ctx->pending = 0;
+    (void)hipEventRecord(ctx->ev0, ctx->stream);
+  }
   if (p.n > 0) {
     if (voxel) {
       if (fp->factor_kind == SGA_GICP)
@@ -298,7 +327,21 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
       }
     }
   }
-  if (ctx->profiling) (void)hipEventRecord(ctx->ev1, ctx->stream);
+  if (ctx->profiling) {
+    (void)hipEventRecord(ctx->ev1, ctx->stream);
+    ctx->pending = 1;
+  }
+  if (dbg_time) {
+    (void)hipStreamSynchronize(ctx->stream);
+    std::fprintf(stderr, "[sga stats] linearize us=%.0f", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - dbg_t0).count());
+    if (!voxel && p.kd.stats) {
+      unsigned long long h[16];
+      (void)hipMemcpy(h, p.kd.stats, sizeof(h), hipMemcpyDeviceToHost);
+      (void)hipMemset(p.kd.stats, 0, sizeof(h));
+      std::fprintf(stderr, " per-lane-queries=%llu internal/q=%.1f leaf/q=%.1f max_steps=%llu coop_waves=%llu leaves/wave=%.1f", h[3], h[3] ? double(h[0]) / h[3] : 0.0, h[3] ? double(h[1]) / h[3] : 0.0, h[2], h[5], h[5] ? double(h[4]) / h[5] : 0.0);
+    }
+    std::fprintf(stderr, "\n");
+  }
   hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, ctx->stream, pb->partials.p, p.n > 0 ? blocks : 0, 29, kRow, d_out30, SGA_ACCUM_DOUBLES);
   SGA_HIP(hipGetLastError());
   return SGA_OK;
@@ -311,7 +354,7 @@ static int error_dispatch(sga_context* ctx, sga_problem* pb, const sga_factor_pa
   p.src_pts = pb->pts.p;
   p.n = static_cast<int>(pb->n);
   p.num_tiles = (p.n + kTile - 1) / kTile;
-  p.tgt_pts = idx->pts.p;
+  p.tgt_pts = idx->kind == SGA_INDEX_VOXELMAP ? idx->pts.p : idx->kd_pts.p;
   p.tgt_nrm = idx->nrm.p;
   p.corr = pb->corr.p;
   if constexpr (sizeof(Real) == 4) {
@@ -326,7 +369,11 @@ static int error_dispatch(sga_context* ctx, sga_problem* pb, const sga_factor_pa
   p.partials = pb->partials.p;
   const int blocks = grid_blocks(p.num_tiles);
   if (fp->factor_kind == SGA_PLANE_ICP && !idx->has_normals) return fail(SGA_ERR_UNSUPPORTED, "PLANE_ICP needs target normals");
-  if (ctx->profiling) (void)hipEventRecord(ctx->ev0, ctx->stream);
+  if (ctx->profiling) {
+    sga_profile_collect_pending(ctx);
+    ctx->pending = 0;
+    (void)hipEventRecord(ctx->ev0, ctx->stream);
+  }
   if (p.n > 0) {
     switch (fp->factor_kind) {
       case SGA_GICP: hipLaunchKernelGGL((error_kernel<Real, SGA_GICP>), dim3(blocks), dim3(kTile), 0, ctx->stream, p); break;
@@ -335,7 +382,10 @@ static int error_dispatch(sga_context* ctx, sga_problem* pb, const sga_factor_pa
       default: return fail(SGA_ERR_INVALID, "invalid factor_kind %d", fp->factor_kind);
     }
   }
-  if (ctx->profiling) (void)hipEventRecord(ctx->ev1, ctx->stream);
+  if (ctx->profiling) {
+    (void)hipEventRecord(ctx->ev1, ctx->stream);
+    ctx->pending = 2;
+  }
   hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, ctx->stream, pb->partials.p, p.n > 0 ? blocks : 0, 1, 1, d_out1, 1);
   SGA_HIP(hipGetLastError());
   return SGA_OK;
@@ -349,19 +399,23 @@ static int check_args(sga_context* ctx, sga_problem* pb, const sga_factor_params
   return SGA_OK;
 }
 
-static void profile_collect(sga_context* ctx, bool lin) {
-  if (!ctx->profiling) return;
+}  // namespace sga
+// Fold the HIP-event pair of the previous launch into the running averages (no-op while that launch is still in flight).
+void sga_profile_collect_pending(sga_context* ctx) {
+  if (!ctx->profiling || ctx->pending == 0) return;
   float ms = 0.f;
   if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) {
-    if (lin) {
+    if (ctx->pending == 1) {
       ctx->lin_ms += ms;
       ctx->lin_calls++;
     } else {
       ctx->err_ms += ms;
       ctx->err_calls++;
     }
+    ctx->pending = 0;
   }
 }
+namespace sga {
 
 }  // namespace sga
 
@@ -402,7 +456,7 @@ int sga_linearize(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp
   SGA_TRY(sga_linearize_async(ctx, pb, fp, T, ctx->d_accum.p));
   SGA_HIP(hipMemcpyAsync(ctx->h_accum, ctx->d_accum.p, sizeof(double) * SGA_ACCUM_DOUBLES, hipMemcpyDeviceToHost, ctx->stream));
   SGA_HIP(hipStreamSynchronize(ctx->stream));
-  profile_collect(ctx, true);
+  sga_profile_collect_pending(ctx);
   sga_unpack_accumulator(ctx->h_accum, H, b, e, num_inliers);
   return SGA_OK;
 }
@@ -413,7 +467,7 @@ int sga_error(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, co
   SGA_TRY(sga_error_async(ctx, pb, fp, T, ctx->d_accum.p));
   SGA_HIP(hipMemcpyAsync(ctx->h_accum, ctx->d_accum.p, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   SGA_HIP(hipStreamSynchronize(ctx->stream));
-  profile_collect(ctx, false);
+  sga_profile_collect_pending(ctx);
   *e = ctx->h_accum[0];
   return SGA_OK;
 }

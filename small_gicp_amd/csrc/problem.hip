@@ -2,8 +2,6 @@
 // (registration/registration.hpp:41 `std::vector<PointFactor> factors(size(source))`), device resident.
 // The source is copied once in a spatially coherent order (sorted by the target-grid cell of init_T * p, Morton order
 // over cells) so that the 64 lanes of a wave query neighbouring cells and share cache lines of the target.
-#include <memory>
-
 #include "common.hpp"
 
 #include <memory>
@@ -78,53 +76,7 @@ __global__ __launch_bounds__(kKnnBlock) void knn_kernel(const GridView g, const 
   }
   if (qi >= m) return;
   const float qx = queries[3 * qi], qy = queries[3 * qi + 1], qz = queries[3 * qi + 2];
-  const int cx = cell_coord(qx, g.ox, g.inv_cell), cy = cell_coord(qy, g.oy, g.inv_cell), cz = cell_coord(qz, g.oz, g.inv_cell);
-  int r_all = max(max(max(cx, g.nx - 1 - cx), max(cy, g.ny - 1 - cy)), max(cz, g.nz - 1 - cz));
-  r_all = max(r_all, 0);
-  const float h = g.cell * 0.9999f;
-  float worst = INFINITY;  // k-th best so far
-  auto push_run = [&](uint32_t s, uint32_t e) {
-    for (uint32_t j = s; j < e; ++j) {
-      const float4 p = g.pts[j];
-      const float dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
-      const float d2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
-      if (d2 >= worst) continue;  // knn_result.hpp:81-83: ties do not displace
-      int loc = k - 1;
-      for (; loc > 0 && d2 < sd[(loc - 1) * kKnnBlock + lane]; loc--) {
-        sd[loc * kKnnBlock + lane] = sd[(loc - 1) * kKnnBlock + lane];
-        si[loc * kKnnBlock + lane] = si[(loc - 1) * kKnnBlock + lane];
-      }
-      sd[loc * kKnnBlock + lane] = d2;
-      si[loc * kKnnBlock + lane] = static_cast<int>(j);
-      worst = sd[(k - 1) * kKnnBlock + lane];
-    }
-  };
-  for (int r = 0;; ++r) {
-    const int zlo = max(cz - r, 0), zhi = min(cz + r, g.nz - 1);
-    const int ylo = max(cy - r, 0), yhi = min(cy + r, g.ny - 1);
-    for (int z = zlo; z <= zhi; ++z) {
-      const int adz = abs(z - cz);
-      const float ddz = (z == cz) ? 0.f : (z > cz ? (g.oz + z * g.cell) - qz : qz - (g.oz + (z + 1) * g.cell));
-      for (int y = ylo; y <= yhi; ++y) {
-        const int ady = abs(y - cy);
-        const float ddy = (y == cy) ? 0.f : (y > cy ? (g.oy + y * g.cell) - qy : qy - (g.oy + (y + 1) * g.cell));
-        const float row_d2 = fmaxf(ddy, 0.f) * fmaxf(ddy, 0.f) + fmaxf(ddz, 0.f) * fmaxf(ddz, 0.f);
-        if (row_d2 * 0.9999f >= worst || row_d2 * 0.9999f > max_sq) continue;
-        const uint32_t row = (static_cast<uint32_t>(z) * g.ny + y) * g.nx;
-        if (max(ady, adz) == r) {
-          const int x0 = max(cx - r, 0), x1 = min(cx + r, g.nx - 1);
-          if (x0 <= x1) push_run(g.cell_start[row + x0], g.cell_start[row + x1 + 1]);
-        } else {
-          const int xa = cx - r, xb = cx + r;
-          if (xa >= 0 && xa < g.nx) push_run(g.cell_start[row + xa], g.cell_start[row + xa + 1]);
-          if (xb >= 0 && xb < g.nx) push_run(g.cell_start[row + xb], g.cell_start[row + xb + 1]);
-        }
-      }
-    }
-    const float reach = r * h;
-    const float reach2 = reach * reach;
-    if (worst <= reach2 || reach2 >= max_sq || r >= r_all) break;
-  }
+  grid_knn_lds<kKnnBlock>(g, qx, qy, qz, k, max_sq, sd, si, lane);
   for (int j = 0; j < k; j++) {
     const float d2 = sd[j * kKnnBlock + lane];
     const int id = si[j * kKnnBlock + lane];
@@ -189,8 +141,10 @@ int sga_problem_create(sga_context* ctx, const sga_index* target, const sga_clou
     SGA_TRY(pb->pts.alloc(n));
     if (source->has_covs) SGA_TRY(pb->cov.alloc(n));
     SGA_TRY(pb->corr.alloc(n));
+    SGA_TRY(pb->hint.alloc(n));
     SGA_TRY(pb->maha.alloc(n * 6));
     SGA_HIP(hipMemsetAsync(pb->corr.p, 0xff, n * sizeof(int), ctx->stream));
+    SGA_HIP(hipMemsetAsync(pb->hint.p, 0xff, n * sizeof(int), ctx->stream));
     SGA_HIP(hipMemsetAsync(pb->maha.p, 0, n * 6 * sizeof(float), ctx->stream));
     DevBuf<unsigned long long> keys, keys_sorted;
     DevBuf<uint32_t> vals, order;
@@ -238,7 +192,7 @@ int sga_problem_get_factors(sga_context* ctx, const sga_problem* pb, int64_t* ta
   DevBuf<float> d_m;
   if (target_index) SGA_TRY(d_idx.alloc(n));
   if (mahalanobis6) SGA_TRY(d_m.alloc(n * 6));
-  hipLaunchKernelGGL((export_factors_kernel<float>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, pb->pts.p, pb->corr.p, pb->maha.p, n, pb->target->pts.p, d_idx.p, d_m.p);
+  hipLaunchKernelGGL((export_factors_kernel<float>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, pb->pts.p, pb->corr.p, pb->maha.p, n, pb->target->kind == SGA_INDEX_VOXELMAP ? pb->target->pts.p : pb->target->kd_pts.p, d_idx.p, d_m.p);
   SGA_HIP(hipGetLastError());
   if (target_index) SGA_HIP(hipMemcpyAsync(target_index, d_idx.p, n * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
   if (mahalanobis6) SGA_HIP(hipMemcpyAsync(mahalanobis6, d_m.p, n * 6 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));

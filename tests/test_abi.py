@@ -1,0 +1,145 @@
+"""CPU-side checks of the product boundary (no GPU compute): the C-ABI library loads, exports every symbol include/*.h declares,
+fails LOUDLY without a GPU (no CPU fallback), and its host logic — the LM/GN optimizer of registration/optimizer.hpp, se3_exp,
+the accumulator layout — reproduces the oracle when driven through sga_optimize with oracle reductions as callbacks."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import small_gicp_amd as sga
+from conftest import ROOT, pose_error
+from small_gicp_amd import _lib
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(sga.LIB_PATH), "run `make lib` / __graft_entry__.build() first"
+    header = open(os.path.join(ROOT, "include", "small_gicp_amd.h")).read()
+    declared = set(re.findall(r"\b(sga_[a-z0-9_]+)\s*\(", header))
+    typedefs = {"sga_linearize_fn", "sga_error_fn"}
+    declared -= typedefs
+    lib = C.CDLL(sga.LIB_PATH)
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+    bound = {name for name, _, _ in _lib.SYMBOLS}
+    assert declared == bound, (declared - bound, bound - declared)
+
+
+def test_no_gpu_fails_loudly():
+    lib = sga.load()
+    if lib.sga_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(sga.SgaError) as ei:
+        sga.Context(0)
+    assert "no CPU fallback" in str(ei.value) or "error 3" in str(ei.value)
+    with pytest.raises(sga.SgaError):
+        sga.PointCloud(np.zeros((10, 3), np.float32))
+
+
+def test_defaults_match_reference():
+    """registration_helper.hpp:37-49, optimizer.hpp:66,83, termination_criteria.hpp:13, rejector.hpp:20."""
+    s = _lib.RegistrationSettingC()
+    sga.load().sga_registration_setting_default(C.byref(s))
+    assert s.factor.factor_kind == sga.GICP and s.factor.max_dist_sq == 1.0 and s.factor.robust_kind == 0 and s.factor.robust_c == 1.0
+    assert (s.optimizer, s.max_iterations, s.max_inner_iterations) == (0, 20, 10)
+    assert (s.init_lambda, s.lambda_factor, s.gn_lambda) == (1e-3, 10.0, 1e-6)
+    assert s.translation_eps == 1e-3 and abs(s.rotation_eps - 0.1 * np.pi / 180.0) < 1e-18
+
+
+def test_se3_exp_matches_oracle(orc):
+    rng = np.random.default_rng(0)
+    for scale in (1e-9, 1e-4, 0.2, 1.5):
+        a = np.ascontiguousarray(rng.normal(size=6) * scale)
+        T = np.empty(16)
+        sga.load().sga_se3_exp(a.ctypes.data_as(C.POINTER(C.c_double)), T.ctypes.data_as(C.POINTER(C.c_double)))
+        assert np.allclose(T.reshape(4, 4).T, orc.se3_exp(a), atol=1e-14)
+
+
+def test_unpack_accumulator_layout():
+    acc = np.arange(30, dtype=np.float64)
+    acc[28] = 1234.0
+    H, b, e, n = sga.unpack_accumulator(acc)
+    assert np.allclose(H, H.T)
+    k = 0
+    for i in range(6):
+        for j in range(i, 6):
+            assert H[i, j] == k
+            k += 1
+    assert (b == np.arange(21, 27)).all() and e == 27 and n == 1234
+
+
+@pytest.mark.parametrize("case", ["GICP", "PLANE_ICP", "ICP", "GN_GICP"])
+def test_host_optimizer_reproduces_oracle(orc, c1_oracle_clouds, case):
+    """sga_optimize (product host code) driven by oracle reductions == the oracle's own optimizer: same pose, iteration count,
+    inliers, H, b, error.  Exercises LM accept/reject, lambda schedule, termination and result bookkeeping on the CPU."""
+    tc, sc = c1_oracle_clouds
+    kind = {"GICP": orc.GICP, "PLANE_ICP": orc.PLANE_ICP, "ICP": orc.ICP, "GN_GICP": orc.GICP}[case]
+    opt = 1 if case.startswith("GN") else 0
+    s = orc.default_setting(factor_kind=kind, num_threads=1, optimizer_type=opt)
+    ref = orc.align(tc, sc, s)
+    f = orc.Factors(len(sc))
+
+    def lin(T):
+        return orc.linearize(tc, sc, s, T, f)
+
+    def err(T):
+        return orc.error(tc, sc, s, T, f)
+
+    st = sga.make_setting({orc.GICP: "GICP", orc.PLANE_ICP: "PLANE_ICP", orc.ICP: "ICP"}[kind], optimizer="GN" if opt else "LM")
+    res = sga.optimize(st, np.eye(4), lin, err)
+    assert res.iterations == ref.iterations and res.converged == ref.converged and res.num_inliers == ref.num_inliers
+    dt, dr = pose_error(res.T_target_source, ref.T_target_source)
+    assert dt < 1e-10 and dr < 1e-7
+    assert np.allclose(res.H, ref.H, rtol=1e-9) and np.allclose(res.b, ref.b, rtol=1e-6, atol=1e-6) and abs(res.error - ref.error) <= 1e-9 * abs(ref.error)
+
+
+def test_host_optimizer_lm_failure_path():
+    """optimizer.hpp:141-143: 10 rejected trials end the optimisation with converged = False."""
+    calls = {"lin": 0, "err": 0}
+
+    def lin(T):
+        calls["lin"] += 1
+        return np.eye(6), np.ones(6), 1.0, 5
+
+    def err(T):
+        calls["err"] += 1
+        return 2.0  # never better
+
+    res = sga.optimize(sga.make_setting("GICP"), np.eye(4), lin, err)
+    assert not res.converged and res.iterations == 0 and calls == {"lin": 1, "err": 10}
+    assert np.allclose(res.T_target_source, np.eye(4))
+
+
+def test_restrict_dof_factor():
+    """general_factor.hpp:41-75: H += lambda * diag(|mask - 1|) freezes the masked twist components."""
+    rng = np.random.default_rng(0)
+    J = rng.normal(size=(40, 6))
+    H0, b0 = J.T @ J, rng.normal(size=6)
+    seen = {}
+
+    def lin(T):
+        return H0, b0, 10.0, 40
+
+    def err(T):
+        seen["T"] = T
+        return 0.0
+
+    mask = [1, 1, 0, 1, 1, 0]  # freeze yaw and z
+    st = sga.make_setting("GICP", max_iterations=1, restrict_dof_lambda=1e9, restrict_dof_mask=mask)
+    res = sga.optimize(st, np.eye(4), lin, err)
+    Hc = H0 + 1e9 * np.diag(np.abs(np.array(mask, dtype=np.float64) - 1.0))
+    delta = np.linalg.solve(Hc + 1e-3 * np.eye(6), -b0)
+    assert abs(delta[2]) < 1e-8 and abs(delta[5]) < 1e-8
+    from oracle import orc
+
+    assert np.allclose(res.T_target_source, orc.se3_exp(delta), atol=1e-9)
+    assert res.H[2, 2] > 1e8 and res.H[5, 5] > 1e8  # result.H carries the general factor like the reference
+
+
+def test_callback_error_propagates():
+    def lin(T):
+        raise ValueError("boom")
+
+    with pytest.raises(ValueError):
+        sga.optimize(sga.make_setting("GICP"), np.eye(4), lin, lambda T: 0.0)

@@ -1,0 +1,360 @@
+"""Parity of the HIP path against the CPU oracle — everything here runs on a real MI355X through the C-ABI.
+
+Tolerances (written once, used below):
+  * pose: 1e-4 m / 1e-4 rad against the oracle (BASELINE.json north_star), with identical iteration and inlier counts;
+  * accumulators at a fixed pose on identical fp32 inputs: fp32 math 2e-5 relative to max|H| (resp. |e|), fp64 math 1e-10;
+  * indices (NN / kNN / correspondences): equal, except where the two nearest candidates tie within fp32 resolution.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import small_gicp_amd as sga
+from conftest import ROOT, pose_error
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL_T, POSE_TOL_R = 1e-4, 1e-4
+FP32_REL, FP64_REL = 2e-5, 1e-10
+
+
+def rot(axis, ang):
+    from scipy.spatial.transform import Rotation
+
+    return Rotation.from_rotvec(np.asarray(axis, dtype=np.float64) / np.linalg.norm(axis) * ang).as_matrix()
+
+
+def se3(axis, ang, t):
+    T = np.eye(4)
+    T[:3, :3] = rot(axis, ang)
+    T[:3, 3] = t
+    return T
+
+
+@pytest.fixture(scope="module")
+def gpu_c1(c1_f32):
+    d = c1_f32
+    tgt = sga.PointCloud(d["tp"], d["tn"], d["tc"])
+    src = sga.PointCloud(d["sp"], d["sn"], d["sc"])
+    tree = sga.KdTree(tgt)
+    return tgt, src, tree
+
+
+POSES = [np.eye(4), se3([0.1, 0.2, 1.0], np.deg2rad(0.7), [0.49, 0.12, -0.02]), se3([1, -1, 0.3], np.deg2rad(5.0), [-0.4, 0.3, 0.2])]
+FACTORS = [("GICP", 2, None), ("PLANE_ICP", 1, None), ("ICP", 0, None), ("GICP", 2, "HUBER"), ("GICP", 2, "CAUCHY"), ("ICP", 0, "HUBER")]
+
+
+@pytest.mark.parametrize("name,kind,robust", FACTORS)
+@pytest.mark.parametrize("mode", ["fp32", "fp64"])
+def test_linearize_and_error_match_oracle(orc, c1_f32, gpu_c1, name, kind, robust, mode):
+    tgt, src, tree = gpu_c1
+    otc, osc = c1_f32["otc"], c1_f32["osc"]
+    rel = FP32_REL if mode == "fp32" else FP64_REL
+    rk = {None: 0, "HUBER": 1, "CAUCHY": 2}[robust]
+    st = sga.make_setting(name, robust_kernel=robust, robust_c=0.7, math_mode=mode)
+    os_ = orc.default_setting(factor_kind=kind, robust_kind=rk, robust_c=0.7, num_threads=4)
+    pb = sga.Problem(tree, src)
+    f = orc.Factors(len(osc))
+    for T in POSES:
+        H, b, e, n = pb.linearize(st.factor, T)
+        Ho, bo, eo, no = orc.linearize(otc, osc, os_, T, f)
+        assert abs(int(n) - int(no)) <= (2 if mode == "fp32" else 0)
+        scale = np.abs(Ho).max()
+        assert np.abs(H - Ho).max() <= rel * scale, (name, mode, np.abs(H - Ho).max() / scale)
+        assert np.abs(H - H.T).max() == 0.0
+        # b is a difference of large terms near the optimum: compare on the scale of |J^T M| ~ sqrt(H_ii * e)
+        bscale = np.sqrt(np.abs(np.diag(Ho)) * max(eo, 1e-30)) + 1e-30
+        assert (np.abs(b - bo) / bscale).max() <= 5 * rel, (name, mode, (np.abs(b - bo) / bscale).max())
+        assert abs(e - eo) <= rel * abs(eo)
+        # the error pass at the linearization point reproduces e (same correspondences, same cached mahalanobis)
+        T2 = T @ se3([0, 0, 1], 1e-3, [1e-3, -2e-3, 5e-4])
+        for Tq in (T, T2):
+            assert abs(pb.error(st.factor, Tq) - orc.error(otc, osc, os_, Tq, f)) <= rel * abs(eo)
+        ti, m6 = pb.factors()
+        oti, om = f.get()
+        agree = (ti == oti).mean()
+        assert agree >= (0.999 if mode == "fp32" else 1.0), agree
+        if name == "GICP" and mode == "fp32":
+            same = ti == oti
+            om6 = np.stack([om[:, 0, 0], om[:, 0, 1], om[:, 0, 2], om[:, 1, 1], om[:, 1, 2], om[:, 2, 2]], axis=1)
+            ok = same & (oti >= 0)
+            assert np.abs(m6[ok] - om6[ok]).max() <= 1e-4 * np.abs(om6[ok]).max()
+
+
+@pytest.mark.parametrize("case", ["GICP", "PLANE_ICP", "ICP", "HUBER_GICP", "CAUCHY_GICP"])
+@pytest.mark.parametrize("mode", ["fp32", "fp64"])
+def test_align_matches_golden(c1_gold, gpu_c1, case, mode):
+    """data/source.ply <-> data/target.ply (config C1): final pose within 1e-4 m / 1e-4 rad of the oracle."""
+    tgt, src, tree = gpu_c1
+    g = c1_gold["cases"][case]
+    reg = case.split("_")[-1] if case not in ("PLANE_ICP",) else "PLANE_ICP"
+    robust = case.split("_")[0] if case.startswith(("HUBER", "CAUCHY")) else None
+    st = sga.make_setting(reg, robust_kernel=robust, math_mode=mode)
+    res = sga.Problem(tree, src).align(st)
+    dt, dr = pose_error(res.T_target_source, np.array(g["T"]))
+    assert dt < POSE_TOL_T and dr < POSE_TOL_R, (case, mode, dt, dr)
+    assert res.iterations == g["iterations"] and res.converged == g["converged"]
+    assert abs(res.num_inliers - g["num_inliers"]) <= 2
+    assert abs(res.error - g["error"]) <= 1e-4 * abs(g["error"])
+    assert np.abs(res.H - np.array(g["H"])).max() <= 1e-3 * np.abs(np.array(g["H"])).max()
+
+
+def test_vgicp_matches_golden(orc, c1_gold, c1_f32, gpu_c1):
+    tgt, src, tree = gpu_c1
+    g = c1_gold["cases"]["VGICP"]
+    vm = sga.GaussianVoxelMap(1.0)
+    vm.insert(tgt)
+    assert vm.size() == g["num_voxels"]
+    # voxel contents and ids (first-insertion order) against the oracle
+    ovm = orc.VoxelMap(c1_f32["otc"], 1.0)
+    oc, om, ocov, ocnt = ovm.get()
+    gc, gm, gc6, gcnt = vm.download()
+    assert (gc == oc).all() and (gcnt == ocnt).all()
+    assert np.abs(gm - om).max() < 1e-5
+    res = sga.align(vm, src)
+    dt, dr = pose_error(res.T_target_source, np.array(g["T"]))
+    assert dt < POSE_TOL_T and dr < POSE_TOL_R, (dt, dr)
+    assert res.iterations == g["iterations"] and abs(res.num_inliers - g["num_inliers"]) <= 2
+
+
+def test_full_gpu_pipeline_from_raw_points(c1_raw, c1_gold):
+    """Config C1 end to end on the GPU: raw points -> voxel grid -> covariances -> index -> GICP, i.e. small_gicp::align(points...)."""
+    tgt, src, T_gt = c1_raw
+    res = sga.align(tgt, src, downsampling_resolution=0.25)
+    dt, dr = pose_error(res.T_target_source, np.array(c1_gold["cases"]["GICP"]["T"]))
+    assert dt < POSE_TOL_T and dr < POSE_TOL_R, (dt, dr)
+    dt, dr = pose_error(res.T_target_source, T_gt)
+    assert dt < 0.05 and dr < 0.05  # the reference's own pin (src/test/python_test.py:52-58)
+    resv = sga.align(tgt, src, registration_type="VGICP", voxel_resolution=1.0)
+    dt, dr = pose_error(resv.T_target_source, np.array(c1_gold["cases"]["VGICP"]["T"]))
+    assert dt < POSE_TOL_T and dr < POSE_TOL_R, (dt, dr)
+
+
+def test_init_guess_and_inverse(orc, c1_f32, gpu_c1, c1_raw):
+    tgt, src, tree = gpu_c1
+    otc, osc = c1_f32["otc"], c1_f32["osc"]
+    T_gt = c1_raw[2]
+    st = sga.make_setting("GICP")
+    os_ = orc.default_setting(factor_kind=orc.GICP, num_threads=4)
+    rng = np.random.default_rng(11)
+    for _ in range(3):
+        init = T_gt @ se3(rng.normal(size=3), np.deg2rad(rng.uniform(0, 8)), rng.uniform(-0.4, 0.4, 3))
+        res = sga.Problem(tree, src, init).align(st, init)
+        ref = orc.align(otc, osc, os_, init_T=init)
+        dt, dr = pose_error(res.T_target_source, ref.T_target_source)
+        assert dt < POSE_TOL_T and dr < POSE_TOL_R and res.iterations == ref.iterations
+    # inverse direction: roles swapped
+    osc_t = orc.Cloud(*[a for a in c1_f32["osc"].get()])
+    otc_s = orc.Cloud(*[a for a in c1_f32["otc"].get()], tree=False)
+    ref = orc.align(osc_t, otc_s, os_)
+    res = sga.Problem(sga.KdTree(src), tgt).align(st)
+    dt, dr = pose_error(res.T_target_source, ref.T_target_source)
+    assert dt < POSE_TOL_T and dr < POSE_TOL_R
+    dt, dr = pose_error(res.T_target_source, np.linalg.inv(T_gt))
+    assert dt < 0.2 and dr < np.deg2rad(2.5)
+
+
+def test_gauss_newton_and_null_rejector(orc, c1_f32, gpu_c1):
+    tgt, src, tree = gpu_c1
+    otc, osc = c1_f32["otc"], c1_f32["osc"]
+    res = sga.Problem(tree, src).align(sga.make_setting("GICP", optimizer="GN"))
+    ref = orc.align(otc, osc, orc.default_setting(factor_kind=orc.GICP, num_threads=4, optimizer_type=1))
+    dt, dr = pose_error(res.T_target_source, ref.T_target_source)
+    assert dt < POSE_TOL_T and dr < POSE_TOL_R and res.iterations == ref.iterations
+    # NullRejector (rejector.hpp:11-16): every source point keeps its (unbounded) nearest neighbour
+    st = sga.make_setting("ICP", max_correspondence_distance=None)
+    pb = sga.Problem(tree, src)
+    H, b, e, n = pb.linearize(st.factor, np.eye(4))
+    f = orc.Factors(len(osc))
+    Ho, bo, eo, no = orc.linearize(otc, osc, orc.default_setting(factor_kind=orc.ICP, max_dist_sq=1e300, num_threads=4), np.eye(4), f)
+    assert n == no == src.size() and abs(e - eo) <= FP32_REL * eo
+
+
+# ---- nearest-neighbour search (kdtree_test.cpp / kdtree_synthetic_test.cpp protocols) ----------------------------------------
+def _brute(target, queries, k):
+    d2 = ((queries[:, None, :].astype(np.float64) - target[None, :, :].astype(np.float64)) ** 2).sum(-1)
+    idx = np.argsort(d2, axis=1, kind="stable")[:, :k]
+    return idx, np.take_along_axis(d2, idx, axis=1)
+
+
+def test_knn_real_data(c1_f32, gpu_c1):
+    tgt, src, tree = gpu_c1
+    pts = c1_f32["tp"]
+    rng = np.random.default_rng(1)
+    q = np.concatenate([pts[rng.choice(len(pts), 50, replace=False)], pts[rng.choice(len(pts), 50, replace=False)] + rng.normal(0, 1.0, (50, 3)).astype(np.float32), rng.uniform(0, 100, (50, 3)).astype(np.float32)]).astype(np.float32)
+    idx, d2 = tree.batch_knn_search(q, 20)
+    bi, bd = _brute(pts, q, 20)
+    assert (np.abs(d2 - bd) <= 1e-3 * np.minimum(1.0, bd) + 3e-7 * bd).all()  # kdtree_test.cpp:81-105 (1e-3), fp32 resolution for the far queries
+    assert (idx == bi).mean() > 0.999  # fp32 near-ties may swap neighbours
+    i1, d1 = tree.batch_nearest_neighbor_search(q)
+    assert (i1 == bi[:, 0]).mean() > 0.995 and (np.abs(d1 - bd[:, 0]) <= 1e-3 * np.minimum(1.0, bd[:, 0]) + 3e-7 * bd[:, 0]).all()
+    # bounded search: everything farther than the radius is reported as not found
+    ib, db = tree.batch_knn_search(q, 5, max_sq_dist=0.25)
+    assert ((ib >= 0) == (bd[:, :5] <= 0.25 + 1e-6)).mean() > 0.999
+
+
+SYN = {
+    "uniform1": lambda rng: rng.uniform(-1, 1, (256, 3)),
+    "uniform1e6": lambda rng: rng.uniform(-1e6, 1e6, (256, 3)),
+    "bimodal": lambda rng: np.concatenate([rng.normal(-5, 0.5, (128, 3)), rng.normal(5, 0.5, (128, 3))]),
+    "lattice": lambda rng: rng.integers(-3, 4, (256, 3)).astype(np.float64),
+}
+
+
+@pytest.mark.parametrize("name", list(SYN))
+@pytest.mark.parametrize("ntrunc", [256, 10, 5])
+def test_knn_synthetic(name, ntrunc):
+    rng = np.random.default_rng(3)
+    target = SYN[name](rng)[:ntrunc].astype(np.float32)
+    queries = SYN[name](rng).astype(np.float32)
+    tree = sga.KdTree(sga.PointCloud(target))
+    idx, d2 = tree.batch_knn_search(queries, 20)
+    k = min(20, ntrunc)
+    _, bd = _brute(target, queries, k)
+    scale = max(1.0, float(bd.max()))
+    assert np.abs(d2[:, :k] - bd).max() <= 2e-6 * scale  # fp32 distances
+    assert (idx[:, k:] == -1).all() and (idx[:, :k] >= 0).all()
+    # returned distance is consistent with the returned index
+    chk = ((queries[:, None, :].astype(np.float64) - target[idx[:, :k]].astype(np.float64)) ** 2).sum(-1)
+    assert np.abs(chk - d2[:, :k]).max() <= 2e-6 * scale
+
+
+def test_empty_and_tiny_inputs(capfd):
+    empty = sga.PointCloud(np.zeros((0, 3), np.float32))
+    assert empty.size() == 0 and sga.voxelgrid_sampling(empty, 0.5).size() == 0  # downsampling.hpp:24-26
+    tree = sga.KdTree(empty)
+    idx, d2 = tree.batch_knn_search(np.zeros((4, 3), np.float32), 3)
+    assert (idx == -1).all()
+    pts = np.random.default_rng(0).uniform(-1, 1, (8, 3)).astype(np.float32)
+    cov = np.tile(np.eye(3, dtype=np.float32), (8, 1, 1))
+    small = sga.PointCloud(pts, covs=cov)
+    # empty source against a real target and vice versa: zero system, no crash, warning like registration.hpp:34-39
+    st = sga.make_setting("GICP")
+    pb = sga.Problem(sga.KdTree(small), sga.PointCloud(np.zeros((0, 3), np.float32), covs=np.zeros((0, 3, 3), np.float32)))
+    H, b, e, n = pb.linearize(st.factor, np.eye(4))
+    assert n == 0 and e == 0 and not H.any()
+    pb2 = sga.Problem(sga.KdTree(sga.PointCloud(np.zeros((0, 3), np.float32), covs=np.zeros((0, 3, 3), np.float32))), small)
+    H, b, e, n = pb2.linearize(st.factor, np.eye(4))
+    assert n == 0 and e == 0
+    res = pb2.align(st)
+    assert not res.converged or res.num_inliers == 0
+    assert "too small" in capfd.readouterr().err
+    # a source far away from the target: every pair is rejected
+    far = sga.PointCloud(pts + 100.0, covs=cov)
+    H, b, e, n = sga.Problem(sga.KdTree(small), far).linearize(st.factor, np.eye(4))
+    assert n == 0 and e == 0
+
+
+def test_error_reporting():
+    pts = np.random.default_rng(0).uniform(-1, 1, (64, 3)).astype(np.float32)
+    nocov = sga.PointCloud(pts)
+    with pytest.raises(sga.SgaError):
+        sga.Problem(sga.KdTree(nocov), nocov).linearize(sga.make_setting("GICP").factor, np.eye(4))
+    with pytest.raises(sga.SgaError):
+        sga.Problem(sga.KdTree(nocov), nocov).linearize(sga.make_setting("PLANE_ICP").factor, np.eye(4))
+    with pytest.raises(sga.SgaError):
+        vm = sga.GaussianVoxelMap(1.0)
+        vm.insert(nocov)
+
+
+# ---- preprocessing ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("leaf", [0.1, 0.25, 1.0])
+def test_voxelgrid_matches_oracle(orc, c1_raw, leaf):
+    pts = c1_raw[0]
+    out = sga.voxelgrid_sampling(pts, leaf).xyz()
+    ref = orc.voxelgrid_sampling(pts, leaf)
+    assert out.shape == ref.shape  # same voxels, same (ascending key) order
+    assert np.abs(out - ref).max() < 1e-5
+
+
+@pytest.mark.parametrize("k", [10, 20])
+def test_normals_covariances_match_oracle(orc, c1_raw, k):
+    down = orc.voxelgrid_sampling(c1_raw[0], 0.25).astype(np.float32)
+    cloud = sga.PointCloud(down)
+    sga.estimate_normals_covariances(cloud, None, k)
+    oc = orc.Cloud(down.astype(np.float64))
+    oc.estimate_normals_covariances(k, 4)
+    _, on, ocov = oc.get()
+    gn, gcov = cloud.normals()[:, :3], cloud.covs()[:, :3, :3]
+    assert np.abs(np.linalg.norm(gn, axis=1) - 1).max() < 1e-5  # normal_estimation_test.cpp: unit normals
+    # neighbourhoods whose k-th and (k+1)-th neighbours tie in fp32, or with near-degenerate spectra, may differ: allow 0.5 %
+    bad_n = (np.abs(gn - on).max(axis=1) > 1e-3).mean()
+    bad_c = (np.abs(gcov - ocov).reshape(len(on), -1).max(axis=1) > 1e-3).mean()
+    assert bad_n < 0.005 and bad_c < 0.005, (bad_n, bad_c)
+    assert np.abs(gcov - np.transpose(gcov, (0, 2, 1))).max() == 0
+    # flows through an explicit index too, and updates the index's own attribute copies
+    cloud2 = sga.PointCloud(down)
+    tree = sga.KdTree(cloud2)
+    sga.estimate_covariances(cloud2, tree, k)
+    assert np.abs(cloud2.covs()[:, :3, :3] - gcov).max() < 1e-6
+    few = sga.PointCloud(down[:4])
+    sga.estimate_normals_covariances(few, None, k)  # < 5 neighbours: normal 0, cov I (normal_estimation.hpp:15,33-37)
+    assert not few.normals()[:, :3].any() and np.allclose(few.covs()[:, :3, :3], np.eye(3))
+
+
+# ---- size-independent properties at the benchmark size (config C3: 1M <-> 1M) ------------------------------------------------------
+@pytest.fixture(scope="module")
+def c3():
+    target, source, T_gt = sga.synthetic.registration_pair(1_000_000)
+    tgt, src = sga.PointCloud(target), sga.PointCloud(source)
+    sga.estimate_covariances(tgt, None, 20)
+    sga.estimate_covariances(src, None, 20)
+    tree = sga.KdTree(tgt)
+    return dict(tgt=tgt, src=src, tree=tree, T_gt=T_gt, source=source, src_cov=src.covs()[:, :3, :3].astype(np.float32))
+
+
+def test_c3_properties(c3):
+    st = sga.make_setting("GICP")
+    pb = sga.Problem(c3["tree"], c3["src"])
+    T = se3([0.2, 0.3, 0.93], np.deg2rad(1.0), [0.1, -0.1, 0.0])
+    H, b, e, n = pb.linearize(st.factor, T)
+    # determinism: same launch, bit-identical sums
+    H2, b2, e2, n2 = pb.linearize(st.factor, T)
+    assert (H == H2).all() and (b == b2).all() and e == e2 and n == n2
+    # idempotence of the cached state: the error pass at the linearization point reproduces e
+    assert abs(pb.error(st.factor, T) - e) <= 1e-6 * e
+    # additivity over source shards (what the multi-GPU all-reduce relies on): halves sum to the whole
+    half = len(c3["source"]) // 2
+    parts = []
+    for sl in (slice(0, half), slice(half, None)):
+        sh = sga.PointCloud(c3["source"][sl], covs=c3["src_cov"][sl])
+        parts.append(sga.Problem(c3["tree"], sh).linearize(st.factor, T))
+    Hs, bs, es, ns = [sum(p[i] for p in parts) for i in range(4)]
+    assert ns == n and abs(es - e) <= 1e-9 * e and np.abs(Hs - H).max() <= 1e-7 * np.abs(H).max()  # fp32 wave sums group differently
+    # fp32 vs fp64 per-pair arithmetic agree
+    st64 = sga.make_setting("GICP", math_mode="fp64")
+    H64, b64, e64, n64 = pb.linearize(st64.factor, T)
+    assert abs(int(n64) - int(n)) <= 50 and abs(e64 - e) <= 1e-5 * e64 and np.abs(H64 - H).max() <= 1e-5 * np.abs(H64).max()
+    # the full registration recovers the synthetic ground truth
+    res = pb.align(st)
+    dt, dr = pose_error(res.T_target_source, c3["T_gt"])
+    assert res.converged and dt < 5e-3 and dr < 5e-4, (dt, dr)
+
+
+def test_c3_frame_invariance(c3):
+    """Moving the target by a rigid G and the pose by G leaves the objective unchanged (up to fp32 rounding of the moved cloud)."""
+    st = sga.make_setting("ICP")
+    T = np.eye(4)
+    e0 = sga.Problem(c3["tree"], c3["src"]).linearize(st.factor, T)[2]
+    G = se3([0, 0, 1], np.deg2rad(30), [3.0, -2.0, 0.5])
+    tp = c3["tgt"].xyz().astype(np.float64)
+    moved = (tp @ G[:3, :3].T + G[:3, 3]).astype(np.float32)
+    tree2 = sga.KdTree(sga.PointCloud(moved))
+    e1 = sga.Problem(tree2, c3["src"], G).linearize(st.factor, G @ T)[2]
+    assert abs(e1 - e0) <= 2e-4 * e0, (e0, e1)
+
+
+def test_bench_contract():
+    """bench.py prints one JSON line with the contract's keys plus roofline and cpu_baseline (small sizes here)."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--points", "100000", "--cpu-iters", "3"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+    j = json.loads(line)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in j, key
+    assert j["value"] > 0 and j["steps"] >= 20 and j["roofline"]["achieved"] > 0 and j["cpu_baseline"]["value"] > 0
+    assert j["final_pose_error"]["trans_m"] < 0.02
