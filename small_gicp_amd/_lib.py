@@ -7,7 +7,7 @@ import os
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsmall_gicp_amd.so")
+LIB_PATH = os.environ.get("SGA_LIB_PATH") or os.path.join(_HERE, "lib", "libsmall_gicp_amd.so")
 
 SGA_OK = 0
 ICP, PLANE_ICP, GICP = 0, 1, 2

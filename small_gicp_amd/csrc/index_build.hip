@@ -9,6 +9,7 @@
 
 #include <memory>
 #include <rocprim/rocprim.hpp>
+#include "kd_search.hpp"
 #include "nn_search.hpp"
 
 namespace sga {
@@ -92,7 +93,7 @@ __global__ void gather_sorted_kernel(
 // Built top-down, one level per pass: per-segment bounding box -> split axis = longest extent -> sort by (segment, coordinate)
 // -> threshold = coordinate of the first point of the right half.  (The reference picks the axis of largest sampled
 // variance, projection.hpp:31-50; any axis gives an exact search.)
-__device__ __forceinline__ uint32_t kd_bound_d(uint32_t n, int d, uint32_t k) { return static_cast<uint32_t>((static_cast<unsigned long long>(k) * n) >> d); }
+__device__ __forceinline__ uint32_t kd_bound_d(uint32_t n, int d, uint32_t k) { return kd_bound(n, d, k); }
 
 __device__ __forceinline__ uint32_t kd_segment_of(uint32_t i, uint32_t n, int d) {
   uint32_t k = static_cast<uint32_t>((static_cast<unsigned long long>(i) << d) / n);
@@ -199,7 +200,7 @@ static int build_kdtree(sga_context* ctx, const sga_cloud* cloud, sga_index* idx
   idx->kd_depth = 0;
   if (n == 0) return SGA_OK;
   int D = 0;
-  while ((n >> D) > 8 || (((n + (1ull << D) - 1) >> D) > 8)) D++;  // ceil(n / 2^D) <= 8
+  while (((n + (1ull << D) - 1) >> D) > static_cast<size_t>(kKdLeafMax)) D++;  // ceil(n / 2^D) <= leaf capacity
   if (D > 24) return fail(SGA_ERR_INVALID, "target too large for the kd-tree (%zu points)", n);
   idx->kd_depth = D;
   DevBuf<uint32_t> perm, perm2;

@@ -18,7 +18,10 @@
 
 namespace sga {
 
-constexpr int kKdLeafMax = 8;    // points per leaf (<=): 8 x 16 B = one 128-byte line
+#ifndef SGA_KD_LEAF
+#define SGA_KD_LEAF 8
+#endif
+constexpr int kKdLeafMax = SGA_KD_LEAF;  // points per leaf (<=); 8 x 16 B = one 128-byte line
 constexpr int kKdMaxDepth = 24;  // stack slots per lane; tree depth D <= 24 (n <= 2^27)
 
 struct KdView {

@@ -235,20 +235,32 @@ __global__ __launch_bounds__(kTile) void error_kernel(const ErrParams<Real> p) {
   }
 }
 
-// Deterministic fp64 sum of `nrows` partial rows of `ncols` (<= 32) doubles -> out[ncols] (+ zero padding up to out_n).
-__global__ __launch_bounds__(256) void reduce_rows_kernel(const double* __restrict__ partials, int nrows, int ncols, int row_stride, double* __restrict__ out, int out_n) {
+// Deterministic fp64 sum of `nrows` partial rows of `ncols` (<= 32) doubles.  Stage 1: workgroup g sums rows g, g+G, g+2G, ...
+// into row g of `stage` (G = gridDim.x); stage 2 (one workgroup, nrows = G) writes out[ncols] (+ zero padding up to out_n).
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const double* __restrict__ partials, int nrows, int ncols, int row_stride, double* __restrict__ out, int out_stride, int out_n) {
   __shared__ double sh[8][32];
   const int c = threadIdx.x & 31, s = threadIdx.x >> 5;
   double acc = 0.0;
   if (c < ncols)
-    for (int r = s; r < nrows; r += 8) acc += partials[static_cast<size_t>(r) * row_stride + c];
+    for (int r = blockIdx.x + s * gridDim.x; r < nrows; r += 8 * gridDim.x) acc += partials[static_cast<size_t>(r) * row_stride + c];
   sh[s][c] = acc;
   __syncthreads();
   if (threadIdx.x < out_n) {
     double t = 0.0;
     if (threadIdx.x < ncols)
       for (int k = 0; k < 8; k++) t += sh[k][threadIdx.x];
-    out[threadIdx.x] = t;
+    out[static_cast<size_t>(blockIdx.x) * out_stride + threadIdx.x] = t;
+  }
+}
+
+constexpr int kReduceGroups = 32;
+
+static void launch_reduce(hipStream_t st, const double* partials, int nrows, int ncols, int row_stride, double* stage, double* out, int out_n) {
+  if (nrows > 2 * kReduceGroups) {
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(kReduceGroups), dim3(256), 0, st, partials, nrows, ncols, row_stride, stage, 32, 32);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, st, stage, kReduceGroups, ncols, 32, out, 0, out_n);
+  } else {
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, st, partials, nrows, ncols, row_stride, out, 0, out_n);
   }
 }
 
@@ -342,7 +354,7 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
     }
     std::fprintf(stderr, "\n");
   }
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, ctx->stream, pb->partials.p, p.n > 0 ? blocks : 0, 29, kRow, d_out30, SGA_ACCUM_DOUBLES);
+  launch_reduce(ctx->stream, pb->partials.p, p.n > 0 ? blocks : 0, 29, kRow, pb->partials.p + static_cast<size_t>(kMaxBlocks) * kRow, d_out30, SGA_ACCUM_DOUBLES);
   SGA_HIP(hipGetLastError());
   return SGA_OK;
 }
@@ -386,12 +398,12 @@ static int error_dispatch(sga_context* ctx, sga_problem* pb, const sga_factor_pa
     (void)hipEventRecord(ctx->ev1, ctx->stream);
     ctx->pending = 2;
   }
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, ctx->stream, pb->partials.p, p.n > 0 ? blocks : 0, 1, 1, d_out1, 1);
+  launch_reduce(ctx->stream, pb->partials.p, p.n > 0 ? blocks : 0, 1, 1, pb->partials.p + static_cast<size_t>(kMaxBlocks) * kRow, d_out1, 1);
   SGA_HIP(hipGetLastError());
   return SGA_OK;
 }
 
-int problem_partials_rows() { return kMaxBlocks; }
+int problem_partials_rows() { return kMaxBlocks + kReduceGroups; }  // K1/K2 partial rows + the stage-1 rows of the reduction
 
 static int check_args(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, const double* T) {
   if (!ctx || !pb || !fp || !T) return fail(SGA_ERR_INVALID, "null argument");
