@@ -127,6 +127,13 @@ int sga_error(sga_context* ctx, sga_problem* problem, const sga_factor_params* p
 #define SGA_ACCUM_DOUBLES 30
 int sga_linearize_async(sga_context* ctx, sga_problem* problem, const sga_factor_params* params, const double T[16], double* d_out30);
 int sga_error_async(sga_context* ctx, sga_problem* problem, const sga_factor_params* params, const double T[16], double* d_out1);
+/* Native multi-GPU form: give the context an RCCL communicator over the ranks that share ONE registration (source sharded, target
+ * replicated).  From then on sga_linearize / sga_error / sga_align all-reduce their accumulators over the ranks on the context's
+ * stream before reading them back, so every rank returns the system of the whole source cloud.  Rank 0 creates the 128-byte id
+ * and hands it to the others out of band (MPI, torch.distributed, a file).  librccl is bound with dlopen on first use. */
+int sga_comm_unique_id(unsigned char id[128]);
+int sga_comm_init(sga_context* ctx, int nranks, int rank, const unsigned char id[128]);
+int sga_comm_destroy(sga_context* ctx);
 /* Expand a 30-double accumulator (host memory) into H[36], b[6], e, num_inliers. */
 void sga_unpack_accumulator(const double acc30[SGA_ACCUM_DOUBLES], double H[36], double b[6], double* e, uint64_t* num_inliers);
 /* Factor state in the caller's source order: target_index n int64 (-1 = outlier; voxel id for voxel maps), mahalanobis6 n*6 floats (GICP only). */

@@ -95,6 +95,9 @@ SYMBOLS = [
     ("sga_error", C.c_int, [_vp, _vp, C.POINTER(FactorParams), _dp, _dp]),
     ("sga_linearize_async", C.c_int, [_vp, _vp, C.POINTER(FactorParams), _dp, _vp]),
     ("sga_error_async", C.c_int, [_vp, _vp, C.POINTER(FactorParams), _dp, _vp]),
+    ("sga_comm_unique_id", C.c_int, [C.POINTER(C.c_ubyte)]),
+    ("sga_comm_init", C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_ubyte)]),
+    ("sga_comm_destroy", C.c_int, [_vp]),
     ("sga_unpack_accumulator", None, [_dp, _dp, _dp, _dp, C.POINTER(C.c_uint64)]),
     ("sga_problem_get_factors", C.c_int, [_vp, _vp, C.POINTER(C.c_int64), _fp]),
     ("sga_context_set_profiling", C.c_int, [_vp, C.c_int]),

@@ -46,6 +46,18 @@ class Context:
     def synchronize(self):
         check(load().sga_context_synchronize(self.h))
 
+    @staticmethod
+    def comm_unique_id():
+        """128-byte RCCL unique id (create on rank 0, hand to the other ranks out of band)."""
+        buf = (C.c_ubyte * 128)()
+        check(load().sga_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, nranks, rank, unique_id):
+        """Join the RCCL communicator: afterwards linearize/error/align all-reduce their accumulators over the ranks."""
+        buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
+        check(load().sga_comm_init(self.h, int(nranks), int(rank), buf))
+
     def set_profiling(self, enabled=True):
         check(load().sga_context_set_profiling(self.h, int(enabled)))
 

@@ -84,6 +84,9 @@ struct sga_context {
   double lin_ms = 0.0, err_ms = 0.0;
   uint64_t lin_calls = 0, err_calls = 0;
   int num_cus = 256;
+  // multi-GPU (comm.hip): RCCL communicator over the ranks that share one registration, or null
+  void* comm = nullptr;
+  int comm_ranks = 1;
 };
 
 struct sga_cloud {

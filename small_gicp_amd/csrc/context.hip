@@ -124,6 +124,7 @@ int sga_context_create_on_stream(int device, void* hip_stream, sga_context** out
 int sga_context_destroy(sga_context* ctx) {
   if (!ctx) return SGA_OK;
   (void)hipSetDevice(ctx->device);
+  (void)sga_comm_destroy(ctx);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);

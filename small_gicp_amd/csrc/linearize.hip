@@ -17,6 +17,8 @@ void sga_profile_collect_pending(sga_context* ctx);
 
 namespace sga {
 
+int comm_allreduce_sum(sga_context* ctx, double* d_buf, size_t count);
+
 constexpr int kTile = 256;           // threads per workgroup = source points per tile
 constexpr int kRow = 32;             // doubles per partial row (28 used + inliers)
 constexpr int kMaxBlocks = 1536;     // 6 workgroups per CU (24 KB of traversal stack each) on 256 CUs: the whole grid is resident
@@ -466,6 +468,7 @@ int sga_linearize(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp
   SGA_TRY(check_args(ctx, pb, fp, T));
   if (!H || !b || !e) return fail(SGA_ERR_INVALID, "null output");
   SGA_TRY(sga_linearize_async(ctx, pb, fp, T, ctx->d_accum.p));
+  SGA_TRY(comm_allreduce_sum(ctx, ctx->d_accum.p, SGA_ACCUM_DOUBLES));  // source sharded over ranks: sum the shards' systems
   SGA_HIP(hipMemcpyAsync(ctx->h_accum, ctx->d_accum.p, sizeof(double) * SGA_ACCUM_DOUBLES, hipMemcpyDeviceToHost, ctx->stream));
   SGA_HIP(hipStreamSynchronize(ctx->stream));
   sga_profile_collect_pending(ctx);
@@ -477,6 +480,7 @@ int sga_error(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, co
   SGA_TRY(check_args(ctx, pb, fp, T));
   if (!e) return fail(SGA_ERR_INVALID, "null output");
   SGA_TRY(sga_error_async(ctx, pb, fp, T, ctx->d_accum.p));
+  SGA_TRY(comm_allreduce_sum(ctx, ctx->d_accum.p, 1));
   SGA_HIP(hipMemcpyAsync(ctx->h_accum, ctx->d_accum.p, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   SGA_HIP(hipStreamSynchronize(ctx->stream));
   sga_profile_collect_pending(ctx);
