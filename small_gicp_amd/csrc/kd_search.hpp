@@ -23,6 +23,7 @@ namespace sga {
 #endif
 constexpr int kKdLeafMax = SGA_KD_LEAF;  // points per leaf (<=); 8 x 16 B = one 128-byte line
 constexpr int kKdMaxDepth = 24;  // stack slots per lane; tree depth D <= 24 (n <= 2^27)
+constexpr int kKdTopLevels = 10;  // nodes of depth < 10 (1023 x 8 B) can be mirrored in LDS: no vector-memory access for the top of every descent
 
 struct KdView {
   const float4* __restrict__ pts;    // kd order, w = original index bits
@@ -79,7 +80,7 @@ __device__ __forceinline__ float kd_cut(uint32_t e) { return __uint_as_float((e 
 //         split plane is closer than the best distance so far.  The result is the same exact nearest neighbour; the hint only
 //         removes the root-to-leaf descent and almost all backtracking once the pose has settled.
 template <int STRIDE>
-__device__ __forceinline__ KdBest kd_nearest(const KdView& t, float qx, float qy, float qz, float bound2, int hint, uint32_t* __restrict__ stack, int tid, bool active) {
+__device__ __forceinline__ KdBest kd_nearest(const KdView& t, float qx, float qy, float qz, float bound2, int hint, uint32_t* __restrict__ stack, int tid, bool active, const float2* __restrict__ top = nullptr) {
   KdBest best;
   best.d2 = bound2;
   best.idx = -1;
@@ -119,7 +120,7 @@ __device__ __forceinline__ KdBest kd_nearest(const KdView& t, float qx, float qy
     uint32_t node = start;
     for (;;) {
       while (depth < D) {
-        const float2 nd = t.nodes[node];
+        const float2 nd = (top != nullptr && depth < kKdTopLevels) ? top[node] : t.nodes[node];
         const int axis = __float_as_int(nd.y);
         const float qa = axis == 0 ? qx : (axis == 1 ? qy : qz);
         const float diff = qa - nd.x;

@@ -7,6 +7,7 @@
 #include <memory>
 #include <rocprim/rocprim.hpp>
 #include "device_math.hpp"
+#include "kd_search.hpp"
 #include "nn_search.hpp"
 
 namespace sga {
@@ -37,6 +38,33 @@ __global__ void source_keys_kernel(const float4* __restrict__ pts, size_t n, Rig
   cy = min(max(cy, 0ll), (1ll << 21) - 1);
   cz = min(max(cz, 0ll), (1ll << 21) - 1);
   keys[i] = spread3(cx) | (spread3(cy) << 1) | (spread3(cz) << 2);
+  vals[i] = static_cast<uint32_t>(i);
+}
+
+// Sort key for a kd-tree target: the leaf the transformed point descends into (high bits) refined by the Morton code of its
+// position inside the target's bounding box (low bits).  The 64 lanes of a wave then start in the same or neighbouring leaves
+// and walk nearly the same nodes in the same order: less divergence, better cache reuse than plain Morton order.
+__global__ void source_kd_keys_kernel(const float4* __restrict__ pts, size_t n, Rigid<float> T, KdView kd, float ox, float oy, float oz, float inv, unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = pts[i];
+  float qx, qy, qz;
+  transform_point<float>(T, p.x, p.y, p.z, qx, qy, qz);
+  uint32_t node = 1;
+  for (int d = 0; d < kd.depth; d++) {
+    const float2 nd = kd.nodes[node];
+    const int axis = __float_as_int(nd.y);
+    const float qa = axis == 0 ? qx : (axis == 1 ? qy : qz);
+    node = 2 * node + (qa - nd.x < 0.f ? 0u : 1u);
+  }
+  const unsigned long long leaf = node - (1u << kd.depth);
+  const long long bias = 1 << 9;
+  long long cx = static_cast<long long>(floorf((qx - ox) * inv)) + bias, cy = static_cast<long long>(floorf((qy - oy) * inv)) + bias, cz = static_cast<long long>(floorf((qz - oz) * inv)) + bias;
+  cx = min(max(cx, 0ll), 1023ll);
+  cy = min(max(cy, 0ll), 1023ll);
+  cz = min(max(cz, 0ll), 1023ll);
+  const unsigned long long fine = (spread3(cx) | (spread3(cy) << 1) | (spread3(cz) << 2)) & 0x3fffffffull;  // 30 bits
+  keys[i] = (leaf << 30) | fine;
   vals[i] = static_cast<uint32_t>(i);
 }
 
@@ -161,7 +189,14 @@ int sga_problem_create(sga_context* ctx, const sga_index* target, const sga_clou
     } else {
       inv = static_cast<float>(4.0 / target->leaf);  // quarter-voxel cells: neighbouring lanes probe the same voxel
     }
-    hipLaunchKernelGGL(source_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, source->pts.p, n, rigid_from_colmajor<float>(T), ox, oy, oz, inv, keys.p, vals.p);
+    static const bool kd_order = !(getenv("SGA_SOURCE_ORDER") && atoi(getenv("SGA_SOURCE_ORDER")) == 0);
+    if (target->kind == SGA_INDEX_GRID && target->n > 0 && kd_order) {
+      KdView kv = make_kd_view(target);
+      kv.stats = nullptr;
+      hipLaunchKernelGGL(source_kd_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, source->pts.p, n, rigid_from_colmajor<float>(T), kv, ox, oy, oz, inv, keys.p, vals.p);
+    } else {
+      hipLaunchKernelGGL(source_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, source->pts.p, n, rigid_from_colmajor<float>(T), ox, oy, oz, inv, keys.p, vals.p);
+    }
     SGA_HIP(hipGetLastError());
     size_t tb = 0;
     SGA_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys.p, keys_sorted.p, vals.p, order.p, n, 0, 63, ctx->stream));
