@@ -45,8 +45,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=10, help="outer LM iterations of the CPU baseline sample")
     ap.add_argument("--math", default="fp32", choices=["fp32", "fp64"])
+    ap.add_argument("--odom-frames", type=int, default=12, help="frames of the KITTI-shaped scan-to-scan odometry leg (config C5); 0 = skip")
     ap.add_argument("--force-dist", action="store_true", help="use the torch.distributed/RCCL path even at world size 1 (validation)")
-    ap.add_argument("--ppc", type=float, default=0.0, help="target points per occupied grid cell (0 = library default)")
     return ap.parse_args()
 
 
@@ -91,7 +91,7 @@ def main():
     src = sga.PointCloud(source, ctx=ctx)
     sga.estimate_covariances(tgt, None, args.neighbors)
     sga.estimate_covariances(src, None, args.neighbors)
-    tree = sga.KdTree(tgt, search_radius=1.0, points_per_cell=args.ppc)
+    tree = sga.KdTree(tgt)
     problem = sga.Problem(tree, src, np.eye(4))
     ctx.synchronize()
     prep_s = time.perf_counter() - t0
@@ -221,10 +221,47 @@ def main():
             out["cpu_baseline"] = cpu_baseline(sga, tgt, src, n, args)
             if out["cpu_baseline"] and out["cpu_baseline"].get("value"):
                 out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        if world == 1 and not use_dist and args.odom_frames > 1:
+            out["kitti_odom"] = odometry_leg(sga, args)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def odometry_leg(sga, args):
+    """Second half of the BASELINE metric: ms/scan of scan-to-scan GICP odometry on the KITTI-shaped synthetic stream (C5), GPU vs
+    the CPU oracle following the same protocol (downsample 0.25 m -> covariances k = 20 -> GICP against the previous scan)."""
+    try:
+        from small_gicp_amd import odometry
+
+        r = odometry.run_synthetic(args.odom_frames)
+        out = {k: v for k, v in r.items() if k not in ("estimated", "ground_truth")}
+        out["unit"] = "ms/scan"
+        out["protocol"] = "src/benchmark/odometry_benchmark_small_gicp_omp.cpp:16-49: registration = index build + covariances + align; total adds the 0.25 m voxel grid"
+        if not args.no_cpu_baseline:
+            from oracle import orc
+
+            ncpu = os.cpu_count() or 1
+            threads = max(1, min(32, ncpu))
+            prev = None
+            reg_ms = []
+            for f in range(min(4, args.odom_frames)):
+                pts, _ = sga.synthetic.kitti_like_scan(f)
+                down = orc.voxelgrid_sampling(pts, 0.25)
+                t0 = time.perf_counter()
+                cloud = orc.Cloud(down, tree=True)
+                cloud.estimate_normals_covariances(20, threads)
+                if prev is not None:
+                    s = orc.default_setting(factor_kind=orc.GICP, num_threads=threads)
+                    orc.align(prev, cloud, s)
+                reg_ms.append(1e3 * (time.perf_counter() - t0))
+                prev = cloud
+            out["cpu_registration_ms_per_scan"] = float(np.mean(reg_ms[1:])) if len(reg_ms) > 1 else None
+            out["cpu_threads"] = threads
+        return out
+    except Exception as ex:  # noqa: BLE001
+        return {"error": repr(ex)}
 
 
 def cpu_baseline(sga, tgt, src, n, args):

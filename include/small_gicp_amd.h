@@ -25,7 +25,7 @@ extern "C" {
 
 typedef struct sga_context sga_context; /* one GPU + one stream */
 typedef struct sga_cloud sga_cloud;     /* device-resident point cloud: points [+ normals] [+ covariances]          (points/point_cloud.hpp:15-71) */
-typedef struct sga_index sga_index;     /* nearest-neighbour search target: uniform-grid index (replaces ann/kdtree.hpp KdTree) or GaussianVoxelMap */
+typedef struct sga_index sga_index;     /* nearest-neighbour search target: kd-tree (replaces ann/kdtree.hpp KdTree) or GaussianVoxelMap */
 typedef struct sga_problem sga_problem; /* a (target index, source cloud) pairing + per-source-point factor state (registration.hpp:41 std::vector<PointFactor>) */
 
 enum sga_status {
@@ -74,27 +74,22 @@ int sga_cloud_download(sga_context* ctx, const sga_cloud* cloud, float* xyz, flo
 /* util/downsampling.hpp:23-78 voxelgrid_sampling: centroid per occupied voxel, output in ascending packed-key order. */
 int sga_voxelgrid_sampling(sga_context* ctx, const sga_cloud* in, double leaf_size, sga_cloud** out);
 /* util/normal_estimation.hpp:65-92 estimate_local_features: kNN(k, incl. self) -> mean/cov -> eigvecs -> normal / covariance.
- * index must be a grid index built over `cloud`.  flags: bit0 = normals, bit1 = covariances. */
+ * index: a kd-tree built over `cloud`, or NULL to build a temporary one.  flags: bit0 = normals, bit1 = covariances. */
 int sga_estimate_normals_covariances(sga_context* ctx, sga_cloud* cloud, const sga_index* index, int num_neighbors, int flags);
 
 /* ---- search indices --------------------------------------------------------------------------------------------- */
-typedef struct sga_grid_params {
-  double cell_size;        /* <= 0: choose automatically from the point density */
-  double search_radius;    /* hint: the largest correspondence distance that will be queried (sizes the automatic cell); <= 0: 1.0 */
-  double points_per_cell;  /* target mean occupancy of non-empty cells for the automatic choice; <= 0: 2.0 */
-  uint64_t max_cells;      /* cap on the dense cell table; 0: max(2^16, 64 * n) */
-} sga_grid_params;
-/* Replaces KdTree<PointCloud>(points) (ann/kdtree.hpp:250-252): exact nearest neighbour / kNN over `target`.
- * The index keeps its own cell-sorted copy of the target's points / normals / covariances. params may be NULL. */
-int sga_index_build_grid(sga_context* ctx, const sga_cloud* target, const sga_grid_params* params, sga_index** out);
+/* Replaces KdTree<PointCloud>(points) (ann/kdtree.hpp:80-126, :250-252): exact nearest neighbour / kNN over `target`.
+ * An implicit, perfectly balanced kd-tree (median splits like the reference, no pointers) built on the GPU; the index keeps its
+ * own kd-ordered copy of the target's points / normals / covariances. */
+int sga_index_build_kdtree(sga_context* ctx, const sga_cloud* target, sga_index** out);
 /* Replaces create_gaussian_voxelmap (registration_helper.cpp:50-54; ann/incremental_voxelmap.hpp:55-92, gaussian_voxelmap.hpp:32-53):
  * one-shot insert of a cloud WITH covariances; voxel ids follow first-insertion order like the reference. */
 int sga_index_build_gaussian_voxelmap(sga_context* ctx, const sga_cloud* points_with_covs, double leaf_size, sga_index** out);
-/* Re-copy normals / covariances from `cloud` (the cloud the grid was built over) into the index's cell-sorted arrays, e.g. after
+/* Re-copy normals / covariances from `cloud` (the cloud the tree was built over) into the index's kd-ordered arrays, e.g. after
  * attributes were estimated or set once the index already existed (reference flow: KdTree first, estimate_covariances second). */
 int sga_index_refresh_attributes(sga_context* ctx, sga_index* index, const sga_cloud* cloud);
 int sga_index_destroy(sga_index* index);
-/* Number of target points (grid) or voxels (voxel map): traits::size(target). */
+/* Number of target points (kd-tree) or voxels (voxel map): traits::size(target). */
 int sga_index_size(const sga_index* index, size_t* n);
 /* Voxel map contents in voxel-id order: coords n*3 int32, means n*3, cov6 n*6, counts n (any may be NULL). */
 int sga_index_voxelmap_download(sga_context* ctx, const sga_index* index, int32_t* coords, float* means, float* cov6, uint32_t* counts);
@@ -113,8 +108,8 @@ typedef struct sga_factor_params {
 } sga_factor_params;
 void sga_factor_params_default(sga_factor_params* p);
 
-/* Pair a target index with a source cloud.  The problem keeps a spatially sorted copy of the source (sorted by the target-grid
- * cell of init_T * p) and the per-point factor state (target index + cached mahalanobis), i.e. registration.hpp:41. */
+/* Pair a target index with a source cloud.  The problem keeps a spatially sorted copy of the source (sorted by the target kd-leaf
+ * init_T * p falls into) and the per-point factor state (target index + cached mahalanobis), i.e. registration.hpp:41. */
 int sga_problem_create(sga_context* ctx, const sga_index* target, const sga_cloud* source, const double init_T[16], sga_problem** out);
 int sga_problem_destroy(sga_problem* problem);
 /* Sum_i (H_i, b_i, e_i) at T over all source points with a correspondence; refreshes the factor state. */

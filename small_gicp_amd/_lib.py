@@ -21,10 +21,6 @@ class SgaError(RuntimeError):
     pass
 
 
-class GridParams(C.Structure):
-    _fields_ = [("cell_size", C.c_double), ("search_radius", C.c_double), ("points_per_cell", C.c_double), ("max_cells", C.c_uint64)]
-
-
 class FactorParams(C.Structure):
     _fields_ = [("factor_kind", C.c_int), ("robust_kind", C.c_int), ("robust_c", C.c_double), ("max_dist_sq", C.c_double), ("math_mode", C.c_int)]
 
@@ -81,7 +77,7 @@ SYMBOLS = [
     ("sga_cloud_download", C.c_int, [_vp, _vp, _fp, _fp, _fp]),
     ("sga_voxelgrid_sampling", C.c_int, [_vp, _vp, C.c_double, _pvp]),
     ("sga_estimate_normals_covariances", C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int]),
-    ("sga_index_build_grid", C.c_int, [_vp, _vp, C.POINTER(GridParams), _pvp]),
+    ("sga_index_build_kdtree", C.c_int, [_vp, _vp, _pvp]),
     ("sga_index_build_gaussian_voxelmap", C.c_int, [_vp, _vp, C.c_double, _pvp]),
     ("sga_index_refresh_attributes", C.c_int, [_vp, _vp, _vp]),
     ("sga_index_destroy", C.c_int, [_vp]),

@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import GICP, ICP, PLANE_ICP, FactorParams, GridParams, RegistrationSettingC, ResultC, check, load
+from ._lib import GICP, ICP, PLANE_ICP, FactorParams, RegistrationSettingC, ResultC, check, load
 
 _FACTOR_BY_NAME = {"ICP": ICP, "PLANE_ICP": PLANE_ICP, "GICP": GICP, "VGICP": GICP}
 
@@ -167,17 +167,16 @@ class PointCloud:
 
 
 class KdTree:
-    """Exact nearest-neighbour index over a PointCloud.  The name mirrors small_gicp.KdTree; the structure is a
-    cell-sorted uniform grid built on the GPU (sga_index_build_grid)."""
+    """Exact nearest-neighbour index over a PointCloud (small_gicp.KdTree): an implicit balanced kd-tree built on the GPU
+    (sga_index_build_kdtree)."""
 
-    def __init__(self, points, cell_size=0.0, search_radius=1.0, points_per_cell=0.0, max_cells=0, num_threads=1):
+    def __init__(self, points, num_threads=1, **_ignored):
         if not isinstance(points, PointCloud):
             points = PointCloud(points)
         self.cloud = points
         self.ctx = points.ctx
-        gp = GridParams(float(cell_size), float(search_radius), float(points_per_cell), int(max_cells))
         self.h = C.c_void_p()
-        check(load().sga_index_build_grid(self.ctx.h, points.h, C.byref(gp), C.byref(self.h)))
+        check(load().sga_index_build_kdtree(self.ctx.h, points.h, C.byref(self.h)))
 
     def __del__(self):
         if getattr(self, "h", None) and self.h.value:
@@ -479,7 +478,7 @@ def align(
             return Problem(vm, src, init_T_target_source).align(setting, init_T_target_source)
         target, source, target_tree = tgt, src, tree
     if target_tree is None:
-        target_tree = KdTree(target, search_radius=max_correspondence_distance or 1.0)
+        target_tree = KdTree(target)
     target_tree.refresh_attributes()
     setting = make_setting(registration_type, max_correspondence_distance, max_iterations, verbose=verbose, **kw)
     return Problem(target_tree, source, init_T_target_source).align(setting, init_T_target_source)

@@ -98,40 +98,28 @@ struct sga_cloud {
   sga::DevBuf<sga::Cov8> cov;
 };
 
-enum { SGA_INDEX_GRID = 0, SGA_INDEX_VOXELMAP = 1 };
-
-struct GridDesc {
-  float origin[3];   // lower corner of cell (0,0,0)
-  float inv_cell;    // 1 / h
-  float cell;        // h
-  int dims[3];       // nx, ny, nz
-  // linear cell id = (z * ny + y) * nx + x  (x fastest: the cells of one (y,z) row are contiguous in the sorted target)
-};
+enum { SGA_INDEX_KDTREE = 0, SGA_INDEX_VOXELMAP = 1 };
 
 struct sga_index {
-  int kind = SGA_INDEX_GRID;
+  int kind = SGA_INDEX_KDTREE;
   int device = 0;
-  size_t n = 0;  // points (grid) or voxels (voxelmap)
+  size_t n = 0;  // points (kd-tree) or voxels (voxel map)
   bool has_normals = false, has_covs = false;
-  // grid
-  GridDesc grid{};
-  sga::DevBuf<float4> pts;          // cell-sorted (kNN / preprocessing walks); w = original index bits.  Voxel maps: means in voxel-id order
-  sga::DevBuf<float4> nrm;          // kd order, like kd_pts
-  sga::DevBuf<sga::Cov8> cov;       // kd order.  Voxel maps: mean covariances in voxel-id order
-  sga::DevBuf<uint32_t> cell_start; // ncells + 1
-  uint64_t ncells = 0;
-  // implicit balanced kd-tree over the target (registration hot path, kd_search.hpp): points in kd order + {threshold, axis} heap
+  // implicit balanced kd-tree over the target (kd_search.hpp): points in kd order + {threshold, axis} heap
   sga::DevBuf<float4> kd_pts;       // kd order; w = original index bits
+  sga::DevBuf<float4> nrm;          // kd order
+  sga::DevBuf<sga::Cov8> cov;       // kd order.  Voxel maps: mean covariances in voxel-id order
   sga::DevBuf<float2> kd_nodes;     // 2^kd_depth entries (index 0 unused)
   int kd_depth = 0;
+  float bbox_lo[3] = {0, 0, 0}, bbox_hi[3] = {0, 0, 0};
   // voxel map
+  sga::DevBuf<float4> pts;                // voxel means in voxel-id order, w = voxel id bits
   double leaf = 0.0;
   sga::DevBuf<unsigned long long> hkeys;  // open addressing, EMPTY = ~0ull
   sga::DevBuf<uint32_t> hvals;            // voxel id
   uint32_t hmask = 0;
   sga::DevBuf<int> vcoords;               // n*3
   sga::DevBuf<uint32_t> vcounts;          // n
-  // (means live in pts, mean covariances in cov)
 };
 
 struct sga_problem {

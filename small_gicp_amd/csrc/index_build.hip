@@ -1,4 +1,4 @@
-// Search-index construction on the GPU: the cell-sorted uniform grid that replaces KdTreeBuilder::build_tree
+// Search-index construction on the GPU: the implicit balanced kd-tree that replaces KdTreeBuilder::build_tree
 // (ann/kdtree.hpp:80-126, reference tree /root/reference) and the one-shot GaussianVoxelMap that replaces
 // IncrementalVoxelMap::insert + GaussianVoxel::add/finalize (ann/incremental_voxelmap.hpp:55-92,
 // ann/gaussian_voxelmap.hpp:32-53).  Build time is outside the per-iteration hot loop; sorts use rocPRIM.
@@ -53,29 +53,6 @@ static inline float dec_ordered(int i) {
   float f;
   memcpy(&f, &j, 4);
   return f;
-}
-
-__device__ __forceinline__ uint32_t point_cell(const float4 p, float ox, float oy, float oz, float inv, int nx, int ny, int nz) {
-  const int cx = min(max(cell_coord(p.x, ox, inv), 0), nx - 1);
-  const int cy = min(max(cell_coord(p.y, oy, inv), 0), ny - 1);
-  const int cz = min(max(cell_coord(p.z, oz, inv), 0), nz - 1);
-  return (static_cast<uint32_t>(cz) * ny + cy) * nx + cx;
-}
-
-__global__ void cell_keys_kernel(const float4* __restrict__ pts, size_t n, float ox, float oy, float oz, float inv, int nx, int ny, int nz, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ counts) {
-  const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t c = point_cell(pts[i], ox, oy, oz, inv, nx, ny, nz);
-  if (keys) keys[i] = c;
-  if (vals) vals[i] = static_cast<uint32_t>(i);
-  atomicAdd(&counts[c], 1u);
-}
-
-__global__ void count_nonzero_kernel(const uint32_t* __restrict__ counts, size_t n, unsigned long long* __restrict__ out) {
-  unsigned int local = 0;
-  for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n; i += static_cast<size_t>(gridDim.x) * blockDim.x) local += counts[i] != 0;
-  for (int off = 32; off > 0; off >>= 1) local += __shfl_xor(local, off);
-  if ((threadIdx.x & 63) == 0 && local) atomicAdd(out, static_cast<unsigned long long>(local));
 }
 
 __global__ void gather_sorted_kernel(
@@ -239,37 +216,6 @@ static int build_kdtree(sga_context* ctx, const sga_cloud* cloud, sga_index* idx
   return SGA_OK;
 }
 
-static void grid_dims(const float lo[3], const float hi[3], double h, int dims[3]) {
-  for (int k = 0; k < 3; k++) {
-    const double ext = std::max(0.0, static_cast<double>(hi[k]) - lo[k]);
-    const double d = std::floor(ext / h) + 1.0;
-    dims[k] = static_cast<int>(std::min(d, 2.0e9));
-  }
-}
-static double grid_cells(const int dims[3]) { return static_cast<double>(dims[0]) * dims[1] * dims[2]; }
-
-struct GridScratch {
-  DevBuf<uint32_t> counts;
-  DevBuf<unsigned long long> occ;
-};
-
-// number of occupied cells at cell size h (dense count table)
-static int count_occupied(sga_context* ctx, const sga_cloud* cloud, const float lo[3], double h, const int dims[3], GridScratch& sc, uint64_t* occupied) {
-  const size_t ncells = static_cast<size_t>(grid_cells(dims));
-  SGA_TRY(sc.counts.reserve(ncells + 1));
-  if (!sc.occ.p) SGA_TRY(sc.occ.alloc(1));
-  SGA_HIP(hipMemsetAsync(sc.counts.p, 0, (ncells + 1) * sizeof(uint32_t), ctx->stream));
-  SGA_HIP(hipMemsetAsync(sc.occ.p, 0, sizeof(unsigned long long), ctx->stream));
-  hipLaunchKernelGGL(cell_keys_kernel, dim3((cloud->n + 255) / 256), dim3(256), 0, ctx->stream, cloud->pts.p, cloud->n, lo[0], lo[1], lo[2], static_cast<float>(1.0 / h), dims[0], dims[1], dims[2], nullptr, nullptr, sc.counts.p);
-  hipLaunchKernelGGL(count_nonzero_kernel, dim3(1024), dim3(256), 0, ctx->stream, sc.counts.p, ncells, sc.occ.p);
-  SGA_HIP(hipGetLastError());
-  unsigned long long occ = 0;
-  SGA_HIP(hipMemcpyAsync(&occ, sc.occ.p, sizeof(occ), hipMemcpyDeviceToHost, ctx->stream));
-  SGA_HIP(hipStreamSynchronize(ctx->stream));
-  *occupied = occ;
-  return SGA_OK;
-}
-
 // ---- voxel map kernels -------------------------------------------------------------------------------------------------------
 __global__ void voxel_keys_kernel(const float4* __restrict__ pts, size_t n, double inv_leaf, unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals) {
   const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
@@ -365,27 +311,18 @@ using namespace sga;
 
 extern "C" {
 
-int sga_index_build_grid(sga_context* ctx, const sga_cloud* target, const sga_grid_params* params, sga_index** out) {
+int sga_index_build_kdtree(sga_context* ctx, const sga_cloud* target, sga_index** out) {
   if (!ctx || !target || !out) return fail(SGA_ERR_INVALID, "null argument");
   if (target->device != ctx->device) return fail(SGA_ERR_INVALID, "cloud lives on another device");
   *out = nullptr;
   SGA_HIP(hipSetDevice(ctx->device));
-  sga_grid_params gp{};
-  if (params) gp = *params;
   const size_t n = target->n;
-  const double radius = gp.search_radius > 0 ? gp.search_radius : 1.0;
-  const double ppc_target = gp.points_per_cell > 0 ? gp.points_per_cell : 2.0;
-  uint64_t max_cells = gp.max_cells ? gp.max_cells : std::max<uint64_t>(1ull << 16, 64ull * n);
-  max_cells = std::min<uint64_t>(max_cells, 1ull << 30);
-
   std::unique_ptr<sga_index> idx(new sga_index);
-  idx->kind = SGA_INDEX_GRID;
+  idx->kind = SGA_INDEX_KDTREE;
   idx->device = ctx->device;
   idx->n = n;
   idx->has_normals = target->has_normals;
   idx->has_covs = target->has_covs;
-
-  float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
   if (n > 0) {
     DevBuf<float> d_bbox;
     SGA_TRY(d_bbox.alloc(6));
@@ -397,92 +334,11 @@ int sga_index_build_grid(sga_context* ctx, const sga_cloud* target, const sga_gr
     SGA_HIP(hipMemcpyAsync(h_bbox, d_bbox.p, sizeof(h_bbox), hipMemcpyDeviceToHost, ctx->stream));
     SGA_HIP(hipStreamSynchronize(ctx->stream));
     for (int k = 0; k < 3; k++) {
-      lo[k] = dec_ordered(h_bbox[k]);
-      hi[k] = dec_ordered(h_bbox[3 + k]);
-      if (!std::isfinite(lo[k]) || !std::isfinite(hi[k])) return fail(SGA_ERR_INVALID, "target cloud contains non-finite coordinates");
+      idx->bbox_lo[k] = dec_ordered(h_bbox[k]);
+      idx->bbox_hi[k] = dec_ordered(h_bbox[3 + k]);
+      if (!std::isfinite(idx->bbox_lo[k]) || !std::isfinite(idx->bbox_hi[k])) return fail(SGA_ERR_INVALID, "target cloud contains non-finite coordinates");
     }
-  }
-
-  // ---- cell size ----
-  const double ext_max = std::max({static_cast<double>(hi[0]) - lo[0], static_cast<double>(hi[1]) - lo[1], static_cast<double>(hi[2]) - lo[2], 1e-6});
-  auto cap_h = [&](double h) {
-    int d[3];
-    grid_dims(lo, hi, h, d);
-    while (grid_cells(d) > static_cast<double>(max_cells)) {
-      h *= 1.2599210498948732;  // 2^(1/3): halves the cell count
-      grid_dims(lo, hi, h, d);
-    }
-    return h;
-  };
-  double h;
-  GridScratch sc;
-  if (gp.cell_size > 0) {
-    h = cap_h(gp.cell_size);
-  } else if (n == 0) {
-    h = radius;
-  } else {
-    const double h_hi = std::min(radius, ext_max);
-    const double h_lo = h_hi / 64.0;
-    h = cap_h(h_hi);
-    double h_prev = 0, ppc_prev = 0;
-    for (int it = 0; it < 4; it++) {
-      int d[3];
-      grid_dims(lo, hi, h, d);
-      uint64_t occ = 0;
-      SGA_TRY(count_occupied(ctx, target, lo, h, d, sc, &occ));
-      const double ppc = static_cast<double>(n) / std::max<uint64_t>(occ, 1);
-      if (ppc <= ppc_target * 1.3 || it == 3) break;  // cells never get larger than the search radius
-      double expo = 2.0;  // surface-like clouds: occupancy ~ h^2
-      if (it > 0 && h_prev != h && ppc_prev > 0) expo = std::min(3.0, std::max(1.0, std::log(ppc / ppc_prev) / std::log(h / h_prev)));
-      h_prev = h;
-      ppc_prev = ppc;
-      double h_new = h * std::pow(ppc_target / ppc, 1.0 / expo);
-      h_new = cap_h(std::max(h_lo, std::min(h_hi, h_new)));
-      if (std::abs(h_new - h) < 1e-3 * h) break;
-      h = h_new;
-    }
-  }
-  int dims[3];
-  grid_dims(lo, hi, h, dims);
-  const size_t ncells = static_cast<size_t>(grid_cells(dims));
-  idx->grid.origin[0] = lo[0];
-  idx->grid.origin[1] = lo[1];
-  idx->grid.origin[2] = lo[2];
-  idx->grid.cell = static_cast<float>(h);
-  idx->grid.inv_cell = static_cast<float>(1.0 / h);
-  idx->grid.dims[0] = dims[0];
-  idx->grid.dims[1] = dims[1];
-  idx->grid.dims[2] = dims[2];
-  idx->ncells = ncells;
-
-  // ---- keys, histogram, scan, stable sort, gather ----
-  SGA_TRY(idx->cell_start.alloc(ncells + 1));
-  SGA_HIP(hipMemsetAsync(idx->cell_start.p, 0, (ncells + 1) * sizeof(uint32_t), ctx->stream));
-  if (n > 0) {
-    DevBuf<uint32_t> keys, keys_sorted, vals, vals_sorted;
-    SGA_TRY(keys.alloc(n));
-    SGA_TRY(keys_sorted.alloc(n));
-    SGA_TRY(vals.alloc(n));
-    SGA_TRY(vals_sorted.alloc(n));
-    hipLaunchKernelGGL(cell_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, target->pts.p, n, lo[0], lo[1], lo[2], idx->grid.inv_cell, dims[0], dims[1], dims[2], keys.p, vals.p, idx->cell_start.p);
-    SGA_HIP(hipGetLastError());
-    size_t tb = 0;
-    SGA_HIP(rocprim::exclusive_scan(nullptr, tb, idx->cell_start.p, idx->cell_start.p, 0u, ncells + 1, rocprim::plus<uint32_t>(), ctx->stream));
-    SGA_TRY(ensure_temp(ctx, tb));
-    SGA_HIP(rocprim::exclusive_scan(ctx->d_temp.p, tb, idx->cell_start.p, idx->cell_start.p, 0u, ncells + 1, rocprim::plus<uint32_t>(), ctx->stream));
-    unsigned end_bit = 1;
-    while (end_bit < 32 && (1ull << end_bit) < ncells) end_bit++;
-    size_t tb2 = 0;
-    SGA_HIP(rocprim::radix_sort_pairs(nullptr, tb2, keys.p, keys_sorted.p, vals.p, vals_sorted.p, n, 0, end_bit, ctx->stream));
-    SGA_TRY(ensure_temp(ctx, tb2));
-    SGA_HIP(rocprim::radix_sort_pairs(ctx->d_temp.p, tb2, keys.p, keys_sorted.p, vals.p, vals_sorted.p, n, 0, end_bit, ctx->stream));
-    SGA_TRY(idx->pts.alloc(n));
-    hipLaunchKernelGGL(gather_sorted_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, vals_sorted.p, n, target->pts.p, static_cast<const float4*>(nullptr), static_cast<const Cov8*>(nullptr), idx->pts.p, static_cast<float4*>(nullptr), static_cast<Cov8*>(nullptr));
-    SGA_HIP(hipGetLastError());
-    SGA_HIP(hipStreamSynchronize(ctx->stream));
     SGA_TRY(build_kdtree(ctx, target, idx.get()));
-  } else {
-    SGA_HIP(hipStreamSynchronize(ctx->stream));
   }
   *out = idx.release();
   return SGA_OK;

@@ -177,6 +177,80 @@ __device__ __forceinline__ KdBest kd_nearest(const KdView& t, float qx, float qy
   return best;
 }
 
+// ---- k nearest neighbours (traits::knn_search; normal / covariance estimation) -----------------------------------------------------
+// Same walk as kd_nearest with the k-th best distance as the pruning bound.  The k-best list lives in LDS as [k][STRIDE]
+// (lane-contiguous, conflict-free), sorted ascending by (distance, position) — KnnResult<-1>::push (ann/knn_result.hpp:80-100)
+// with a canonical tie rule.  sd / si must be initialised to +inf / -1 by the caller.  bound2: ignore points with d2 >= bound2.
+template <int STRIDE>
+__device__ __forceinline__ void kd_knn(const KdView& t, float qx, float qy, float qz, int k, float bound2, float* __restrict__ sd, int* __restrict__ si, uint32_t* __restrict__ stack, int tid) {
+  if (t.n == 0) return;
+  const int D = t.depth;
+  float worst = bound2;     // k-th best squared distance so far
+  int worst_id = 0x7fffffff;
+  auto leaf_scan = [&](uint32_t leaf_node) {
+    const uint32_t kk = leaf_node - (1u << D);
+    const uint32_t first = kd_bound(t.n, D, kk), end = kd_bound(t.n, D, kk + 1);
+    for (uint32_t j0 = first; j0 < end; j0 += 4) {
+      float4 p[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) p[u] = t.pts[min(j0 + u, end - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        if (j0 + u >= end) continue;
+        const int id = static_cast<int>(j0 + u);
+        const float dx = p[u].x - qx, dy = p[u].y - qy, dz = p[u].z - qz;
+        const float d2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+        if (!(d2 < worst || (d2 == worst && id < worst_id))) continue;
+        int loc = k - 1;
+        for (; loc > 0; loc--) {
+          const float pd = sd[(loc - 1) * STRIDE + tid];
+          const int pi = si[(loc - 1) * STRIDE + tid];
+          if (!(d2 < pd || (d2 == pd && (pi < 0 || id < pi)))) break;
+          sd[loc * STRIDE + tid] = pd;
+          si[loc * STRIDE + tid] = pi;
+        }
+        sd[loc * STRIDE + tid] = d2;
+        si[loc * STRIDE + tid] = id;
+        const int li = si[(k - 1) * STRIDE + tid];
+        if (li >= 0) {  // list full: the bound tightens to the k-th best
+          worst = sd[(k - 1) * STRIDE + tid];
+          worst_id = li;
+        }
+      }
+    }
+  };
+  int sp = 0, depth = 0;
+  uint32_t node = 1;
+  for (;;) {
+    while (depth < D) {
+      const float2 nd = t.nodes[node];
+      const int axis = __float_as_int(nd.y);
+      const float qa = axis == 0 ? qx : (axis == 1 ? qy : qz);
+      const float diff = qa - nd.x;
+      const float cut = diff * diff;
+      depth++;
+      if (cut <= worst) {
+        stack[sp * STRIDE + tid] = kd_pack(cut, depth);
+        sp++;
+      }
+      node = 2 * node + (diff < 0.f ? 0u : 1u);
+    }
+    leaf_scan(node);
+    bool found = false;
+    while (sp > 0) {
+      sp--;
+      const uint32_t e = stack[sp * STRIDE + tid];
+      if (kd_cut(e) <= worst) {
+        depth = static_cast<int>(e & 31u);
+        node = (node >> (D - depth)) ^ 1u;
+        found = true;
+        break;
+      }
+    }
+    if (!found) break;
+  }
+}
+
 // ---- wave-cooperative search ---------------------------------------------------------------------------------------------------------
 // The source cloud is Morton-sorted, so the 64 queries of a wave are neighbours in space and need (almost) the same leaves.
 // Instead of 64 divergent tree walks the wave

@@ -8,7 +8,7 @@
 #include <memory>
 #include <rocprim/rocprim.hpp>
 
-#include "nn_search.hpp"
+#include "kd_search.hpp"
 
 namespace sga {
 
@@ -180,13 +180,14 @@ __device__ __forceinline__ Eig3 eigen_sym3(const double a[3][3] /* lower triangl
 // ---- normals / covariances -----------------------------------------------------------------------------------------------------
 constexpr int kFeatBlock = 64;
 
-// One lane per point of the (cell-sorted) index; neighbours come from the same index.  Results are written both to the
-// index's sorted attribute arrays and, through the original index kept in pts.w, to the caller's cloud.
+// One lane per point of the kd-ordered index; neighbours come from the same tree.  Results are written both to the index's
+// kd-ordered attribute arrays and, through the original index kept in pts.w, to the caller's cloud.
 __global__ __launch_bounds__(kFeatBlock) void local_features_kernel(
-  const GridView g, size_t n, int k, int flags, float4* __restrict__ idx_nrm, Cov8* __restrict__ idx_cov, float4* __restrict__ cloud_nrm, Cov8* __restrict__ cloud_cov) {
+  const KdView g, size_t n, int k, int flags, float4* __restrict__ idx_nrm, Cov8* __restrict__ idx_cov, float4* __restrict__ cloud_nrm, Cov8* __restrict__ cloud_cov) {
   extern __shared__ float sh[];
   float* sd = sh;
   int* si = reinterpret_cast<int*>(sh + static_cast<size_t>(k) * kFeatBlock);
+  uint32_t* stack = reinterpret_cast<uint32_t*>(sh + 2 * static_cast<size_t>(k) * kFeatBlock);
   const int lane = threadIdx.x;
   const size_t i = blockIdx.x * static_cast<size_t>(kFeatBlock) + lane;
   for (int j = 0; j < k; j++) {
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(kFeatBlock) void local_features_kernel(
   }
   if (i >= n) return;
   const float4 p = g.pts[i];
-  grid_knn_lds<kFeatBlock>(g, p.x, p.y, p.z, k, INFINITY, sd, si, lane);
+  kd_knn<kFeatBlock>(g, p.x, p.y, p.z, k, INFINITY, sd, si, stack, lane);
   int found = 0;
   double sp[3] = {0, 0, 0}, sc[6] = {0, 0, 0, 0, 0, 0};
   for (int j = 0; j < k; j++) {
@@ -338,7 +339,7 @@ int sga_voxelgrid_sampling(sga_context* ctx, const sga_cloud* in, double leaf, s
 
 int sga_index_refresh_attributes(sga_context* ctx, sga_index* index, const sga_cloud* cloud) {
   if (!ctx || !index || !cloud) return fail(SGA_ERR_INVALID, "null argument");
-  if (index->kind != SGA_INDEX_GRID) return fail(SGA_ERR_INVALID, "not a grid index");
+  if (index->kind != SGA_INDEX_KDTREE) return fail(SGA_ERR_INVALID, "not a kd-tree index");
   if (index->n != cloud->n) return fail(SGA_ERR_INVALID, "index was built over a cloud of %zu points, got %zu", index->n, cloud->n);
   SGA_HIP(hipSetDevice(ctx->device));
   const size_t n = index->n;
@@ -364,23 +365,23 @@ int sga_estimate_normals_covariances(sga_context* ctx, sga_cloud* cloud, const s
   sga_index* index = const_cast<sga_index*>(index_in);
   sga_index* temp = nullptr;
   if (!index) {
-    // a coarser grid than the registration index: ring 1 should already hold ~k neighbours
-    sga_grid_params gp{};
-    gp.points_per_cell = k / 3.0 < 2.0 ? 2.0 : k / 3.0;
-    gp.search_radius = 0.0;
-    SGA_TRY(sga_index_build_grid(ctx, cloud, &gp, &temp));
+    SGA_TRY(sga_index_build_kdtree(ctx, cloud, &temp));
     index = temp;
   } else {
-    if (index->kind != SGA_INDEX_GRID) return fail(SGA_ERR_INVALID, "a grid index is required");
+    if (index->kind != SGA_INDEX_KDTREE) return fail(SGA_ERR_INVALID, "a kd-tree index is required");
     if (index->n != n) return fail(SGA_ERR_INVALID, "index was built over a cloud of %zu points, got %zu", index->n, n);
   }
   int rc = SGA_OK;
   if ((flags & 1) && cloud->nrm.n < n) rc = cloud->nrm.alloc(n);
   if (rc == SGA_OK && (flags & 2) && cloud->cov.n < n) rc = cloud->cov.alloc(n);
   if (rc == SGA_OK && n > 0) {
-    const size_t shmem = static_cast<size_t>(k) * kFeatBlock * 8;
+    const size_t shmem = (static_cast<size_t>(k) * 8 + kKdMaxDepth * 4) * kFeatBlock;
+    if ((flags & 1) && !temp && index->nrm.n < n) rc = index->nrm.alloc(n);
+    if (rc == SGA_OK && (flags & 2) && !temp && index->cov.n < n) rc = index->cov.alloc(n);
+    KdView kv = make_kd_view(index);
+    kv.stats = nullptr;
     hipLaunchKernelGGL(
-      local_features_kernel, dim3((n + kFeatBlock - 1) / kFeatBlock), dim3(kFeatBlock), shmem, ctx->stream, make_grid_view(index), n, k, flags, static_cast<float4*>(nullptr), static_cast<Cov8*>(nullptr), cloud->nrm.p, cloud->cov.p);
+      local_features_kernel, dim3((n + kFeatBlock - 1) / kFeatBlock), dim3(kFeatBlock), shmem, ctx->stream, kv, n, k, flags, temp ? nullptr : index->nrm.p, temp ? nullptr : index->cov.p, cloud->nrm.p, cloud->cov.p);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) rc = fail(SGA_ERR_HIP, "local_features_kernel: %s", hipGetErrorString(e));
@@ -389,7 +390,10 @@ int sga_estimate_normals_covariances(sga_context* ctx, sga_cloud* cloud, const s
     if (flags & 1) cloud->has_normals = true;
     if (flags & 2) cloud->has_covs = true;
   }
-  if (rc == SGA_OK && !temp) rc = sga_index_refresh_attributes(ctx, index, cloud);  // the index keeps Morton-ordered copies
+  if (rc == SGA_OK && !temp) {  // the kernel wrote the index's kd-ordered copies as well
+    if (flags & 1) index->has_normals = true;
+    if (flags & 2) index->has_covs = true;
+  }
   if (temp) sga_index_destroy(temp);
   return rc;
 }

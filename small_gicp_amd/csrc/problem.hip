@@ -58,7 +58,7 @@ __global__ void source_kd_keys_kernel(const float4* __restrict__ pts, size_t n, 
     node = 2 * node + (qa - nd.x < 0.f ? 0u : 1u);
   }
   const unsigned long long leaf = node - (1u << kd.depth);
-  const long long bias = 1 << 9;
+  const long long bias = 0;
   long long cx = static_cast<long long>(floorf((qx - ox) * inv)) + bias, cy = static_cast<long long>(floorf((qy - oy) * inv)) + bias, cz = static_cast<long long>(floorf((qz - oz) * inv)) + bias;
   cx = min(max(cx, 0ll), 1023ll);
   cy = min(max(cy, 0ll), 1023ll);
@@ -89,13 +89,14 @@ __global__ void export_factors_kernel(const float4* __restrict__ src_pts, const 
   }
 }
 
-// ---- standalone kNN over the grid (traits::knn_search).  One lane per query, k-best kept in LDS as [k][64]. ----------------
+// ---- standalone kNN (traits::knn_search).  One lane per query, k-best in LDS [k][64], traversal stack in LDS [level][64]. ----
 constexpr int kKnnBlock = 64;
 
-__global__ __launch_bounds__(kKnnBlock) void knn_kernel(const GridView g, const float* __restrict__ queries, size_t m, int k, float max_sq, long long* __restrict__ out_idx, float* __restrict__ out_d2) {
-  extern __shared__ float sh[];  // k*64 distances then k*64 indices
+__global__ __launch_bounds__(kKnnBlock) void knn_kernel(const KdView t, const float* __restrict__ queries, size_t m, int k, float max_sq, long long* __restrict__ out_idx, float* __restrict__ out_d2) {
+  extern __shared__ float sh[];  // k*64 distances, k*64 indices, kKdMaxDepth*64 stack words
   float* sd = sh;
   int* si = reinterpret_cast<int*>(sh + static_cast<size_t>(k) * kKnnBlock);
+  uint32_t* stack = reinterpret_cast<uint32_t*>(sh + 2 * static_cast<size_t>(k) * kKnnBlock);
   const int lane = threadIdx.x;
   const size_t qi = blockIdx.x * static_cast<size_t>(kKnnBlock) + lane;
   for (int j = 0; j < k; j++) {
@@ -104,12 +105,13 @@ __global__ __launch_bounds__(kKnnBlock) void knn_kernel(const GridView g, const 
   }
   if (qi >= m) return;
   const float qx = queries[3 * qi], qy = queries[3 * qi + 1], qz = queries[3 * qi + 2];
-  grid_knn_lds<kKnnBlock>(g, qx, qy, qz, k, max_sq, sd, si, lane);
+  const float bound2 = max_sq < 3.0e38f ? max_sq * 1.0000002f : INFINITY;
+  kd_knn<kKnnBlock>(t, qx, qy, qz, k, bound2, sd, si, stack, lane);
   for (int j = 0; j < k; j++) {
     const float d2 = sd[j * kKnnBlock + lane];
     const int id = si[j * kKnnBlock + lane];
     const bool ok = id >= 0 && !(d2 > max_sq);
-    out_idx[qi * k + j] = ok ? static_cast<long long>(__float_as_uint(g.pts[id].w)) : -1ll;
+    out_idx[qi * k + j] = ok ? static_cast<long long>(__float_as_uint(t.pts[id].w)) : -1ll;
     out_d2[qi * k + j] = ok ? d2 : INFINITY;
   }
 }
@@ -181,16 +183,17 @@ int sga_problem_create(sga_context* ctx, const sga_index* target, const sga_clou
     SGA_TRY(vals.alloc(n));
     SGA_TRY(order.alloc(n));
     float ox = 0, oy = 0, oz = 0, inv = 1.f;
-    if (target->kind == SGA_INDEX_GRID) {
-      ox = target->grid.origin[0];
-      oy = target->grid.origin[1];
-      oz = target->grid.origin[2];
-      inv = target->grid.inv_cell;
+    if (target->kind == SGA_INDEX_KDTREE) {
+      ox = target->bbox_lo[0];
+      oy = target->bbox_lo[1];
+      oz = target->bbox_lo[2];
+      const float ext = fmaxf(fmaxf(target->bbox_hi[0] - ox, target->bbox_hi[1] - oy), fmaxf(target->bbox_hi[2] - oz, 1e-6f));
+      inv = 512.f / ext;  // 10-bit Morton cells over the target's extent refine the kd-leaf key
     } else {
       inv = static_cast<float>(4.0 / target->leaf);  // quarter-voxel cells: neighbouring lanes probe the same voxel
     }
     static const bool kd_order = !(getenv("SGA_SOURCE_ORDER") && atoi(getenv("SGA_SOURCE_ORDER")) == 0);
-    if (target->kind == SGA_INDEX_GRID && target->n > 0 && kd_order) {
+    if (target->kind == SGA_INDEX_KDTREE && target->n > 0 && kd_order) {
       KdView kv = make_kd_view(target);
       kv.stats = nullptr;
       hipLaunchKernelGGL(source_kd_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, source->pts.p, n, rigid_from_colmajor<float>(T), kv, ox, oy, oz, inv, keys.p, vals.p);
@@ -257,8 +260,10 @@ int sga_index_knn(sga_context* ctx, const sga_index* index, const float* queries
     SGA_HIP(hipMemcpyAsync(d_d.p, inf.data(), m * k * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     SGA_HIP(hipStreamSynchronize(ctx->stream));
   } else {
-    const size_t shmem = static_cast<size_t>(k) * kKnnBlock * 8;
-    hipLaunchKernelGGL(knn_kernel, dim3((m + kKnnBlock - 1) / kKnnBlock), dim3(kKnnBlock), shmem, ctx->stream, make_grid_view(index), d_q.p, m, k, max_sq, d_i.p, d_d.p);
+    const size_t shmem = (static_cast<size_t>(k) * 8 + kKdMaxDepth * 4) * kKnnBlock;
+    KdView kv = make_kd_view(index);
+    kv.stats = nullptr;
+    hipLaunchKernelGGL(knn_kernel, dim3((m + kKnnBlock - 1) / kKnnBlock), dim3(kKnnBlock), shmem, ctx->stream, kv, d_q.p, m, k, max_sq, d_i.p, d_d.p);
   }
   SGA_HIP(hipGetLastError());
   SGA_HIP(hipMemcpyAsync(idx, d_i.p, m * k * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));

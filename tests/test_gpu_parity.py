@@ -358,3 +358,27 @@ def test_bench_contract():
         assert key in j, key
     assert j["value"] > 0 and j["steps"] >= 20 and j["roofline"]["achieved"] > 0 and j["cpu_baseline"]["value"] > 0
     assert j["final_pose_error"]["trans_m"] < 0.02
+
+
+def test_scan_to_scan_odometry_matches_oracle(orc):
+    """Config C5 protocol on four KITTI-shaped scans: the GPU pipeline (raw scan -> 0.25 m voxel grid -> covariances k = 20 -> GICP
+    against the previous scan) tracks the CPU oracle following the same steps, and both recover the simulated motion."""
+    from small_gicp_amd import odometry
+
+    odom = odometry.OnlineOdometry()
+    prev = None
+    for f in range(4):
+        pts, Tws = sga.synthetic.kitti_like_scan(f)
+        before = odom.T_world.copy()
+        odom.estimate(pts)
+        down = orc.voxelgrid_sampling(pts, 0.25)
+        cloud = orc.Cloud(down.astype(np.float32).astype(np.float64), tree=True)
+        cloud.estimate_normals_covariances(20, 8)
+        if prev is not None:
+            ref = orc.align(prev, cloud, orc.default_setting(factor_kind=orc.GICP, num_threads=8))
+            rel = np.linalg.inv(before) @ odom.T_world
+            dt, dr = pose_error(rel, ref.T_target_source)
+            assert dt < 2e-4 and dr < 1e-4, (f, dt, dr)
+            # simulated motion: 1 m forward, 1 deg yaw per frame
+            assert abs(np.linalg.norm(rel[:3, 3]) - 1.0) < 0.02
+        prev = cloud
