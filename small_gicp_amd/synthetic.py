@@ -89,8 +89,8 @@ def kitti_like_scan(frame, n_rings=64, n_az=2030, layout_seed=12345, noise=0.02,
     # ground z = 0
     with np.errstate(divide="ignore", invalid="ignore"):
         tg = -o[2] / d[:, 2]
+        hit = o + tg[:, None] * d
     ok = (tg > 0) & np.isfinite(tg)
-    hit = o + tg[:, None] * d
     ok &= (np.abs(hit[:, 0]) <= 50) & (np.abs(hit[:, 1]) <= 50)
     t_best = np.where(ok, tg, t_best)
     for w in range(nwalls):
@@ -98,7 +98,7 @@ def kitti_like_scan(frame, n_rings=64, n_az=2030, layout_seed=12345, noise=0.02,
         other = 1 - ax
         with np.errstate(divide="ignore", invalid="ignore"):
             tw = (centers[w, ax] - o[ax]) / d[:, ax]
-        hitw = o + tw[:, None] * d
+            hitw = o + tw[:, None] * d
         okw = (tw > 0) & np.isfinite(tw) & (np.abs(hitw[:, other] - centers[w, other]) <= 0.5 * lengths[w]) & (hitw[:, 2] >= 0) & (hitw[:, 2] <= heights[w])
         t_best = np.where(okw & (tw < t_best), tw, t_best)
     keep = np.isfinite(t_best) & (t_best >= 3.0) & (t_best <= 80.0)

@@ -382,3 +382,41 @@ def test_scan_to_scan_odometry_matches_oracle(orc):
             # simulated motion: 1 m forward, 1 deg yaw per frame
             assert abs(np.linalg.norm(rel[:3, 3]) - 1.0) < 0.02
         prev = cloud
+
+
+def test_cpp_header_layer(tmp_path, c1_raw, c1_gold):
+    """include/small_gicp_amd.hpp — Registration<Factor, ParallelReductionHIP> and the helper align() overloads, compiled with g++
+    against the C-ABI library and run on config C1: same poses as the oracle goldens (1e-4 m / 1e-4 rad)."""
+    exe = tmp_path / "test_cpp_api"
+    libdir = os.path.dirname(sga.LIB_PATH)
+    cmd = ["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "test_cpp_api.cpp"), "-o", str(exe), "-L" + libdir, "-lsmall_gicp_amd", "-Wl,-rpath," + libdir, "-Wl,-rpath-link,/opt/rocm/lib"]
+    subprocess.check_call(cmd)
+    tgt, src, T_gt = c1_raw
+    (tmp_path / "t.f32").write_bytes(np.ascontiguousarray(tgt, dtype=np.float32).tobytes())
+    (tmp_path / "s.f32").write_bytes(np.ascontiguousarray(src, dtype=np.float32).tobytes())
+    p = subprocess.run([str(exe), str(tmp_path / "t.f32"), str(tmp_path / "s.f32")], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    cases = {}
+    for ln in p.stdout.splitlines():
+        tok = ln.split()
+        if tok[0] == "CASE":
+            cases[tok[1]] = dict(iterations=int(tok[2]), inliers=int(tok[3]), converged=int(tok[4]), error=float(tok[5]), T=np.array([float(x) for x in tok[6:22]]).reshape(4, 4).T)
+        elif tok[0] == "SIZES":
+            assert [int(tok[1]), int(tok[2])] == c1_gold["downsampled_sizes"]
+        elif tok[0] == "VOXELS":
+            assert int(tok[1]) == c1_gold["cases"]["VGICP"]["num_voxels"]
+        elif tok[0] == "ACCESS":
+            assert int(tok[1]) == 1 and int(tok[2]) == 0 and float(tok[3]) < 1e-9 and float(tok[4]) == 1.0 and abs(float(tok[5]) - 2.001) < 1e-3
+    for name, gold in [("HELPER_GICP", "GICP"), ("GICP", "GICP"), ("PLANE_ICP", "PLANE_ICP"), ("ICP", "ICP"), ("HUBER_GICP", "HUBER_GICP"), ("CAUCHY_GICP", "CAUCHY_GICP"), ("VGICP", "VGICP"), ("HELPER_VGICP", "VGICP")]:
+        g = c1_gold["cases"][gold]
+        c = cases[name]
+        dt, dr = pose_error(c["T"], np.array(g["T"]))
+        assert dt < POSE_TOL_T and dr < POSE_TOL_R, (name, dt, dr)
+        assert c["iterations"] == g["iterations"] and abs(c["inliers"] - g["num_inliers"]) <= 2 and c["converged"] == int(g["converged"])
+    # Gauss-Newton and the DoF-restricted run land near the ground truth as well
+    for name in ("GN_GICP", "RESTRICT_GICP"):
+        dt, dr = pose_error(cases[name]["T"], T_gt)
+        assert dt < 0.1 and dr < 0.03, (name, dt, dr)
+    # RestrictDoF: roll/pitch and z stay (softly) frozen
+    Tr = cases["RESTRICT_GICP"]["T"]
+    assert abs(Tr[2, 3]) < 2e-3 and abs(Tr[2, 0]) < 1e-3 and abs(Tr[2, 1]) < 1e-3  # soft constraints (general_factor.hpp:42)
