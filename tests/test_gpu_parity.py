@@ -420,3 +420,57 @@ def test_cpp_header_layer(tmp_path, c1_raw, c1_gold):
     # RestrictDoF: roll/pitch and z stay (softly) frozen
     Tr = cases["RESTRICT_GICP"]["T"]
     assert abs(Tr[2, 3]) < 2e-3 and abs(Tr[2, 0]) < 1e-3 and abs(Tr[2, 1]) < 1e-3  # soft constraints (general_factor.hpp:42)
+
+
+def test_c2_plane_icp_100k_matches_oracle(orc):
+    """Config C2 (point-to-plane ICP, 100k <-> 100k synthetic fp32 points, normals k = 20): accumulators at two poses and the final
+    pose against the oracle fed the very same fp32 points and normals."""
+    target, source, T_gt = sga.synthetic.registration_pair(100_000)
+    tgt = sga.PointCloud(target)
+    sga.estimate_normals(tgt, None, 20)
+    tree = sga.KdTree(tgt)
+    src = sga.PointCloud(source)
+    nrm = tgt.normals()[:, :3]
+    otc = orc.Cloud(target.astype(np.float64), nrm)
+    osc = orc.Cloud(source.astype(np.float64), tree=False)
+    st = sga.make_setting("PLANE_ICP")
+    os_ = orc.default_setting(factor_kind=orc.PLANE_ICP, num_threads=8)
+    pb = sga.Problem(tree, src)
+    f = orc.Factors(len(osc))
+    for T in (np.eye(4), T_gt):
+        H, b, e, n = pb.linearize(st.factor, T)
+        Ho, bo, eo, no = orc.linearize(otc, osc, os_, T, f)
+        assert abs(int(n) - int(no)) <= 5
+        assert np.abs(H - Ho).max() <= FP32_REL * np.abs(Ho).max() and abs(e - eo) <= FP32_REL * eo
+    res = pb.align(st)
+    ref = orc.align(otc, osc, os_)
+    dt, dr = pose_error(res.T_target_source, ref.T_target_source)
+    assert dt < POSE_TOL_T and dr < POSE_TOL_R and res.iterations == ref.iterations, (dt, dr, res.iterations, ref.iterations)
+    dt, dr = pose_error(res.T_target_source, T_gt)
+    assert dt < 0.02 and dr < 2e-3
+
+
+def test_c4_vgicp_1m_properties(c3):
+    """Config C4 (VGICP: GaussianVoxelMap(0.5 m) of the 1M target, 1M source points): determinism, idempotence of the cached state,
+    shard additivity, agreement of fp32 and fp64 math, and recovery of the ground truth."""
+    vm = sga.GaussianVoxelMap(0.5)
+    vm.insert(c3["tgt"])
+    coords, means, c6, counts = vm.download()
+    assert counts.sum() == 1_000_000 and len(np.unique(coords, axis=0)) == len(coords)
+    # every voxel mean lies inside its voxel
+    assert (np.floor(means.astype(np.float64) / 0.5).astype(np.int64) == coords).mean() > 0.9999
+    st = sga.make_setting("GICP")
+    pb = sga.Problem(vm, c3["src"])
+    T = c3["T_gt"]
+    H, b, e, n = pb.linearize(st.factor, T)
+    H2, b2, e2, n2 = pb.linearize(st.factor, T)
+    assert (H == H2).all() and e == e2 and n == n2 and n > 500_000
+    assert abs(pb.error(st.factor, T) - e) <= 1e-6 * e
+    half = len(c3["source"]) // 2
+    parts = [sga.Problem(vm, sga.PointCloud(c3["source"][sl], covs=c3["src_cov"][sl])).linearize(st.factor, T) for sl in (slice(0, half), slice(half, None))]
+    assert sum(p[3] for p in parts) == n and abs(sum(p[2] for p in parts) - e) <= 1e-9 * e
+    H64, b64, e64, n64 = pb.linearize(sga.make_setting("GICP", math_mode="fp64").factor, T)
+    assert abs(int(n64) - int(n)) <= 50 and abs(e64 - e) <= 1e-5 * e64
+    res = pb.align(st)
+    dt, dr = pose_error(res.T_target_source, c3["T_gt"])
+    assert res.converged and dt < 0.02 and dr < 2e-3, (dt, dr)
