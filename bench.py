@@ -265,38 +265,50 @@ def odometry_leg(sga, args):
 
 
 def cpu_baseline(sga, tgt, src, n, args):
-    """The CPU oracle (oracle/: restatement of ParallelReductionOMP + KdTree + GICPFactor + LM, kind = "port") on the SAME clouds
-    and covariances, all host threads; timed region = the optimizer loop only (index build excluded, as on the GPU side)."""
+    """CPU baseline on the SAME clouds and covariances, all host threads, timed region = the optimizer loop only (index build
+    excluded, as on the GPU side).  kind "reference": the unmodified reference code (registration_helper.cpp align ->
+    Registration<GICPFactor, ParallelReductionOMP>) from oracle/_ref, when that library travelled with the repository;
+    kind "port": the oracle's restatement of the same path (oracle/), otherwise."""
     try:
-        from oracle import orc
+        from oracle import orc, ref
 
         orc.build()
         tp = tgt.xyz().astype(np.float64)
         sp = src.xyz().astype(np.float64)
         tcov = tgt.covs()[:, :3, :3]
         scov = src.covs()[:, :3, :3]
-        t0 = time.perf_counter()
-        otc = orc.Cloud(tp, None, tcov, tree=True)
-        osc = orc.Cloud(sp, None, scov, tree=False)
-        build_s = time.perf_counter() - t0
         ncpu = os.cpu_count() or 1
+        counts = sorted({ncpu, max(1, ncpu // 2), max(1, ncpu // 4), max(1, ncpu // 8)}, reverse=True)
+        use_ref = ref.available()
+        t0 = time.perf_counter()
+        if use_ref:
+            otc = ref.Cloud(tp, None, tcov, tree=True, tree_threads=min(32, ncpu))
+            osc = ref.Cloud(sp, None, scov, tree=False)
+        else:
+            otc = orc.Cloud(tp, None, tcov, tree=True)
+            osc = orc.Cloud(sp, None, scov, tree=False)
+        build_s = time.perf_counter() - t0
         best = None
         tried = {}
-        for threads in sorted({ncpu, max(1, ncpu // 2), max(1, ncpu // 4), max(1, ncpu // 8)}, reverse=True):
-            s = orc.default_setting(factor_kind=orc.GICP, num_threads=threads, max_iterations=args.cpu_iters, rotation_eps=0.0, translation_eps=0.0)
-            r = orc.align(otc, osc, s)
+        for threads in counts:
+            if use_ref:
+                r = ref.align(otc, osc, ref.GICP, 1.0, 1.0, threads, args.cpu_iters, 0.0, 0.0)
+            else:
+                s = orc.default_setting(factor_kind=orc.GICP, num_threads=threads, max_iterations=args.cpu_iters, rotation_eps=0.0, translation_eps=0.0)
+                r = orc.align(otc, osc, s)
             ips = (r.iterations + 1) / r.elapsed_sec
             tried[str(threads)] = ips
             if best is None or ips > best[0]:
                 best = (ips, threads, r)
         ips, threads, r = best
+        what = "unmodified reference code (oracle/_ref: registration_helper.cpp align, Registration<GICPFactor, ParallelReductionOMP>, built over an Eigen stand-in)" if use_ref else "oracle/ restatement of ParallelReductionOMP + KdTree + GICPFactor + LM"
         return {
             "value": ips,
             "unit": "iterations/s",
             "cores": threads,
-            "kind": "port",
-            "sample": "full C3 pair (%d<->%d), %d outer LM iterations from identity, OpenMP schedule(guided,8); kd-tree build %.2fs excluded; iterations/s by thread count: %s"
-            % (n, n, r.iterations + 1, build_s, json.dumps(tried)),
+            "kind": "reference" if use_ref else "port",
+            "sample": "%s; full C3 pair (%d<->%d), %d outer LM iterations from identity, OpenMP schedule(guided,8); kd-tree build %.2fs excluded; iterations/s by thread count: %s"
+            % (what, n, n, r.iterations + 1, build_s, json.dumps(tried)),
             "host_threads_available": ncpu,
         }
     except Exception as ex:  # noqa: BLE001

@@ -3,11 +3,12 @@
 // (reference tree at /root/reference, citations are relative to it).  It exists to CHECK the HIP path and to be
 // timed as the CPU baseline (bench.py cpu_baseline, kind "port").  Nothing in small_gicp_amd/ may call it.
 //
-// Pinning: tests/test_oracle_pins.py checks this restatement against every known-answer fixture the reference's
-// own tests hold for this path (data/T_target_source.txt within the reference tolerances for all factor types,
-// exact kNN vs brute force / scipy incl. the synthetic tie/lattice/tiny/huge clouds, fast_floor == floor, H
-// symmetric with lambda_min > 10) and, when /root/reference is present, against oracle/_ref (the UNMODIFIED reference
-// headers compiled against a home-made Eigen shim).  The reference ships no bit-exact numeric goldens.
+// Pinning (both green): (1) tests/test_oracle_pins.py checks this restatement against every known-answer fixture the
+// reference's own tests hold for this path (data/T_target_source.txt within the reference tolerances for all factor types, exact
+// kNN vs brute force / scipy incl. the synthetic tie/lattice/tiny/huge clouds, fast_floor == floor, H symmetric with
+// lambda_min > 10); (2) tests/test_oracle_vs_reference.py checks it stage by stage against oracle/_ref — the UNMODIFIED reference
+// headers + registration_helper.cpp compiled in place over a home-made Eigen stand-in (oracle/ref/): same voxels, same kNN
+// indices, same inliers and iteration counts, poses equal to 1e-9.  The reference ships no bit-exact numeric goldens.
 //
 // Homogeneous coordinates: the reference stores (x,y,z,1) / (nx,ny,nz,0) / 4x4 covs with a zero last row+column.
 // Every formula below is the 3-D restriction of the reference's 4-D expression; the w terms cancel identically.

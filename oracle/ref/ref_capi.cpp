@@ -1,0 +1,217 @@
+// TEST INFRASTRUCTURE — NOT PRODUCT CODE.
+// C entry points over the UNMODIFIED reference (koide3/small_gicp v1.0.1): its headers under /root/reference/include and its one
+// compiled source, src/small_gicp/registration/registration_helper.cpp, are compiled where they lie (nothing is copied into this
+// repository) against the home-made Eigen stand-in in eigen_shim/.  Output: oracle/_ref/libsmall_gicp_ref.so (git-ignored).
+// Used to validate the CPU restatement in oracle/ (tests/test_oracle_vs_reference.py) and, optionally, as the timed CPU baseline.
+#include <chrono>
+#include <cstdint>
+#include <cstring>
+
+#include <small_gicp/ann/kdtree.hpp>
+#include <small_gicp/ann/kdtree_omp.hpp>
+#include <small_gicp/ann/gaussian_voxelmap.hpp>
+#include <small_gicp/factors/gicp_factor.hpp>
+#include <small_gicp/factors/icp_factor.hpp>
+#include <small_gicp/factors/plane_icp_factor.hpp>
+#include <small_gicp/factors/robust_kernel.hpp>
+#include <small_gicp/points/point_cloud.hpp>
+#include <small_gicp/registration/reduction.hpp>
+#include <small_gicp/registration/reduction_omp.hpp>
+#include <small_gicp/registration/registration.hpp>
+#include <small_gicp/registration/registration_helper.hpp>
+#include <small_gicp/util/downsampling.hpp>
+#include <small_gicp/util/normal_estimation.hpp>
+#include <small_gicp/util/normal_estimation_omp.hpp>
+
+using namespace small_gicp;
+
+namespace {
+struct RefCloud {
+  std::shared_ptr<PointCloud> cloud;
+  std::shared_ptr<KdTree<PointCloud>> tree;
+};
+Eigen::Isometry3d to_iso(const double* T16) {
+  Eigen::Isometry3d T = Eigen::Isometry3d::Identity();
+  std::memcpy(T.matrix().data(), T16, sizeof(double) * 16);
+  return T;
+}
+}  // namespace
+
+// One linearization at T with the reference's own factors and reduction (robust: 0 none, 1 Huber, 2 Cauchy with width c)
+template <typename Factor>
+static void linearize_with(const RefCloud& t, const RefCloud& s, double max_dist_sq, int num_threads, const Eigen::Isometry3d& T, const typename Factor::Setting& fs, double* H36, double* b6, double* e, double* e_again,
+                           std::uint64_t* inliers) {
+  std::vector<Factor> factors(s.cloud->size(), Factor(fs));
+  DistanceRejector rejector;
+  rejector.max_dist_sq = max_dist_sq;
+  Eigen::Matrix<double, 6, 6> H;
+  Eigen::Matrix<double, 6, 1> b;
+  double err;
+  if (num_threads > 1) {
+    ParallelReductionOMP red;
+    red.num_threads = num_threads;
+    std::tie(H, b, err) = red.linearize(*t.cloud, *s.cloud, *t.tree, rejector, T, factors);
+    *e_again = red.error(*t.cloud, *s.cloud, T, factors);
+  } else {
+    SerialReduction red;
+    std::tie(H, b, err) = red.linearize(*t.cloud, *s.cloud, *t.tree, rejector, T, factors);
+    *e_again = red.error(*t.cloud, *s.cloud, T, factors);
+  }
+  for (int i = 0; i < 6; i++) {
+    b6[i] = b(i);
+    for (int j = 0; j < 6; j++) H36[6 * i + j] = H(i, j);
+  }
+  *e = err;
+  *inliers = std::count_if(factors.begin(), factors.end(), [](const Factor& f) { return f.inlier(); });
+}
+
+
+extern "C" {
+
+struct ref_result {
+  double T[16];
+  int converged;
+  std::uint64_t iterations, num_inliers;
+  double H[36];
+  double b[6];
+  double error;
+};
+
+static void fill_result(const RegistrationResult& r, ref_result* out, double seconds, double* elapsed) {
+  std::memcpy(out->T, r.T_target_source.matrix().data(), sizeof(double) * 16);
+  out->converged = r.converged;
+  out->iterations = r.iterations;
+  out->num_inliers = r.num_inliers;
+  for (int i = 0; i < 6; i++) {
+    out->b[i] = r.b(i);
+    for (int j = 0; j < 6; j++) out->H[6 * i + j] = r.H(i, j);
+  }
+  out->error = r.error;
+  if (elapsed) *elapsed = seconds;
+}
+
+// points n*3 doubles; normals n*3 / covs n*9 (row-major 3x3) optional
+void* ref_cloud_create(const double* pts, const double* normals, const double* covs, size_t n, int build_tree, int tree_threads) {
+  auto* rc = new RefCloud;
+  rc->cloud = std::make_shared<PointCloud>();
+  rc->cloud->resize(n);
+  for (size_t i = 0; i < n; i++) {
+    rc->cloud->point(i) = Eigen::Vector4d(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], 1.0);
+    rc->cloud->normal(i) = normals ? Eigen::Vector4d(normals[3 * i], normals[3 * i + 1], normals[3 * i + 2], 0.0) : Eigen::Vector4d::Zero();
+    Eigen::Matrix4d c = Eigen::Matrix4d::Zero();
+    if (covs)
+      for (int r = 0; r < 3; r++)
+        for (int k = 0; k < 3; k++) c(r, k) = covs[9 * i + 3 * r + k];
+    rc->cloud->cov(i) = c;
+  }
+  if (build_tree) {
+    if (tree_threads > 1)
+      rc->tree = std::make_shared<KdTree<PointCloud>>(rc->cloud, KdTreeBuilderOMP(tree_threads));
+    else
+      rc->tree = std::make_shared<KdTree<PointCloud>>(rc->cloud);
+  }
+  return rc;
+}
+void ref_cloud_destroy(void* h) { delete static_cast<RefCloud*>(h); }
+size_t ref_cloud_size(void* h) { return static_cast<RefCloud*>(h)->cloud->size(); }
+void ref_cloud_get(void* h, double* pts, double* normals, double* covs) {
+  const PointCloud& c = *static_cast<RefCloud*>(h)->cloud;
+  for (size_t i = 0; i < c.size(); i++) {
+    for (int k = 0; k < 3; k++) {
+      if (pts) pts[3 * i + k] = c.point(i)(k);
+      if (normals) normals[3 * i + k] = c.normal(i)(k);
+    }
+    if (covs)
+      for (int r = 0; r < 3; r++)
+        for (int k = 0; k < 3; k++) covs[9 * i + 3 * r + k] = c.cov(i)(r, k);
+  }
+}
+
+// util/downsampling.hpp voxelgrid_sampling (serial)
+void* ref_voxelgrid_sampling(void* h, double leaf) {
+  auto* rc = new RefCloud;
+  rc->cloud = voxelgrid_sampling(*static_cast<RefCloud*>(h)->cloud, leaf);
+  return rc;
+}
+
+void ref_estimate_normals_covariances(void* h, int k, int num_threads) {
+  auto* rc = static_cast<RefCloud*>(h);
+  if (!rc->tree) rc->tree = std::make_shared<KdTree<PointCloud>>(rc->cloud);
+  if (num_threads > 1)
+    estimate_normals_covariances_omp(*rc->cloud, *rc->tree, k, num_threads);
+  else
+    estimate_normals_covariances(*rc->cloud, *rc->tree, k);
+}
+
+size_t ref_knn(void* h, const double* q, size_t m, int k, std::int64_t* idx, double* sqd) {
+  auto* rc = static_cast<RefCloud*>(h);
+  size_t total = 0;
+  std::vector<size_t> ki(k);
+  std::vector<double> kd(k);
+  for (size_t i = 0; i < m; i++) {
+    const Eigen::Vector4d pt(q[3 * i], q[3 * i + 1], q[3 * i + 2], 1.0);
+    const size_t n = rc->cloud->size() ? rc->tree->knn_search(pt, k, ki.data(), kd.data()) : 0;
+    for (int j = 0; j < k; j++) {
+      idx[i * k + j] = static_cast<size_t>(j) < n ? static_cast<std::int64_t>(ki[j]) : -1;
+      sqd[i * k + j] = static_cast<size_t>(j) < n ? kd[j] : std::numeric_limits<double>::infinity();
+    }
+    total += n;
+  }
+  return total;
+}
+
+// registration_helper.cpp align(PointCloud, PointCloud, KdTree, init_T, setting) / align(GaussianVoxelMap, PointCloud, ...)
+// type: 0 ICP, 1 PLANE_ICP, 2 GICP, 3 VGICP
+int ref_align(void* target_h, void* source_h, int type, double voxel_resolution, double max_corr_dist, int num_threads, int max_iterations, double rotation_eps, double translation_eps, const double* init_T16, ref_result* out, double* elapsed_sec) {
+  auto* t = static_cast<RefCloud*>(target_h);
+  auto* s = static_cast<RefCloud*>(source_h);
+  RegistrationSetting setting;
+  setting.type = static_cast<RegistrationSetting::RegistrationType>(type);
+  setting.voxel_resolution = voxel_resolution;
+  setting.max_correspondence_distance = max_corr_dist;
+  setting.num_threads = num_threads;
+  setting.max_iterations = max_iterations;
+  setting.rotation_eps = rotation_eps;
+  setting.translation_eps = translation_eps;
+  const Eigen::Isometry3d init_T = to_iso(init_T16);
+  RegistrationResult r;
+  std::chrono::steady_clock::time_point t0, t1;
+  if (type == 3) {
+    auto voxelmap = create_gaussian_voxelmap(*t->cloud, voxel_resolution);
+    t0 = std::chrono::steady_clock::now();
+    r = align(*voxelmap, *s->cloud, init_T, setting);
+    t1 = std::chrono::steady_clock::now();
+  } else {
+    if (!t->tree) return -1;
+    t0 = std::chrono::steady_clock::now();
+    r = align(*t->cloud, *s->cloud, *t->tree, init_T, setting);
+    t1 = std::chrono::steady_clock::now();
+  }
+  fill_result(r, out, std::chrono::duration<double>(t1 - t0).count(), elapsed_sec);
+  return 0;
+}
+
+int ref_linearize(void* target_h, void* source_h, int type, int robust, double robust_c, double max_dist_sq, int num_threads, const double* T16, double* H36, double* b6, double* e, double* e_again, std::uint64_t* inliers) {
+  const auto& t = *static_cast<RefCloud*>(target_h);
+  const auto& s = *static_cast<RefCloud*>(source_h);
+  if (!t.tree) return -1;
+  const Eigen::Isometry3d T = to_iso(T16);
+  if (robust == 0) {
+    if (type == 0) linearize_with<ICPFactor>(t, s, max_dist_sq, num_threads, T, {}, H36, b6, e, e_again, inliers);
+    else if (type == 1) linearize_with<PointToPlaneICPFactor>(t, s, max_dist_sq, num_threads, T, {}, H36, b6, e, e_again, inliers);
+    else linearize_with<GICPFactor>(t, s, max_dist_sq, num_threads, T, {}, H36, b6, e, e_again, inliers);
+  } else if (robust == 1) {
+    RobustFactor<Huber, GICPFactor>::Setting fs;
+    fs.robust_kernel.c = robust_c;
+    linearize_with<RobustFactor<Huber, GICPFactor>>(t, s, max_dist_sq, num_threads, T, fs, H36, b6, e, e_again, inliers);
+  } else {
+    RobustFactor<Cauchy, GICPFactor>::Setting fs;
+    fs.robust_kernel.c = robust_c;
+    linearize_with<RobustFactor<Cauchy, GICPFactor>>(t, s, max_dist_sq, num_threads, T, fs, H36, b6, e, e_again, inliers);
+  }
+  return 0;
+}
+
+size_t ref_voxelmap_size(void* cloud_h, double leaf) { return create_gaussian_voxelmap(*static_cast<RefCloud*>(cloud_h)->cloud, leaf)->size(); }
+
+}  // extern "C"

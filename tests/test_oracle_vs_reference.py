@@ -1,0 +1,91 @@
+"""The CPU restatement (oracle/) against the REFERENCE ITSELF: oracle/_ref/libsmall_gicp_ref.so is the unmodified koide3/small_gicp
+code (headers + registration_helper.cpp) compiled in place from /root/reference over a home-made Eigen stand-in
+(oracle/ref/eigen_shim: the reference needs Eigen, which this image does not ship).  Every stage of the hot path must agree to
+rounding: voxel grid, kd-tree kNN, normals/covariances, per-factor linearization incl. robust kernels, the error pass, and the
+full registrations of registration_helper.cpp (ICP / PLANE_ICP / GICP / VGICP, serial and OpenMP reductions).
+Skipped where the library cannot be built (no /root/reference, e.g. on the GPU box unless the built .so travelled with the repo)."""
+import numpy as np
+import pytest
+
+from conftest import pose_error
+from oracle import ref
+
+pytestmark = pytest.mark.skipif(not (ref.available() or ref.build()), reason="oracle/_ref not built (needs /root/reference)")
+
+
+@pytest.fixture(scope="module")
+def clouds(orc, c1_raw):
+    tgt, src, _ = c1_raw
+    rt_raw, rs_raw = ref.Cloud(tgt, tree=False), ref.Cloud(src, tree=False)
+    rt, rs = rt_raw.voxelgrid_sampling(0.25), rs_raw.voxelgrid_sampling(0.25)
+    rt.estimate_normals_covariances(10, 1)
+    rs.estimate_normals_covariances(10, 1)
+    td, sd = orc.voxelgrid_sampling(tgt, 0.25), orc.voxelgrid_sampling(src, 0.25)
+    ot, os_ = orc.Cloud(td), orc.Cloud(sd)
+    ot.estimate_normals_covariances(10, 1)
+    os_.estimate_normals_covariances(10, 1)
+    return dict(rt=rt, rs=rs, ot=ot, os=os_)
+
+
+def test_voxelgrid_and_features(clouds):
+    for r, o in ((clouds["rt"], clouds["ot"]), (clouds["rs"], clouds["os"])):
+        rp, rn, rc = r.get()
+        op, on, oc = o.get()
+        assert rp.shape == op.shape
+        assert np.abs(rp - op).max() < 1e-10  # same voxels in the same (ascending key) order
+        assert np.abs(rn - on).max() < 1e-6 and np.abs(rc - oc).max() < 1e-6  # eigenvectors of near-degenerate neighbourhoods amplify summation-order rounding
+
+
+def test_knn(clouds):
+    rp = clouds["rt"].get()[0]
+    rng = np.random.default_rng(1)
+    q = np.concatenate([rp[rng.choice(len(rp), 60)], rp[rng.choice(len(rp), 60)] + rng.normal(0, 1, (60, 3)), rng.uniform(0, 100, (60, 3))])
+    ri, rd = clouds["rt"].knn(q, 20)
+    oi, od = clouds["ot"].knn(q, 20)
+    assert (ri == oi).all() and (np.abs(rd - od) <= 1e-13 * np.maximum(1.0, od)).all()
+
+
+@pytest.mark.parametrize("type_,robust", [(0, 0), (1, 0), (2, 0), (2, 1), (2, 2)])
+@pytest.mark.parametrize("threads", [1, 4])
+def test_linearize_and_error(orc, clouds, type_, robust, threads):
+    T = np.eye(4)
+    T[:3, 3] = [0.3, 0.1, -0.02]
+    c, s = np.cos(0.01), np.sin(0.01)
+    T[:3, :3] = [[c, -s, 0], [s, c, 0], [0, 0, 1]]
+    for pose in (np.eye(4), T):
+        H, b, e, e2, n = ref.linearize(clouds["rt"], clouds["rs"], type_, robust, 0.7, 1.0, threads, pose)
+        st = orc.default_setting(factor_kind=type_, robust_kind=robust, robust_c=0.7, num_threads=threads)
+        f = orc.Factors(len(clouds["os"]))
+        Ho, bo, eo, no = orc.linearize(clouds["ot"], clouds["os"], st, pose, f)
+        assert n == no
+        assert np.abs(H - Ho).max() <= 1e-8 * np.abs(H).max()  # the two sides estimate their own covariances (equal to ~1e-8)
+        assert np.abs(b - bo).max() <= 1e-7 * np.sqrt(np.abs(np.diag(H)).max() * e)
+        assert abs(e - eo) <= 1e-8 * e
+        assert abs(e2 - orc.error(clouds["ot"], clouds["os"], st, pose, f)) <= 1e-8 * e
+
+
+@pytest.mark.parametrize("type_", [0, 1, 2, 3])
+@pytest.mark.parametrize("threads", [1, 4])
+def test_align(orc, clouds, c1_raw, type_, threads):
+    r = ref.align(clouds["rt"], clouds["rs"], type_, 1.0, 1.0, threads)
+    st = orc.default_setting(factor_kind=min(type_, 2), num_threads=threads)
+    target = orc.VoxelMap(clouds["ot"], 1.0) if type_ == 3 else clouds["ot"]
+    o = orc.align(target, clouds["os"], st)
+    assert (r.iterations, r.converged, r.num_inliers) == (o.iterations, o.converged, o.num_inliers)
+    dt, dr = pose_error(r.T_target_source, o.T_target_source)
+    assert dt < 1e-9 and dr < 1e-7, (dt, dr)
+    assert abs(r.error - o.error) <= 1e-9 * abs(o.error) and np.abs(r.H - o.H).max() <= 1e-9 * np.abs(o.H).max()
+    # and the reference itself meets its own test tolerance on this pair (src/test/helper_test.cpp:27-39)
+    dt, dr = pose_error(r.T_target_source, c1_raw[2])
+    assert dt < 0.2 and dr < np.deg2rad(2.5)
+    if type_ == 3:
+        assert clouds["rt"].voxelmap_size(1.0) == len(target)
+
+
+def test_goldens_equal_reference(clouds, c1_gold):
+    """tests/golden/c1_oracle.json (the 1e-4 anchor of the GPU tests) is what the reference computes."""
+    for name, t in (("ICP", 0), ("PLANE_ICP", 1), ("GICP", 2), ("VGICP", 3)):
+        r = ref.align(clouds["rt"], clouds["rs"], t, 1.0, 1.0, 1)
+        g = c1_gold["cases"][name]
+        dt, dr = pose_error(r.T_target_source, np.array(g["T"]))
+        assert dt < 1e-9 and dr < 1e-7 and r.iterations == g["iterations"] and r.num_inliers == g["num_inliers"]
