@@ -6,14 +6,17 @@ OUT=$PWD/gpurun_out/pmc_$TAG
 mkdir -p "$OUT"
 ROOT=$PWD
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline"
+BENCH="python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --odom-frames 0"
 rocprofv3 -L > "$OUT/counters.txt" 2>&1
 i=0
 for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY" \
            "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_SCA" \
-           "TCC_HIT_sum TCC_MISS_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "GRBM_GUI_ACTIVE GRBM_COUNT"; do
+           "SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_FLAT" \
+           "TA_TA_BUSY_sum TA_BUFFER_WAVEFRONTS_sum TA_FLAT_READ_WAVEFRONTS_sum TA_FLAT_WAVEFRONTS_sum" "TD_TD_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum" \
+           "TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum" "TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_TCC_READ_REQ_LATENCY_sum" \
+           "TCC_HIT_sum TCC_MISS_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "TCP_TOTAL_ACCESSES_sum TCP_TOTAL_READ_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$OUT/p$i" -o pmc -- $BENCH > "$OUT/p$i.log" 2>&1
+  timeout 100 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$OUT/p$i" -o pmc -- $BENCH > "$OUT/p$i.log" 2>&1
 done
 cd "$ROOT"
 python - "$OUT" <<'PY'
@@ -24,9 +27,19 @@ agg = defaultdict(lambda: [0.0, 0])
 for f in glob.glob(os.path.join(out, "p*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         kn = r.get("Kernel_Name", "")
-        if "linearize_kernel" not in kn and "error_kernel" not in kn: continue
-        k = ("K1" if "linearize" in kn else "K2", r.get("Counter_Name"))
+        if "linearize_kernel" not in kn and "error_kernel" not in kn and "nn_search_kernel" not in kn: continue
+        k = ("K1a" if "nn_search" in kn else ("K1b" if "linearize" in kn else "K2"), r.get("Counter_Name"))
         agg[k][0] += float(r.get("Counter_Value", 0)); agg[k][1] += 1
+dur = defaultdict(lambda: [0.0, 0])
+for f in glob.glob(os.path.join(out, "p1", "**", "*kernel_trace.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        kn = r.get("Kernel_Name", "")
+        for tag, key in (("nn_search_kernel", "K1a"), ("linearize_kernel", "K1b"), ("error_kernel", "K2")):
+            if tag in kn:
+                dur[key][0] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3; dur[key][1] += 1
+for k, (v, c) in sorted(dur.items()):
+    print("%s avg_us=%.2f (n=%d)" % (k, v / max(c, 1), c))
 for (kn, cn), (v, c) in sorted(agg.items()):
     print("%s %-32s per_launch=%.4g (n=%d)" % (kn, cn, v / max(c, 1), c))
 PY
+rm -rf "$OUT"/p*/  # raw per-dispatch tables are large; only the aggregate above travels back

@@ -110,6 +110,7 @@ struct sga_index {
   sga::DevBuf<float4> nrm;          // kd order
   sga::DevBuf<sga::Cov8> cov;       // kd order.  Voxel maps: mean covariances in voxel-id order
   sga::DevBuf<float2> kd_nodes;     // 2^kd_depth entries (index 0 unused)
+  sga::DevBuf<float4> kd_nodes4;    // pair records of the even depths (kd_search.hpp)
   int kd_depth = 0;
   float bbox_lo[3] = {0, 0, 0}, bbox_hi[3] = {0, 0, 0};
   // voxel map

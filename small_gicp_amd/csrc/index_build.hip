@@ -58,7 +58,10 @@ static inline float dec_ordered(int i) {
 __global__ void gather_sorted_kernel(
   const uint32_t* __restrict__ order, size_t n, const float4* __restrict__ pts, const float4* __restrict__ nrm, const Cov8* __restrict__ cov, float4* __restrict__ opts, float4* __restrict__ onrm, Cov8* __restrict__ ocov) {
   const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
-  if (i >= n) return;
+  if (i >= n) {
+    if (i < n + kKdLeafMax) opts[i] = make_float4(INFINITY, INFINITY, INFINITY, __uint_as_float(0xffffffffu));  // padding leaf (kd_search.hpp)
+    return;
+  }
   const uint32_t s = order[i];
   opts[i] = pts[s];  // w keeps the original index bits
   if (nrm) onrm[i] = nrm[s];
@@ -128,27 +131,50 @@ __global__ void kd_init_box_kernel(int* __restrict__ seg_box, uint32_t nseg) {
 
 __device__ __forceinline__ float float_from_ordered(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
 
-__global__ void kd_keys_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ perm, uint32_t n, int d, const int* __restrict__ seg_box, unsigned long long* __restrict__ keys) {
+// keys for a sort along a FIXED axis (trial sorts) or along each segment's chosen axis (axis_of_seg != null)
+__global__ void kd_keys_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ perm, uint32_t n, int d, int fixed_axis, const int* __restrict__ axis_of_seg, unsigned long long* __restrict__ keys) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t seg = kd_segment_of(i, n, d);
-  const float ex = float_from_ordered(seg_box[6 * seg + 3]) - float_from_ordered(seg_box[6 * seg + 0]);
-  const float ey = float_from_ordered(seg_box[6 * seg + 4]) - float_from_ordered(seg_box[6 * seg + 1]);
-  const float ez = float_from_ordered(seg_box[6 * seg + 5]) - float_from_ordered(seg_box[6 * seg + 2]);
-  const int axis = ex >= ey ? (ex >= ez ? 0 : 2) : (ey >= ez ? 1 : 2);
+  const int axis = axis_of_seg ? axis_of_seg[seg] : fixed_axis;
   const float4 p = pts[perm[i]];
   const float c = axis == 0 ? p.x : (axis == 1 ? p.y : p.z);
   const uint32_t oc = static_cast<uint32_t>(ordered_from_float(c)) ^ 0x80000000u;  // unsigned order
   keys[i] = (static_cast<unsigned long long>(seg) << 32) | oc;
 }
 
-__global__ void kd_nodes_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ perm, uint32_t n, int d, const int* __restrict__ seg_box, float2* __restrict__ nodes) {
+// after a trial sort along `axis`: score[seg][axis] = min(median - lo, hi - median), the extent the smaller child keeps.
+// A median split is only useful along an axis where BOTH children get a real share of the extent: on a noisy plane with a few
+// points floating above it, the longest extent is the plane's normal direction, yet the median there cuts the plane itself
+// into noise-thin slabs that every query ball crosses.  (The reference takes the axis of largest sampled variance,
+// projection.hpp:31-50, and suffers from exactly that on such data; any axis choice keeps the search exact.)
+__global__ void kd_score_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ perm_sorted, uint32_t n, int d, int axis, const int* __restrict__ seg_box, float* __restrict__ score) {
   const uint32_t seg = blockIdx.x * blockDim.x + threadIdx.x;
   if (seg >= (1u << d)) return;
-  const float ex = float_from_ordered(seg_box[6 * seg + 3]) - float_from_ordered(seg_box[6 * seg + 0]);
-  const float ey = float_from_ordered(seg_box[6 * seg + 4]) - float_from_ordered(seg_box[6 * seg + 1]);
-  const float ez = float_from_ordered(seg_box[6 * seg + 5]) - float_from_ordered(seg_box[6 * seg + 2]);
-  const int axis = ex >= ey ? (ex >= ez ? 0 : 2) : (ey >= ez ? 1 : 2);
+  const uint32_t first = kd_bound_d(n, d, seg), end = kd_bound_d(n, d, seg + 1);
+  float sc = -1.f;
+  if (first < end) {
+    const uint32_t m = min(kd_bound_d(n, d + 1, 2 * seg + 1), end - 1);
+    const float4 p = pts[perm_sorted[m]];
+    const float med = axis == 0 ? p.x : (axis == 1 ? p.y : p.z);
+    const float lo = float_from_ordered(seg_box[6 * seg + axis]), hi = float_from_ordered(seg_box[6 * seg + 3 + axis]);
+    sc = fminf(med - lo, hi - med);
+  }
+  score[3 * seg + axis] = sc;
+}
+
+__global__ void kd_choose_axis_kernel(const float* __restrict__ score, const int* __restrict__ seg_box, uint32_t nseg, int balanced, int* __restrict__ axis_of_seg) {
+  const uint32_t seg = blockIdx.x * blockDim.x + threadIdx.x;
+  if (seg >= nseg) return;
+  float v[3];
+  for (int a = 0; a < 3; a++) v[a] = balanced ? score[3 * seg + a] : float_from_ordered(seg_box[6 * seg + 3 + a]) - float_from_ordered(seg_box[6 * seg + a]);
+  axis_of_seg[seg] = v[0] >= v[1] ? (v[0] >= v[2] ? 0 : 2) : (v[1] >= v[2] ? 1 : 2);
+}
+
+__global__ void kd_nodes_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ perm, uint32_t n, int d, const int* __restrict__ axis_of_seg, float2* __restrict__ nodes) {
+  const uint32_t seg = blockIdx.x * blockDim.x + threadIdx.x;
+  if (seg >= (1u << d)) return;
+  const int axis = axis_of_seg[seg];
   const uint32_t first = kd_bound_d(n, d, seg), end = kd_bound_d(n, d, seg + 1);
   const uint32_t m = kd_bound_d(n, d + 1, 2 * seg + 1);  // first point of the right child
   float thr = 0.f;
@@ -157,6 +183,21 @@ __global__ void kd_nodes_kernel(const float4* __restrict__ pts, const uint32_t* 
     thr = axis == 0 ? p.x : (axis == 1 ? p.y : p.z);
   }
   nodes[(1u << d) + seg] = make_float2(thr, __int_as_float(axis));
+}
+
+// pair records for the 1-NN walk (kd_search.hpp): node of even depth + its two children in one 16-byte record
+__global__ void kd_pairs_kernel(const float2* __restrict__ nodes, int D, int d, float4* __restrict__ pairs) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= (1u << d)) return;
+  const uint32_t node = (1u << d) + k;
+  const float2 a = nodes[node];
+  float2 l = make_float2(0.f, 0.f), r = make_float2(0.f, 0.f);
+  if (d + 1 < D) {
+    l = nodes[2 * node];
+    r = nodes[2 * node + 1];
+  }
+  const uint32_t axes = static_cast<uint32_t>(__float_as_int(a.y)) | (static_cast<uint32_t>(__float_as_int(l.y)) << 2) | (static_cast<uint32_t>(__float_as_int(r.y)) << 4);
+  pairs[kd_pair_index(d, node)] = make_float4(a.x, l.x, r.x, __uint_as_float(axes));
 }
 
 __global__ void iota_kernel(uint32_t* __restrict__ v, size_t n) {
@@ -189,6 +230,7 @@ static int build_kdtree(sga_context* ctx, const sga_cloud* cloud, sga_index* idx
   SGA_TRY(keys2.alloc(n));
   SGA_TRY(seg_box.alloc(6ull << (D > 0 ? D - 1 : 0)));
   SGA_TRY(idx->kd_nodes.alloc(1ull << D));
+  SGA_TRY(idx->kd_nodes4.alloc(kd_pair_count(D)));
   const dim3 grid((n + 255) / 256), block(256);
   hipLaunchKernelGGL(iota_kernel, grid, block, 0, ctx->stream, perm.p, n);
   uint32_t* cur = perm.p;
@@ -196,21 +238,38 @@ static int build_kdtree(sga_context* ctx, const sga_cloud* cloud, sga_index* idx
   size_t tb = 0;
   SGA_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys.p, keys2.p, cur, nxt, n, 0, 64, ctx->stream));
   SGA_TRY(ensure_temp(ctx, tb));
+  // axis rule: 0 (default) = longest extent (one sort per level), 1 = balanced extent (three trial sorts per level; fewer node
+  // visits on average but a heavier tail for isolated points — measured slower on the C3 scene, kept for experiments)
+  static const int balanced = getenv("SGA_KD_AXIS") ? atoi(getenv("SGA_KD_AXIS")) : 0;
+  DevBuf<int> axis_of_seg;
+  DevBuf<float> score;
+  SGA_TRY(axis_of_seg.alloc(1ull << (D > 0 ? D - 1 : 0)));
+  SGA_TRY(score.alloc(3ull << (D > 0 ? D - 1 : 0)));
   for (int d = 0; d < D; d++) {
     const uint32_t nseg = 1u << d;
-    hipLaunchKernelGGL(kd_init_box_kernel, dim3((nseg + 255) / 256), block, 0, ctx->stream, seg_box.p, nseg);
-    hipLaunchKernelGGL(kd_segment_box_kernel, grid, block, 0, ctx->stream, cloud->pts.p, cur, static_cast<uint32_t>(n), d, seg_box.p);
-    hipLaunchKernelGGL(kd_keys_kernel, grid, block, 0, ctx->stream, cloud->pts.p, cur, static_cast<uint32_t>(n), d, seg_box.p, keys.p);
+    const dim3 sgrid((nseg + 255) / 256);
     const unsigned end_bit = 32 + (d > 0 ? d : 1);
+    hipLaunchKernelGGL(kd_init_box_kernel, sgrid, block, 0, ctx->stream, seg_box.p, nseg);
+    hipLaunchKernelGGL(kd_segment_box_kernel, grid, block, 0, ctx->stream, cloud->pts.p, cur, static_cast<uint32_t>(n), d, seg_box.p);
+    if (balanced) {
+      for (int a = 0; a < 3; a++) {
+        hipLaunchKernelGGL(kd_keys_kernel, grid, block, 0, ctx->stream, cloud->pts.p, cur, static_cast<uint32_t>(n), d, a, static_cast<const int*>(nullptr), keys.p);
+        SGA_HIP(rocprim::radix_sort_pairs(ctx->d_temp.p, tb, keys.p, keys2.p, cur, nxt, n, 0, end_bit, ctx->stream));
+        hipLaunchKernelGGL(kd_score_kernel, sgrid, block, 0, ctx->stream, cloud->pts.p, nxt, static_cast<uint32_t>(n), d, a, seg_box.p, score.p);
+      }
+    }
+    hipLaunchKernelGGL(kd_choose_axis_kernel, sgrid, block, 0, ctx->stream, score.p, seg_box.p, nseg, balanced, axis_of_seg.p);
+    hipLaunchKernelGGL(kd_keys_kernel, grid, block, 0, ctx->stream, cloud->pts.p, cur, static_cast<uint32_t>(n), d, 0, axis_of_seg.p, keys.p);
     SGA_HIP(rocprim::radix_sort_pairs(ctx->d_temp.p, tb, keys.p, keys2.p, cur, nxt, n, 0, end_bit, ctx->stream));
     std::swap(cur, nxt);
-    hipLaunchKernelGGL(kd_nodes_kernel, dim3((nseg + 255) / 256), block, 0, ctx->stream, cloud->pts.p, cur, static_cast<uint32_t>(n), d, seg_box.p, idx->kd_nodes.p);
+    hipLaunchKernelGGL(kd_nodes_kernel, sgrid, block, 0, ctx->stream, cloud->pts.p, cur, static_cast<uint32_t>(n), d, axis_of_seg.p, idx->kd_nodes.p);
   }
+  for (int d = 0; d < D; d += 2) hipLaunchKernelGGL(kd_pairs_kernel, dim3(((1u << d) + 255) / 256), block, 0, ctx->stream, idx->kd_nodes.p, D, d, idx->kd_nodes4.p);
   SGA_HIP(hipGetLastError());
-  SGA_TRY(idx->kd_pts.alloc(n));
+  SGA_TRY(idx->kd_pts.alloc(n + kKdLeafMax));  // + one leaf of points at infinity: leaf scans read 8 slots unconditionally
   if (cloud->has_normals) SGA_TRY(idx->nrm.alloc(n));
   if (cloud->has_covs) SGA_TRY(idx->cov.alloc(n));
-  hipLaunchKernelGGL(gather_sorted_kernel, grid, block, 0, ctx->stream, cur, n, cloud->pts.p, cloud->has_normals ? cloud->nrm.p : nullptr, cloud->has_covs ? cloud->cov.p : nullptr, idx->kd_pts.p, idx->nrm.p, idx->cov.p);
+  hipLaunchKernelGGL(gather_sorted_kernel, dim3((n + kKdLeafMax + 255) / 256), block, 0, ctx->stream, cur, n, cloud->pts.p, cloud->has_normals ? cloud->nrm.p : nullptr, cloud->has_covs ? cloud->cov.p : nullptr, idx->kd_pts.p, idx->nrm.p, idx->cov.p);
   SGA_HIP(hipGetLastError());
   SGA_HIP(hipStreamSynchronize(ctx->stream));
   return SGA_OK;

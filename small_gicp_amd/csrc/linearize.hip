@@ -6,6 +6,7 @@
 // ann/incremental_voxelmap.hpp:99-119).  One lane per source point; tiles of 256 points; per-pair values reduced with
 // DPP inside a wave (fp32), accumulated per wave in fp64 in LDS, one 32-double partial row per workgroup, then a single
 // deterministic fp64 tree over the partial rows.  The 6x6 solve stays on the host (optimizer.cpp).
+#include <algorithm>
 #include <chrono>
 
 #include "common.hpp"
@@ -21,7 +22,7 @@ int comm_allreduce_sum(sga_context* ctx, double* d_buf, size_t count);
 
 constexpr int kTile = 256;           // threads per workgroup = source points per tile
 constexpr int kRow = 32;             // doubles per partial row (28 used + inliers)
-constexpr int kMaxBlocks = 1536;     // 6 workgroups per CU (24 KB of traversal stack each) on 256 CUs: the whole grid is resident
+constexpr int kMaxBlocks = 2048;     // K1b / K2: 8 workgroups per CU, the whole grid is resident
 
 template <typename Real>
 struct LinParams {
@@ -35,8 +36,7 @@ struct LinParams {
   KdView kd;
   VoxelView vox;
   int* __restrict__ corr;
-  int* __restrict__ hint;   // last nearest neighbour found for each source point (kd position) or -1
-  int use_hints;            // SGA_KD_HINTS=1: start the search bottom-up from the previous neighbour
+  const int* __restrict__ hint;  // nearest neighbour per source point from nn_search_kernel (kd position) or -1
   Real* __restrict__ maha;  // n*6
   Rigid<Real> T;
   float max_sq;  // INFINITY = no rejector
@@ -68,6 +68,33 @@ __device__ __forceinline__ Sym3<Real> load_sym(const Cov8* __restrict__ c, int i
   const float4 a = reinterpret_cast<const float4*>(c)[2 * i];
   const float4 b = reinterpret_cast<const float4*>(c)[2 * i + 1];
   return {Real(a.x), Real(a.y), Real(a.z), Real(a.w), Real(b.x), Real(b.y)};
+}
+
+// K1a: nearest neighbour of every transformed source point (kd_search.hpp); writes its kd position (or -1 when nothing lies
+// within the search bound) to nn[i].  One 256-point tile per workgroup: the hardware dispatcher balances the uneven walks, and
+// without the per-pair algebra the kernel fits 8 waves per SIMD, which the latency-bound walk needs.  K1b (linearize_kernel)
+// evaluates the factors over nn[].
+template <typename Real>
+struct NNParams {
+  const float4* __restrict__ src_pts;
+  int n;
+  KdView kd;
+  Rigid<Real> T;
+  float max_sq;
+  int* __restrict__ nn;
+};
+
+template <typename Real>
+__global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) void nn_search_kernel(const NNParams<Real> p) {
+  extern __shared__ uint32_t kd_stack[];  // tree depth x kTile traversal stack slots
+  const int i = blockIdx.x * kTile + threadIdx.x;
+  if (i >= p.n) return;
+  const float4 ps = p.src_pts[i];
+  Real x, y, z;
+  transform_point<Real>(p.T, ps.x, ps.y, ps.z, x, y, z);
+  const float bound2 = p.max_sq < 3.0e38f ? p.max_sq * 1.0000002f : INFINITY;  // d2 == max_sq must still be found (strict '>' rejector)
+  const KdBest nb = kd_nearest<kTile>(p.kd, static_cast<float>(x), static_cast<float>(y), static_cast<float>(z), bound2, kd_stack, threadIdx.x);
+  p.nn[i] = nb.idx;
 }
 
 template <typename Real, int FACTOR, bool VOXELMAP>
@@ -106,15 +133,15 @@ __global__ __launch_bounds__(kTile) void linearize_kernel(const LinParams<Real> 
         }
       }
     } else {
-      __shared__ uint32_t kd_stack[kKdMaxDepth * kTile];
-      // d2 == max_sq must still be found (the rejector is a strict '>'): search bound one ulp above
-      const float bound2 = p.max_sq < 3.0e38f ? p.max_sq * 1.0000002f : INFINITY;
-      const KdBest nb = kd_nearest<kTile>(p.kd, static_cast<float>(qx), static_cast<float>(qy), static_cast<float>(qz), bound2, p.use_hints && active ? p.hint[i] : -1, kd_stack, threadIdx.x, active);
-      if (active) p.hint[i] = nb.idx;  // also kept for rejected pairs: next iteration's search starts from here
-      j = nb.idx;
-      tx = nb.x;
-      ty = nb.y;
-      tz = nb.z;
+      if (active) {
+        j = p.hint[i];  // nearest neighbour found by nn_search_kernel (kd position) or -1
+        if (j >= 0) {
+          const float4 m = p.tgt_pts[j];
+          tx = m.x;
+          ty = m.y;
+          tz = m.z;
+        }
+      }
     }
     if (active) {
       const Real rx = tx - qx, ry = ty - qy, rz = tz - qz;
@@ -299,10 +326,6 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
   }
   p.corr = pb->corr.p;
   p.hint = pb->hint.p;
-  {
-    static const int use_hints = getenv("SGA_KD_HINTS") ? atoi(getenv("SGA_KD_HINTS")) : 0;
-    p.use_hints = use_hints;
-  }
   if constexpr (sizeof(Real) == 4) {
     p.maha = pb->maha.p;
   } else {
@@ -327,6 +350,17 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
     ctx->pending = 0;
     (void)hipEventRecord(ctx->ev0, ctx->stream);
   }
+  if (p.n > 0 && !voxel) {
+    NNParams<Real> q{};
+    q.src_pts = pb->pts.p;
+    q.n = p.n;
+    q.kd = p.kd;
+    q.T = p.T;
+    q.max_sq = p.max_sq;
+    q.nn = pb->hint.p;
+    const int sblocks = (p.n + kTile - 1) / kTile;
+    hipLaunchKernelGGL((nn_search_kernel<Real>), dim3(sblocks), dim3(kTile), static_cast<size_t>(std::max(p.kd.depth, 1)) * kTile * sizeof(uint32_t), ctx->stream, q);
+  }
   if (p.n > 0) {
     if (voxel) {
       if (fp->factor_kind == SGA_GICP)
@@ -348,12 +382,6 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
   if (dbg_time) {
     (void)hipStreamSynchronize(ctx->stream);
     std::fprintf(stderr, "[sga stats] linearize us=%.0f", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - dbg_t0).count());
-    if (!voxel && p.kd.stats) {
-      unsigned long long h[16];
-      (void)hipMemcpy(h, p.kd.stats, sizeof(h), hipMemcpyDeviceToHost);
-      (void)hipMemset(p.kd.stats, 0, sizeof(h));
-      std::fprintf(stderr, " per-lane-queries=%llu internal/q=%.1f leaf/q=%.1f max_steps=%llu coop_waves=%llu leaves/wave=%.1f", h[3], h[3] ? double(h[0]) / h[3] : 0.0, h[3] ? double(h[1]) / h[3] : 0.0, h[2], h[5], h[5] ? double(h[4]) / h[5] : 0.0);
-    }
     std::fprintf(stderr, "\n");
   }
   launch_reduce(ctx->stream, pb->partials.p, p.n > 0 ? blocks : 0, 29, kRow, pb->partials.p + static_cast<size_t>(kMaxBlocks) * kRow, d_out30, SGA_ACCUM_DOUBLES);

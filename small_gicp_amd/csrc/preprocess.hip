@@ -379,7 +379,6 @@ int sga_estimate_normals_covariances(sga_context* ctx, sga_cloud* cloud, const s
     if ((flags & 1) && !temp && index->nrm.n < n) rc = index->nrm.alloc(n);
     if (rc == SGA_OK && (flags & 2) && !temp && index->cov.n < n) rc = index->cov.alloc(n);
     KdView kv = make_kd_view(index);
-    kv.stats = nullptr;
     hipLaunchKernelGGL(
       local_features_kernel, dim3((n + kFeatBlock - 1) / kFeatBlock), dim3(kFeatBlock), shmem, ctx->stream, kv, n, k, flags, temp ? nullptr : index->nrm.p, temp ? nullptr : index->cov.p, cloud->nrm.p, cloud->cov.p);
     hipError_t e = hipGetLastError();
