@@ -75,12 +75,14 @@ struct sga_context {
   bool owns_stream = false;
   // scratch
   sga::DevBuf<double> d_accum;    // SGA_ACCUM_DOUBLES
-  double* h_accum = nullptr;      // pinned, SGA_ACCUM_DOUBLES
+  double* h_accum = nullptr;      // pinned + device-mapped: [0, 64) results, word 64 = sequence number of the last published result
+  double* h_accum_dev = nullptr;  // device address of h_accum
+  unsigned long long publish_seq = 0;
   sga::DevBuf<uint8_t> d_temp;    // rocPRIM temp storage (grow-only)
   // profiling
   bool profiling = false;
-  int pending = 0;  // 1 = a linearize event pair awaits collection, 2 = an error pair
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int pending = 0;  // bit 0 = the linearize event pair (ev0, ev1) awaits collection, bit 1 = the error pair (ev2, ev3)
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
   double lin_ms = 0.0, err_ms = 0.0;
   uint64_t lin_calls = 0, err_calls = 0;
   int num_cus = 256;

@@ -108,8 +108,12 @@ static int context_create_impl(int device, void* stream, bool borrow, sga_contex
     ctx->owns_stream = true;
   }
   int rc = ctx->d_accum.alloc(64);
-  if (rc == SGA_OK && hipHostMalloc(reinterpret_cast<void**>(&ctx->h_accum), 64 * sizeof(double), hipHostMallocDefault) != hipSuccess) rc = fail(SGA_ERR_HIP, "hipHostMalloc failed");
-  if (rc == SGA_OK && (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess)) rc = fail(SGA_ERR_HIP, "hipEventCreate failed");
+  if (rc == SGA_OK && hipHostMalloc(reinterpret_cast<void**>(&ctx->h_accum), 128 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) rc = fail(SGA_ERR_HIP, "hipHostMalloc failed");
+  if (rc == SGA_OK) {
+    std::memset(ctx->h_accum, 0, 128 * sizeof(double));
+    if (hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->h_accum_dev), ctx->h_accum, 0) != hipSuccess) rc = fail(SGA_ERR_HIP, "hipHostGetDevicePointer failed");
+  }
+  if (rc == SGA_OK && (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess || hipEventCreate(&ctx->ev2) != hipSuccess || hipEventCreate(&ctx->ev3) != hipSuccess)) rc = fail(SGA_ERR_HIP, "hipEventCreate failed");
   if (rc != SGA_OK) {
     sga_context_destroy(ctx);
     return rc;
@@ -128,6 +132,8 @@ int sga_context_destroy(sga_context* ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
+  if (ctx->ev3) (void)hipEventDestroy(ctx->ev3);
   if (ctx->h_accum) (void)hipHostFree(ctx->h_accum);
   if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;

@@ -70,11 +70,23 @@ __device__ __forceinline__ float kd_cut(uint32_t e) { return __uint_as_float((e 
 
 // stack: LDS, D * STRIDE words (STRIDE = threads per workgroup); this lane uses stack[level * STRIDE + tid].
 // bound2: only points with d2 < bound2 can win (pass max_sq nudged up by one ulp so that d2 == max_sq is still found).
+// seed:   kd position of a target point believed to be close to the query (the neighbour found for this source point at the
+//         previous pose) or -1.  Its distance only tightens the pruning bound from the first descent on — far sides that cannot
+//         beat it are never pushed — the result is still the exact nearest neighbour.
 template <int STRIDE>
-__device__ __forceinline__ KdBest kd_nearest(const KdView& t, float qx, float qy, float qz, float bound2, uint32_t* __restrict__ stack, int tid) {
+__device__ __forceinline__ KdBest kd_nearest(const KdView& t, float qx, float qy, float qz, float bound2, int seed, uint32_t* __restrict__ stack, int tid) {
   KdBest best;
   best.d2 = bound2;
   best.idx = -1;
+  if (seed >= 0 && static_cast<uint32_t>(seed) < t.n) {
+    const float4 c = t.pts[seed];
+    const float dx = c.x - qx, dy = c.y - qy, dz = c.z - qz;
+    const float d2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+    if (d2 < bound2) {
+      best.d2 = d2;
+      best.idx = seed;
+    }
+  }
   if (t.n == 0) return best;
   const int D = t.depth;
   int sp = 0, depth = 0;

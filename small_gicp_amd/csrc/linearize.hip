@@ -81,6 +81,7 @@ struct NNParams {
   KdView kd;
   Rigid<Real> T;
   float max_sq;
+  int use_seed;  // nn[] holds the neighbours found at the previous pose (or -1)
   int* __restrict__ nn;
 };
 
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) v
   Real x, y, z;
   transform_point<Real>(p.T, ps.x, ps.y, ps.z, x, y, z);
   const float bound2 = p.max_sq < 3.0e38f ? p.max_sq * 1.0000002f : INFINITY;  // d2 == max_sq must still be found (strict '>' rejector)
-  const KdBest nb = kd_nearest<kTile>(p.kd, static_cast<float>(x), static_cast<float>(y), static_cast<float>(z), bound2, kd_stack, threadIdx.x);
+  const KdBest nb = kd_nearest<kTile>(p.kd, static_cast<float>(x), static_cast<float>(y), static_cast<float>(z), bound2, p.use_seed ? p.nn[i] : -1, kd_stack, threadIdx.x);
   p.nn[i] = nb.idx;
 }
 
@@ -265,8 +266,11 @@ __global__ __launch_bounds__(kTile) void error_kernel(const ErrParams<Real> p) {
 }
 
 // Deterministic fp64 sum of `nrows` partial rows of `ncols` (<= 32) doubles.  Stage 1: workgroup g sums rows g, g+G, g+2G, ...
-// into row g of `stage` (G = gridDim.x); stage 2 (one workgroup, nrows = G) writes out[ncols] (+ zero padding up to out_n).
-__global__ __launch_bounds__(256) void reduce_rows_kernel(const double* __restrict__ partials, int nrows, int ncols, int row_stride, double* __restrict__ out, int out_stride, int out_n) {
+// into row g of `stage` (G = gridDim.x); stage 2 (one workgroup, nrows = G) writes out[ncols] (+ zero padding up to out_n) and,
+// when `host` is given, hands the result to the host: it copies it into pinned, device-mapped host memory and then publishes a
+// sequence number (system-scope release) on which the host spins.  This replaces hipMemcpyAsync + hipStreamSynchronize, whose
+// fixed cost is paid twice per optimizer iteration.
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const double* __restrict__ partials, int nrows, int ncols, int row_stride, double* __restrict__ out, int out_stride, int out_n, double* __restrict__ host, unsigned long long seq) {
   __shared__ double sh[8][32];
   const int c = threadIdx.x & 31, s = threadIdx.x >> 5;
   double acc = 0.0;
@@ -279,17 +283,23 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const double* __restri
     if (threadIdx.x < ncols)
       for (int k = 0; k < 8; k++) t += sh[k][threadIdx.x];
     out[static_cast<size_t>(blockIdx.x) * out_stride + threadIdx.x] = t;
+    if (host != nullptr) host[threadIdx.x] = t;
+  }
+  if (host != nullptr) {
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(reinterpret_cast<unsigned long long*>(host + 64), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
 constexpr int kReduceGroups = 32;
 
-static void launch_reduce(hipStream_t st, const double* partials, int nrows, int ncols, int row_stride, double* stage, double* out, int out_n) {
+static void launch_reduce(hipStream_t st, const double* partials, int nrows, int ncols, int row_stride, double* stage, double* out, int out_n, double* host, unsigned long long seq) {
   if (nrows > 2 * kReduceGroups) {
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3(kReduceGroups), dim3(256), 0, st, partials, nrows, ncols, row_stride, stage, 32, 32);
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, st, stage, kReduceGroups, ncols, 32, out, 0, out_n);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(kReduceGroups), dim3(256), 0, st, partials, nrows, ncols, row_stride, stage, 32, 32, static_cast<double*>(nullptr), 0ull);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, st, stage, kReduceGroups, ncols, 32, out, 0, out_n, host, seq);
   } else {
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, st, partials, nrows, ncols, row_stride, out, 0, out_n);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, st, partials, nrows, ncols, row_stride, out, 0, out_n, host, seq);
   }
 }
 
@@ -301,7 +311,7 @@ static void launch_linearize(hipStream_t st, const LinParams<Real>& p, int block
 }
 
 template <typename Real>
-static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, const double T[16], double* d_out30) {
+static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, const double T[16], double* d_out30, double* host, unsigned long long seq) {
   const sga_index* idx = pb->target;
   const bool voxel = idx->kind == SGA_INDEX_VOXELMAP;
   if (fp->factor_kind == SGA_GICP && ((pb->n > 0 && !pb->has_covs) || (idx->n > 0 && !idx->has_covs))) return fail(SGA_ERR_INVALID, "GICP needs covariances on both source and target");
@@ -347,7 +357,6 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
   }
   if (ctx->profiling) {
     sga_profile_collect_pending(ctx);
-    ctx->pending = 0;
     (void)hipEventRecord(ctx->ev0, ctx->stream);
   }
   if (p.n > 0 && !voxel) {
@@ -358,6 +367,8 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
     q.T = p.T;
     q.max_sq = p.max_sq;
     q.nn = pb->hint.p;
+    static const int use_seed = getenv("SGA_NN_SEED") ? atoi(getenv("SGA_NN_SEED")) : 1;
+    q.use_seed = use_seed;
     const int sblocks = (p.n + kTile - 1) / kTile;
     hipLaunchKernelGGL((nn_search_kernel<Real>), dim3(sblocks), dim3(kTile), static_cast<size_t>(std::max(p.kd.depth, 1)) * kTile * sizeof(uint32_t), ctx->stream, q);
   }
@@ -377,20 +388,20 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
   }
   if (ctx->profiling) {
     (void)hipEventRecord(ctx->ev1, ctx->stream);
-    ctx->pending = 1;
+    ctx->pending |= 1;
   }
   if (dbg_time) {
     (void)hipStreamSynchronize(ctx->stream);
     std::fprintf(stderr, "[sga stats] linearize us=%.0f", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - dbg_t0).count());
     std::fprintf(stderr, "\n");
   }
-  launch_reduce(ctx->stream, pb->partials.p, p.n > 0 ? blocks : 0, 29, kRow, pb->partials.p + static_cast<size_t>(kMaxBlocks) * kRow, d_out30, SGA_ACCUM_DOUBLES);
+  launch_reduce(ctx->stream, pb->partials.p, p.n > 0 ? blocks : 0, 29, kRow, pb->partials.p + static_cast<size_t>(kMaxBlocks) * kRow, d_out30, SGA_ACCUM_DOUBLES, host, seq);
   SGA_HIP(hipGetLastError());
   return SGA_OK;
 }
 
 template <typename Real>
-static int error_dispatch(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, const double T[16], double* d_out1) {
+static int error_dispatch(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, const double T[16], double* d_out1, double* host, unsigned long long seq) {
   const sga_index* idx = pb->target;
   ErrParams<Real> p{};
   p.src_pts = pb->pts.p;
@@ -413,8 +424,7 @@ static int error_dispatch(sga_context* ctx, sga_problem* pb, const sga_factor_pa
   if (fp->factor_kind == SGA_PLANE_ICP && !idx->has_normals) return fail(SGA_ERR_UNSUPPORTED, "PLANE_ICP needs target normals");
   if (ctx->profiling) {
     sga_profile_collect_pending(ctx);
-    ctx->pending = 0;
-    (void)hipEventRecord(ctx->ev0, ctx->stream);
+    (void)hipEventRecord(ctx->ev2, ctx->stream);
   }
   if (p.n > 0) {
     switch (fp->factor_kind) {
@@ -425,15 +435,49 @@ static int error_dispatch(sga_context* ctx, sga_problem* pb, const sga_factor_pa
     }
   }
   if (ctx->profiling) {
-    (void)hipEventRecord(ctx->ev1, ctx->stream);
-    ctx->pending = 2;
+    (void)hipEventRecord(ctx->ev3, ctx->stream);
+    ctx->pending |= 2;
   }
-  launch_reduce(ctx->stream, pb->partials.p, p.n > 0 ? blocks : 0, 1, 1, pb->partials.p + static_cast<size_t>(kMaxBlocks) * kRow, d_out1, 1);
+  launch_reduce(ctx->stream, pb->partials.p, p.n > 0 ? blocks : 0, 1, 1, pb->partials.p + static_cast<size_t>(kMaxBlocks) * kRow, d_out1, 1, host, seq);
   SGA_HIP(hipGetLastError());
   return SGA_OK;
 }
 
 int problem_partials_rows() { return kMaxBlocks + kReduceGroups; }  // K1/K2 partial rows + the stage-1 rows of the reduction
+
+// Hand `count` doubles to the host after an all-reduce (see reduce_rows_kernel for the protocol).
+__global__ void publish_kernel(const double* __restrict__ src, int count, double* __restrict__ host, unsigned long long seq) {
+  if (static_cast<int>(threadIdx.x) < count) host[threadIdx.x] = src[threadIdx.x];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(reinterpret_cast<unsigned long long*>(host + 64), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+static int wait_result(sga_context* ctx, unsigned long long seq) {
+  const volatile unsigned long long* flag = reinterpret_cast<const volatile unsigned long long*>(ctx->h_accum + 64);
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 0;; spins++) {
+    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return SGA_OK;
+    if ((spins & 0xfffu) == 0xfffu) {
+      // the stream has drained without publishing (a fault), or this is taking implausibly long: let the runtime report it
+      const hipError_t q = hipStreamQuery(ctx->stream);
+      if (q != hipErrorNotReady || std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
+        SGA_HIP(hipStreamSynchronize(ctx->stream));
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return SGA_OK;
+        return fail(SGA_ERR_HIP, "result was not published by the device");
+      }
+    }
+  }
+}
+
+// single GPU: the final reduction kernel publishes; with a communicator the all-reduce comes first
+static int fetch_result(sga_context* ctx, const double* d_src, int count, unsigned long long seq, bool published_by_kernel) {
+  if (!published_by_kernel) {
+    hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, ctx->stream, d_src, count, ctx->h_accum_dev, seq);
+    SGA_HIP(hipGetLastError());
+  }
+  return wait_result(ctx, seq);
+}
 
 static int check_args(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, const double* T) {
   if (!ctx || !pb || !fp || !T) return fail(SGA_ERR_INVALID, "null argument");
@@ -444,18 +488,23 @@ static int check_args(sga_context* ctx, sga_problem* pb, const sga_factor_params
 }  // namespace sga
 // Fold the HIP-event pair of the previous launch into the running averages (no-op while that launch is still in flight).
 void sga_profile_collect_pending(sga_context* ctx) {
+  // Called before the next launch of either kind: the previous launches have long finished (their results were consumed), the
+  // event synchronisation only covers the short gap between the result flag and the event's own completion signal.
   if (!ctx->profiling || ctx->pending == 0) return;
   float ms = 0.f;
-  if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) {
-    if (ctx->pending == 1) {
+  if (ctx->pending & 1) {
+    if (hipEventSynchronize(ctx->ev1) == hipSuccess && hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) {
       ctx->lin_ms += ms;
       ctx->lin_calls++;
-    } else {
+    }
+  }
+  if (ctx->pending & 2) {
+    if (hipEventSynchronize(ctx->ev3) == hipSuccess && hipEventElapsedTime(&ms, ctx->ev2, ctx->ev3) == hipSuccess) {
       ctx->err_ms += ms;
       ctx->err_calls++;
     }
-    ctx->pending = 0;
   }
+  ctx->pending = 0;
 }
 namespace sga {
 
@@ -482,24 +531,26 @@ int sga_linearize_async(sga_context* ctx, sga_problem* pb, const sga_factor_para
   SGA_TRY(check_args(ctx, pb, fp, T));
   if (!d_out30) return fail(SGA_ERR_INVALID, "null output");
   SGA_HIP(hipSetDevice(ctx->device));
-  return fp->math_mode == SGA_MATH_FP64 ? linearize_dispatch<double>(ctx, pb, fp, T, d_out30) : linearize_dispatch<float>(ctx, pb, fp, T, d_out30);
+  return fp->math_mode == SGA_MATH_FP64 ? linearize_dispatch<double>(ctx, pb, fp, T, d_out30, nullptr, 0) : linearize_dispatch<float>(ctx, pb, fp, T, d_out30, nullptr, 0);
 }
 
 int sga_error_async(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, const double T[16], double* d_out1) {
   SGA_TRY(check_args(ctx, pb, fp, T));
   if (!d_out1) return fail(SGA_ERR_INVALID, "null output");
   SGA_HIP(hipSetDevice(ctx->device));
-  return fp->math_mode == SGA_MATH_FP64 ? error_dispatch<double>(ctx, pb, fp, T, d_out1) : error_dispatch<float>(ctx, pb, fp, T, d_out1);
+  return fp->math_mode == SGA_MATH_FP64 ? error_dispatch<double>(ctx, pb, fp, T, d_out1, nullptr, 0) : error_dispatch<float>(ctx, pb, fp, T, d_out1, nullptr, 0);
 }
 
 int sga_linearize(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, const double T[16], double H[36], double b[6], double* e, uint64_t* num_inliers) {
   SGA_TRY(check_args(ctx, pb, fp, T));
   if (!H || !b || !e) return fail(SGA_ERR_INVALID, "null output");
-  SGA_TRY(sga_linearize_async(ctx, pb, fp, T, ctx->d_accum.p));
+  SGA_HIP(hipSetDevice(ctx->device));
+  const unsigned long long seq = ++ctx->publish_seq;
+  const bool direct = ctx->comm == nullptr;
+  double* host = direct ? ctx->h_accum_dev : nullptr;
+  SGA_TRY(fp->math_mode == SGA_MATH_FP64 ? linearize_dispatch<double>(ctx, pb, fp, T, ctx->d_accum.p, host, seq) : linearize_dispatch<float>(ctx, pb, fp, T, ctx->d_accum.p, host, seq));
   SGA_TRY(comm_allreduce_sum(ctx, ctx->d_accum.p, SGA_ACCUM_DOUBLES));  // source sharded over ranks: sum the shards' systems
-  SGA_HIP(hipMemcpyAsync(ctx->h_accum, ctx->d_accum.p, sizeof(double) * SGA_ACCUM_DOUBLES, hipMemcpyDeviceToHost, ctx->stream));
-  SGA_HIP(hipStreamSynchronize(ctx->stream));
-  sga_profile_collect_pending(ctx);
+  SGA_TRY(fetch_result(ctx, ctx->d_accum.p, SGA_ACCUM_DOUBLES, seq, direct));
   sga_unpack_accumulator(ctx->h_accum, H, b, e, num_inliers);
   return SGA_OK;
 }
@@ -507,11 +558,13 @@ int sga_linearize(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp
 int sga_error(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, const double T[16], double* e) {
   SGA_TRY(check_args(ctx, pb, fp, T));
   if (!e) return fail(SGA_ERR_INVALID, "null output");
-  SGA_TRY(sga_error_async(ctx, pb, fp, T, ctx->d_accum.p));
+  SGA_HIP(hipSetDevice(ctx->device));
+  const unsigned long long seq = ++ctx->publish_seq;
+  const bool direct = ctx->comm == nullptr;
+  double* host = direct ? ctx->h_accum_dev : nullptr;
+  SGA_TRY(fp->math_mode == SGA_MATH_FP64 ? error_dispatch<double>(ctx, pb, fp, T, ctx->d_accum.p, host, seq) : error_dispatch<float>(ctx, pb, fp, T, ctx->d_accum.p, host, seq));
   SGA_TRY(comm_allreduce_sum(ctx, ctx->d_accum.p, 1));
-  SGA_HIP(hipMemcpyAsync(ctx->h_accum, ctx->d_accum.p, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  SGA_HIP(hipStreamSynchronize(ctx->stream));
-  sga_profile_collect_pending(ctx);
+  SGA_TRY(fetch_result(ctx, ctx->d_accum.p, 1, seq, direct));
   *e = ctx->h_accum[0];
   return SGA_OK;
 }
