@@ -136,6 +136,8 @@ int sga_problem_get_factors(sga_context* ctx, const sga_problem* problem, int64_
 /* Average device time (ms) of the last linearize / error kernel chains measured with HIP events on the context's stream (0 if profiling off). */
 int sga_context_set_profiling(sga_context* ctx, int enabled);
 int sga_context_get_kernel_ms(sga_context* ctx, double* linearize_ms, uint64_t* linearize_calls, double* error_ms, uint64_t* error_calls);
+/* The part of linearize_ms spent in the nearest-neighbour search kernel (the rest: factor evaluation + block reduction). */
+int sga_context_get_search_ms(sga_context* ctx, double* search_ms, uint64_t* search_calls);
 
 /* ---- the driver: Registration<>::align + optimizers (registration/registration.hpp:33-54, optimizer.hpp:24-149) -------- */
 typedef struct sga_registration_setting {

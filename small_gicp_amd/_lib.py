@@ -98,6 +98,7 @@ SYMBOLS = [
     ("sga_problem_get_factors", C.c_int, [_vp, _vp, C.POINTER(C.c_int64), _fp]),
     ("sga_context_set_profiling", C.c_int, [_vp, C.c_int]),
     ("sga_context_get_kernel_ms", C.c_int, [_vp, _dp, C.POINTER(C.c_uint64), _dp, C.POINTER(C.c_uint64)]),
+    ("sga_context_get_search_ms", C.c_int, [_vp, _dp, C.POINTER(C.c_uint64)]),
     ("sga_registration_setting_default", None, [C.POINTER(RegistrationSettingC)]),
     ("sga_align", C.c_int, [_vp, _vp, _vp, _dp, C.POINTER(RegistrationSettingC), C.POINTER(ResultC)]),
     ("sga_align_problem", C.c_int, [_vp, _vp, _dp, C.POINTER(RegistrationSettingC), C.POINTER(ResultC)]),

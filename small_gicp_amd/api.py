@@ -65,7 +65,9 @@ class Context:
         lm, em = C.c_double(), C.c_double()
         lc, ec = C.c_uint64(), C.c_uint64()
         check(load().sga_context_get_kernel_ms(self.h, C.byref(lm), C.byref(lc), C.byref(em), C.byref(ec)))
-        return {"linearize_ms": lm.value, "linearize_calls": lc.value, "error_ms": em.value, "error_calls": ec.value}
+        sm, sc = C.c_double(), C.c_uint64()
+        check(load().sga_context_get_search_ms(self.h, C.byref(sm), C.byref(sc)))
+        return {"linearize_ms": lm.value, "linearize_calls": lc.value, "error_ms": em.value, "error_calls": ec.value, "search_ms": sm.value, "search_calls": sc.value}
 
 
 _DEFAULT_CTX = None

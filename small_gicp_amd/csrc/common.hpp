@@ -82,7 +82,10 @@ struct sga_context {
   // profiling
   bool profiling = false;
   int pending = 0;  // bit 0 = the linearize event pair (ev0, ev1) awaits collection, bit 1 = the error pair (ev2, ev3)
-  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr, ev_mid = nullptr;  // ev_mid: between the search and the factor kernel
+  bool mid_recorded = false;
+  double search_ms = 0.0;
+  unsigned long long search_calls = 0;
   double lin_ms = 0.0, err_ms = 0.0;
   uint64_t lin_calls = 0, err_calls = 0;
   int num_cus = 256;
@@ -113,6 +116,7 @@ struct sga_index {
   sga::DevBuf<sga::Cov8> cov;       // kd order.  Voxel maps: mean covariances in voxel-id order
   sga::DevBuf<float2> kd_nodes;     // 2^kd_depth entries (index 0 unused)
   sga::DevBuf<float4> kd_nodes4;    // pair records of the even depths (kd_search.hpp)
+  sga::DevBuf<float4> kd_boxes;     // tight bounding box of every node: [2 * node] = min corner, [2 * node + 1] = max corner
   int kd_depth = 0;
   float bbox_lo[3] = {0, 0, 0}, bbox_hi[3] = {0, 0, 0};
   // voxel map

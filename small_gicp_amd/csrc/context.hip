@@ -113,7 +113,7 @@ static int context_create_impl(int device, void* stream, bool borrow, sga_contex
     std::memset(ctx->h_accum, 0, 128 * sizeof(double));
     if (hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->h_accum_dev), ctx->h_accum, 0) != hipSuccess) rc = fail(SGA_ERR_HIP, "hipHostGetDevicePointer failed");
   }
-  if (rc == SGA_OK && (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess || hipEventCreate(&ctx->ev2) != hipSuccess || hipEventCreate(&ctx->ev3) != hipSuccess)) rc = fail(SGA_ERR_HIP, "hipEventCreate failed");
+  if (rc == SGA_OK && (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess || hipEventCreate(&ctx->ev2) != hipSuccess || hipEventCreate(&ctx->ev3) != hipSuccess || hipEventCreate(&ctx->ev_mid) != hipSuccess)) rc = fail(SGA_ERR_HIP, "hipEventCreate failed");
   if (rc != SGA_OK) {
     sga_context_destroy(ctx);
     return rc;
@@ -134,6 +134,7 @@ int sga_context_destroy(sga_context* ctx) {
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
   if (ctx->ev3) (void)hipEventDestroy(ctx->ev3);
+  if (ctx->ev_mid) (void)hipEventDestroy(ctx->ev_mid);
   if (ctx->h_accum) (void)hipHostFree(ctx->h_accum);
   if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -153,6 +154,8 @@ int sga_context_set_profiling(sga_context* ctx, int enabled) {
   ctx->profiling = enabled != 0;
   ctx->lin_ms = ctx->err_ms = 0.0;
   ctx->lin_calls = ctx->err_calls = 0;
+  ctx->search_ms = 0.0;
+  ctx->search_calls = 0;
   ctx->pending = 0;
   return SGA_OK;
 }
@@ -164,6 +167,14 @@ int sga_context_get_kernel_ms(sga_context* ctx, double* lin_ms, uint64_t* lin_ca
   if (lin_calls) *lin_calls = ctx->lin_calls;
   if (err_ms) *err_ms = ctx->err_calls ? ctx->err_ms / ctx->err_calls : 0.0;
   if (err_calls) *err_calls = ctx->err_calls;
+  return SGA_OK;
+}
+
+int sga_context_get_search_ms(sga_context* ctx, double* search_ms, uint64_t* search_calls) {
+  if (!ctx) return fail(SGA_ERR_INVALID, "null context");
+  sga_profile_collect_pending(ctx);
+  if (search_ms) *search_ms = ctx->search_calls ? ctx->search_ms / ctx->search_calls : 0.0;
+  if (search_calls) *search_calls = ctx->search_calls;
   return SGA_OK;
 }
 

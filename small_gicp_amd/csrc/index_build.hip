@@ -200,6 +200,35 @@ __global__ void kd_pairs_kernel(const float2* __restrict__ nodes, int D, int d, 
   pairs[kd_pair_index(d, node)] = make_float4(a.x, l.x, r.x, __uint_as_float(axes));
 }
 
+// Tight bounding boxes of all nodes, bottom-up (kd_search.hpp: a pending far side is opened only if its box can hold a closer point).
+__global__ void kd_leaf_boxes_kernel(const float4* __restrict__ pts, uint32_t n, int D, float4* __restrict__ boxes) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= (1u << D)) return;
+  const uint32_t first = kd_bound(n, D, k), end = kd_bound(n, D, k + 1);
+  float3 lo = make_float3(INFINITY, INFINITY, INFINITY), hi = make_float3(-INFINITY, -INFINITY, -INFINITY);
+  for (uint32_t i = first; i < end; i++) {
+    const float4 p = pts[i];
+    lo.x = fminf(lo.x, p.x);
+    lo.y = fminf(lo.y, p.y);
+    lo.z = fminf(lo.z, p.z);
+    hi.x = fmaxf(hi.x, p.x);
+    hi.y = fmaxf(hi.y, p.y);
+    hi.z = fmaxf(hi.z, p.z);
+  }
+  const uint32_t node = (1u << D) + k;
+  boxes[2 * node] = make_float4(lo.x, lo.y, lo.z, 0.f);
+  boxes[2 * node + 1] = make_float4(hi.x, hi.y, hi.z, 0.f);
+}
+
+__global__ void kd_inner_boxes_kernel(int d, float4* __restrict__ boxes) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= (1u << d)) return;
+  const uint32_t node = (1u << d) + k;
+  const float4 l0 = boxes[4 * node], h0 = boxes[4 * node + 1], l1 = boxes[4 * node + 2], h1 = boxes[4 * node + 3];
+  boxes[2 * node] = make_float4(fminf(l0.x, l1.x), fminf(l0.y, l1.y), fminf(l0.z, l1.z), 0.f);
+  boxes[2 * node + 1] = make_float4(fmaxf(h0.x, h1.x), fmaxf(h0.y, h1.y), fmaxf(h0.z, h1.z), 0.f);
+}
+
 __global__ void iota_kernel(uint32_t* __restrict__ v, size_t n) {
   const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
   if (i < n) v[i] = static_cast<uint32_t>(i);
@@ -270,6 +299,9 @@ static int build_kdtree(sga_context* ctx, const sga_cloud* cloud, sga_index* idx
   if (cloud->has_normals) SGA_TRY(idx->nrm.alloc(n));
   if (cloud->has_covs) SGA_TRY(idx->cov.alloc(n));
   hipLaunchKernelGGL(gather_sorted_kernel, dim3((n + kKdLeafMax + 255) / 256), block, 0, ctx->stream, cur, n, cloud->pts.p, cloud->has_normals ? cloud->nrm.p : nullptr, cloud->has_covs ? cloud->cov.p : nullptr, idx->kd_pts.p, idx->nrm.p, idx->cov.p);
+  SGA_TRY(idx->kd_boxes.alloc(4ull << D));
+  hipLaunchKernelGGL(kd_leaf_boxes_kernel, dim3(((1u << D) + 255) / 256), block, 0, ctx->stream, idx->kd_pts.p, static_cast<uint32_t>(n), D, idx->kd_boxes.p);
+  for (int d = D - 1; d >= 0; d--) hipLaunchKernelGGL(kd_inner_boxes_kernel, dim3(((1u << d) + 255) / 256), block, 0, ctx->stream, d, idx->kd_boxes.p);
   SGA_HIP(hipGetLastError());
   SGA_HIP(hipStreamSynchronize(ctx->stream));
   return SGA_OK;

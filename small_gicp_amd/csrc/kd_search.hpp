@@ -29,6 +29,7 @@ struct KdView {
   const float4* __restrict__ pts;     // kd order, w = original index bits
   const float2* __restrict__ nodes;   // [2^D] heap: x = threshold, y = bitcast(axis)
   const float4* __restrict__ nodes4;  // pair records: x = own threshold, y / z = thresholds of the left / right child, w = axes (2 bits each)
+  const float4* __restrict__ boxes;   // tight bounding boxes: [2 * node] = min corner, [2 * node + 1] = max corner
   uint32_t n;
   int depth;  // D; leaves are the 2^D ranges at depth D
 };
@@ -38,6 +39,7 @@ inline KdView make_kd_view(const sga_index* idx) {
   k.pts = idx->kd_pts.p;
   k.nodes = idx->kd_nodes.p;
   k.nodes4 = idx->kd_nodes4.p;
+  k.boxes = idx->kd_boxes.p;
   k.n = static_cast<uint32_t>(idx->n);
   k.depth = idx->kd_depth;
   return k;
@@ -73,6 +75,19 @@ __device__ __forceinline__ float kd_cut(uint32_t e) { return __uint_as_float((e 
 // seed:   kd position of a target point believed to be close to the query (the neighbour found for this source point at the
 //         previous pose) or -1.  Its distance only tightens the pruning bound from the first descent on — far sides that cannot
 //         beat it are never pushed — the result is still the exact nearest neighbour.
+// Squared distance from the query to the tight bounding box of `node`, evaluated with the same operations (and rounding) as a
+// point distance: it never exceeds the distance to any point inside the box.  The split planes alone are a weak bound on
+// surface-like data — a cell reaches far beyond the points it holds — so a pending far side that passed the plane test is opened
+// only if its box can still hold a closer point.  (The reference prunes with the planes only, kdtree.hpp:224-230; the result is
+// the same nearest neighbour, found in about half the rounds.)
+__device__ __forceinline__ float kd_box_dist2(const KdView& t, uint32_t node, float qx, float qy, float qz) {
+  const float4 lo = t.boxes[2 * node], hi = t.boxes[2 * node + 1];
+  const float dx = fmaxf(fmaxf(lo.x - qx, qx - hi.x), 0.f);
+  const float dy = fmaxf(fmaxf(lo.y - qy, qy - hi.y), 0.f);
+  const float dz = fmaxf(fmaxf(lo.z - qz, qz - hi.z), 0.f);
+  return fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+}
+
 template <int STRIDE>
 __device__ __forceinline__ KdBest kd_nearest(const KdView& t, float qx, float qy, float qz, float bound2, int seed, uint32_t* __restrict__ stack, int tid) {
   KdBest best;
@@ -93,10 +108,14 @@ __device__ __forceinline__ KdBest kd_nearest(const KdView& t, float qx, float qy
   uint32_t node = 1;
   for (;;) {
     while (depth < D) {
-      // one pair record covers the node itself (if it is of even depth) and the child the walk continues into
+      // one pair record covers the node itself (if it is of even depth) and the child the walk continues into; it is fetched with
+      // ONE 16-byte load per lane
       const int odd = depth & 1;
-      const float4 nd = t.nodes4[kd_pair_index(depth - odd, node >> odd)];
-      const uint32_t axes = __float_as_uint(nd.w);
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      u32x4 raw;
+      asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(raw) : "v"(t.nodes4 + kd_pair_index(depth - odd, node >> odd)) : "memory");
+      const float4 nd = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y), __uint_as_float(raw.z), __uint_as_float(raw.w));
+      const uint32_t axes = raw.w;
       if (!odd) {
         const uint32_t axis = axes & 3u;
         const float qa = axis == 0 ? qx : (axis == 1 ? qy : qz);
@@ -145,13 +164,13 @@ __device__ __forceinline__ KdBest kd_nearest(const KdView& t, float qx, float qy
       }
       best.idx = slot >= 0 ? static_cast<int>(first) + slot : best.idx;
     }
-    // next pending far side that can still hold a closer point
+    // next pending far side that can still hold a closer point: plane test on the stored cut, then the box test
     uint32_t e = 0;
     bool found = false;
     while (sp > 0 && !found) {
       sp--;
       e = stack[sp * STRIDE + tid];
-      found = kd_cut(e) < best.d2;
+      if (kd_cut(e) < best.d2) found = kd_box_dist2(t, (node >> (D - static_cast<int>(e & 31u))) ^ 1u, qx, qy, qz) < best.d2;
     }
     if (!found) break;
     depth = static_cast<int>(e & 31u);

@@ -371,6 +371,10 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
     q.use_seed = use_seed;
     const int sblocks = (p.n + kTile - 1) / kTile;
     hipLaunchKernelGGL((nn_search_kernel<Real>), dim3(sblocks), dim3(kTile), static_cast<size_t>(std::max(p.kd.depth, 1)) * kTile * sizeof(uint32_t), ctx->stream, q);
+    if (ctx->profiling) {
+      (void)hipEventRecord(ctx->ev_mid, ctx->stream);
+      ctx->mid_recorded = true;
+    }
   }
   if (p.n > 0) {
     if (voxel) {
@@ -496,7 +500,12 @@ void sga_profile_collect_pending(sga_context* ctx) {
     if (hipEventSynchronize(ctx->ev1) == hipSuccess && hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) {
       ctx->lin_ms += ms;
       ctx->lin_calls++;
+      if (ctx->mid_recorded && hipEventElapsedTime(&ms, ctx->ev0, ctx->ev_mid) == hipSuccess) {
+        ctx->search_ms += ms;
+        ctx->search_calls++;
+      }
     }
+    ctx->mid_recorded = false;
   }
   if (ctx->pending & 2) {
     if (hipEventSynchronize(ctx->ev3) == hipSuccess && hipEventElapsedTime(&ms, ctx->ev2, ctx->ev3) == hipSuccess) {
