@@ -201,32 +201,65 @@ __global__ void kd_pairs_kernel(const float2* __restrict__ nodes, int D, int d, 
 }
 
 // Tight bounding boxes of all nodes, bottom-up (kd_search.hpp: a pending far side is opened only if its box can hold a closer point).
-__global__ void kd_leaf_boxes_kernel(const float4* __restrict__ pts, uint32_t n, int D, float4* __restrict__ boxes) {
-  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= (1u << D)) return;
-  const uint32_t first = kd_bound(n, D, k), end = kd_bound(n, D, k + 1);
-  float3 lo = make_float3(INFINITY, INFINITY, INFINITY), hi = make_float3(-INFINITY, -INFINITY, -INFINITY);
-  for (uint32_t i = first; i < end; i++) {
-    const float4 p = pts[i];
-    lo.x = fminf(lo.x, p.x);
-    lo.y = fminf(lo.y, p.y);
-    lo.z = fminf(lo.z, p.z);
-    hi.x = fmaxf(hi.x, p.x);
-    hi.y = fmaxf(hi.y, p.y);
-    hi.z = fmaxf(hi.z, p.z);
+// One launch covers up to 8 levels: every workgroup takes 256 adjacent nodes of depth `base` — their boxes come from the points
+// (base = D, leaves) or from the previous launch — and merges them pairwise in LDS up to depth base - 8.
+__global__ __launch_bounds__(256) void kd_boxes_kernel(const float4* __restrict__ pts, uint32_t n, int D, int base, float4* __restrict__ boxes) {
+  __shared__ float slo[3][256], shi[3][256];
+  const uint32_t t = threadIdx.x, k = blockIdx.x * 256u + t;
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  if (k < (1u << base)) {
+    const uint32_t node = (1u << base) + k;
+    if (base == D) {
+      const uint32_t first = kd_bound(n, D, k), end = kd_bound(n, D, k + 1);
+      for (uint32_t i = first; i < end; i++) {
+        const float4 p = pts[i];
+        lo[0] = fminf(lo[0], p.x);
+        lo[1] = fminf(lo[1], p.y);
+        lo[2] = fminf(lo[2], p.z);
+        hi[0] = fmaxf(hi[0], p.x);
+        hi[1] = fmaxf(hi[1], p.y);
+        hi[2] = fmaxf(hi[2], p.z);
+      }
+      boxes[2 * node] = make_float4(lo[0], lo[1], lo[2], 0.f);
+      boxes[2 * node + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
+    } else {
+      const float4 l = boxes[2 * node], h = boxes[2 * node + 1];
+      lo[0] = l.x;
+      lo[1] = l.y;
+      lo[2] = l.z;
+      hi[0] = h.x;
+      hi[1] = h.y;
+      hi[2] = h.z;
+    }
   }
-  const uint32_t node = (1u << D) + k;
-  boxes[2 * node] = make_float4(lo.x, lo.y, lo.z, 0.f);
-  boxes[2 * node + 1] = make_float4(hi.x, hi.y, hi.z, 0.f);
-}
-
-__global__ void kd_inner_boxes_kernel(int d, float4* __restrict__ boxes) {
-  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= (1u << d)) return;
-  const uint32_t node = (1u << d) + k;
-  const float4 l0 = boxes[4 * node], h0 = boxes[4 * node + 1], l1 = boxes[4 * node + 2], h1 = boxes[4 * node + 3];
-  boxes[2 * node] = make_float4(fminf(l0.x, l1.x), fminf(l0.y, l1.y), fminf(l0.z, l1.z), 0.f);
-  boxes[2 * node + 1] = make_float4(fmaxf(h0.x, h1.x), fmaxf(h0.y, h1.y), fmaxf(h0.z, h1.z), 0.f);
+  for (int a = 0; a < 3; a++) {
+    slo[a][t] = lo[a];
+    shi[a][t] = hi[a];
+  }
+  __syncthreads();
+  for (int l = 1; l <= 8 && l <= base; l++) {
+    const uint32_t width = 256u >> l;  // nodes of depth base - l in this workgroup
+    if (t < width) {
+      for (int a = 0; a < 3; a++) {
+        lo[a] = fminf(slo[a][2 * t], slo[a][2 * t + 1]);
+        hi[a] = fmaxf(shi[a][2 * t], shi[a][2 * t + 1]);
+      }
+    }
+    __syncthreads();
+    if (t < width) {
+      for (int a = 0; a < 3; a++) {
+        slo[a][t] = lo[a];
+        shi[a][t] = hi[a];
+      }
+      const uint32_t kk = (blockIdx.x * 256u >> l) + t;
+      if (kk < (1u << (base - l))) {
+        const uint32_t node = (1u << (base - l)) + kk;
+        boxes[2 * node] = make_float4(lo[0], lo[1], lo[2], 0.f);
+        boxes[2 * node + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
+      }
+    }
+    __syncthreads();
+  }
 }
 
 __global__ void iota_kernel(uint32_t* __restrict__ v, size_t n) {
@@ -300,8 +333,10 @@ static int build_kdtree(sga_context* ctx, const sga_cloud* cloud, sga_index* idx
   if (cloud->has_covs) SGA_TRY(idx->cov.alloc(n));
   hipLaunchKernelGGL(gather_sorted_kernel, dim3((n + kKdLeafMax + 255) / 256), block, 0, ctx->stream, cur, n, cloud->pts.p, cloud->has_normals ? cloud->nrm.p : nullptr, cloud->has_covs ? cloud->cov.p : nullptr, idx->kd_pts.p, idx->nrm.p, idx->cov.p);
   SGA_TRY(idx->kd_boxes.alloc(4ull << D));
-  hipLaunchKernelGGL(kd_leaf_boxes_kernel, dim3(((1u << D) + 255) / 256), block, 0, ctx->stream, idx->kd_pts.p, static_cast<uint32_t>(n), D, idx->kd_boxes.p);
-  for (int d = D - 1; d >= 0; d--) hipLaunchKernelGGL(kd_inner_boxes_kernel, dim3(((1u << d) + 255) / 256), block, 0, ctx->stream, d, idx->kd_boxes.p);
+  for (int base = D;; base -= 8) {
+    hipLaunchKernelGGL(kd_boxes_kernel, dim3(((1u << base) + 255) / 256), block, 0, ctx->stream, idx->kd_pts.p, static_cast<uint32_t>(n), D, base, idx->kd_boxes.p);
+    if (base <= 8) break;
+  }
   SGA_HIP(hipGetLastError());
   SGA_HIP(hipStreamSynchronize(ctx->stream));
   return SGA_OK;

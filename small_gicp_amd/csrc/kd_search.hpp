@@ -243,10 +243,14 @@ __device__ __forceinline__ void kd_knn(const KdView& t, float qx, float qy, floa
       sp--;
       const uint32_t e = stack[sp * STRIDE + tid];
       if (kd_cut(e) <= worst) {
-        depth = static_cast<int>(e & 31u);
-        node = (node >> (D - depth)) ^ 1u;
-        found = true;
-        break;
+        const int dd = static_cast<int>(e & 31u);
+        const uint32_t far_node = (node >> (D - dd)) ^ 1u;
+        if (kd_box_dist2(t, far_node, qx, qy, qz) <= worst) {  // plane test, then the tight box of the pending sub-tree
+          depth = dd;
+          node = far_node;
+          found = true;
+          break;
+        }
       }
     }
     if (!found) break;
