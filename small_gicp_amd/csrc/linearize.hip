@@ -88,7 +88,11 @@ struct NNParams {
 template <typename Real>
 __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) void nn_search_kernel(const NNParams<Real> p) {
   extern __shared__ uint32_t kd_stack[];  // tree depth x kTile traversal stack slots
-  const int i = blockIdx.x * kTile + threadIdx.x;
+  // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed placement; only speed depends on it), and the source is sorted by
+  // target leaf, so giving each XCD one contiguous eighth of the tiles makes its L2 hold one eighth of the target instead of all of it
+  const int nblk = gridDim.x, per_xcd = nblk >> 3, b = blockIdx.x;
+  const int tile = b < 8 * per_xcd ? (b & 7) * per_xcd + (b >> 3) : b;
+  const int i = tile * kTile + threadIdx.x;
   if (i >= p.n) return;
   const float4 ps = p.src_pts[i];
   Real x, y, z;
