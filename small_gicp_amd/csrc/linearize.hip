@@ -71,9 +71,9 @@ __device__ __forceinline__ Sym3<Real> load_sym(const Cov8* __restrict__ c, int i
 }
 
 // K1a: nearest neighbour of every transformed source point (kd_search.hpp); writes its kd position (or -1 when nothing lies
-// within the search bound) to nn[i].  One 256-point tile per workgroup: the hardware dispatcher balances the uneven walks, and
-// without the per-pair algebra the kernel fits 8 waves per SIMD, which the latency-bound walk needs.  K1b (linearize_kernel)
-// evaluates the factors over nn[].
+// within the search bound) to nn[i].  One wave per workgroup (a finished wave frees its slot and its 4 KB of stack at once; the
+// hardware dispatcher balances the uneven walks), and without the per-pair algebra the kernel fits 8 waves per SIMD, which the
+// latency-bound walk needs.  K1b (linearize_kernel) evaluates the factors over nn[].
 template <typename Real>
 struct NNParams {
   const float4* __restrict__ src_pts;
@@ -85,20 +85,20 @@ struct NNParams {
   int* __restrict__ nn;
 };
 
-template <typename Real>
-__global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) void nn_search_kernel(const NNParams<Real> p) {
-  extern __shared__ uint32_t kd_stack[];  // tree depth x kTile traversal stack slots
+template <typename Real, int BLOCK>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void nn_search_kernel(const NNParams<Real> p) {
+  extern __shared__ uint32_t kd_stack[];  // tree depth x BLOCK traversal stack slots
   // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed placement; only speed depends on it), and the source is sorted by
   // target leaf, so giving each XCD one contiguous eighth of the tiles makes its L2 hold one eighth of the target instead of all of it
   const int nblk = gridDim.x, per_xcd = nblk >> 3, b = blockIdx.x;
   const int tile = b < 8 * per_xcd ? (b & 7) * per_xcd + (b >> 3) : b;
-  const int i = tile * kTile + threadIdx.x;
+  const int i = tile * BLOCK + threadIdx.x;
   if (i >= p.n) return;
   const float4 ps = p.src_pts[i];
   Real x, y, z;
   transform_point<Real>(p.T, ps.x, ps.y, ps.z, x, y, z);
   const float bound2 = p.max_sq < 3.0e38f ? p.max_sq * 1.0000002f : INFINITY;  // d2 == max_sq must still be found (strict '>' rejector)
-  const KdBest nb = kd_nearest<kTile>(p.kd, static_cast<float>(x), static_cast<float>(y), static_cast<float>(z), bound2, p.use_seed ? p.nn[i] : -1, kd_stack, threadIdx.x);
+  const KdBest nb = kd_nearest<BLOCK>(p.kd, static_cast<float>(x), static_cast<float>(y), static_cast<float>(z), bound2, p.use_seed ? p.nn[i] : -1, kd_stack, threadIdx.x);
   p.nn[i] = nb.idx;
 }
 
@@ -373,8 +373,14 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
     q.nn = pb->hint.p;
     static const int use_seed = getenv("SGA_NN_SEED") ? atoi(getenv("SGA_NN_SEED")) : 1;
     q.use_seed = use_seed;
-    const int sblocks = (p.n + kTile - 1) / kTile;
-    hipLaunchKernelGGL((nn_search_kernel<Real>), dim3(sblocks), dim3(kTile), static_cast<size_t>(std::max(p.kd.depth, 1)) * kTile * sizeof(uint32_t), ctx->stream, q);
+    static const int sb = getenv("SGA_NN_BLOCK") ? atoi(getenv("SGA_NN_BLOCK")) : 64;
+    const size_t words = static_cast<size_t>(std::max(p.kd.depth, 1));
+    if (sb == 64)
+      hipLaunchKernelGGL((nn_search_kernel<Real, 64>), dim3((p.n + 63) / 64), dim3(64), words * 64 * sizeof(uint32_t), ctx->stream, q);
+    else if (sb == 128)
+      hipLaunchKernelGGL((nn_search_kernel<Real, 128>), dim3((p.n + 127) / 128), dim3(128), words * 128 * sizeof(uint32_t), ctx->stream, q);
+    else
+      hipLaunchKernelGGL((nn_search_kernel<Real, 256>), dim3((p.n + 255) / 256), dim3(256), words * 256 * sizeof(uint32_t), ctx->stream, q);
     if (ctx->profiling) {
       (void)hipEventRecord(ctx->ev_mid, ctx->stream);
       ctx->mid_recorded = true;
