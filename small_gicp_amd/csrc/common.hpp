@@ -75,6 +75,7 @@ struct sga_context {
   bool owns_stream = false;
   // scratch
   sga::DevBuf<double> d_accum;    // SGA_ACCUM_DOUBLES
+  sga::DevBuf<unsigned> d_ticket; // arrival counter of the reduction kernel (linearize.hip), zero between launches
   double* h_accum = nullptr;      // pinned + device-mapped: [0, 64) results, word 64 = sequence number of the last published result
   double* h_accum_dev = nullptr;  // device address of h_accum
   unsigned long long publish_seq = 0;

@@ -108,6 +108,8 @@ static int context_create_impl(int device, void* stream, bool borrow, sga_contex
     ctx->owns_stream = true;
   }
   int rc = ctx->d_accum.alloc(64);
+  if (rc == SGA_OK) rc = ctx->d_ticket.alloc(16);
+  if (rc == SGA_OK && hipMemsetAsync(ctx->d_ticket.p, 0, 16 * sizeof(unsigned), ctx->stream) != hipSuccess) rc = fail(SGA_ERR_HIP, "hipMemsetAsync failed");
   if (rc == SGA_OK && hipHostMalloc(reinterpret_cast<void**>(&ctx->h_accum), 128 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) rc = fail(SGA_ERR_HIP, "hipHostMalloc failed");
   if (rc == SGA_OK) {
     std::memset(ctx->h_accum, 0, 128 * sizeof(double));

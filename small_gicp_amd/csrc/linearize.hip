@@ -269,26 +269,53 @@ __global__ __launch_bounds__(kTile) void error_kernel(const ErrParams<Real> p) {
   }
 }
 
-// Deterministic fp64 sum of `nrows` partial rows of `ncols` (<= 32) doubles.  Stage 1: workgroup g sums rows g, g+G, g+2G, ...
-// into row g of `stage` (G = gridDim.x); stage 2 (one workgroup, nrows = G) writes out[ncols] (+ zero padding up to out_n) and,
-// when `host` is given, hands the result to the host: it copies it into pinned, device-mapped host memory and then publishes a
-// sequence number (system-scope release) on which the host spins.  This replaces hipMemcpyAsync + hipStreamSynchronize, whose
-// fixed cost is paid twice per optimizer iteration.
-__global__ __launch_bounds__(256) void reduce_rows_kernel(const double* __restrict__ partials, int nrows, int ncols, int row_stride, double* __restrict__ out, int out_stride, int out_n, double* __restrict__ host, unsigned long long seq) {
+// Deterministic fp64 sum of `nrows` partial rows of `ncols` (<= 32) doubles in ONE launch of G = 32 workgroups: workgroup g sums
+// rows g, g+G, g+2G, ... into row g of `stage`; the workgroup that finishes LAST (a ticket counter) adds the G stage rows in fixed
+// order — which workgroup that is changes nothing in the arithmetic — and writes out[ncols] (+ zero padding up to out_n).
+// Hand-off between workgroups (per-CU L1s and per-XCD L2s are not coherent): stage rows are written and read with agent-scope
+// relaxed atomics (write-through / cache-bypassing accesses) and drained (s_waitcnt vmcnt(0)) before the ticket is taken; only
+// these 32 workgroups touch the ticket.  (Putting the ticket into the 2048 workgroups of the producer kernel was measured: +20 us.)
+// When `host` is given the result is handed to the host right here: copied into pinned, device-mapped host memory, then a
+// sequence number is published (system-scope release) on which the host spins.  This replaces hipMemcpyAsync +
+// hipStreamSynchronize, whose fixed cost is paid twice per optimizer iteration.
+constexpr int kReduceGroups = 32;
+
+__global__ __launch_bounds__(256) void reduce_rows_kernel(
+  const double* __restrict__ partials, int nrows, int ncols, int row_stride, double* __restrict__ stage, unsigned* __restrict__ ticket, double* __restrict__ out, int out_n, double* __restrict__ host,
+  unsigned long long seq) {
   __shared__ double sh[8][32];
+  __shared__ unsigned sh_ticket;
   const int c = threadIdx.x & 31, s = threadIdx.x >> 5;
+  const int G = gridDim.x;
   double acc = 0.0;
   if (c < ncols)
-    for (int r = blockIdx.x + s * gridDim.x; r < nrows; r += 8 * gridDim.x) acc += partials[static_cast<size_t>(r) * row_stride + c];
+    for (int r = blockIdx.x + s * G; r < nrows; r += 8 * G) acc += partials[static_cast<size_t>(r) * row_stride + c];
   sh[s][c] = acc;
   __syncthreads();
-  if (threadIdx.x < out_n) {
+  if (threadIdx.x < 32) {
     double t = 0.0;
-    if (threadIdx.x < ncols)
-      for (int k = 0; k < 8; k++) t += sh[k][threadIdx.x];
-    out[static_cast<size_t>(blockIdx.x) * out_stride + threadIdx.x] = t;
-    if (host != nullptr) host[threadIdx.x] = t;
+    for (int k = 0; k < 8; k++) t += sh[k][threadIdx.x];
+    __hip_atomic_store(&stage[blockIdx.x * 32 + threadIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) sh_ticket = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (sh_ticket != static_cast<unsigned>(G - 1)) return;  // workgroup-uniform
+  if (threadIdx.x < 32) {
+    double v[kReduceGroups];
+#pragma unroll
+    for (int g = 0; g < kReduceGroups; g++) v[g] = g < G ? __hip_atomic_load(&stage[g * 32 + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    double t = 0.0;
+#pragma unroll
+    for (int g = 0; g < kReduceGroups; g++) t += v[g];
+    if (static_cast<int>(threadIdx.x) < out_n) {
+      const double r = static_cast<int>(threadIdx.x) < ncols ? t : 0.0;
+      out[threadIdx.x] = r;
+      if (host != nullptr) host[threadIdx.x] = r;
+    }
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch on this stream
   if (host != nullptr) {
     __threadfence_system();
     __syncthreads();
@@ -296,15 +323,9 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const double* __restri
   }
 }
 
-constexpr int kReduceGroups = 32;
-
-static void launch_reduce(hipStream_t st, const double* partials, int nrows, int ncols, int row_stride, double* stage, double* out, int out_n, double* host, unsigned long long seq) {
-  if (nrows > 2 * kReduceGroups) {
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3(kReduceGroups), dim3(256), 0, st, partials, nrows, ncols, row_stride, stage, 32, 32, static_cast<double*>(nullptr), 0ull);
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, st, stage, kReduceGroups, ncols, 32, out, 0, out_n, host, seq);
-  } else {
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, st, partials, nrows, ncols, row_stride, out, 0, out_n, host, seq);
-  }
+static void launch_reduce(sga_context* ctx, const double* partials, int nrows, int ncols, int row_stride, double* stage, double* out, int out_n, double* host, unsigned long long seq) {
+  const int groups = nrows > 2 * kReduceGroups ? kReduceGroups : 1;
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(groups), dim3(256), 0, ctx->stream, partials, nrows, ncols, row_stride, stage, ctx->d_ticket.p, out, out_n, host, seq);
 }
 
 static int grid_blocks(int num_tiles) { return num_tiles < kMaxBlocks ? (num_tiles < 1 ? 1 : num_tiles) : kMaxBlocks; }
@@ -409,7 +430,7 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
     std::fprintf(stderr, "[sga stats] linearize us=%.0f", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - dbg_t0).count());
     std::fprintf(stderr, "\n");
   }
-  launch_reduce(ctx->stream, pb->partials.p, p.n > 0 ? blocks : 0, 29, kRow, pb->partials.p + static_cast<size_t>(kMaxBlocks) * kRow, d_out30, SGA_ACCUM_DOUBLES, host, seq);
+  launch_reduce(ctx, pb->partials.p, p.n > 0 ? blocks : 0, 29, kRow, pb->partials.p + static_cast<size_t>(kMaxBlocks) * kRow, d_out30, SGA_ACCUM_DOUBLES, host, seq);
   SGA_HIP(hipGetLastError());
   return SGA_OK;
 }
@@ -452,7 +473,7 @@ static int error_dispatch(sga_context* ctx, sga_problem* pb, const sga_factor_pa
     (void)hipEventRecord(ctx->ev3, ctx->stream);
     ctx->pending |= 2;
   }
-  launch_reduce(ctx->stream, pb->partials.p, p.n > 0 ? blocks : 0, 1, 1, pb->partials.p + static_cast<size_t>(kMaxBlocks) * kRow, d_out1, 1, host, seq);
+  launch_reduce(ctx, pb->partials.p, p.n > 0 ? blocks : 0, 1, 1, pb->partials.p + static_cast<size_t>(kMaxBlocks) * kRow, d_out1, 1, host, seq);
   SGA_HIP(hipGetLastError());
   return SGA_OK;
 }
