@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 
 ALG_BYTES_PER_POINT = {"linearize_gicp": 100, "error_gicp": 52}
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PROFILE_PERIOD = 7  # coprime with ITERS_PER_ALIGN: the sampled passes cover every iteration index of a registration
 ITERS_PER_ALIGN = 10
 
 
@@ -149,7 +150,7 @@ def main():
         ctx.synchronize()
 
     run_steps(args.warmup)
-    ctx.set_profiling(True)
+    ctx.set_profiling(PROFILE_PERIOD)  # HIP events around every PROFILE_PERIOD-th pass, inside the timed region
     barrier()
     t0 = time.perf_counter()
     steps_done, last = run_steps(args.steps)

@@ -133,7 +133,8 @@ int sga_comm_destroy(sga_context* ctx);
 void sga_unpack_accumulator(const double acc30[SGA_ACCUM_DOUBLES], double H[36], double b[6], double* e, uint64_t* num_inliers);
 /* Factor state in the caller's source order: target_index n int64 (-1 = outlier; voxel id for voxel maps), mahalanobis6 n*6 floats (GICP only). */
 int sga_problem_get_factors(sga_context* ctx, const sga_problem* problem, int64_t* target_index, float* mahalanobis6);
-/* Average device time (ms) of the last linearize / error kernel chains measured with HIP events on the context's stream (0 if profiling off). */
+/* Average device time (ms) of the linearize / error kernel chains measured with HIP events on the context's stream (0 if profiling
+ * off).  enabled = 0: off; 1: every pass is bracketed with events; N > 1: every N-th pass (an event record costs microseconds). */
 int sga_context_set_profiling(sga_context* ctx, int enabled);
 int sga_context_get_kernel_ms(sga_context* ctx, double* linearize_ms, uint64_t* linearize_calls, double* error_ms, uint64_t* error_calls);
 /* The part of linearize_ms spent in the nearest-neighbour search kernel (the rest: factor evaluation + block reduction). */

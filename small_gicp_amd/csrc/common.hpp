@@ -82,6 +82,8 @@ struct sga_context {
   sga::DevBuf<uint8_t> d_temp;    // rocPRIM temp storage (grow-only)
   // profiling
   bool profiling = false;
+  unsigned profile_period = 1;  // every profile_period-th linearize / error pass is bracketed with events
+  unsigned lin_seq = 0, err_seq = 0;
   int pending = 0;  // bit 0 = the linearize event pair (ev0, ev1) awaits collection, bit 1 = the error pair (ev2, ev3)
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr, ev_mid = nullptr;  // ev_mid: between the search and the factor kernel
   bool mid_recorded = false;

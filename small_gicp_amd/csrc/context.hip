@@ -154,6 +154,8 @@ void* sga_context_stream(sga_context* ctx) { return ctx ? static_cast<void*>(ctx
 int sga_context_set_profiling(sga_context* ctx, int enabled) {
   if (!ctx) return fail(SGA_ERR_INVALID, "null context");
   ctx->profiling = enabled != 0;
+  ctx->profile_period = enabled > 1 ? static_cast<unsigned>(enabled) : 1u;
+  ctx->lin_seq = ctx->err_seq = 0;
   ctx->lin_ms = ctx->err_ms = 0.0;
   ctx->lin_calls = ctx->err_calls = 0;
   ctx->search_ms = 0.0;

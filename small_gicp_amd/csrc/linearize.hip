@@ -380,7 +380,8 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
     (void)hipStreamSynchronize(ctx->stream);
     dbg_t0 = std::chrono::steady_clock::now();
   }
-  if (ctx->profiling) {
+  const bool timed = ctx->profiling && (ctx->lin_seq++ % ctx->profile_period) == 0;  // sampled: event records cost ~7 us each
+  if (timed) {
     sga_profile_collect_pending(ctx);
     (void)hipEventRecord(ctx->ev0, ctx->stream);
   }
@@ -402,7 +403,7 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
       hipLaunchKernelGGL((nn_search_kernel<Real, 128>), dim3((p.n + 127) / 128), dim3(128), words * 128 * sizeof(uint32_t), ctx->stream, q);
     else
       hipLaunchKernelGGL((nn_search_kernel<Real, 256>), dim3((p.n + 255) / 256), dim3(256), words * 256 * sizeof(uint32_t), ctx->stream, q);
-    if (ctx->profiling) {
+    if (timed) {
       (void)hipEventRecord(ctx->ev_mid, ctx->stream);
       ctx->mid_recorded = true;
     }
@@ -421,7 +422,7 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
       }
     }
   }
-  if (ctx->profiling) {
+  if (timed) {
     (void)hipEventRecord(ctx->ev1, ctx->stream);
     ctx->pending |= 1;
   }
@@ -457,7 +458,8 @@ static int error_dispatch(sga_context* ctx, sga_problem* pb, const sga_factor_pa
   p.partials = pb->partials.p;
   const int blocks = grid_blocks(p.num_tiles);
   if (fp->factor_kind == SGA_PLANE_ICP && !idx->has_normals) return fail(SGA_ERR_UNSUPPORTED, "PLANE_ICP needs target normals");
-  if (ctx->profiling) {
+  const bool timed = ctx->profiling && (ctx->err_seq++ % ctx->profile_period) == 0;
+  if (timed) {
     sga_profile_collect_pending(ctx);
     (void)hipEventRecord(ctx->ev2, ctx->stream);
   }
@@ -469,7 +471,7 @@ static int error_dispatch(sga_context* ctx, sga_problem* pb, const sga_factor_pa
       default: return fail(SGA_ERR_INVALID, "invalid factor_kind %d", fp->factor_kind);
     }
   }
-  if (ctx->profiling) {
+  if (timed) {
     (void)hipEventRecord(ctx->ev3, ctx->stream);
     ctx->pending |= 2;
   }
