@@ -87,11 +87,16 @@ __device__ __forceinline__ int ordered_from_float(float f) {
   return i >= 0 ? i : i ^ 0x7fffffff;
 }
 
-// seg_box: 6 ints per segment (min xyz, max xyz) in the order-preserving int encoding
-__global__ __launch_bounds__(256) void kd_segment_box_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ perm, uint32_t n, int d, int* __restrict__ seg_box) {
+// seg_box: 6 ints per segment (min xyz, max xyz) in the order-preserving int encoding.  Only the top levels of the build come here
+// (segments of more than kFinishCap points), so a workgroup of 1024 consecutive points nearly always lies inside one segment: it
+// reduces in registers + LDS and issues six atomics; mixed workgroups fall back to per-wave / per-lane atomics.
+__global__ __launch_bounds__(1024) void kd_segment_box_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ perm, uint32_t n, int d, int* __restrict__ seg_box) {
+  __shared__ float sh_lo[16][3], sh_hi[16][3];
+  __shared__ uint32_t sh_seg[16];
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const bool valid = i < n;
-  const uint32_t seg = valid ? kd_segment_of(i, n, d) : 0xffffffffu;
+  const uint32_t seg = kd_segment_of(valid ? i : n - 1, n, d);  // tail lanes join the last segment with neutral values
   float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
   if (valid) {
     const float4 p = pts[perm[i]];
@@ -100,16 +105,42 @@ __global__ __launch_bounds__(256) void kd_segment_box_kernel(const float4* __res
     lo[2] = hi[2] = p.z;
   }
   const uint32_t seg0 = __shfl(seg, 0);
-  if (__all(seg == seg0)) {  // the whole wave sits in one segment: reduce first, six atomics per wave
+  const bool wave_uniform = __all(seg == seg0);
+  if (wave_uniform) {
     for (int k = 0; k < 3; k++)
       for (int off = 32; off > 0; off >>= 1) {
         lo[k] = fminf(lo[k], __shfl_xor(lo[k], off));
         hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
       }
-    if ((threadIdx.x & 63) == 0 && valid) {
+  }
+  if (lane == 0) {
+    sh_seg[wave] = wave_uniform ? seg0 : 0xffffffffu;
+    for (int k = 0; k < 3; k++) {
+      sh_lo[wave][k] = lo[k];
+      sh_hi[wave][k] = hi[k];
+    }
+  }
+  __syncthreads();
+  bool block_uniform = true;
+  for (int w = 0; w < nwaves; w++) block_uniform = block_uniform && sh_seg[w] == sh_seg[0] && sh_seg[0] != 0xffffffffu;
+  if (block_uniform) {
+    if (threadIdx.x < 3) {
+      const int k = threadIdx.x;
+      float l = INFINITY, h = -INFINITY;
+      for (int w = 0; w < nwaves; w++) {
+        l = fminf(l, sh_lo[w][k]);
+        h = fmaxf(h, sh_hi[w][k]);
+      }
+      if (l <= h) {
+        atomicMin(&seg_box[6 * sh_seg[0] + k], ordered_from_float(l));
+        atomicMax(&seg_box[6 * sh_seg[0] + 3 + k], ordered_from_float(h));
+      }
+    }
+  } else if (wave_uniform) {
+    if (lane == 0 && lo[0] <= hi[0]) {
       for (int k = 0; k < 3; k++) {
-        atomicMin(&seg_box[6 * seg + k], ordered_from_float(lo[k]));
-        atomicMax(&seg_box[6 * seg + 3 + k], ordered_from_float(hi[k]));
+        atomicMin(&seg_box[6 * seg0 + k], ordered_from_float(lo[k]));
+        atomicMax(&seg_box[6 * seg0 + 3 + k], ordered_from_float(hi[k]));
       }
     }
   } else if (valid) {
@@ -183,6 +214,104 @@ __global__ void kd_nodes_kernel(const float4* __restrict__ pts, const uint32_t* 
     thr = axis == 0 ? p.x : (axis == 1 ? p.y : p.z);
   }
   nodes[(1u << d) + seg] = make_float2(thr, __int_as_float(axis));
+}
+
+// ---- bottom levels of the build inside LDS ----------------------------------------------------------------------------------------
+// Once a segment holds at most kFinishCap points, ONE workgroup finishes its whole sub-tree: the points' coordinates are loaded
+// into LDS once, and every remaining level is (per sub-segment box -> longest extent -> sort by (sub-segment, coordinate) ->
+// threshold) without touching global memory or launching anything.  The sort is a bitonic network over 64-bit keys
+// (sub-segment | ordered coordinate | current position); the position field makes it reproduce the STABLE order of the
+// radix sorts of the top levels, so the tree is the same whichever path builds a level.
+constexpr int kFinishCap = 2048;      // points per workgroup (power of two)
+constexpr int kFinishThreads = 512;
+constexpr int kFinishMaxSub = 256;    // sub-segments at the last level: kFinishCap / 8
+
+__device__ __forceinline__ uint32_t ordered_u32(float c) { return static_cast<uint32_t>(ordered_from_float(c)) ^ 0x80000000u; }
+
+__global__ __launch_bounds__(kFinishThreads) void kd_finish_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ perm_in, uint32_t* __restrict__ perm_out, uint32_t n, int dA, int D, float2* __restrict__ nodes) {
+  __shared__ float cx[kFinishCap], cy[kFinishCap], cz[kFinishCap];
+  __shared__ uint32_t gidx[kFinishCap];
+  __shared__ unsigned long long key[kFinishCap];
+  __shared__ unsigned short ord[kFinishCap], ord2[kFinishCap];
+  __shared__ int box[kFinishMaxSub][6];
+  __shared__ int axis_of[kFinishMaxSub];
+  const uint32_t seg = blockIdx.x;
+  const uint32_t B0 = kd_bound(n, dA, seg), B1 = kd_bound(n, dA, seg + 1);
+  const uint32_t m = B1 - B0;
+  const int tid = threadIdx.x;
+  for (uint32_t i = tid; i < m; i += kFinishThreads) {
+    const uint32_t g = perm_in[B0 + i];
+    const float4 p = pts[g];
+    cx[i] = p.x;
+    cy[i] = p.y;
+    cz[i] = p.z;
+    gidx[i] = g;
+    ord[i] = static_cast<unsigned short>(i);
+  }
+  __syncthreads();
+  for (int d = dA; d < D; d++) {
+    const uint32_t nsub = 1u << (d - dA), sub0 = seg << (d - dA);
+    for (uint32_t j = tid; j < nsub * 6; j += kFinishThreads) box[j / 6][j % 6] = (j % 6) < 3 ? 0x7f800000 : (static_cast<int>(0xff800000u) ^ 0x7fffffff);
+    __syncthreads();
+    for (uint32_t pos = tid; pos < m; pos += kFinishThreads) {
+      const uint32_t e = ord[pos], j = kd_segment_of(B0 + pos, n, d) - sub0;
+      atomicMin(&box[j][0], ordered_from_float(cx[e]));
+      atomicMin(&box[j][1], ordered_from_float(cy[e]));
+      atomicMin(&box[j][2], ordered_from_float(cz[e]));
+      atomicMax(&box[j][3], ordered_from_float(cx[e]));
+      atomicMax(&box[j][4], ordered_from_float(cy[e]));
+      atomicMax(&box[j][5], ordered_from_float(cz[e]));
+    }
+    __syncthreads();
+    for (uint32_t j = tid; j < nsub; j += kFinishThreads) {
+      float v[3];
+      for (int a = 0; a < 3; a++) v[a] = float_from_ordered(box[j][3 + a]) - float_from_ordered(box[j][a]);
+      axis_of[j] = v[0] >= v[1] ? (v[0] >= v[2] ? 0 : 2) : (v[1] >= v[2] ? 1 : 2);  // same rule as kd_choose_axis_kernel
+    }
+    __syncthreads();
+    for (uint32_t pos = tid; pos < kFinishCap; pos += kFinishThreads) {
+      unsigned long long k = ~0ull;  // padding sorts to the end
+      if (pos < m) {
+        const uint32_t e = ord[pos], j = kd_segment_of(B0 + pos, n, d) - sub0;
+        const int a = axis_of[j];
+        const float c = a == 0 ? cx[e] : (a == 1 ? cy[e] : cz[e]);
+        k = (static_cast<unsigned long long>(j) << 43) | (static_cast<unsigned long long>(ordered_u32(c)) << 11) | pos;
+      }
+      key[pos] = k;
+    }
+    __syncthreads();
+    for (uint32_t k = 2; k <= kFinishCap; k <<= 1) {
+      for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+        for (uint32_t t = tid; t < kFinishCap / 2; t += kFinishThreads) {
+          const uint32_t i = 2 * t - (t & (j - 1));  // index with bit j clear
+          const unsigned long long a = key[i], b = key[i + j];
+          const bool up = (i & k) == 0;
+          if ((a > b) == up) {
+            key[i] = b;
+            key[i + j] = a;
+          }
+        }
+        __syncthreads();
+      }
+    }
+    for (uint32_t pos = tid; pos < m; pos += kFinishThreads) ord2[pos] = ord[key[pos] & 2047u];
+    __syncthreads();
+    for (uint32_t pos = tid; pos < m; pos += kFinishThreads) ord[pos] = ord2[pos];
+    __syncthreads();
+    for (uint32_t j = tid; j < nsub; j += kFinishThreads) {
+      const uint32_t gs = sub0 + j;
+      const uint32_t first = kd_bound(n, d, gs), end = kd_bound(n, d, gs + 1), mid = kd_bound(n, d + 1, 2 * gs + 1);
+      const int a = axis_of[j];
+      float thr = 0.f;
+      if (first < end) {
+        const uint32_t e = ord[min(mid, end - 1) - B0];
+        thr = a == 0 ? cx[e] : (a == 1 ? cy[e] : cz[e]);
+      }
+      nodes[(1u << d) + gs] = make_float2(thr, __int_as_float(a));
+    }
+    __syncthreads();
+  }
+  for (uint32_t pos = tid; pos < m; pos += kFinishThreads) perm_out[B0 + pos] = gidx[ord[pos]];
 }
 
 // pair records for the 1-NN walk (kd_search.hpp): node of even depth + its two children in one 16-byte record
@@ -307,12 +436,17 @@ static int build_kdtree(sga_context* ctx, const sga_cloud* cloud, sga_index* idx
   DevBuf<float> score;
   SGA_TRY(axis_of_seg.alloc(1ull << (D > 0 ? D - 1 : 0)));
   SGA_TRY(score.alloc(3ull << (D > 0 ? D - 1 : 0)));
-  for (int d = 0; d < D; d++) {
+  // top levels in global memory until a segment fits one workgroup, the rest of the sub-tree in LDS (kd_finish_kernel)
+  int dA = 0;
+  while (dA < D && ((n + (1ull << dA) - 1) >> dA) > static_cast<size_t>(kFinishCap)) dA++;
+  static const bool lds_finish = !(getenv("SGA_KD_FINISH") && atoi(getenv("SGA_KD_FINISH")) == 0);
+  if (balanced || !lds_finish || D - dA > 8) dA = D;
+  for (int d = 0; d < dA; d++) {
     const uint32_t nseg = 1u << d;
     const dim3 sgrid((nseg + 255) / 256);
     const unsigned end_bit = 32 + (d > 0 ? d : 1);
     hipLaunchKernelGGL(kd_init_box_kernel, sgrid, block, 0, ctx->stream, seg_box.p, nseg);
-    hipLaunchKernelGGL(kd_segment_box_kernel, grid, block, 0, ctx->stream, cloud->pts.p, cur, static_cast<uint32_t>(n), d, seg_box.p);
+    hipLaunchKernelGGL(kd_segment_box_kernel, dim3((n + 1023) / 1024), dim3(1024), 0, ctx->stream, cloud->pts.p, cur, static_cast<uint32_t>(n), d, seg_box.p);
     if (balanced) {
       for (int a = 0; a < 3; a++) {
         hipLaunchKernelGGL(kd_keys_kernel, grid, block, 0, ctx->stream, cloud->pts.p, cur, static_cast<uint32_t>(n), d, a, static_cast<const int*>(nullptr), keys.p);
@@ -325,6 +459,10 @@ static int build_kdtree(sga_context* ctx, const sga_cloud* cloud, sga_index* idx
     SGA_HIP(rocprim::radix_sort_pairs(ctx->d_temp.p, tb, keys.p, keys2.p, cur, nxt, n, 0, end_bit, ctx->stream));
     std::swap(cur, nxt);
     hipLaunchKernelGGL(kd_nodes_kernel, sgrid, block, 0, ctx->stream, cloud->pts.p, cur, static_cast<uint32_t>(n), d, axis_of_seg.p, idx->kd_nodes.p);
+  }
+  if (dA < D) {
+    hipLaunchKernelGGL(kd_finish_kernel, dim3(1u << dA), dim3(kFinishThreads), 0, ctx->stream, cloud->pts.p, cur, nxt, static_cast<uint32_t>(n), dA, D, idx->kd_nodes.p);
+    std::swap(cur, nxt);
   }
   for (int d = 0; d < D; d += 2) hipLaunchKernelGGL(kd_pairs_kernel, dim3(((1u << d) + 255) / 256), block, 0, ctx->stream, idx->kd_nodes.p, D, d, idx->kd_nodes4.p);
   SGA_HIP(hipGetLastError());
