@@ -29,6 +29,14 @@ int fail(int code, const char* fmt, ...);
     if (_rc != SGA_OK) return _rc; \
   } while (0)
 
+// ---- device memory --------------------------------------------------------------------------------------------------------
+// hipMalloc / hipFree cost tens of microseconds each and hipFree synchronises the device; a registration of a 30k-point scan
+// allocates ~30 buffers.  Freed blocks are therefore kept per device in size-bucketed free lists (context.hip) and handed out
+// again.  Reuse is safe because every entry point that allocates runs on its context's stream and synchronises it before
+// returning; the cache is emptied when the last context is destroyed.
+int dev_alloc(void** p, size_t bytes);
+void dev_free(void* p);
+
 // ---- device buffer -----------------------------------------------------------------------------------------------------
 template <typename T>
 struct DevBuf {
@@ -39,17 +47,17 @@ struct DevBuf {
   DevBuf& operator=(const DevBuf&) = delete;
   ~DevBuf() { release(); }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p) dev_free(p);
     p = nullptr;
     n = 0;
   }
   int alloc(size_t count) {
     release();
     if (count == 0) return SGA_OK;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
-    if (e != hipSuccess) {
+    const int rc = dev_alloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+    if (rc != SGA_OK) {
       p = nullptr;
-      return fail(SGA_ERR_HIP, "hipMalloc(%zu bytes) -> %s", count * sizeof(T), hipGetErrorString(e));
+      return rc;
     }
     n = count;
     return SGA_OK;

@@ -1,6 +1,10 @@
 // Context (one GPU + one stream), error plumbing and device-resident clouds.
 #include "common.hpp"
 
+#include <map>
+#include <mutex>
+#include <unordered_map>
+
 namespace sga {
 
 static thread_local char g_err[1024] = "";
@@ -18,6 +22,100 @@ int fail(int code, const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
   return code;
+}
+
+// ---- caching device allocator (see common.hpp) ---------------------------------------------------------------------------------
+namespace {
+struct DevCache {
+  std::mutex mu;
+  std::unordered_map<void*, std::pair<int, size_t>> live;             // every block handed out: device, bucket size
+  std::map<std::pair<int, size_t>, std::vector<void*>> free_blocks;   // (device, bucket size) -> cached blocks
+  size_t cached_bytes = 0;
+  int contexts = 0;
+};
+DevCache& dev_cache() {
+  static DevCache* c = new DevCache;  // never destroyed: no HIP calls during static destruction
+  return *c;
+}
+constexpr size_t kCacheLimitBytes = 8ull << 30;
+
+// < 1 MiB: next power of two (>= 256 B); above: 8 buckets per octave (<= 12.5 % slack)
+size_t bucket_bytes(size_t bytes) {
+  size_t p2 = 256;
+  while (p2 < bytes) p2 <<= 1;
+  if (p2 <= (1ull << 20)) return p2;
+  const size_t step = p2 >> 4;  // p2/2 < bytes <= p2: steps of (p2/2)/8
+  return ((bytes + step - 1) / step) * step;
+}
+
+void release_cached_locked(DevCache& c) {
+  for (auto& kv : c.free_blocks)
+    for (void* q : kv.second) (void)hipFree(q);
+  c.free_blocks.clear();
+  c.cached_bytes = 0;
+}
+}  // namespace
+
+int dev_alloc(void** p, size_t bytes) {
+  *p = nullptr;
+  if (bytes == 0) return SGA_OK;
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess) return fail(SGA_ERR_HIP, "hipGetDevice failed");
+  const size_t bucket = bucket_bytes(bytes);
+  DevCache& c = dev_cache();
+  std::lock_guard<std::mutex> lock(c.mu);
+  auto it = c.free_blocks.find({device, bucket});
+  if (it != c.free_blocks.end() && !it->second.empty()) {
+    *p = it->second.back();
+    it->second.pop_back();
+    c.cached_bytes -= bucket;
+  } else {
+    hipError_t e = hipMalloc(p, bucket);
+    if (e != hipSuccess) {  // out of memory with blocks parked in the cache: give them back and retry once
+      (void)hipGetLastError();
+      release_cached_locked(c);
+      e = hipMalloc(p, bucket);
+    }
+    if (e != hipSuccess) {
+      *p = nullptr;
+      return fail(SGA_ERR_HIP, "hipMalloc(%zu bytes) -> %s", bucket, hipGetErrorString(e));
+    }
+  }
+  c.live[*p] = {device, bucket};
+  return SGA_OK;
+}
+
+void dev_free(void* p) {
+  if (!p) return;
+  DevCache& c = dev_cache();
+  std::lock_guard<std::mutex> lock(c.mu);
+  auto it = c.live.find(p);
+  if (it == c.live.end()) {
+    (void)hipFree(p);
+    return;
+  }
+  const std::pair<int, size_t> key = it->second;
+  c.live.erase(it);
+  if (c.contexts == 0 || c.cached_bytes + key.second > kCacheLimitBytes) {
+    (void)hipFree(p);
+    return;
+  }
+  c.free_blocks[key].push_back(p);
+  c.cached_bytes += key.second;
+}
+
+static void dev_cache_context_created() {
+  DevCache& c = dev_cache();
+  std::lock_guard<std::mutex> lock(c.mu);
+  c.contexts++;
+}
+static void dev_cache_context_destroyed() {
+  DevCache& c = dev_cache();
+  std::lock_guard<std::mutex> lock(c.mu);
+  if (--c.contexts <= 0) {
+    c.contexts = 0;
+    release_cached_locked(c);
+  }
 }
 
 __global__ void pack_cloud_f32_kernel(const float* __restrict__ xyz, const float* __restrict__ nrm, const float* __restrict__ cov6, size_t n, float4* __restrict__ pts, float4* __restrict__ onrm, Cov8* __restrict__ ocov) {
@@ -95,6 +193,7 @@ static int context_create_impl(int device, void* stream, bool borrow, sga_contex
   SGA_HIP(hipGetDeviceProperties(&prop, device));
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(SGA_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
   auto* ctx = new sga_context;
+  dev_cache_context_created();
   ctx->device = device;
   ctx->num_cus = prop.multiProcessorCount;
   if (borrow) {
@@ -103,6 +202,7 @@ static int context_create_impl(int device, void* stream, bool borrow, sga_contex
   } else {
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
       delete ctx;
+      dev_cache_context_destroyed();
       return fail(SGA_ERR_HIP, "hipStreamCreate failed");
     }
     ctx->owns_stream = true;
@@ -140,6 +240,7 @@ int sga_context_destroy(sga_context* ctx) {
   if (ctx->h_accum) (void)hipHostFree(ctx->h_accum);
   if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
+  dev_cache_context_destroyed();  // the last context gives the cached device memory back
   return SGA_OK;
 }
 
