@@ -219,20 +219,21 @@ __global__ void kd_nodes_kernel(const float4* __restrict__ pts, const uint32_t* 
 // ---- bottom levels of the build inside LDS ----------------------------------------------------------------------------------------
 // Once a segment holds at most kFinishCap points, ONE workgroup finishes its whole sub-tree: the points' coordinates are loaded
 // into LDS once, and every remaining level is (per sub-segment box -> longest extent -> sort by (sub-segment, coordinate) ->
-// threshold) without touching global memory or launching anything.  The sort is a bitonic network over 64-bit keys
+// threshold) without touching global memory or launching anything.  The sort is a rank sort over 64-bit keys
 // (sub-segment | ordered coordinate | current position); the position field makes it reproduce the STABLE order of the
 // radix sorts of the top levels, so the tree is the same whichever path builds a level.
-constexpr int kFinishCap = 2048;      // points per workgroup (power of two)
+constexpr int kFinishCap = 2048;      // points per workgroup, large clouds (small ones: 1024, to spread over more CUs)
 constexpr int kFinishThreads = 512;
 constexpr int kFinishMaxSub = 256;    // sub-segments at the last level: kFinishCap / 8
 
 __device__ __forceinline__ uint32_t ordered_u32(float c) { return static_cast<uint32_t>(ordered_from_float(c)) ^ 0x80000000u; }
 
+template <int CAP>
 __global__ __launch_bounds__(kFinishThreads) void kd_finish_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ perm_in, uint32_t* __restrict__ perm_out, uint32_t n, int dA, int D, float2* __restrict__ nodes) {
-  __shared__ float cx[kFinishCap], cy[kFinishCap], cz[kFinishCap];
-  __shared__ uint32_t gidx[kFinishCap];
-  __shared__ unsigned long long key[kFinishCap];
-  __shared__ unsigned short ord[kFinishCap], ord2[kFinishCap];
+  __shared__ float cx[CAP], cy[CAP], cz[CAP];
+  __shared__ uint32_t gidx[CAP];
+  __shared__ unsigned long long key[CAP];
+  __shared__ unsigned short ord[CAP], ord2[CAP];
   __shared__ int box[kFinishMaxSub][6];
   __shared__ int axis_of[kFinishMaxSub];
   const uint32_t seg = blockIdx.x;
@@ -253,14 +254,29 @@ __global__ __launch_bounds__(kFinishThreads) void kd_finish_kernel(const float4*
     const uint32_t nsub = 1u << (d - dA), sub0 = seg << (d - dA);
     for (uint32_t j = tid; j < nsub * 6; j += kFinishThreads) box[j / 6][j % 6] = (j % 6) < 3 ? 0x7f800000 : (static_cast<int>(0xff800000u) ^ 0x7fffffff);
     __syncthreads();
-    for (uint32_t pos = tid; pos < m; pos += kFinishThreads) {
-      const uint32_t e = ord[pos], j = kd_segment_of(B0 + pos, n, d) - sub0;
-      atomicMin(&box[j][0], ordered_from_float(cx[e]));
-      atomicMin(&box[j][1], ordered_from_float(cy[e]));
-      atomicMin(&box[j][2], ordered_from_float(cz[e]));
-      atomicMax(&box[j][3], ordered_from_float(cx[e]));
-      atomicMax(&box[j][4], ordered_from_float(cy[e]));
-      atomicMax(&box[j][5], ordered_from_float(cz[e]));
+    for (uint32_t base = 0; base < m; base += kFinishThreads) {  // whole waves take part in the shuffles below
+      const uint32_t pos = base + tid;
+      const bool valid = pos < m;
+      const uint32_t e = ord[valid ? pos : m - 1], j = kd_segment_of(B0 + (valid ? pos : m - 1), n, d) - sub0;
+      float lo[3] = {cx[e], cy[e], cz[e]}, hi[3] = {cx[e], cy[e], cz[e]};
+      const uint32_t j0 = __shfl(j, 0);
+      if (__all(j == j0)) {  // the usual case on the upper levels: one LDS atomic per wave and value instead of 64 on one address
+        for (int a = 0; a < 3; a++)
+          for (int off = 32; off > 0; off >>= 1) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], off));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off));
+          }
+        if ((tid & 63) == 0)
+          for (int a = 0; a < 3; a++) {
+            atomicMin(&box[j][a], ordered_from_float(lo[a]));
+            atomicMax(&box[j][3 + a], ordered_from_float(hi[a]));
+          }
+      } else if (valid) {
+        for (int a = 0; a < 3; a++) {
+          atomicMin(&box[j][a], ordered_from_float(lo[a]));
+          atomicMax(&box[j][3 + a], ordered_from_float(hi[a]));
+        }
+      }
     }
     __syncthreads();
     for (uint32_t j = tid; j < nsub; j += kFinishThreads) {
@@ -269,32 +285,32 @@ __global__ __launch_bounds__(kFinishThreads) void kd_finish_kernel(const float4*
       axis_of[j] = v[0] >= v[1] ? (v[0] >= v[2] ? 0 : 2) : (v[1] >= v[2] ? 1 : 2);  // same rule as kd_choose_axis_kernel
     }
     __syncthreads();
-    for (uint32_t pos = tid; pos < kFinishCap; pos += kFinishThreads) {
-      unsigned long long k = ~0ull;  // padding sorts to the end
-      if (pos < m) {
-        const uint32_t e = ord[pos], j = kd_segment_of(B0 + pos, n, d) - sub0;
-        const int a = axis_of[j];
-        const float c = a == 0 ? cx[e] : (a == 1 ? cy[e] : cz[e]);
-        k = (static_cast<unsigned long long>(j) << 43) | (static_cast<unsigned long long>(ordered_u32(c)) << 11) | pos;
-      }
-      key[pos] = k;
+    for (uint32_t pos = tid; pos < m; pos += kFinishThreads) {
+      const uint32_t e = ord[pos], j = kd_segment_of(B0 + pos, n, d) - sub0;
+      const int a = axis_of[j];
+      const float c = a == 0 ? cx[e] : (a == 1 ? cy[e] : cz[e]);
+      key[pos] = (static_cast<unsigned long long>(j) << 43) | (static_cast<unsigned long long>(ordered_u32(c)) << 11) | pos;
     }
     __syncthreads();
-    for (uint32_t k = 2; k <= kFinishCap; k <<= 1) {
-      for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-        for (uint32_t t = tid; t < kFinishCap / 2; t += kFinishThreads) {
-          const uint32_t i = 2 * t - (t & (j - 1));  // index with bit j clear
-          const unsigned long long a = key[i], b = key[i + j];
-          const bool up = (i & k) == 0;
-          if ((a > b) == up) {
-            key[i] = b;
-            key[i + j] = a;
-          }
-        }
-        __syncthreads();
+    // rank sort inside every sub-segment: the new position of an element is the sub-segment's first position + the number of
+    // its keys that are smaller (keys are distinct: they end with the current position).  All lanes of a wave read the same
+    // key[i] (LDS broadcast), and the total work halves with every level — far cheaper than a sorting network here.
+    for (uint32_t pos = tid; pos < m; pos += kFinishThreads) {
+      const unsigned long long mine = key[pos];
+      const uint32_t gs = sub0 + static_cast<uint32_t>(mine >> 43);
+      const uint32_t first = kd_bound(n, d, gs) - B0, end = kd_bound(n, d, gs + 1) - B0;
+      uint32_t smaller = 0;
+      uint32_t i = first;
+      for (; i + 8 <= end; i += 8) {  // 8 LDS reads in flight
+        unsigned long long k8[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) k8[u] = key[i + u];
+#pragma unroll
+        for (int u = 0; u < 8; u++) smaller += k8[u] < mine ? 1u : 0u;
       }
+      for (; i < end; i++) smaller += key[i] < mine ? 1u : 0u;
+      ord2[first + smaller] = ord[pos];
     }
-    for (uint32_t pos = tid; pos < m; pos += kFinishThreads) ord2[pos] = ord[key[pos] & 2047u];
     __syncthreads();
     for (uint32_t pos = tid; pos < m; pos += kFinishThreads) ord[pos] = ord2[pos];
     __syncthreads();
@@ -437,9 +453,10 @@ static int build_kdtree(sga_context* ctx, const sga_cloud* cloud, sga_index* idx
   SGA_TRY(axis_of_seg.alloc(1ull << (D > 0 ? D - 1 : 0)));
   SGA_TRY(score.alloc(3ull << (D > 0 ? D - 1 : 0)));
   // top levels in global memory until a segment fits one workgroup, the rest of the sub-tree in LDS (kd_finish_kernel)
+  const int cap = n >= 400000 ? kFinishCap : kFinishCap / 2;
   int dA = 0;
-  while (dA < D && ((n + (1ull << dA) - 1) >> dA) > static_cast<size_t>(kFinishCap)) dA++;
-  static const bool lds_finish = !(getenv("SGA_KD_FINISH") && atoi(getenv("SGA_KD_FINISH")) == 0);
+  while (dA < D && ((n + (1ull << dA) - 1) >> dA) > static_cast<size_t>(cap)) dA++;
+  const bool lds_finish = !(getenv("SGA_KD_FINISH") && atoi(getenv("SGA_KD_FINISH")) == 0);  // read per build: the tests compare both paths
   if (balanced || !lds_finish || D - dA > 8) dA = D;
   for (int d = 0; d < dA; d++) {
     const uint32_t nseg = 1u << d;
@@ -461,7 +478,10 @@ static int build_kdtree(sga_context* ctx, const sga_cloud* cloud, sga_index* idx
     hipLaunchKernelGGL(kd_nodes_kernel, sgrid, block, 0, ctx->stream, cloud->pts.p, cur, static_cast<uint32_t>(n), d, axis_of_seg.p, idx->kd_nodes.p);
   }
   if (dA < D) {
-    hipLaunchKernelGGL(kd_finish_kernel, dim3(1u << dA), dim3(kFinishThreads), 0, ctx->stream, cloud->pts.p, cur, nxt, static_cast<uint32_t>(n), dA, D, idx->kd_nodes.p);
+    if (cap == kFinishCap)
+      hipLaunchKernelGGL(kd_finish_kernel<kFinishCap>, dim3(1u << dA), dim3(kFinishThreads), 0, ctx->stream, cloud->pts.p, cur, nxt, static_cast<uint32_t>(n), dA, D, idx->kd_nodes.p);
+    else
+      hipLaunchKernelGGL(kd_finish_kernel<kFinishCap / 2>, dim3(1u << dA), dim3(kFinishThreads), 0, ctx->stream, cloud->pts.p, cur, nxt, static_cast<uint32_t>(n), dA, D, idx->kd_nodes.p);
     std::swap(cur, nxt);
   }
   for (int d = 0; d < D; d += 2) hipLaunchKernelGGL(kd_pairs_kernel, dim3(((1u << d) + 255) / 256), block, 0, ctx->stream, idx->kd_nodes.p, D, d, idx->kd_nodes4.p);
