@@ -10,7 +10,7 @@
 #include <memory>
 #include <rocprim/rocprim.hpp>
 #include "kd_search.hpp"
-#include "nn_search.hpp"
+#include "voxel_hash.hpp"
 
 namespace sga {
 
@@ -162,43 +162,23 @@ __global__ void kd_init_box_kernel(int* __restrict__ seg_box, uint32_t nseg) {
 
 __device__ __forceinline__ float float_from_ordered(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
 
-// keys for a sort along a FIXED axis (trial sorts) or along each segment's chosen axis (axis_of_seg != null)
-__global__ void kd_keys_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ perm, uint32_t n, int d, int fixed_axis, const int* __restrict__ axis_of_seg, unsigned long long* __restrict__ keys) {
+// keys for the sort of one level: (segment, coordinate along the segment's split axis)
+__global__ void kd_keys_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ perm, uint32_t n, int d, const int* __restrict__ axis_of_seg, unsigned long long* __restrict__ keys) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t seg = kd_segment_of(i, n, d);
-  const int axis = axis_of_seg ? axis_of_seg[seg] : fixed_axis;
+  const int axis = axis_of_seg[seg];
   const float4 p = pts[perm[i]];
   const float c = axis == 0 ? p.x : (axis == 1 ? p.y : p.z);
   const uint32_t oc = static_cast<uint32_t>(ordered_from_float(c)) ^ 0x80000000u;  // unsigned order
   keys[i] = (static_cast<unsigned long long>(seg) << 32) | oc;
 }
 
-// after a trial sort along `axis`: score[seg][axis] = min(median - lo, hi - median), the extent the smaller child keeps.
-// A median split is only useful along an axis where BOTH children get a real share of the extent: on a noisy plane with a few
-// points floating above it, the longest extent is the plane's normal direction, yet the median there cuts the plane itself
-// into noise-thin slabs that every query ball crosses.  (The reference takes the axis of largest sampled variance,
-// projection.hpp:31-50, and suffers from exactly that on such data; any axis choice keeps the search exact.)
-__global__ void kd_score_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ perm_sorted, uint32_t n, int d, int axis, const int* __restrict__ seg_box, float* __restrict__ score) {
-  const uint32_t seg = blockIdx.x * blockDim.x + threadIdx.x;
-  if (seg >= (1u << d)) return;
-  const uint32_t first = kd_bound_d(n, d, seg), end = kd_bound_d(n, d, seg + 1);
-  float sc = -1.f;
-  if (first < end) {
-    const uint32_t m = min(kd_bound_d(n, d + 1, 2 * seg + 1), end - 1);
-    const float4 p = pts[perm_sorted[m]];
-    const float med = axis == 0 ? p.x : (axis == 1 ? p.y : p.z);
-    const float lo = float_from_ordered(seg_box[6 * seg + axis]), hi = float_from_ordered(seg_box[6 * seg + 3 + axis]);
-    sc = fminf(med - lo, hi - med);
-  }
-  score[3 * seg + axis] = sc;
-}
-
-__global__ void kd_choose_axis_kernel(const float* __restrict__ score, const int* __restrict__ seg_box, uint32_t nseg, int balanced, int* __restrict__ axis_of_seg) {
+__global__ void kd_choose_axis_kernel(const int* __restrict__ seg_box, uint32_t nseg, int* __restrict__ axis_of_seg) {
   const uint32_t seg = blockIdx.x * blockDim.x + threadIdx.x;
   if (seg >= nseg) return;
   float v[3];
-  for (int a = 0; a < 3; a++) v[a] = balanced ? score[3 * seg + a] : float_from_ordered(seg_box[6 * seg + 3 + a]) - float_from_ordered(seg_box[6 * seg + a]);
+  for (int a = 0; a < 3; a++) v[a] = float_from_ordered(seg_box[6 * seg + 3 + a]) - float_from_ordered(seg_box[6 * seg + a]);
   axis_of_seg[seg] = v[0] >= v[1] ? (v[0] >= v[2] ? 0 : 2) : (v[1] >= v[2] ? 1 : 2);
 }
 
@@ -445,34 +425,22 @@ static int build_kdtree(sga_context* ctx, const sga_cloud* cloud, sga_index* idx
   size_t tb = 0;
   SGA_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys.p, keys2.p, cur, nxt, n, 0, 64, ctx->stream));
   SGA_TRY(ensure_temp(ctx, tb));
-  // axis rule: 0 (default) = longest extent (one sort per level), 1 = balanced extent (three trial sorts per level; fewer node
-  // visits on average but a heavier tail for isolated points — measured slower on the C3 scene, kept for experiments)
-  static const int balanced = getenv("SGA_KD_AXIS") ? atoi(getenv("SGA_KD_AXIS")) : 0;
   DevBuf<int> axis_of_seg;
-  DevBuf<float> score;
   SGA_TRY(axis_of_seg.alloc(1ull << (D > 0 ? D - 1 : 0)));
-  SGA_TRY(score.alloc(3ull << (D > 0 ? D - 1 : 0)));
   // top levels in global memory until a segment fits one workgroup, the rest of the sub-tree in LDS (kd_finish_kernel)
   const int cap = n >= 400000 ? kFinishCap : kFinishCap / 2;
   int dA = 0;
   while (dA < D && ((n + (1ull << dA) - 1) >> dA) > static_cast<size_t>(cap)) dA++;
   const bool lds_finish = !(getenv("SGA_KD_FINISH") && atoi(getenv("SGA_KD_FINISH")) == 0);  // read per build: the tests compare both paths
-  if (balanced || !lds_finish || D - dA > 8) dA = D;
+  if (!lds_finish || D - dA > 8) dA = D;
   for (int d = 0; d < dA; d++) {
     const uint32_t nseg = 1u << d;
     const dim3 sgrid((nseg + 255) / 256);
     const unsigned end_bit = 32 + (d > 0 ? d : 1);
     hipLaunchKernelGGL(kd_init_box_kernel, sgrid, block, 0, ctx->stream, seg_box.p, nseg);
     hipLaunchKernelGGL(kd_segment_box_kernel, dim3((n + 1023) / 1024), dim3(1024), 0, ctx->stream, cloud->pts.p, cur, static_cast<uint32_t>(n), d, seg_box.p);
-    if (balanced) {
-      for (int a = 0; a < 3; a++) {
-        hipLaunchKernelGGL(kd_keys_kernel, grid, block, 0, ctx->stream, cloud->pts.p, cur, static_cast<uint32_t>(n), d, a, static_cast<const int*>(nullptr), keys.p);
-        SGA_HIP(rocprim::radix_sort_pairs(ctx->d_temp.p, tb, keys.p, keys2.p, cur, nxt, n, 0, end_bit, ctx->stream));
-        hipLaunchKernelGGL(kd_score_kernel, sgrid, block, 0, ctx->stream, cloud->pts.p, nxt, static_cast<uint32_t>(n), d, a, seg_box.p, score.p);
-      }
-    }
-    hipLaunchKernelGGL(kd_choose_axis_kernel, sgrid, block, 0, ctx->stream, score.p, seg_box.p, nseg, balanced, axis_of_seg.p);
-    hipLaunchKernelGGL(kd_keys_kernel, grid, block, 0, ctx->stream, cloud->pts.p, cur, static_cast<uint32_t>(n), d, 0, axis_of_seg.p, keys.p);
+    hipLaunchKernelGGL(kd_choose_axis_kernel, sgrid, block, 0, ctx->stream, seg_box.p, nseg, axis_of_seg.p);
+    hipLaunchKernelGGL(kd_keys_kernel, grid, block, 0, ctx->stream, cloud->pts.p, cur, static_cast<uint32_t>(n), d, axis_of_seg.p, keys.p);
     SGA_HIP(rocprim::radix_sort_pairs(ctx->d_temp.p, tb, keys.p, keys2.p, cur, nxt, n, 0, end_bit, ctx->stream));
     std::swap(cur, nxt);
     hipLaunchKernelGGL(kd_nodes_kernel, sgrid, block, 0, ctx->stream, cloud->pts.p, cur, static_cast<uint32_t>(n), d, axis_of_seg.p, idx->kd_nodes.p);

@@ -12,7 +12,7 @@
 #include "common.hpp"
 #include "device_math.hpp"
 #include "kd_search.hpp"
-#include "nn_search.hpp"
+#include "voxel_hash.hpp"
 
 void sga_profile_collect_pending(sga_context* ctx);
 
@@ -22,6 +22,7 @@ int comm_allreduce_sum(sga_context* ctx, double* d_buf, size_t count);
 
 constexpr int kTile = 256;           // threads per workgroup = source points per tile
 constexpr int kRow = 32;             // doubles per partial row (28 used + inliers)
+constexpr int kSearchBlock = 64;      // K1a: one wave per workgroup
 constexpr int kMaxBlocks = 2048;     // K1b / K2: 8 workgroups per CU, the whole grid is resident
 
 template <typename Real>
@@ -374,12 +375,6 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
   p.partials = pb->partials.p;
   const int blocks = grid_blocks(p.num_tiles);
 
-  static const bool dbg_time = getenv("SGA_DEBUG_STATS") != nullptr;
-  std::chrono::steady_clock::time_point dbg_t0;
-  if (dbg_time) {
-    (void)hipStreamSynchronize(ctx->stream);
-    dbg_t0 = std::chrono::steady_clock::now();
-  }
   const bool timed = ctx->profiling && (ctx->lin_seq++ % ctx->profile_period) == 0;  // sampled: event records cost ~7 us each
   if (timed) {
     sga_profile_collect_pending(ctx);
@@ -393,16 +388,9 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
     q.T = p.T;
     q.max_sq = p.max_sq;
     q.nn = pb->hint.p;
-    static const int use_seed = getenv("SGA_NN_SEED") ? atoi(getenv("SGA_NN_SEED")) : 1;
-    q.use_seed = use_seed;
-    static const int sb = getenv("SGA_NN_BLOCK") ? atoi(getenv("SGA_NN_BLOCK")) : 64;
+    q.use_seed = 1;
     const size_t words = static_cast<size_t>(std::max(p.kd.depth, 1));
-    if (sb == 64)
-      hipLaunchKernelGGL((nn_search_kernel<Real, 64>), dim3((p.n + 63) / 64), dim3(64), words * 64 * sizeof(uint32_t), ctx->stream, q);
-    else if (sb == 128)
-      hipLaunchKernelGGL((nn_search_kernel<Real, 128>), dim3((p.n + 127) / 128), dim3(128), words * 128 * sizeof(uint32_t), ctx->stream, q);
-    else
-      hipLaunchKernelGGL((nn_search_kernel<Real, 256>), dim3((p.n + 255) / 256), dim3(256), words * 256 * sizeof(uint32_t), ctx->stream, q);
+    hipLaunchKernelGGL((nn_search_kernel<Real, kSearchBlock>), dim3((p.n + kSearchBlock - 1) / kSearchBlock), dim3(kSearchBlock), words * kSearchBlock * sizeof(uint32_t), ctx->stream, q);
     if (timed) {
       (void)hipEventRecord(ctx->ev_mid, ctx->stream);
       ctx->mid_recorded = true;
@@ -425,11 +413,6 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
   if (timed) {
     (void)hipEventRecord(ctx->ev1, ctx->stream);
     ctx->pending |= 1;
-  }
-  if (dbg_time) {
-    (void)hipStreamSynchronize(ctx->stream);
-    std::fprintf(stderr, "[sga stats] linearize us=%.0f", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - dbg_t0).count());
-    std::fprintf(stderr, "\n");
   }
   launch_reduce(ctx, pb->partials.p, p.n > 0 ? blocks : 0, 29, kRow, pb->partials.p + static_cast<size_t>(kMaxBlocks) * kRow, d_out30, SGA_ACCUM_DOUBLES, host, seq);
   SGA_HIP(hipGetLastError());

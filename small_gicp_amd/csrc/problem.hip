@@ -8,7 +8,7 @@
 #include <rocprim/rocprim.hpp>
 #include "device_math.hpp"
 #include "kd_search.hpp"
-#include "nn_search.hpp"
+#include "voxel_hash.hpp"
 
 namespace sga {
 
@@ -193,8 +193,7 @@ int sga_problem_create(sga_context* ctx, const sga_index* target, const sga_clou
     } else {
       inv = static_cast<float>(4.0 / target->leaf);  // quarter-voxel cells: neighbouring lanes probe the same voxel
     }
-    static const bool kd_order = !(getenv("SGA_SOURCE_ORDER") && atoi(getenv("SGA_SOURCE_ORDER")) == 0);
-    if (target->kind == SGA_INDEX_KDTREE && target->n > 0 && kd_order) {
+    if (target->kind == SGA_INDEX_KDTREE && target->n > 0) {
       KdView kv = make_kd_view(target);
       hipLaunchKernelGGL(source_kd_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, source->pts.p, n, rigid_from_colmajor<float>(T), kv, ox, oy, oz, inv, keys.p, vals.p);
     } else {
