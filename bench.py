@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--cpu-iters", type=int, default=10, help="outer LM iterations of the CPU baseline sample")
     ap.add_argument("--math", default="fp32", choices=["fp32", "fp64"])
     ap.add_argument("--odom-frames", type=int, default=12, help="frames of the KITTI-shaped scan-to-scan odometry leg (config C5); 0 = skip")
+    ap.add_argument("--no-vgicp", action="store_true", help="skip the VGICP (config C4) leg")
     ap.add_argument("--force-dist", action="store_true", help="use the torch.distributed/RCCL path even at world size 1 (validation)")
     return ap.parse_args()
 
@@ -224,12 +225,43 @@ def main():
             out["cpu_baseline"] = cpu_baseline(sga, tgt, src, n, args)
             if out["cpu_baseline"] and out["cpu_baseline"].get("value"):
                 out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        if world == 1 and not use_dist and not args.no_vgicp:
+            out["vgicp_c4"] = vgicp_leg(sga, ctx, tgt, src, args)
         if world == 1 and not use_dist and args.odom_frames > 1:
             out["kitti_odom"] = odometry_leg(sga, args)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def vgicp_leg(sga, ctx, tgt, src, args):
+    """Config C4: VGICP against a GaussianVoxelMap (0.5 m voxels) of the same target, same step definition as the headline; the
+    voxel lookup replaces the tree search, so a pass is the factor kernel alone.  Extra information, not the headline metric."""
+    try:
+        t0 = time.perf_counter()
+        vm = sga.GaussianVoxelMap(0.5, ctx=ctx)
+        vm.insert(tgt)
+        problem = sga.Problem(vm, src, np.eye(4))
+        ctx.synchronize()
+        build_s = time.perf_counter() - t0
+        s = sga.make_setting("GICP", max_correspondence_distance=1.0, max_iterations=ITERS_PER_ALIGN, rotation_eps=0.0, translation_eps=0.0, math_mode=args.math)
+        for _ in range(2):
+            problem.align(s, np.eye(4))
+        ctx.set_profiling(PROFILE_PERIOD)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        steps = 0
+        while steps < 100:
+            steps += problem.align(s, np.eye(4)).iterations + 1
+        ctx.synchronize()
+        el = time.perf_counter() - t0
+        kms = ctx.kernel_ms()
+        ctx.set_profiling(False)
+        return {"value": steps / el, "unit": "iterations/s", "ms_per_step": 1e3 * el / steps, "voxelmap_build_s": build_s, "linearize_kernel_avg_us": kms["linearize_ms"] * 1e3, "error_kernel_avg_us": kms["error_ms"] * 1e3,
+                "workload": "C4: VGICP, GaussianVoxelMap(0.5 m) of the 1M-point target, 1M source points"}
+    except Exception as ex:  # noqa: BLE001
+        return {"error": repr(ex)}
 
 
 def odometry_leg(sga, args):
