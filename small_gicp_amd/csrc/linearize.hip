@@ -341,7 +341,7 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
   const sga_index* idx = pb->target;
   const bool voxel = idx->kind == SGA_INDEX_VOXELMAP;
   if (fp->factor_kind == SGA_GICP && ((pb->n > 0 && !pb->has_covs) || (idx->n > 0 && !idx->has_covs))) return fail(SGA_ERR_INVALID, "GICP needs covariances on both source and target");
-  if (fp->factor_kind == SGA_PLANE_ICP && (voxel || (idx->n > 0 && !idx->has_normals))) return fail(SGA_ERR_UNSUPPORTED, "PLANE_ICP needs a grid index over a target with normals");
+  if (fp->factor_kind == SGA_PLANE_ICP && (voxel || (idx->n > 0 && !idx->has_normals))) return fail(SGA_ERR_UNSUPPORTED, "PLANE_ICP needs a kd-tree index over a target with normals");
   if (fp->factor_kind < 0 || fp->factor_kind > 2) return fail(SGA_ERR_INVALID, "invalid factor_kind %d", fp->factor_kind);
 
   LinParams<Real> p{};
