@@ -84,3 +84,80 @@ def run_synthetic(num_frames=20, **kw):
         "estimated": est,
         "ground_truth": gt,
     }
+
+
+class Summarizer:
+    """mean +- std (last=...) of a stream, formatted like benchmark.hpp:36-79."""
+
+    def __init__(self):
+        self.n, self.sum, self.sq, self.last = 0, 0.0, 0.0, 0.0
+
+    def push(self, x):
+        self.n += 1
+        self.sum += x
+        self.sq += x * x
+        self.last = x
+
+    def __str__(self):
+        if self.n == 0:
+            return "nan +- nan (last=nan)"
+        mean = self.sum / self.n
+        var = max(0.0, (self.sq - mean * self.sum) / self.n)
+        return "%.3f +- %.3f (last=%.3f)" % (mean, var ** 0.5, self.last)
+
+
+def run_kitti(dataset_path, output_path=None, num_frames=None, downsampling_resolution=0.25, num_neighbors=20, quiet=False):
+    """The reference's odometry benchmark on a directory of KITTI `.bin` scans (src/benchmark/odometry_benchmark.cpp:20-97 with the
+    small_gicp engine, odometry_benchmark_small_gicp_omp.cpp:16-57): prints the same parameter / report lines and writes the
+    trajectory in the KITTI text format.  Returns the list of poses T_world_sensor."""
+    from . import io
+
+    names = io.list_kitti_scans(dataset_path, num_frames or 1000000)
+    if not quiet:
+        print("dataset_path=%s" % dataset_path)
+        print("registration_engine=small_gicp_amd")
+        print("num_neighbors=%d" % num_neighbors)
+        print("downsampling_resolution=%g" % downsampling_resolution)
+        print("num_frames=%d" % len(names))
+    odom = OnlineOdometry(downsampling_resolution=downsampling_resolution, num_neighbors=num_neighbors)
+    reg, tot = Summarizer(), Summarizer()
+    traj = []
+    for i, name in enumerate(names):
+        if i and i % 256 == 0 and not quiet:
+            print("registration_time_stats=%s [msec/scan]  total_throughput=%s [msec/scan]" % (reg, tot))
+        pts = io.read_points(name)
+        traj.append(odom.estimate(pts[:, :3]))
+        reg.push(odom.reg_ms[-1])
+        tot.push(odom.total_ms[-1])
+    if not quiet:
+        print("done!")
+        print("registration_time_stats=%s [msec/scan]  total_throughput=%s [msec/scan]" % (reg, tot))
+    if output_path:
+        io.write_trajectory(output_path, traj)
+    return traj
+
+
+def main(argv=None):
+    import argparse
+
+    ap = argparse.ArgumentParser(description="scan-to-scan GICP odometry on the GPU: odometry <dataset_path> <output_path> [options]")
+    ap.add_argument("dataset_path", help="directory of KITTI .bin scans, or 'synthetic' for the frozen synthetic sequence")
+    ap.add_argument("output_path", nargs="?", default=None, help="trajectory file (KITTI text format)")
+    ap.add_argument("--num_frames", type=int, default=None)
+    ap.add_argument("--num_neighbors", type=int, default=20)
+    ap.add_argument("--downsampling_resolution", type=float, default=0.25)
+    a = ap.parse_args(argv)
+    if a.dataset_path == "synthetic":
+        from . import io
+
+        r = run_synthetic(a.num_frames or 20, downsampling_resolution=a.downsampling_resolution, num_neighbors=a.num_neighbors)
+        print("registration_time=%.3f [msec/scan]  total=%.3f [msec/scan]  rpe_trans=%.4f m  rpe_rot=%.5f rad" % (r["registration_ms_per_scan"], r["total_ms_per_scan"], r["rpe_trans_m_mean"], r["rpe_rot_rad_mean"]))
+        if a.output_path:
+            io.write_trajectory(a.output_path, r["estimated"])
+    else:
+        run_kitti(a.dataset_path, a.output_path, a.num_frames, a.downsampling_resolution, a.num_neighbors)
+
+
+if __name__ == "__main__":
+    main()
+

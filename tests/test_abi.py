@@ -143,3 +143,22 @@ def test_callback_error_propagates():
 
     with pytest.raises(ValueError):
         sga.optimize(sga.make_setting("GICP"), np.eye(4), lin, lambda T: 0.0)
+
+
+def test_small_gicp_module_name_exports_the_reference_surface():
+    """`import small_gicp` resolves to this repository's drop-in package and lists the names the reference's Python tests use
+    (no device call is made by importing it)."""
+    import inspect
+
+    import small_gicp
+
+    for name in ("PointCloud", "KdTree", "GaussianVoxelMap", "RegistrationResult", "read_ply", "voxelgrid_sampling", "estimate_normals", "estimate_covariances",
+                 "estimate_normals_covariances", "preprocess_points", "align", "DistanceRejector", "ICPFactor", "PointToPlaneICPFactor", "GICPFactor"):
+        assert hasattr(small_gicp, name), name
+    # keyword names and defaults of the binding (src/python/align.cpp:95-106, preprocess.cpp:233-236)
+    p = inspect.signature(small_gicp._align_points).parameters
+    assert list(p)[:5] == ["target_points", "source_points", "init_T_target_source", "registration_type", "voxel_resolution"]
+    assert p["downsampling_resolution"].default == 0.25 and p["max_iterations"].default == 20 and p["translation_epsilon"].default == 1e-3
+    q = inspect.signature(small_gicp.preprocess_points).parameters
+    assert q["num_neighbors"].default == 10 and q["downsampling_resolution"].default == 0.25
+    assert small_gicp.DistanceRejector().max_dist_sq == 1.0
