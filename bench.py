@@ -273,6 +273,13 @@ def odometry_leg(sga, args):
         r = odometry.run_synthetic(args.odom_frames)
         out = {k: v for k, v in r.items() if k not in ("estimated", "ground_truth")}
         out["unit"] = "ms/scan"
+        try:
+            pr = odometry.run_synthetic_pipelined(max(args.odom_frames, 36))
+            same = all(np.abs(a - b).max() < 1e-9 for a, b in zip(pr["estimated"], r["estimated"]))
+            out["pipelined_total_ms_per_scan"] = pr["ms_per_scan"]  # throughput with 3 preprocessing streams + 1 registration stream in flight
+            out["pipelined_poses_identical"] = bool(same)
+        except Exception as ex:  # noqa: BLE001
+            out["pipelined_error"] = repr(ex)
         out["protocol"] = "src/benchmark/odometry_benchmark_small_gicp_omp.cpp:16-49: registration = index build + covariances + align; total adds the 0.25 m voxel grid"
         if not args.no_cpu_baseline:
             from oracle import orc

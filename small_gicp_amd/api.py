@@ -324,9 +324,9 @@ def make_setting(
 class Problem:
     """(target index, source cloud) pairing with device-resident factor state: the Reduction slot of Registration<>."""
 
-    def __init__(self, target, source, init_T=None):
+    def __init__(self, target, source, init_T=None, ctx=None):
         self.target, self.source = target, source
-        self.ctx = source.ctx
+        self.ctx = ctx or source.ctx  # a problem may run on another context (stream) of the same device than the one that built its inputs
         self.h = C.c_void_p()
         t16 = _T16(init_T)
         check(load().sga_problem_create(self.ctx.h, target.h, source.h, _dp(t16), C.byref(self.h)))

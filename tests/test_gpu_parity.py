@@ -617,3 +617,15 @@ def test_kitti_driver_and_formats(tmp_path, capsys):
     assert len(traj) == frames
     for T, E in zip(traj, ref["estimated"]):
         assert np.abs(T[:3] - E[:3]).max() < 5e-6  # "%.6f"
+
+
+def test_pipelined_odometry_gives_the_same_poses():
+    """Two contexts (streams) + a producer thread: preprocessing of frame i+1 overlaps the registration of frame i; the poses are
+    bit-identical to the sequential driver's."""
+    from small_gicp_amd import odometry
+
+    seq = odometry.run_synthetic(6)
+    pipe = odometry.run_synthetic_pipelined(6)
+    assert len(pipe["estimated"]) == 6
+    for a, b in zip(seq["estimated"], pipe["estimated"]):
+        assert (a == b).all()
