@@ -93,6 +93,14 @@ int sga_index_destroy(sga_index* index);
 int sga_index_size(const sga_index* index, size_t* n);
 /* Voxel map contents in voxel-id order: coords n*3 int32, means n*3, cov6 n*6, counts n (any may be NULL). */
 int sga_index_voxelmap_download(sga_context* ctx, const sga_index* index, int32_t* coords, float* means, float* cov6, uint32_t* counts);
+/* Incremental GaussianVoxelMap (ann/incremental_voxelmap.hpp:55-92, the scan-to-model target): an empty map, then any number of
+ * insert(points_with_covs, T): the points are moved by T (column-major 4x4, NULL = identity), voxels keep running means over
+ * everything ever inserted while they live, voxel ids follow the creation order, and every `clear_cycle` inserts the voxels not
+ * touched for more than `horizon` inserts are removed (defaults 100 / 10, incremental_voxelmap.hpp:46).  Usable as the target of
+ * sga_problem_create / sga_align like a one-shot map; problems created before an insert must be re-created. */
+int sga_voxelmap_create(sga_context* ctx, double leaf_size, sga_index** out);
+int sga_voxelmap_insert(sga_context* ctx, sga_index* voxelmap, const sga_cloud* points_with_covs, const double T[16]);
+int sga_voxelmap_set_lru(sga_index* voxelmap, uint32_t horizon, uint32_t clear_cycle);
 /* traits::knn_search / nearest_neighbor_search (ann/traits.hpp:22-57) for m host queries (m*3 floats):
  * idx m*k int64 (original target indices, -1 = none), sq_dist m*k floats ascending (inf = none).
  * max_sq_dist < 0 means unbounded.  Voxel maps support k = 1 only (own voxel, incremental_voxelmap.hpp:99-119). */

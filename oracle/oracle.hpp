@@ -269,13 +269,17 @@ inline void estimate_normals_covariances(PointCloud& cloud, const KdTree& tree, 
 // ann/incremental_voxelmap.hpp:55-119,151-153 + ann/gaussian_voxelmap.hpp:15-60 — one-shot GaussianVoxelMap
 // (LRU bookkeeping is a no-op for a single insert: lru_counter 0 -> 1, 1 % 10 != 0).
 struct GaussianVoxelMap {
+  // ann/gaussian_voxelmap.hpp:15-60 (GaussianVoxel) + the VoxelInfo of ann/incremental_voxelmap.hpp:21-31
   struct Voxel {
     int coord[3];
+    size_t lru = 0;
+    bool finalized = false;
     size_t num_points = 0;
     Vec3 mean{0, 0, 0};
     Mat3 cov = Mat3::zero();
   };
   double inv_leaf_size;
+  size_t lru_horizon = 100, lru_clear_cycle = 10, lru_counter = 0;  // incremental_voxelmap.hpp:46
   std::vector<Voxel> flat_voxels;  // insertion order of the first point of each voxel
   std::unordered_map<std::uint64_t, size_t> voxels;
   int num_search_offsets = 1;
@@ -288,9 +292,10 @@ struct GaussianVoxelMap {
   }
   size_t size() const { return flat_voxels.size(); }
 
-  void insert(const PointCloud& points) {
+  // incremental_voxelmap.hpp:55-92: insert (with a pose), LRU sweep every lru_clear_cycle inserts, finalize
+  void insert(const PointCloud& points, const SE3& T = SE3::identity()) {
     for (size_t i = 0; i < points.size(); i++) {
-      const Vec3& pt = points.points[i];
+      const Vec3 pt = T * points.points[i];
       int c[3] = {fast_floor(pt[0] * inv_leaf_size), fast_floor(pt[1] * inv_leaf_size), fast_floor(pt[2] * inv_leaf_size)};
       const std::uint64_t k = key(c);
       auto found = voxels.find(k);
@@ -300,16 +305,39 @@ struct GaussianVoxelMap {
         v.coord[0] = c[0];
         v.coord[1] = c[1];
         v.coord[2] = c[2];
+        v.lru = lru_counter;
         flat_voxels.push_back(v);
       }
       Voxel& v = flat_voxels[found->second];
+      v.lru = lru_counter;
+      // GaussianVoxel::add (gaussian_voxelmap.hpp:32-42)
+      if (v.finalized) {
+        v.finalized = false;
+        v.mean = static_cast<double>(v.num_points) * v.mean;
+        v.cov = static_cast<double>(v.num_points) * v.cov;
+      }
       v.num_points++;
       v.mean = v.mean + pt;
-      v.cov = v.cov + points.covs[i];  // T = identity
+      v.cov = v.cov + T.R * points.covs[i] * transpose(T.R);  // T.matrix() * cov4 * T.matrix()^T: the 3x3 block is R C R^T
     }
-    for (auto& v : flat_voxels) {
-      v.mean = (1.0 / v.num_points) * v.mean;
-      v.cov = (1.0 / v.num_points) * v.cov;
+    if ((++lru_counter) % lru_clear_cycle == 0) {
+      // remove the least recently used voxels, keep the order of the others, rehash (:76-88)
+      std::vector<Voxel> kept;
+      kept.reserve(flat_voxels.size());
+      for (const auto& v : flat_voxels)
+        if (!(v.lru + lru_horizon < lru_counter)) kept.push_back(v);
+      flat_voxels.swap(kept);
+      voxels.clear();
+      for (size_t i = 0; i < flat_voxels.size(); i++) voxels[key(flat_voxels[i].coord)] = i;
+    }
+    for (auto& v : flat_voxels) {  // GaussianVoxel::finalize (:45-53)
+      if (v.finalized) continue;
+      const double np = static_cast<double>(v.num_points);  // `mean /= num_points; cov /= num_points;` element by element
+      for (int r = 0; r < 3; r++) {
+        v.mean[r] = v.mean[r] / np;
+        for (int c = 0; c < 3; c++) v.cov(r, c) = v.cov(r, c) / np;
+      }
+      v.finalized = true;
     }
   }
 

@@ -180,6 +180,16 @@ void* orc_voxelmap_create(void* cloud_h, double leaf) {
   vm->map.insert(static_cast<OrcCloud*>(cloud_h)->cloud);
   return vm;
 }
+// incremental use: an empty map, then insert(cloud, T) any number of times (incremental_voxelmap.hpp:55-92)
+void* orc_voxelmap_new(double leaf) { return new OrcVoxelMap(leaf); }
+void orc_voxelmap_insert(void* h, void* cloud_h, const double* T16) {
+  static_cast<OrcVoxelMap*>(h)->map.insert(static_cast<OrcCloud*>(cloud_h)->cloud, T16 ? se3_from_colmajor16(T16) : SE3::identity());
+}
+void orc_voxelmap_set_lru(void* h, size_t horizon, size_t clear_cycle) {
+  auto& m = static_cast<OrcVoxelMap*>(h)->map;
+  m.lru_horizon = horizon;
+  m.lru_clear_cycle = clear_cycle;
+}
 void orc_voxelmap_destroy(void* h) { delete static_cast<OrcVoxelMap*>(h); }
 size_t orc_voxelmap_size(void* h) { return static_cast<OrcVoxelMap*>(h)->map.size(); }
 void orc_voxelmap_set_search_offsets(void* h, int n) { static_cast<OrcVoxelMap*>(h)->map.num_search_offsets = n; }

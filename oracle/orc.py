@@ -84,6 +84,10 @@ def lib():
         L.orc_voxelmap_create.argtypes = [vp, C.c_double]
         L.orc_voxelmap_create.restype = vp
         L.orc_voxelmap_destroy.argtypes = [vp]
+        L.orc_voxelmap_new.argtypes = [C.c_double]
+        L.orc_voxelmap_new.restype = vp
+        L.orc_voxelmap_insert.argtypes = [vp, vp, dp]
+        L.orc_voxelmap_set_lru.argtypes = [vp, C.c_size_t, C.c_size_t]
         L.orc_voxelmap_size.argtypes = [vp]
         L.orc_voxelmap_size.restype = C.c_size_t
         L.orc_voxelmap_set_search_offsets.argtypes = [vp, C.c_int]
@@ -173,11 +177,24 @@ class Cloud:
 
 
 class VoxelMap:
-    """GaussianVoxelMap built by one insert() of a cloud with covariances (registration_helper.cpp:50-54)."""
+    """GaussianVoxelMap: VoxelMap(cloud, leaf) = one insert() of a cloud with covariances (registration_helper.cpp:50-54);
+    VoxelMap(None, leaf) = empty map for incremental use: insert(cloud, T) any number of times, set_lru(horizon, clear_cycle)
+    (incremental_voxelmap.hpp:46,55-92)."""
 
     def __init__(self, cloud, leaf):
-        self.h = lib().orc_voxelmap_create(cloud.h, float(leaf))
+        if cloud is None:
+            self.h = lib().orc_voxelmap_new(float(leaf))
+        else:
+            self.h = lib().orc_voxelmap_create(cloud.h, float(leaf))
         self.n = lib().orc_voxelmap_size(self.h)
+
+    def insert(self, cloud, T=None):
+        t = None if T is None else np.ascontiguousarray(np.asarray(T, dtype=np.float64).T).ravel()  # column-major 4x4
+        lib().orc_voxelmap_insert(self.h, cloud.h, None if t is None else _dp(t))
+        self.n = lib().orc_voxelmap_size(self.h)
+
+    def set_lru(self, horizon=100, clear_cycle=10):
+        lib().orc_voxelmap_set_lru(self.h, int(horizon), int(clear_cycle))
 
     def __del__(self):
         if getattr(self, "h", None):

@@ -54,6 +54,14 @@ def lib():
         L.ref_linearize.argtypes = [vp, vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, dp, dp, dp, dp, dp, C.POINTER(C.c_uint64)]
         L.ref_voxelmap_size.argtypes = [vp, C.c_double]
         L.ref_voxelmap_size.restype = C.c_size_t
+        L.ref_ivm_create.argtypes = [C.c_double]
+        L.ref_ivm_create.restype = vp
+        L.ref_ivm_destroy.argtypes = [vp]
+        L.ref_ivm_set_lru.argtypes = [vp, C.c_size_t, C.c_size_t]
+        L.ref_ivm_insert.argtypes = [vp, vp, dp]
+        L.ref_ivm_size.argtypes = [vp]
+        L.ref_ivm_size.restype = C.c_size_t
+        L.ref_ivm_get.argtypes = [vp, C.POINTER(C.c_int), dp, dp, C.POINTER(C.c_uint64)]
         _LIB = L
     return _LIB
 
@@ -109,6 +117,37 @@ class Cloud:
 
     def voxelmap_size(self, leaf):
         return lib().ref_voxelmap_size(self.h, float(leaf))
+
+
+class VoxelMap:
+    """The reference's GaussianVoxelMap used incrementally: insert(cloud, T) any number of times (incremental_voxelmap.hpp:55-92)."""
+
+    def __init__(self, leaf):
+        self.h = lib().ref_ivm_create(float(leaf))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().ref_ivm_destroy(self.h)
+            self.h = None
+
+    def set_lru(self, horizon=100, clear_cycle=10):
+        lib().ref_ivm_set_lru(self.h, int(horizon), int(clear_cycle))
+
+    def insert(self, cloud, T=None):
+        t16 = None if T is None else _T16(T)
+        lib().ref_ivm_insert(self.h, cloud.h, _dp(t16))
+
+    def __len__(self):
+        return lib().ref_ivm_size(self.h)
+
+    def get(self):
+        n = len(self)
+        coords = np.empty((n, 3), np.int32)
+        means = np.empty((n, 3))
+        covs = np.empty((n, 9))
+        counts = np.empty(n, np.uint64)
+        lib().ref_ivm_get(self.h, coords.ctypes.data_as(C.POINTER(C.c_int)), _dp(means), _dp(covs), counts.ctypes.data_as(C.POINTER(C.c_uint64)))
+        return coords, means, covs.reshape(n, 3, 3), counts
 
 
 class AlignResult:

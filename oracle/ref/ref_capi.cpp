@@ -214,4 +214,32 @@ int ref_linearize(void* target_h, void* source_h, int type, int robust, double r
 
 size_t ref_voxelmap_size(void* cloud_h, double leaf) { return create_gaussian_voxelmap(*static_cast<RefCloud*>(cloud_h)->cloud, leaf)->size(); }
 
+
+// ---- incremental GaussianVoxelMap of the reference (ann/incremental_voxelmap.hpp, ann/gaussian_voxelmap.hpp), unmodified ----
+struct RefVoxelMap {
+  GaussianVoxelMap map;
+  explicit RefVoxelMap(double leaf) : map(leaf) {}
+};
+void* ref_ivm_create(double leaf) { return new RefVoxelMap(leaf); }
+void ref_ivm_destroy(void* h) { delete static_cast<RefVoxelMap*>(h); }
+void ref_ivm_set_lru(void* h, size_t horizon, size_t clear_cycle) {
+  static_cast<RefVoxelMap*>(h)->map.lru_horizon = horizon;
+  static_cast<RefVoxelMap*>(h)->map.lru_clear_cycle = clear_cycle;
+}
+void ref_ivm_insert(void* h, void* cloud_h, const double* T16) {
+  static_cast<RefVoxelMap*>(h)->map.insert(*static_cast<RefCloud*>(cloud_h)->cloud, T16 ? to_iso(T16) : Eigen::Isometry3d::Identity());
+}
+size_t ref_ivm_size(void* h) { return static_cast<RefVoxelMap*>(h)->map.size(); }
+void ref_ivm_get(void* h, int* coords, double* means, double* covs, std::uint64_t* counts) {
+  const auto& fv = static_cast<RefVoxelMap*>(h)->map.flat_voxels;
+  for (size_t i = 0; i < fv.size(); i++) {
+    for (int k = 0; k < 3; k++) {
+      coords[3 * i + k] = fv[i]->first.coord[k];
+      means[3 * i + k] = fv[i]->second.mean[k];
+      for (int c = 0; c < 3; c++) covs[9 * i + 3 * k + c] = fv[i]->second.cov(k, c);
+    }
+    counts[i] = fv[i]->second.num_points;
+  }
+}
+
 }  // extern "C"

@@ -83,6 +83,9 @@ SYMBOLS = [
     ("sga_index_destroy", C.c_int, [_vp]),
     ("sga_index_size", C.c_int, [_vp, C.POINTER(C.c_size_t)]),
     ("sga_index_voxelmap_download", C.c_int, [_vp, _vp, C.POINTER(C.c_int32), _fp, _fp, C.POINTER(C.c_uint32)]),
+    ("sga_voxelmap_create", C.c_int, [_vp, C.c_double, _pvp]),
+    ("sga_voxelmap_insert", C.c_int, [_vp, _vp, _vp, _dp]),
+    ("sga_voxelmap_set_lru", C.c_int, [_vp, C.c_uint32, C.c_uint32]),
     ("sga_index_knn", C.c_int, [_vp, _vp, _fp, C.c_size_t, C.c_int, C.c_double, C.POINTER(C.c_int64), _fp]),
     ("sga_factor_params_default", None, [C.POINTER(FactorParams)]),
     ("sga_problem_create", C.c_int, [_vp, _vp, _vp, _dp, _pvp]),

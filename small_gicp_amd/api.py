@@ -215,12 +215,15 @@ class KdTree:
 
 
 class GaussianVoxelMap:
-    """small_gicp.GaussianVoxelMap: `GaussianVoxelMap(leaf); insert(cloud_with_covs)` (one-shot)."""
+    """small_gicp.GaussianVoxelMap (src/python/voxelmap.cpp:20-140): `GaussianVoxelMap(leaf_size)`, then any number of
+    `insert(cloud_with_covs, T)`; `set_lru(horizon, clear_cycle)`; `size()`, `voxel_points()`, `voxel_covs()`.
+    Device side: the incremental map of csrc/voxelmap.hip."""
 
     def __init__(self, leaf_size, ctx=None):
         self.leaf = float(leaf_size)
         self.ctx = ctx or default_context()
         self.h = C.c_void_p()
+        check(load().sga_voxelmap_create(self.ctx.h, self.leaf, C.byref(self.h)))
 
     def __del__(self):
         if getattr(self, "h", None) and self.h.value:
@@ -228,12 +231,14 @@ class GaussianVoxelMap:
             self.h = C.c_void_p()
 
     def insert(self, cloud, T=None):
-        if T is not None and not np.allclose(np.asarray(T), np.eye(4)):
-            raise NotImplementedError("insert() with a transform")
-        if self.h.value:
-            raise NotImplementedError("incremental insertion is out of scope (SURVEY.md §8f row 3); build one map per target")
-        self.ctx = cloud.ctx
-        check(load().sga_index_build_gaussian_voxelmap(self.ctx.h, cloud.h, self.leaf, C.byref(self.h)))
+        t16 = None if T is None else _T16(T)
+        check(load().sga_voxelmap_insert(self.ctx.h, self.h, cloud.h, None if t16 is None else _dp(t16)))
+
+    def set_lru(self, horizon=100, clear_cycle=10):
+        check(load().sga_voxelmap_set_lru(self.h, int(horizon), int(clear_cycle)))
+
+    def __len__(self):
+        return self.size()
 
     def size(self):
         if not self.h.value:

@@ -64,6 +64,14 @@ struct DevBuf {
   }
   // grow-only
   int reserve(size_t count) { return (count <= n) ? SGA_OK : alloc(count); }
+  void swap(DevBuf& o) {
+    T* tp = p;
+    p = o.p;
+    o.p = tp;
+    const size_t tn = n;
+    n = o.n;
+    o.n = tn;
+  }
 };
 
 // ---- packed records (HBM layout) ---------------------------------------------------------------------------------------
@@ -138,6 +146,13 @@ struct sga_index {
   uint32_t hmask = 0;
   sga::DevBuf<int> vcoords;               // n*3
   sga::DevBuf<uint32_t> vcounts;          // n
+  // incremental voxel maps (voxelmap.hip: repeated insert() with a pose, running means in fp64, LRU removal)
+  bool incremental = false;
+  size_t vcap = 0;                        // capacity of the per-voxel arrays (voxels)
+  sga::DevBuf<double> vmean64;            // 3 per voxel: finalized mean
+  sga::DevBuf<double> vcov64;             // 6 per voxel: finalized mean covariance (xx, xy, xz, yy, yz, zz)
+  sga::DevBuf<uint32_t> vlru;             // insert counter at the voxel's last update
+  uint32_t lru_counter = 0, lru_horizon = 100, lru_clear_cycle = 10;
 };
 
 struct sga_problem {

@@ -50,6 +50,71 @@ class OnlineOdometry:
         return self.T_world.copy()
 
 
+class ModelOdometry:
+    """Scan-to-MODEL VGICP odometry (src/benchmark/odometry_benchmark_small_vgicp_model_omp.cpp:12-57): the target is one
+    GaussianVoxelMap accumulating every registered scan (incremental insert with the estimated pose + LRU removal of voxels the
+    sensor has left behind); each new scan is registered against it starting from the previous pose, then inserted."""
+
+    def __init__(self, downsampling_resolution=0.25, num_neighbors=20, voxel_resolution=1.0, max_correspondence_distance=1.0, ctx=None):
+        self.res = downsampling_resolution
+        self.k = num_neighbors
+        self.voxel_resolution = voxel_resolution
+        self.setting = api.make_setting("GICP", max_correspondence_distance=max_correspondence_distance)
+        self.ctx = ctx or api.default_context()
+        self.voxelmap = None
+        self.T_world = np.eye(4)
+        self.reg_ms, self.total_ms, self.iterations = [], [], []
+
+    def estimate(self, points):
+        t0 = time.perf_counter()
+        raw = api.PointCloud(points, ctx=self.ctx)
+        cloud = api.voxelgrid_sampling(raw, self.res)
+        self.ctx.synchronize()
+        t1 = time.perf_counter()
+        api.estimate_covariances(cloud, None, self.k)
+        if self.voxelmap is None:  # the very first frame
+            self.voxelmap = api.GaussianVoxelMap(self.voxel_resolution, ctx=self.ctx)
+            self.voxelmap.insert(cloud)
+        else:
+            res = api.Problem(self.voxelmap, cloud, self.T_world).align(self.setting, self.T_world)
+            self.T_world = res.T_target_source
+            self.iterations.append(res.iterations + 1)
+            self.voxelmap.insert(cloud, self.T_world)
+            self.ctx.synchronize()
+            self.reg_ms.append(1e3 * (time.perf_counter() - t1))
+        self.ctx.synchronize()
+        self.total_ms.append(1e3 * (time.perf_counter() - t0))
+        return self.T_world.copy()
+
+
+def run_synthetic_model(num_frames=20, **kw):
+    """ModelOdometry over the frozen synthetic sequence; absolute trajectory error against the generator's ground truth."""
+    from . import synthetic
+
+    odom = ModelOdometry(**kw)
+    est, gt = [], []
+    T0 = None
+    for f in range(num_frames):
+        pts, Tws = synthetic.kitti_like_scan(f)
+        if T0 is None:
+            T0 = Tws
+        est.append(odom.estimate(pts))
+        gt.append(np.linalg.inv(T0) @ Tws)
+    ate = [float(np.linalg.norm(e[:3, 3] - g[:3, 3])) for e, g in zip(est, gt)]
+    skip = 2 if num_frames > 4 else 0
+    return {
+        "frames": num_frames,
+        "registration_ms_per_scan": float(np.mean(odom.reg_ms[skip:])) if len(odom.reg_ms) > skip else float("nan"),
+        "total_ms_per_scan": float(np.mean(odom.total_ms[skip + 1 :])) if len(odom.total_ms) > skip + 1 else float("nan"),
+        "total_ms_per_scan_median": float(np.median(odom.total_ms[skip + 1 :])) if len(odom.total_ms) > skip + 1 else float("nan"),
+        "mean_iterations": float(np.mean(odom.iterations)) if odom.iterations else 0.0,
+        "ate_trans_m_max": max(ate),
+        "num_voxels": odom.voxelmap.size(),
+        "estimated": est,
+        "ground_truth": gt,
+    }
+
+
 class PipelinedOdometry:
     """The same scan-to-scan odometry with the stages of a frame spread over HIP streams (one context each): `workers` threads
     preprocess the frames i, i + workers, ... (upload, voxel grid, index build, covariances) while the caller's thread registers

@@ -629,3 +629,88 @@ def test_pipelined_odometry_gives_the_same_poses():
     assert len(pipe["estimated"]) == 6
     for a, b in zip(seq["estimated"], pipe["estimated"]):
         assert (a == b).all()
+
+
+# ---- §8f row 3: incremental GaussianVoxelMap (scan-to-model target) -----------------------------------------------------------------
+def test_incremental_voxelmap_matches_oracle(orc, c1_f32, gpu_c1):
+    """The same sequence of insert(cloud, T) on the device (csrc/voxelmap.hip) and in the oracle (pinned to the reference's
+    IncrementalVoxelMap in tests/test_oracle_vs_reference.py): voxel creation order, counts, running means / covariances, and the
+    LRU sweep.  Inputs are the identical fp32 clouds; the map state is fp64 on both sides, the device exports fp32."""
+    d = c1_f32
+    tgt, src, _ = gpu_c1
+    ot, os_ = orc.Cloud(d["tp"], d["tn"], d["tc"]), orc.Cloud(d["sp"], d["sn"], d["sc"])
+    gv, ov = sga.GaussianVoxelMap(1.0), orc.VoxelMap(None, 1.0)
+    gv.set_lru(2, 3)
+    ov.set_lru(2, 3)
+    sizes = []
+    for step in range(8):
+        T = se3([0.1, 0.2, 1.0], 0.02 * step, [6.0 * step, -2.0 * step, 0.1 * step])
+        g, o = (tgt, ot) if step % 2 == 0 else (src, os_)
+        gv.insert(g, T)
+        ov.insert(o, T)
+        gc, gm, g6, gn = gv.download()
+        oc, om, ocv, on = ov.get()
+        assert gv.size() == len(ov) and (gc == oc).all() and (gn == on).all(), step
+        scale = max(1.0, float(np.abs(om).max()))
+        assert np.abs(gm - om).max() <= 2e-7 * scale, step  # fp32 export of identical fp64 state
+        assert np.abs(sga.api.mats_from_sym6(g6.astype(np.float64)) - ocv).max() <= 2e-7, step
+        sizes.append(gv.size())
+    assert min(np.diff(sizes)) < 0
+    # registering against the accumulated model agrees with the oracle doing the same (VGICP, registration_helper.cpp:125-137)
+    st = sga.make_setting("GICP")
+    T0 = se3([0.1, 0.2, 1.0], 0.02 * 7, [42.0, -14.0, 0.7])
+    res = sga.Problem(gv, src, T0).align(st, T0)
+    ores = orc.align(ov, os_, orc.default_setting(factor_kind=orc.GICP, num_threads=1), T0)
+    dt, dr = pose_error(res.T_target_source, ores.T_target_source)
+    assert dt < POSE_TOL_T and dr < POSE_TOL_R and res.iterations == ores.iterations and res.num_inliers == ores.num_inliers, (dt, dr)
+
+
+def test_incremental_single_insert_equals_one_shot_build(gpu_c1):
+    """One insert into an empty incremental map == sga_index_build_gaussian_voxelmap (the helper's one-shot path)."""
+    import ctypes as C
+
+    tgt, _, _ = gpu_c1
+    inc = sga.GaussianVoxelMap(0.5)
+    inc.insert(tgt)
+    lib = sga._lib.load()
+    h = C.c_void_p()
+    sga._lib.check(lib.sga_index_build_gaussian_voxelmap(tgt.ctx.h, tgt.h, 0.5, C.byref(h)))
+    try:
+        one = sga.GaussianVoxelMap.__new__(sga.GaussianVoxelMap)
+        one.leaf, one.ctx, one.h = 0.5, tgt.ctx, h
+        a, b = inc.download(), one.download()
+        assert (a[0] == b[0]).all() and (a[3] == b[3]).all()
+        assert np.abs(a[1] - b[1]).max() <= 1e-6 and np.abs(a[2] - b[2]).max() <= 1e-7  # multiply-by-reciprocal vs division
+    finally:
+        one.h = C.c_void_p()
+        lib.sga_index_destroy(h)
+    # empty and degenerate inserts
+    empty = sga.PointCloud(np.zeros((0, 3), np.float32), covs=np.zeros((0, 6), np.float32))
+    inc.insert(empty)
+    assert inc.size() == len(a[0])
+
+
+def test_scan_to_model_odometry_matches_oracle(orc):
+    """odometry_benchmark_small_vgicp_model_omp.cpp on the synthetic sequence: every pose of the GPU driver against the oracle
+    running the same protocol (downsample -> covariances -> VGICP against the accumulated voxel map from the previous pose ->
+    insert with the estimated pose)."""
+    from small_gicp_amd import odometry
+
+    frames = 6
+    r = odometry.run_synthetic_model(frames)
+    vm = None
+    T = np.eye(4)
+    for f in range(frames):
+        pts, _ = sga.synthetic.kitti_like_scan(f)
+        cloud = orc.Cloud(orc.voxelgrid_sampling(pts, 0.25))
+        cloud.estimate_normals_covariances(20, 4)
+        if vm is None:
+            vm = orc.VoxelMap(None, 1.0)
+            vm.insert(cloud)
+        else:
+            res = orc.align(vm, cloud, orc.default_setting(factor_kind=orc.GICP, num_threads=4), T)
+            T = res.T_target_source
+            vm.insert(cloud, T)
+        dt, dr = pose_error(r["estimated"][f], T)
+        assert dt < 2e-4 and dr < 2e-4, (f, dt, dr)  # the chain feeds every pose into the next map: twice the single-registration tolerance
+    assert abs(r["num_voxels"] - len(vm)) <= 2

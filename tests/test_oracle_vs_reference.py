@@ -89,3 +89,39 @@ def test_goldens_equal_reference(clouds, c1_gold):
         g = c1_gold["cases"][name]
         dt, dr = pose_error(r.T_target_source, np.array(g["T"]))
         assert dt < 1e-9 and dr < 1e-7 and r.iterations == g["iterations"] and r.num_inliers == g["num_inliers"]
+
+
+def _se3(axis, ang, t):
+    from scipy.spatial.transform import Rotation
+
+    T = np.eye(4)
+    T[:3, :3] = Rotation.from_rotvec(np.asarray(axis, dtype=np.float64) / np.linalg.norm(axis) * ang).as_matrix()
+    T[:3, 3] = t
+    return T
+
+
+def test_incremental_voxelmap(orc, clouds):
+    """Scan-to-model target: the same sequence of insert(cloud, T) into the reference's GaussianVoxelMap and into the oracle's —
+    creation order of the voxels, running means / mean covariances, point counts, and the LRU sweep (small horizon and cycle so
+    that voxels really get removed) — incremental_voxelmap.hpp:55-92, gaussian_voxelmap.hpp:32-53."""
+    rv, ov = ref.VoxelMap(1.0), orc.VoxelMap(None, 1.0)
+    rv.set_lru(2, 3)
+    ov.set_lru(2, 3)
+    # identical inputs on both sides (the oracle's points and covariances), so that only the map arithmetic is compared
+    pairs = []
+    for o in (clouds["ot"], clouds["os"]):
+        p, n, c = o.get()
+        pairs.append((ref.Cloud(p, n, c, tree=False), o))
+    sizes = []
+    for step in range(8):
+        # a "sensor" drifting away: later scans stop touching the first voxels, which the sweep then removes
+        T = _se3([0.1, 0.2, 1.0], 0.02 * step, [6.0 * step, -2.0 * step, 0.1 * step])
+        r, o = pairs[step % 2]
+        rv.insert(r, T)
+        ov.insert(o, T)
+        rc, rm, rcv, rn = rv.get()
+        oc, om, ocv, on = ov.get()
+        assert len(rv) == len(ov) and (rc == oc).all() and (rn == on).all(), step
+        assert np.abs(rm - om).max() < 1e-12 and np.abs(rcv - ocv).max() < 1e-13, step
+        sizes.append(len(ov))
+    assert min(np.diff(sizes)) < 0  # the sweep did remove voxels at some step
