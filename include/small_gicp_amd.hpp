@@ -195,11 +195,16 @@ struct GaussianVoxelMap {
   GaussianVoxelMap(const GaussianVoxelMap&) = delete;
   GaussianVoxelMap& operator=(const GaussianVoxelMap&) = delete;
   ~GaussianVoxelMap() { sga_index_destroy(h); }
-  void insert(const PointCloud& points) {
-    if (h) throw std::runtime_error("GaussianVoxelMap: incremental insertion is not supported (one insert per map)");
-    ctx = points.ctx;
-    check(sga_index_build_gaussian_voxelmap(ctx, points.h, leaf, &h), "sga_index_build_gaussian_voxelmap");
+  // ann/incremental_voxelmap.hpp:55-92: any number of inserts, each with a pose; LRU removal of voxels not touched recently
+  void insert(const PointCloud& points, const Isometry3d& T = Isometry3d::Identity()) {
+    if (!h) {
+      ctx = points.ctx;
+      check(sga_voxelmap_create(ctx, leaf, &h), "sga_voxelmap_create");
+      check(sga_voxelmap_set_lru(h, static_cast<uint32_t>(lru_horizon), static_cast<uint32_t>(lru_clear_cycle)), "sga_voxelmap_set_lru");
+    }
+    check(sga_voxelmap_insert(ctx, h, points.h, T.data()), "sga_voxelmap_insert");
   }
+  size_t lru_horizon = 100, lru_clear_cycle = 10;  // set before the first insert (incremental_voxelmap.hpp:46)
   size_t size() const {
     size_t n = 0;
     if (h) sga_index_size(h, &n);
