@@ -101,6 +101,15 @@ int sga_index_voxelmap_download(sga_context* ctx, const sga_index* index, int32_
 int sga_voxelmap_create(sga_context* ctx, double leaf_size, sga_index** out);
 int sga_voxelmap_insert(sga_context* ctx, sga_index* voxelmap, const sga_cloud* points_with_covs, const double T[16]);
 int sga_voxelmap_set_lru(sga_index* voxelmap, uint32_t horizon, uint32_t clear_cycle);
+/* IncrementalVoxelMap<FlatContainerCov> (ann/flat_container.hpp:15-100): voxels that keep up to max_num_points_in_cell (default 10,
+ * at most 16) of the inserted points, at least sqrt(min_sq_dist_in_cell) (default 0.1 m) apart, with their covariances — the
+ * scan-to-model GICP target (odometry_benchmark_small_gicp_model_omp.cpp).  Inserted with sga_voxelmap_insert / _set_lru like a
+ * Gaussian map; searched over 1, 7 or 27 voxels (incremental_voxelmap.hpp:157-186); target indices are (voxel_id << 32) | point_id. */
+int sga_flatmap_create(sga_context* ctx, double leaf_size, sga_index** out);
+int sga_flatmap_set_setting(sga_index* flatmap, double min_sq_dist_in_cell, uint32_t max_num_points_in_cell);
+int sga_voxelmap_set_search_offsets(sga_index* voxelmap, int num_offsets);
+/* coords n*3, counts n, points n*16*3 and cov6 n*16*6 (16 slots per voxel, the first counts[v] of them valid); any pointer may be NULL */
+int sga_flatmap_download(sga_context* ctx, const sga_index* flatmap, int32_t* coords, uint32_t* counts, float* points, float* cov6);
 /* traits::knn_search / nearest_neighbor_search (ann/traits.hpp:22-57) for m host queries (m*3 floats):
  * idx m*k int64 (original target indices, -1 = none), sq_dist m*k floats ascending (inf = none).
  * max_sq_dist < 0 means unbounded.  Voxel maps support k = 1 only (own voxel, incremental_voxelmap.hpp:99-119). */

@@ -215,6 +215,49 @@ struct GaussianVoxelMap {
   sga_index* h = nullptr;
 };
 
+// ann/flat_container.hpp + ann/incremental_voxelmap.hpp: IncrementalVoxelMap<FlatContainerCov>, the scan-to-model GICP target
+struct FlatContainerCov {
+  struct Setting {
+    double min_sq_dist_in_cell = 0.1 * 0.1;
+    size_t max_num_points_in_cell = 10;
+  };
+};
+template <typename VoxelContents>
+struct IncrementalVoxelMap;
+template <>
+struct IncrementalVoxelMap<FlatContainerCov> {
+  using Ptr = std::shared_ptr<IncrementalVoxelMap>;
+  explicit IncrementalVoxelMap(double leaf_size) : leaf(leaf_size) {}
+  IncrementalVoxelMap(const IncrementalVoxelMap&) = delete;
+  IncrementalVoxelMap& operator=(const IncrementalVoxelMap&) = delete;
+  ~IncrementalVoxelMap() { sga_index_destroy(h); }
+  void insert(const PointCloud& points, const Isometry3d& T = Isometry3d::Identity()) {
+    if (!h) {
+      ctx = points.ctx;
+      check(sga_flatmap_create(ctx, leaf, &h), "sga_flatmap_create");
+      check(sga_flatmap_set_setting(h, voxel_setting.min_sq_dist_in_cell, static_cast<uint32_t>(voxel_setting.max_num_points_in_cell)), "sga_flatmap_set_setting");
+      check(sga_voxelmap_set_lru(h, static_cast<uint32_t>(lru_horizon), static_cast<uint32_t>(lru_clear_cycle)), "sga_voxelmap_set_lru");
+      check(sga_voxelmap_set_search_offsets(h, num_search_offsets), "sga_voxelmap_set_search_offsets");
+    }
+    check(sga_voxelmap_insert(ctx, h, points.h, T.data()), "sga_voxelmap_insert");
+  }
+  void set_search_offsets(int num_offsets) {
+    num_search_offsets = num_offsets;
+    if (h) check(sga_voxelmap_set_search_offsets(h, num_offsets), "sga_voxelmap_set_search_offsets");
+  }
+  size_t size() const {
+    size_t n = 0;
+    if (h) sga_index_size(h, &n);
+    return n;
+  }
+  double leaf;
+  size_t lru_horizon = 100, lru_clear_cycle = 10;  // set before the first insert
+  FlatContainerCov::Setting voxel_setting;          // set before the first insert
+  int num_search_offsets = 1;
+  sga_context* ctx = nullptr;
+  sga_index* h = nullptr;
+};
+
 // ---- util/downsampling.hpp, util/normal_estimation.hpp ------------------------------------------------------------------------
 inline PointCloud::Ptr voxelgrid_sampling(const PointCloud& points, double leaf_size) {
   sga_cloud* out = nullptr;
@@ -390,6 +433,12 @@ struct Registration {
   }
   /// VGICP form (registration_helper.cpp:136: the voxel map is both target cloud and search structure)
   RegistrationResult align(const GaussianVoxelMap& target, const PointCloud& source, const GaussianVoxelMap& target_tree, const Isometry3d& init_T = Isometry3d::Identity()) const {
+    (void)target_tree;
+    return run(target.h, source, init_T);
+  }
+  /// scan-to-model GICP form (odometry_benchmark_small_gicp_model_omp.cpp:33-36)
+  RegistrationResult align(
+    const IncrementalVoxelMap<FlatContainerCov>& target, const PointCloud& source, const IncrementalVoxelMap<FlatContainerCov>& target_tree, const Isometry3d& init_T = Isometry3d::Identity()) const {
     (void)target_tree;
     return run(target.h, source, init_T);
   }

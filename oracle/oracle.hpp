@@ -372,15 +372,120 @@ struct GaussianVoxelMap {
 };
 
 // ------------------------------------------------------------------------------------------------------------------
+// IncrementalVoxelMap<FlatContainerCov>: voxels that keep (a bounded number of) the inserted points themselves with their
+// covariances — the scan-to-model GICP target (ann/flat_container.hpp:15-100, ann/incremental_voxelmap.hpp:55-190;
+// src/benchmark/odometry_benchmark_small_gicp_model_omp.cpp).
+struct FlatVoxelMap {
+  struct Voxel {
+    int coord[3];
+    size_t lru = 0;
+    std::vector<Vec3> points;
+    std::vector<Mat3> covs;
+  };
+  double inv_leaf_size;
+  size_t lru_horizon = 100, lru_clear_cycle = 10, lru_counter = 0;   // incremental_voxelmap.hpp:46
+  double min_sq_dist_in_cell = 0.1 * 0.1;                            // flat_container.hpp:19
+  size_t max_num_points_in_cell = 10;                                // flat_container.hpp:20
+  std::vector<std::array<int, 3>> search_offsets{{{0, 0, 0}}};
+  std::vector<Voxel> flat_voxels;
+  std::unordered_map<std::uint64_t, size_t> voxels;
+
+  explicit FlatVoxelMap(double leaf_size) : inv_leaf_size(1.0 / leaf_size) {}
+  size_t size() const { return flat_voxels.size(); }
+
+  // incremental_voxelmap.hpp:157-186 (for 27 the reference APPENDS to the offsets set by the constructor: the centre comes first
+  // and once more in the middle of the cube — harmless, a second visit of the same voxel only meets ties)
+  void set_search_offsets(int n) {
+    if (n == 7) {
+      search_offsets = {{{0, 0, 0}}, {{1, 0, 0}}, {{0, 1, 0}}, {{0, 0, 1}}, {{-1, 0, 0}}, {{0, -1, 0}}, {{0, 0, -1}}};
+    } else if (n == 27) {
+      search_offsets = {{{0, 0, 0}}};
+      for (int i = -1; i <= 1; i++)
+        for (int j = -1; j <= 1; j++)
+          for (int k = -1; k <= 1; k++) search_offsets.push_back({{i, j, k}});
+    } else {
+      search_offsets = {{{0, 0, 0}}};
+    }
+  }
+
+  void insert(const PointCloud& pts, const SE3& T = SE3::identity()) {
+    for (size_t i = 0; i < pts.size(); i++) {
+      const Vec3 pt = T * pts.points[i];
+      int c[3] = {fast_floor(pt[0] * inv_leaf_size), fast_floor(pt[1] * inv_leaf_size), fast_floor(pt[2] * inv_leaf_size)};
+      const std::uint64_t k = GaussianVoxelMap::key(c);
+      auto found = voxels.find(k);
+      if (found == voxels.end()) {
+        found = voxels.emplace(k, flat_voxels.size()).first;
+        Voxel v;
+        v.coord[0] = c[0];
+        v.coord[1] = c[1];
+        v.coord[2] = c[2];
+        v.lru = lru_counter;
+        flat_voxels.push_back(v);
+      }
+      Voxel& v = flat_voxels[found->second];
+      v.lru = lru_counter;
+      // FlatContainer::add (flat_container.hpp:33-51)
+      bool reject = v.points.size() >= max_num_points_in_cell;
+      for (size_t j = 0; j < v.points.size() && !reject; j++) reject = sqnorm(v.points[j] - pt) < min_sq_dist_in_cell;
+      if (reject) continue;
+      v.points.push_back(pt);
+      v.covs.push_back(T.R * pts.covs[i] * transpose(T.R));
+    }
+    if ((++lru_counter) % lru_clear_cycle == 0) {
+      std::vector<Voxel> kept;
+      kept.reserve(flat_voxels.size());
+      for (auto& v : flat_voxels)
+        if (!(v.lru + lru_horizon < lru_counter)) kept.push_back(std::move(v));
+      flat_voxels.swap(kept);
+      voxels.clear();
+      for (size_t i = 0; i < flat_voxels.size(); i++) voxels[GaussianVoxelMap::key(flat_voxels[i].coord)] = i;
+    }
+  }
+
+  // incremental_voxelmap.hpp:99-119 with FlatContainer::knn_search (flat_container.hpp:84-93) and KnnResult<1>::push (>= keeps the first)
+  size_t nearest_neighbor_search(const Vec3& pt, size_t* index, double* sq_dist) const {
+    const int center[3] = {fast_floor(pt[0] * inv_leaf_size), fast_floor(pt[1] * inv_leaf_size), fast_floor(pt[2] * inv_leaf_size)};
+    double best = std::numeric_limits<double>::max();
+    size_t found_n = 0;
+    for (const auto& o : search_offsets) {
+      const int c[3] = {center[0] + o[0], center[1] + o[1], center[2] + o[2]};
+      auto found = voxels.find(GaussianVoxelMap::key(c));
+      if (found == voxels.end()) continue;
+      const Voxel& v = flat_voxels[found->second];
+      for (size_t i = 0; i < v.points.size(); i++) {
+        const double d = sqnorm(v.points[i] - pt);
+        if (d >= best) continue;
+        best = d;
+        *index = (found->second << 32) | i;
+        *sq_dist = d;
+        found_n = 1;
+      }
+    }
+    return found_n;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------------------------
 // Target abstraction: (cloud + kd-tree) or GaussianVoxelMap used as both cloud and tree (registration_helper.cpp:136).
 struct Target {
   const PointCloud* cloud = nullptr;
   const KdTree* tree = nullptr;
   const GaussianVoxelMap* voxelmap = nullptr;
-  size_t nn(const Vec3& q, size_t* idx, double* sqd) const { return voxelmap ? voxelmap->nearest_neighbor_search(q, idx, sqd) : tree->nearest_neighbor_search(q, idx, sqd); }
-  const Vec3& point(size_t i) const { return voxelmap ? voxelmap->flat_voxels[i >> 32].mean : cloud->points[i]; }
+  const FlatVoxelMap* flatmap = nullptr;
+  size_t nn(const Vec3& q, size_t* idx, double* sqd) const {
+    if (flatmap) return flatmap->nearest_neighbor_search(q, idx, sqd);
+    return voxelmap ? voxelmap->nearest_neighbor_search(q, idx, sqd) : tree->nearest_neighbor_search(q, idx, sqd);
+  }
+  const Vec3& point(size_t i) const {
+    if (flatmap) return flatmap->flat_voxels[i >> 32].points[i & 0xffffffffu];
+    return voxelmap ? voxelmap->flat_voxels[i >> 32].mean : cloud->points[i];
+  }
   const Vec3& normal(size_t i) const { return cloud->normals[i]; }
-  const Mat3& cov(size_t i) const { return voxelmap ? voxelmap->flat_voxels[i >> 32].cov : cloud->covs[i]; }
+  const Mat3& cov(size_t i) const {
+    if (flatmap) return flatmap->flat_voxels[i >> 32].covs[i & 0xffffffffu];
+    return voxelmap ? voxelmap->flat_voxels[i >> 32].cov : cloud->covs[i];
+  }
 };
 
 enum FactorKind { FACTOR_ICP = 0, FACTOR_PLANE_ICP = 1, FACTOR_GICP = 2 };

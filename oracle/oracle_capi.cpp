@@ -14,8 +14,10 @@ struct OrcCloud {
   bool has_tree = false;
 };
 struct OrcVoxelMap {
-  GaussianVoxelMap map;
-  explicit OrcVoxelMap(double leaf) : map(leaf) {}
+  GaussianVoxelMap map;   // flat == false
+  FlatVoxelMap fmap;      // flat == true: IncrementalVoxelMap<FlatContainerCov>
+  bool flat = false;
+  explicit OrcVoxelMap(double leaf, bool flat_ = false) : map(leaf), fmap(leaf), flat(flat_) {}
 };
 struct OrcFactors {
   std::vector<Factor> factors;
@@ -182,17 +184,53 @@ void* orc_voxelmap_create(void* cloud_h, double leaf) {
 }
 // incremental use: an empty map, then insert(cloud, T) any number of times (incremental_voxelmap.hpp:55-92)
 void* orc_voxelmap_new(double leaf) { return new OrcVoxelMap(leaf); }
+void* orc_flatmap_new(double leaf) { return new OrcVoxelMap(leaf, true); }
 void orc_voxelmap_insert(void* h, void* cloud_h, const double* T16) {
-  static_cast<OrcVoxelMap*>(h)->map.insert(static_cast<OrcCloud*>(cloud_h)->cloud, T16 ? se3_from_colmajor16(T16) : SE3::identity());
+  auto* vm = static_cast<OrcVoxelMap*>(h);
+  const SE3 T = T16 ? se3_from_colmajor16(T16) : SE3::identity();
+  if (vm->flat)
+    vm->fmap.insert(static_cast<OrcCloud*>(cloud_h)->cloud, T);
+  else
+    vm->map.insert(static_cast<OrcCloud*>(cloud_h)->cloud, T);
 }
 void orc_voxelmap_set_lru(void* h, size_t horizon, size_t clear_cycle) {
-  auto& m = static_cast<OrcVoxelMap*>(h)->map;
-  m.lru_horizon = horizon;
-  m.lru_clear_cycle = clear_cycle;
+  auto* vm = static_cast<OrcVoxelMap*>(h);
+  vm->map.lru_horizon = vm->fmap.lru_horizon = horizon;
+  vm->map.lru_clear_cycle = vm->fmap.lru_clear_cycle = clear_cycle;
+}
+void orc_flatmap_set_setting(void* h, double min_sq_dist_in_cell, size_t max_num_points_in_cell) {
+  auto& m = static_cast<OrcVoxelMap*>(h)->fmap;
+  m.min_sq_dist_in_cell = min_sq_dist_in_cell;
+  m.max_num_points_in_cell = max_num_points_in_cell;
+}
+// per voxel: coords (3 ints), number of points; points / covs packed voxel after voxel (total = sum of counts)
+size_t orc_flatmap_total_points(void* h) {
+  size_t n = 0;
+  for (const auto& v : static_cast<OrcVoxelMap*>(h)->fmap.flat_voxels) n += v.points.size();
+  return n;
+}
+void orc_flatmap_get(void* h, int* coords, std::uint64_t* counts, double* points, double* covs) {
+  const auto& fv = static_cast<OrcVoxelMap*>(h)->fmap.flat_voxels;
+  size_t o = 0;
+  for (size_t i = 0; i < fv.size(); i++) {
+    for (int k = 0; k < 3; k++) coords[3 * i + k] = fv[i].coord[k];
+    counts[i] = fv[i].points.size();
+    for (size_t j = 0; j < fv[i].points.size(); j++, o++) {
+      for (int k = 0; k < 3; k++) points[3 * o + k] = fv[i].points[j][k];
+      for (int r = 0; r < 3; r++)
+        for (int k = 0; k < 3; k++) covs[9 * o + 3 * r + k] = fv[i].covs[j](r, k);
+    }
+  }
 }
 void orc_voxelmap_destroy(void* h) { delete static_cast<OrcVoxelMap*>(h); }
-size_t orc_voxelmap_size(void* h) { return static_cast<OrcVoxelMap*>(h)->map.size(); }
-void orc_voxelmap_set_search_offsets(void* h, int n) { static_cast<OrcVoxelMap*>(h)->map.num_search_offsets = n; }
+size_t orc_voxelmap_size(void* h) {
+  auto* vm = static_cast<OrcVoxelMap*>(h);
+  return vm->flat ? vm->fmap.size() : vm->map.size();
+}
+void orc_voxelmap_set_search_offsets(void* h, int n) {
+  static_cast<OrcVoxelMap*>(h)->map.num_search_offsets = n;
+  static_cast<OrcVoxelMap*>(h)->fmap.set_search_offsets(n);
+}
 void orc_voxelmap_get(void* h, int* coords, double* means, double* covs, std::uint64_t* counts) {
   const auto& fv = static_cast<OrcVoxelMap*>(h)->map.flat_voxels;
   for (size_t i = 0; i < fv.size(); i++) {
@@ -217,7 +255,7 @@ void orc_factors_destroy(void* h) { delete static_cast<OrcFactors*>(h); }
 void orc_factors_get(void* h, int is_voxelmap, std::int64_t* target_index, double* mahalanobis) {
   const auto& fs = static_cast<OrcFactors*>(h)->factors;
   for (size_t i = 0; i < fs.size(); i++) {
-    if (target_index) target_index[i] = fs[i].inlier() ? static_cast<std::int64_t>(is_voxelmap ? (fs[i].target_index >> 32) : fs[i].target_index) : -1;
+    if (target_index) target_index[i] = fs[i].inlier() ? static_cast<std::int64_t>(is_voxelmap == 1 ? (fs[i].target_index >> 32) : fs[i].target_index) : -1;  // 2 = flat map: (voxel << 32) | point
     if (mahalanobis)
       for (int r = 0; r < 3; r++)
         for (int k = 0; k < 3; k++) mahalanobis[9 * i + 3 * r + k] = fs[i].mahalanobis(r, k);
@@ -227,7 +265,11 @@ void orc_factors_get(void* h, int is_voxelmap, std::int64_t* target_index, doubl
 static Target make_target(void* target_cloud, void* target_voxelmap) {
   Target t;
   if (target_voxelmap) {
-    t.voxelmap = &static_cast<OrcVoxelMap*>(target_voxelmap)->map;
+    auto* vm = static_cast<OrcVoxelMap*>(target_voxelmap);
+    if (vm->flat)
+      t.flatmap = &vm->fmap;
+    else
+      t.voxelmap = &vm->map;
   } else {
     auto* c = static_cast<OrcCloud*>(target_cloud);
     t.cloud = &c->cloud;

@@ -88,6 +88,12 @@ def lib():
         L.orc_voxelmap_new.restype = vp
         L.orc_voxelmap_insert.argtypes = [vp, vp, dp]
         L.orc_voxelmap_set_lru.argtypes = [vp, C.c_size_t, C.c_size_t]
+        L.orc_flatmap_new.argtypes = [C.c_double]
+        L.orc_flatmap_new.restype = vp
+        L.orc_flatmap_set_setting.argtypes = [vp, C.c_double, C.c_size_t]
+        L.orc_flatmap_total_points.argtypes = [vp]
+        L.orc_flatmap_total_points.restype = C.c_size_t
+        L.orc_flatmap_get.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_uint64), dp, dp]
         L.orc_voxelmap_size.argtypes = [vp]
         L.orc_voxelmap_size.restype = C.c_size_t
         L.orc_voxelmap_set_search_offsets.argtypes = [vp, C.c_int]
@@ -214,6 +220,28 @@ class VoxelMap:
         counts = np.empty(self.n, dtype=np.uint64)
         lib().orc_voxelmap_get(self.h, coords.ctypes.data_as(C.POINTER(C.c_int)), _dp(means), _dp(covs), counts.ctypes.data_as(C.POINTER(C.c_uint64)))
         return coords, means, covs.reshape(self.n, 3, 3), counts
+
+
+class FlatMap(VoxelMap):
+    """IncrementalVoxelMap<FlatContainerCov> (flat_container.hpp, incremental_voxelmap.hpp): voxels that keep up to
+    max_num_points_in_cell of the inserted points (at least sqrt(min_sq_dist_in_cell) apart) with their covariances."""
+
+    def __init__(self, leaf):
+        self.h = lib().orc_flatmap_new(float(leaf))
+        self.n = 0
+
+    def set_setting(self, min_sq_dist_in_cell=0.01, max_num_points_in_cell=10):
+        lib().orc_flatmap_set_setting(self.h, float(min_sq_dist_in_cell), int(max_num_points_in_cell))
+
+    def get(self):
+        """coords (V,3), counts (V,), points (P,3), covs (P,3,3) with the points of voxel 0 first, then voxel 1, ..."""
+        total = lib().orc_flatmap_total_points(self.h)
+        coords = np.empty((self.n, 3), dtype=np.int32)
+        counts = np.empty(self.n, dtype=np.uint64)
+        pts = np.empty((total, 3))
+        covs = np.empty((total, 9))
+        lib().orc_flatmap_get(self.h, coords.ctypes.data_as(C.POINTER(C.c_int)), counts.ctypes.data_as(C.POINTER(C.c_uint64)), _dp(pts), _dp(covs))
+        return coords, counts, pts, covs.reshape(total, 3, 3)
 
 
 class Factors:

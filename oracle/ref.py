@@ -62,6 +62,19 @@ def lib():
         L.ref_ivm_size.argtypes = [vp]
         L.ref_ivm_size.restype = C.c_size_t
         L.ref_ivm_get.argtypes = [vp, C.POINTER(C.c_int), dp, dp, C.POINTER(C.c_uint64)]
+        L.ref_fvm_create.argtypes = [C.c_double]
+        L.ref_fvm_create.restype = vp
+        L.ref_fvm_destroy.argtypes = [vp]
+        L.ref_fvm_set_lru.argtypes = [vp, C.c_size_t, C.c_size_t]
+        L.ref_fvm_set_setting.argtypes = [vp, C.c_double, C.c_size_t]
+        L.ref_fvm_set_search_offsets.argtypes = [vp, C.c_int]
+        L.ref_fvm_insert.argtypes = [vp, vp, dp]
+        L.ref_fvm_size.argtypes = [vp]
+        L.ref_fvm_size.restype = C.c_size_t
+        L.ref_fvm_total_points.argtypes = [vp]
+        L.ref_fvm_total_points.restype = C.c_size_t
+        L.ref_fvm_get.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_uint64), dp, dp]
+        L.ref_fvm_align.argtypes = [vp, vp, C.c_int, dp, C.POINTER(Result)]
         _LIB = L
     return _LIB
 
@@ -150,6 +163,49 @@ class VoxelMap:
         return coords, means, covs.reshape(n, 3, 3), counts
 
 
+class FlatMap:
+    """The reference's IncrementalVoxelMap<FlatContainerCov> (scan-to-model GICP target)."""
+
+    def __init__(self, leaf):
+        self.h = lib().ref_fvm_create(float(leaf))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().ref_fvm_destroy(self.h)
+            self.h = None
+
+    def set_lru(self, horizon=100, clear_cycle=10):
+        lib().ref_fvm_set_lru(self.h, int(horizon), int(clear_cycle))
+
+    def set_setting(self, min_sq_dist_in_cell=0.01, max_num_points_in_cell=10):
+        lib().ref_fvm_set_setting(self.h, float(min_sq_dist_in_cell), int(max_num_points_in_cell))
+
+    def set_search_offsets(self, n):
+        lib().ref_fvm_set_search_offsets(self.h, int(n))
+
+    def insert(self, cloud, T=None):
+        t16 = None if T is None else _T16(T)
+        lib().ref_fvm_insert(self.h, cloud.h, _dp(t16))
+
+    def __len__(self):
+        return lib().ref_fvm_size(self.h)
+
+    def get(self):
+        n, total = len(self), lib().ref_fvm_total_points(self.h)
+        coords = np.empty((n, 3), np.int32)
+        counts = np.empty(n, np.uint64)
+        pts = np.empty((total, 3))
+        covs = np.empty((total, 9))
+        lib().ref_fvm_get(self.h, coords.ctypes.data_as(C.POINTER(C.c_int)), counts.ctypes.data_as(C.POINTER(C.c_uint64)), _dp(pts), _dp(covs))
+        return coords, counts, pts, covs.reshape(total, 3, 3)
+
+    def align(self, source, init_T=None, num_threads=4):
+        res = Result()
+        t16 = _T16(np.eye(4) if init_T is None else init_T)
+        assert lib().ref_fvm_align(self.h, source.h, int(num_threads), _dp(t16), C.byref(res)) == 0
+        return _result(res)
+
+
 class AlignResult:
     pass
 
@@ -160,11 +216,16 @@ def align(target, source, type=GICP, voxel_resolution=1.0, max_correspondence_di
     t16 = _T16(np.eye(4) if init_T is None else init_T)
     rc = lib().ref_align(target.h, source.h, int(type), float(voxel_resolution), float(max_correspondence_distance), int(num_threads), int(max_iterations), float(rotation_eps), float(translation_eps), _dp(t16), C.byref(res), C.byref(el))
     assert rc == 0
+    r = _result(res)
+    r.elapsed_sec = el.value
+    return r
+
+
+def _result(res):
     r = AlignResult()
     r.T_target_source = np.array(res.T).reshape(4, 4).T.copy()
     r.converged, r.iterations, r.num_inliers = bool(res.converged), int(res.iterations), int(res.num_inliers)
     r.H, r.b, r.error = np.array(res.H).reshape(6, 6), np.array(res.b), float(res.error)
-    r.elapsed_sec = el.value
     return r
 
 

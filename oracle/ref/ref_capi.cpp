@@ -10,6 +10,8 @@
 #include <small_gicp/ann/kdtree.hpp>
 #include <small_gicp/ann/kdtree_omp.hpp>
 #include <small_gicp/ann/gaussian_voxelmap.hpp>
+#include <small_gicp/ann/flat_container.hpp>
+#include <small_gicp/ann/incremental_voxelmap.hpp>
 #include <small_gicp/factors/gicp_factor.hpp>
 #include <small_gicp/factors/icp_factor.hpp>
 #include <small_gicp/factors/plane_icp_factor.hpp>
@@ -240,6 +242,57 @@ void ref_ivm_get(void* h, int* coords, double* means, double* covs, std::uint64_
     }
     counts[i] = fv[i]->second.num_points;
   }
+}
+
+
+// ---- IncrementalVoxelMap<FlatContainerCov> of the reference (ann/flat_container.hpp, ann/incremental_voxelmap.hpp), unmodified ----
+struct RefFlatMap {
+  IncrementalVoxelMap<FlatContainerCov> map;
+  explicit RefFlatMap(double leaf) : map(leaf) {}
+};
+void* ref_fvm_create(double leaf) { return new RefFlatMap(leaf); }
+void ref_fvm_destroy(void* h) { delete static_cast<RefFlatMap*>(h); }
+void ref_fvm_set_lru(void* h, size_t horizon, size_t clear_cycle) {
+  static_cast<RefFlatMap*>(h)->map.lru_horizon = horizon;
+  static_cast<RefFlatMap*>(h)->map.lru_clear_cycle = clear_cycle;
+}
+void ref_fvm_set_setting(void* h, double min_sq_dist_in_cell, size_t max_num_points_in_cell) {
+  static_cast<RefFlatMap*>(h)->map.voxel_setting.min_sq_dist_in_cell = min_sq_dist_in_cell;
+  static_cast<RefFlatMap*>(h)->map.voxel_setting.max_num_points_in_cell = max_num_points_in_cell;
+}
+void ref_fvm_set_search_offsets(void* h, int n) { static_cast<RefFlatMap*>(h)->map.set_search_offsets(n); }
+void ref_fvm_insert(void* h, void* cloud_h, const double* T16) {
+  static_cast<RefFlatMap*>(h)->map.insert(*static_cast<RefCloud*>(cloud_h)->cloud, T16 ? to_iso(T16) : Eigen::Isometry3d::Identity());
+}
+size_t ref_fvm_size(void* h) { return static_cast<RefFlatMap*>(h)->map.size(); }
+size_t ref_fvm_total_points(void* h) {
+  size_t n = 0;
+  for (const auto& v : static_cast<RefFlatMap*>(h)->map.flat_voxels) n += v->second.size();
+  return n;
+}
+void ref_fvm_get(void* h, int* coords, std::uint64_t* counts, double* points, double* covs) {
+  const auto& fv = static_cast<RefFlatMap*>(h)->map.flat_voxels;
+  size_t o = 0;
+  for (size_t i = 0; i < fv.size(); i++) {
+    for (int k = 0; k < 3; k++) coords[3 * i + k] = fv[i]->first.coord[k];
+    counts[i] = fv[i]->second.size();
+    for (size_t j = 0; j < fv[i]->second.size(); j++, o++) {
+      for (int k = 0; k < 3; k++) {
+        points[3 * o + k] = fv[i]->second.points[j][k];
+        for (int c = 0; c < 3; c++) covs[9 * o + 3 * k + c] = fv[i]->second.covs[j](k, c);
+      }
+    }
+  }
+}
+// odometry_benchmark_small_gicp_model_omp.cpp:33-36: Registration<GICPFactor, ParallelReductionOMP>::align(voxelmap, points, voxelmap, T)
+int ref_fvm_align(void* h, void* source_h, int num_threads, const double* init_T16, ref_result* out) {
+  auto& vm = static_cast<RefFlatMap*>(h)->map;
+  auto* s = static_cast<RefCloud*>(source_h);
+  Registration<GICPFactor, ParallelReductionOMP> registration;
+  registration.reduction.num_threads = num_threads;
+  const RegistrationResult r = registration.align(vm, *s->cloud, vm, to_iso(init_T16));
+  fill_result(r, out, 0.0, nullptr);
+  return 0;
 }
 
 }  // extern "C"

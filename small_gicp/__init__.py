@@ -13,7 +13,7 @@ import numpy as np
 
 import small_gicp_amd.api as _api
 from small_gicp_amd import io as _io
-from small_gicp_amd.api import GaussianVoxelMap, KdTree, PointCloud, RegistrationResult  # noqa: F401
+from small_gicp_amd.api import GaussianVoxelMap, IncrementalVoxelMapCov, KdTree, PointCloud, RegistrationResult  # noqa: F401
 
 _DEG01 = 0.1 * np.pi / 180.0
 
@@ -217,6 +217,6 @@ class GICPFactor(_PointFactor):
 
 
 __all__ = [
-    "PointCloud", "KdTree", "GaussianVoxelMap", "RegistrationResult", "read_ply", "voxelgrid_sampling", "estimate_normals", "estimate_covariances",
+    "PointCloud", "KdTree", "GaussianVoxelMap", "IncrementalVoxelMapCov", "RegistrationResult", "read_ply", "voxelgrid_sampling", "estimate_normals", "estimate_covariances",
     "estimate_normals_covariances", "preprocess_points", "align", "DistanceRejector", "ICPFactor", "PointToPlaneICPFactor", "GICPFactor",
 ]

@@ -4,11 +4,12 @@ The compute lives in lib/libsmall_gicp_amd.so (hand-written HIP for gfx950 behin
 This package is the thin host layer: ctypes binding (_lib), a Python mirror of the reference's module (api) and the frozen
 synthetic workloads of the benchmark configs (synthetic).
 """
-from . import synthetic  # noqa: F401
+from . import api, synthetic  # noqa: F401
 from ._lib import GICP, ICP, LIB_PATH, PLANE_ICP, SgaError, load  # noqa: F401
 from .api import (  # noqa: F401
     Context,
     GaussianVoxelMap,
+    IncrementalVoxelMapCov,
     KdTree,
     PointCloud,
     Problem,

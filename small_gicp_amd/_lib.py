@@ -86,6 +86,10 @@ SYMBOLS = [
     ("sga_voxelmap_create", C.c_int, [_vp, C.c_double, _pvp]),
     ("sga_voxelmap_insert", C.c_int, [_vp, _vp, _vp, _dp]),
     ("sga_voxelmap_set_lru", C.c_int, [_vp, C.c_uint32, C.c_uint32]),
+    ("sga_flatmap_create", C.c_int, [_vp, C.c_double, _pvp]),
+    ("sga_flatmap_set_setting", C.c_int, [_vp, C.c_double, C.c_uint32]),
+    ("sga_voxelmap_set_search_offsets", C.c_int, [_vp, C.c_int]),
+    ("sga_flatmap_download", C.c_int, [_vp, _vp, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), _fp, _fp]),
     ("sga_index_knn", C.c_int, [_vp, _vp, _fp, C.c_size_t, C.c_int, C.c_double, C.POINTER(C.c_int64), _fp]),
     ("sga_factor_params_default", None, [C.POINTER(FactorParams)]),
     ("sga_problem_create", C.c_int, [_vp, _vp, _vp, _dp, _pvp]),

@@ -267,6 +267,66 @@ class GaussianVoxelMap:
         return out
 
 
+class IncrementalVoxelMapCov:
+    """small_gicp.IncrementalVoxelMapCov (src/python/voxelmap.cpp:110-140) = IncrementalVoxelMap<FlatContainerCov>: voxels keep up
+    to `max_num_points_in_cell` of the inserted points (with covariances); the scan-to-model GICP target.  `insert(cloud, T)`,
+    `set_lru`, `set_search_offsets(1 | 7 | 27)`, `size()`, `voxel_points()`, `voxel_covs()`."""
+
+    FLAT_CAP = 16
+
+    def __init__(self, leaf_size, ctx=None):
+        self.leaf = float(leaf_size)
+        self.ctx = ctx or default_context()
+        self.h = C.c_void_p()
+        check(load().sga_flatmap_create(self.ctx.h, self.leaf, C.byref(self.h)))
+
+    def __del__(self):
+        if getattr(self, "h", None) and self.h.value:
+            load().sga_index_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def insert(self, cloud, T=None):
+        t16 = None if T is None else _T16(T)
+        check(load().sga_voxelmap_insert(self.ctx.h, self.h, cloud.h, None if t16 is None else _dp(t16)))
+
+    def set_lru(self, horizon=100, clear_cycle=10):
+        check(load().sga_voxelmap_set_lru(self.h, int(horizon), int(clear_cycle)))
+
+    def set_setting(self, min_sq_dist_in_cell=0.01, max_num_points_in_cell=10):
+        check(load().sga_flatmap_set_setting(self.h, float(min_sq_dist_in_cell), int(max_num_points_in_cell)))
+
+    def set_search_offsets(self, num_offsets):
+        check(load().sga_voxelmap_set_search_offsets(self.h, int(num_offsets)))
+
+    def size(self):
+        n = C.c_size_t()
+        check(load().sga_index_size(self.h, C.byref(n)))
+        return n.value
+
+    __len__ = size
+
+    def download(self):
+        """coords (V,3), counts (V,), points (P,3), cov6 (P,6): the points of voxel 0 first, then voxel 1, ... (P = sum of counts)."""
+        n = self.size()
+        coords = np.empty((n, 3), np.int32)
+        counts = np.empty(n, np.uint32)
+        pts = np.empty((n, self.FLAT_CAP, 3), np.float32)
+        c6 = np.empty((n, self.FLAT_CAP, 6), np.float32)
+        check(load().sga_flatmap_download(self.ctx.h, self.h, coords.ctypes.data_as(C.POINTER(C.c_int32)), counts.ctypes.data_as(C.POINTER(C.c_uint32)), _fp(pts), _fp(c6)))
+        valid = np.arange(self.FLAT_CAP)[None, :] < counts[:, None]
+        return coords, counts, pts[valid], c6[valid]
+
+    def voxel_points(self):
+        p = self.download()[2].astype(np.float64)
+        return np.concatenate([p, np.ones((len(p), 1))], axis=1)
+
+    def voxel_covs(self):
+        c6 = self.download()[3].astype(np.float64)
+        out = np.zeros((len(c6), 4, 4))
+        out[:, :3, :3] = mats_from_sym6(c6)
+        return out
+
+
 class RegistrationResult:
     """registration_result.hpp:11-30, field for field."""
 

@@ -122,7 +122,8 @@ struct sga_cloud {
   sga::DevBuf<sga::Cov8> cov;
 };
 
-enum { SGA_INDEX_KDTREE = 0, SGA_INDEX_VOXELMAP = 1 };
+enum { SGA_INDEX_KDTREE = 0, SGA_INDEX_VOXELMAP = 1, SGA_INDEX_FLATMAP = 2 };
+constexpr int kFlatCap = 16;  // point slots per voxel of a flat map (max_num_points_in_cell <= 16)
 
 struct sga_index {
   int kind = SGA_INDEX_KDTREE;
@@ -153,6 +154,13 @@ struct sga_index {
   sga::DevBuf<double> vcov64;             // 6 per voxel: finalized mean covariance (xx, xy, xz, yy, yz, zz)
   sga::DevBuf<uint32_t> vlru;             // insert counter at the voxel's last update
   uint32_t lru_counter = 0, lru_horizon = 100, lru_clear_cycle = 10;
+  // flat maps (IncrementalVoxelMap<FlatContainerCov>): voxels keep up to flat_max of the inserted points; pts / cov then hold
+  // kFlatCap slots per voxel (slot = voxel * kFlatCap + i), vcounts the number of points of a voxel
+  sga::DevBuf<double> fpts64;             // 3 per slot
+  sga::DevBuf<double> fcov64;             // 6 per slot
+  uint32_t flat_max = 10;                 // flat_container.hpp:20
+  double flat_min_sq = 0.1 * 0.1;         // flat_container.hpp:19
+  int search_offsets = 1;                 // 1, 7 or 27 (incremental_voxelmap.hpp:157-186)
 };
 
 struct sga_problem {

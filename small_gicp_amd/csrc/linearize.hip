@@ -36,6 +36,7 @@ struct LinParams {
   const Cov8* __restrict__ tgt_cov;
   KdView kd;
   VoxelView vox;
+  FlatView flat;
   int* __restrict__ corr;
   const int* __restrict__ hint;  // nearest neighbour per source point from nn_search_kernel (kd position) or -1
   Real* __restrict__ maha;  // n*6
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
   p.nn[i] = nb.idx;
 }
 
-template <typename Real, int FACTOR, bool VOXELMAP>
+template <typename Real, int FACTOR, int TARGET>  // TARGET: 0 kd-tree (neighbours from nn_search_kernel), 1 Gaussian voxel map, 2 flat voxel map
 __global__ __launch_bounds__(kTile) void linearize_kernel(const LinParams<Real> p) {
   __shared__ double sh_acc[kTile / 64][kRow];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -128,7 +129,15 @@ __global__ __launch_bounds__(kTile) void linearize_kernel(const LinParams<Real> 
     }
     int j = -1;
     Real tx = 0, ty = 0, tz = 0;
-    if constexpr (VOXELMAP) {
+    if constexpr (TARGET == 2) {
+      if (active) {
+        float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+        j = flat_nearest<Real>(p.flat, p.tgt_pts, qx, qy, qz, m);
+        tx = m.x;
+        ty = m.y;
+        tz = m.z;
+      }
+    } else if constexpr (TARGET == 1) {
       if (active) {
         j = voxel_lookup(p.vox, static_cast<float>(qx), static_cast<float>(qy), static_cast<float>(qz));
         if (j >= 0) {
@@ -331,15 +340,16 @@ static void launch_reduce(sga_context* ctx, const double* partials, int nrows, i
 
 static int grid_blocks(int num_tiles) { return num_tiles < kMaxBlocks ? (num_tiles < 1 ? 1 : num_tiles) : kMaxBlocks; }
 
-template <typename Real, int FACTOR, bool VOXELMAP>
+template <typename Real, int FACTOR, int TARGET>
 static void launch_linearize(hipStream_t st, const LinParams<Real>& p, int blocks) {
-  hipLaunchKernelGGL((linearize_kernel<Real, FACTOR, VOXELMAP>), dim3(blocks), dim3(kTile), 0, st, p);
+  hipLaunchKernelGGL((linearize_kernel<Real, FACTOR, TARGET>), dim3(blocks), dim3(kTile), 0, st, p);
 }
 
 template <typename Real>
 static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, const double T[16], double* d_out30, double* host, unsigned long long seq) {
   const sga_index* idx = pb->target;
-  const bool voxel = idx->kind == SGA_INDEX_VOXELMAP;
+  const bool voxel = idx->kind != SGA_INDEX_KDTREE;  // Gaussian or flat voxel map: the lookup happens inside the factor kernel
+  const bool flat = idx->kind == SGA_INDEX_FLATMAP;
   if (fp->factor_kind == SGA_GICP && ((pb->n > 0 && !pb->has_covs) || (idx->n > 0 && !idx->has_covs))) return fail(SGA_ERR_INVALID, "GICP needs covariances on both source and target");
   if (fp->factor_kind == SGA_PLANE_ICP && (voxel || (idx->n > 0 && !idx->has_normals))) return fail(SGA_ERR_UNSUPPORTED, "PLANE_ICP needs a kd-tree index over a target with normals");
   if (fp->factor_kind < 0 || fp->factor_kind > 2) return fail(SGA_ERR_INVALID, "invalid factor_kind %d", fp->factor_kind);
@@ -352,7 +362,14 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
   p.tgt_pts = voxel ? idx->pts.p : idx->kd_pts.p;
   p.tgt_nrm = idx->nrm.p;
   p.tgt_cov = idx->cov.p;
-  if (voxel) {
+  if (flat) {
+    p.flat.hkeys = idx->hkeys.p;
+    p.flat.hvals = idx->hvals.p;
+    p.flat.hmask = idx->hmask;
+    p.flat.inv_leaf = 1.0 / idx->leaf;
+    p.flat.vnum = idx->vcounts.p;
+    p.flat.offsets = idx->search_offsets;
+  } else if (voxel) {
     p.vox.hkeys = idx->hkeys.p;
     p.vox.hvals = idx->hvals.p;
     p.vox.hmask = idx->hmask;
@@ -397,16 +414,21 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
     }
   }
   if (p.n > 0) {
-    if (voxel) {
+    if (flat) {
       if (fp->factor_kind == SGA_GICP)
-        launch_linearize<Real, SGA_GICP, true>(ctx->stream, p, blocks);
+        launch_linearize<Real, SGA_GICP, 2>(ctx->stream, p, blocks);
       else
-        launch_linearize<Real, SGA_ICP, true>(ctx->stream, p, blocks);
+        launch_linearize<Real, SGA_ICP, 2>(ctx->stream, p, blocks);
+    } else if (voxel) {
+      if (fp->factor_kind == SGA_GICP)
+        launch_linearize<Real, SGA_GICP, 1>(ctx->stream, p, blocks);
+      else
+        launch_linearize<Real, SGA_ICP, 1>(ctx->stream, p, blocks);
     } else {
       switch (fp->factor_kind) {
-        case SGA_GICP: launch_linearize<Real, SGA_GICP, false>(ctx->stream, p, blocks); break;
-        case SGA_PLANE_ICP: launch_linearize<Real, SGA_PLANE_ICP, false>(ctx->stream, p, blocks); break;
-        default: launch_linearize<Real, SGA_ICP, false>(ctx->stream, p, blocks); break;
+        case SGA_GICP: launch_linearize<Real, SGA_GICP, 0>(ctx->stream, p, blocks); break;
+        case SGA_PLANE_ICP: launch_linearize<Real, SGA_PLANE_ICP, 0>(ctx->stream, p, blocks); break;
+        default: launch_linearize<Real, SGA_ICP, 0>(ctx->stream, p, blocks); break;
       }
     }
   }
@@ -426,7 +448,7 @@ static int error_dispatch(sga_context* ctx, sga_problem* pb, const sga_factor_pa
   p.src_pts = pb->pts.p;
   p.n = static_cast<int>(pb->n);
   p.num_tiles = (p.n + kTile - 1) / kTile;
-  p.tgt_pts = idx->kind == SGA_INDEX_VOXELMAP ? idx->pts.p : idx->kd_pts.p;
+  p.tgt_pts = idx->kind != SGA_INDEX_KDTREE ? idx->pts.p : idx->kd_pts.p;
   p.tgt_nrm = idx->nrm.p;
   p.corr = pb->corr.p;
   if constexpr (sizeof(Real) == 4) {

@@ -79,12 +79,16 @@ __global__ void gather_source_kernel(const uint32_t* __restrict__ order, size_t 
 
 // Factor state back in the caller's source order with original target indices.
 template <typename Real>
-__global__ void export_factors_kernel(const float4* __restrict__ src_pts, const int* __restrict__ corr, const Real* __restrict__ maha, size_t n, const float4* __restrict__ tgt_pts, long long* __restrict__ out_idx, float* __restrict__ out_m) {
+__global__ void export_factors_kernel(const float4* __restrict__ src_pts, const int* __restrict__ corr, const Real* __restrict__ maha, size_t n, const float4* __restrict__ tgt_pts, int flat, long long* __restrict__ out_idx, float* __restrict__ out_m) {
   const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
   if (i >= n) return;
   const uint32_t orig = __float_as_uint(src_pts[i].w);
   const int j = corr[i];
-  if (out_idx) out_idx[orig] = j < 0 ? -1ll : static_cast<long long>(__float_as_uint(tgt_pts[j].w));
+  if (out_idx) {
+    long long t = j < 0 ? -1ll : static_cast<long long>(__float_as_uint(tgt_pts[j].w));
+    if (flat && t >= 0) t = ((t / kFlatCap) << 32) | (t % kFlatCap);  // incremental_voxelmap.hpp:151: (voxel_id << 32) | point_id
+    out_idx[orig] = t;
+  }
   if (out_m) {
     for (int k = 0; k < 6; k++) out_m[6 * static_cast<size_t>(orig) + k] = (j >= 0 && maha) ? static_cast<float>(maha[6 * i + k]) : 0.f;
   }
@@ -229,7 +233,7 @@ int sga_problem_get_factors(sga_context* ctx, const sga_problem* pb, int64_t* ta
   DevBuf<float> d_m;
   if (target_index) SGA_TRY(d_idx.alloc(n));
   if (mahalanobis6) SGA_TRY(d_m.alloc(n * 6));
-  hipLaunchKernelGGL((export_factors_kernel<float>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, pb->pts.p, pb->corr.p, pb->maha.p, n, pb->target->kind == SGA_INDEX_VOXELMAP ? pb->target->pts.p : pb->target->kd_pts.p, d_idx.p, d_m.p);
+  hipLaunchKernelGGL((export_factors_kernel<float>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, pb->pts.p, pb->corr.p, pb->maha.p, n, pb->target->kind != SGA_INDEX_KDTREE ? pb->target->pts.p : pb->target->kd_pts.p, pb->target->kind == SGA_INDEX_FLATMAP ? 1 : 0, d_idx.p, d_m.p);
   SGA_HIP(hipGetLastError());
   if (target_index) SGA_HIP(hipMemcpyAsync(target_index, d_idx.p, n * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
   if (mahalanobis6) SGA_HIP(hipMemcpyAsync(mahalanobis6, d_m.p, n * 6 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
@@ -240,6 +244,7 @@ int sga_problem_get_factors(sga_context* ctx, const sga_problem* pb, int64_t* ta
 int sga_index_knn(sga_context* ctx, const sga_index* index, const float* queries, size_t m, int k, double max_sq_dist, int64_t* idx, float* sq_dist) {
   if (!ctx || !index || (m > 0 && (!queries || !idx || !sq_dist))) return fail(SGA_ERR_INVALID, "null argument");
   if (k < 1 || k > 128) return fail(SGA_ERR_INVALID, "k must be in [1,128]");
+  if (index->kind == SGA_INDEX_FLATMAP) return fail(SGA_ERR_UNSUPPORTED, "flat voxel maps are searched inside the registration only");
   if (index->kind == SGA_INDEX_VOXELMAP && k != 1) return fail(SGA_ERR_UNSUPPORTED, "voxel maps answer k = 1 only");
   if (m == 0) return SGA_OK;
   SGA_HIP(hipSetDevice(ctx->device));

@@ -52,4 +52,68 @@ __device__ __forceinline__ int voxel_lookup(const VoxelView& v, float qx, float 
   return -1;
 }
 
+// Flat maps: nearest stored point over the search-offset pattern (incremental_voxelmap.hpp:99-119 + flat_container.hpp:84-93 with
+// KnnResult<1>::push, which keeps the FIRST of equal distances).  Offsets in the reference's order: centre, then +x +y +z -x -y -z
+// (7) or the 3x3x3 cube in i, j, k order (27; its second visit of the centre cannot change the result and is skipped).
+struct FlatView {
+  const unsigned long long* __restrict__ hkeys;
+  const uint32_t* __restrict__ hvals;
+  uint32_t hmask;
+  double inv_leaf;
+  const uint32_t* __restrict__ vnum;  // points per voxel
+  int offsets;                        // 1, 7, 27
+};
+
+__device__ __forceinline__ int flat_voxel_at(const FlatView& v, int cx, int cy, int cz) {
+  if (abs(cx) >= (1 << 20) || abs(cy) >= (1 << 20) || abs(cz) >= (1 << 20)) return -1;
+  const unsigned long long key = voxel_key(cx, cy, cz);
+  uint32_t slot = voxel_hash(key) & v.hmask;
+  for (uint32_t probe = 0; probe <= v.hmask; ++probe) {
+    const unsigned long long k = v.hkeys[slot];
+    if (k == key) return static_cast<int>(v.hvals[slot]);
+    if (k == SGA_HASH_EMPTY) return -1;
+    slot = (slot + 1) & v.hmask;
+  }
+  return -1;
+}
+
+// returns the slot (voxel * kFlatCap + i) of the nearest stored point or -1; t = that point
+template <typename Real>
+__device__ __forceinline__ int flat_nearest(const FlatView& v, const float4* __restrict__ pts, Real qx, Real qy, Real qz, float4& t) {
+  const int cx = fast_floor_d(static_cast<double>(qx) * v.inv_leaf);
+  const int cy = fast_floor_d(static_cast<double>(qy) * v.inv_leaf);
+  const int cz = fast_floor_d(static_cast<double>(qz) * v.inv_leaf);
+  Real best = static_cast<Real>(INFINITY);
+  int j = -1;
+  auto scan = [&](int ox, int oy, int oz) {
+    const int vox = flat_voxel_at(v, cx + ox, cy + oy, cz + oz);
+    if (vox < 0) return;
+    const uint32_t n = v.vnum[vox];
+    for (uint32_t i = 0; i < n; i++) {
+      const float4 p = pts[static_cast<size_t>(vox) * kFlatCap + i];
+      const Real dx = static_cast<Real>(p.x) - qx, dy = static_cast<Real>(p.y) - qy, dz = static_cast<Real>(p.z) - qz;
+      const Real d2 = dx * dx + dy * dy + dz * dz;
+      if (d2 >= best) continue;
+      best = d2;
+      j = vox * kFlatCap + static_cast<int>(i);
+      t = p;
+    }
+  };
+  scan(0, 0, 0);
+  if (v.offsets == 7) {
+    scan(1, 0, 0);
+    scan(0, 1, 0);
+    scan(0, 0, 1);
+    scan(-1, 0, 0);
+    scan(0, -1, 0);
+    scan(0, 0, -1);
+  } else if (v.offsets == 27) {
+    for (int a = -1; a <= 1; a++)
+      for (int b = -1; b <= 1; b++)
+        for (int c = -1; c <= 1; c++)
+          if (a || b || c) scan(a, b, c);
+  }
+  return j;
+}
+
 }  // namespace sga

@@ -186,6 +186,96 @@ __global__ void ivm_export_kernel(uint32_t n, const double* __restrict__ mean64,
   mcov[v] = o;
 }
 
+// ---- flat maps: IncrementalVoxelMap<FlatContainerCov> ---------------------------------------------------------------------------
+// One lane per voxel of the batch: FlatContainer::add for its points in insertion order (flat_container.hpp:33-51): a point is
+// kept iff the cell holds fewer than max_points and no kept point lies closer than sqrt(min_sq); kept = T p with covariance R C R^T.
+__global__ void fvm_update_kernel(
+  uint32_t nseg, const uint32_t* __restrict__ seg_start, const uint32_t* __restrict__ seg_vid, uint32_t n_valid, const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ order, const float4* __restrict__ pts,
+  const Cov8* __restrict__ cov, Pose12 T, uint32_t n_old, uint32_t lru_counter, uint32_t max_points, double min_sq, double* __restrict__ fpts64, double* __restrict__ fcov64, uint32_t* __restrict__ counts,
+  uint32_t* __restrict__ lru, int* __restrict__ coords, unsigned long long* __restrict__ hkeys, uint32_t* __restrict__ hvals, uint32_t hmask) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nseg) return;
+  const uint32_t v = seg_vid[s];
+  const uint32_t first = seg_start[s];
+  const unsigned long long key = keys[first];
+  const bool is_new = v >= n_old;
+  uint32_t cnt = is_new ? 0u : counts[v];
+  double* P = fpts64 + static_cast<size_t>(v) * kFlatCap * 3;
+  double* C6 = fcov64 + static_cast<size_t>(v) * kFlatCap * 6;
+  for (uint32_t i = first; i < n_valid && keys[i] == key; ++i) {
+    if (cnt >= max_points) break;  // every further point of this batch would be rejected as well
+    const uint32_t src = order[i];
+    const float4 p = pts[src];
+    const double x = T.r[0] * p.x + T.r[1] * p.y + T.r[2] * p.z + T.t[0];
+    const double y = T.r[3] * p.x + T.r[4] * p.y + T.r[5] * p.z + T.t[1];
+    const double z = T.r[6] * p.x + T.r[7] * p.y + T.r[8] * p.z + T.t[2];
+    bool reject = false;
+    for (uint32_t j = 0; j < cnt && !reject; j++) {
+      const double dx = P[3 * j] - x, dy = P[3 * j + 1] - y, dz = P[3 * j + 2] - z;
+      reject = dx * dx + dy * dy + dz * dz < min_sq;
+    }
+    if (reject) continue;
+    P[3 * cnt] = x;
+    P[3 * cnt + 1] = y;
+    P[3 * cnt + 2] = z;
+    const Cov8 q = cov[src];
+    const double Cm[3][3] = {{q.xx, q.xy, q.xz}, {q.xy, q.yy, q.yz}, {q.xz, q.yz, q.zz}};
+    double RC[3][3];
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < 3; b++) RC[a][b] = T.r[3 * a] * Cm[0][b] + T.r[3 * a + 1] * Cm[1][b] + T.r[3 * a + 2] * Cm[2][b];
+    int k = 0;
+    for (int a = 0; a < 3; a++)
+      for (int b = a; b < 3; b++) C6[6 * cnt + (k++)] = RC[a][0] * T.r[3 * b] + RC[a][1] * T.r[3 * b + 1] + RC[a][2] * T.r[3 * b + 2];
+    cnt++;
+  }
+  counts[v] = cnt;
+  lru[v] = lru_counter;
+  if (is_new) {
+    coords[3 * v + 0] = static_cast<int>(key & 0x1fffffu) - (1 << 20);
+    coords[3 * v + 1] = static_cast<int>((key >> 21) & 0x1fffffu) - (1 << 20);
+    coords[3 * v + 2] = static_cast<int>((key >> 42) & 0x1fffffu) - (1 << 20);
+    ivm_hash_insert(hkeys, hvals, hmask, key, v);
+  }
+}
+
+__global__ void fvm_compact_kernel(
+  uint32_t n, const uint32_t* __restrict__ keep, const uint32_t* __restrict__ pos, const double* __restrict__ p_in, const double* __restrict__ c_in, const uint32_t* __restrict__ cnt_in, const uint32_t* __restrict__ lru_in,
+  const int* __restrict__ co_in, double* __restrict__ p_out, double* __restrict__ c_out, uint32_t* __restrict__ cnt_out, uint32_t* __restrict__ lru_out, int* __restrict__ co_out) {
+  const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= n || !keep[v]) return;
+  const uint32_t w = pos[v];
+  for (int k = 0; k < 3; k++) co_out[3 * w + k] = co_in[3 * v + k];
+  const uint32_t cnt = cnt_in[v];
+  for (uint32_t j = 0; j < cnt; j++) {
+    for (int k = 0; k < 3; k++) p_out[(static_cast<size_t>(w) * kFlatCap + j) * 3 + k] = p_in[(static_cast<size_t>(v) * kFlatCap + j) * 3 + k];
+    for (int k = 0; k < 6; k++) c_out[(static_cast<size_t>(w) * kFlatCap + j) * 6 + k] = c_in[(static_cast<size_t>(v) * kFlatCap + j) * 6 + k];
+  }
+  cnt_out[w] = cnt;
+  lru_out[w] = lru_in[v];
+}
+
+// fp32 records read by the factor kernels: slot = voxel * kFlatCap + i, w = slot
+__global__ void fvm_export_kernel(uint32_t n, const uint32_t* __restrict__ counts, const double* __restrict__ fpts64, const double* __restrict__ fcov64, float4* __restrict__ pts, Cov8* __restrict__ cov) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t v = t / kFlatCap, j = t % kFlatCap;
+  if (v >= n) return;
+  if (j >= counts[v]) {
+    pts[t] = make_float4(INFINITY, INFINITY, INFINITY, __uint_as_float(t));
+    return;
+  }
+  pts[t] = make_float4(static_cast<float>(fpts64[3 * static_cast<size_t>(t)]), static_cast<float>(fpts64[3 * static_cast<size_t>(t) + 1]), static_cast<float>(fpts64[3 * static_cast<size_t>(t) + 2]), __uint_as_float(t));
+  Cov8 o;
+  const double* c = fcov64 + 6 * static_cast<size_t>(t);
+  o.xx = static_cast<float>(c[0]);
+  o.xy = static_cast<float>(c[1]);
+  o.xz = static_cast<float>(c[2]);
+  o.yy = static_cast<float>(c[3]);
+  o.yz = static_cast<float>(c[4]);
+  o.zz = static_cast<float>(c[5]);
+  o.pad0 = o.pad1 = 0.f;
+  cov[t] = o;
+}
+
 template <typename T>
 static int grow(sga_context* ctx, DevBuf<T>& buf, size_t used, size_t want) {
   if (buf.n >= want) return SGA_OK;
@@ -229,6 +319,67 @@ int sga_voxelmap_create(sga_context* ctx, double leaf, sga_index** out) {
   idx->has_covs = true;
   idx->incremental = true;
   *out = idx.release();
+  return SGA_OK;
+}
+
+int sga_flatmap_create(sga_context* ctx, double leaf, sga_index** out) {
+  SGA_TRY(sga_voxelmap_create(ctx, leaf, out));
+  (*out)->kind = SGA_INDEX_FLATMAP;
+  return SGA_OK;
+}
+
+int sga_flatmap_set_setting(sga_index* index, double min_sq_dist_in_cell, uint32_t max_num_points_in_cell) {
+  if (!index || index->kind != SGA_INDEX_FLATMAP) return fail(SGA_ERR_INVALID, "not a flat voxel map");
+  if (max_num_points_in_cell == 0 || max_num_points_in_cell > static_cast<uint32_t>(kFlatCap)) return fail(SGA_ERR_INVALID, "max_num_points_in_cell must be in [1, %d]", kFlatCap);
+  if (index->n > 0) return fail(SGA_ERR_INVALID, "the cell setting must be chosen before the first insert");
+  index->flat_min_sq = min_sq_dist_in_cell;
+  index->flat_max = max_num_points_in_cell;
+  return SGA_OK;
+}
+
+int sga_voxelmap_set_search_offsets(sga_index* index, int num_offsets) {
+  if (!index || !index->incremental) return fail(SGA_ERR_INVALID, "not an incremental voxel map");
+  if (index->kind != SGA_INDEX_FLATMAP && num_offsets != 1) return fail(SGA_ERR_UNSUPPORTED, "Gaussian voxel maps are searched with one offset (the voxel of the query)");
+  if (num_offsets != 1 && num_offsets != 7 && num_offsets != 27) return fail(SGA_ERR_INVALID, "search offsets must be 1, 7 or 27");
+  index->search_offsets = num_offsets;
+  return SGA_OK;
+}
+
+// per voxel: coords (3 ints) and number of points; points (3 floats) and cov6 (6 floats) for kFlatCap slots per voxel
+int sga_flatmap_download(sga_context* ctx, const sga_index* index, int32_t* coords, uint32_t* counts, float* points, float* cov6) {
+  if (!ctx || !index) return fail(SGA_ERR_INVALID, "null argument");
+  if (index->kind != SGA_INDEX_FLATMAP) return fail(SGA_ERR_INVALID, "not a flat voxel map");
+  const size_t n = index->n;
+  if (n == 0) return SGA_OK;
+  SGA_HIP(hipSetDevice(ctx->device));
+  std::vector<float4> hp;
+  std::vector<Cov8> hc;
+  if (points) {
+    hp.resize(n * kFlatCap);
+    SGA_HIP(hipMemcpyAsync(hp.data(), index->pts.p, hp.size() * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  if (cov6) {
+    hc.resize(n * kFlatCap);
+    SGA_HIP(hipMemcpyAsync(hc.data(), index->cov.p, hc.size() * sizeof(Cov8), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  if (coords) SGA_HIP(hipMemcpyAsync(coords, index->vcoords.p, n * 3 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  if (counts) SGA_HIP(hipMemcpyAsync(counts, index->vcounts.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  SGA_HIP(hipStreamSynchronize(ctx->stream));
+  for (size_t i = 0; i < n * kFlatCap; i++) {
+    if (points) {
+      points[3 * i] = hp[i].x;
+      points[3 * i + 1] = hp[i].y;
+      points[3 * i + 2] = hp[i].z;
+    }
+    if (cov6) {
+      cov6[6 * i] = hc[i].xx;
+      cov6[6 * i + 1] = hc[i].xy;
+      cov6[6 * i + 2] = hc[i].xz;
+      cov6[6 * i + 3] = hc[i].yy;
+      cov6[6 * i + 4] = hc[i].yz;
+      cov6[6 * i + 5] = hc[i].zz;
+    }
+  }
   return SGA_OK;
 }
 
@@ -305,20 +456,31 @@ int sga_voxelmap_insert(sga_context* ctx, sga_index* idx, const sga_cloud* cloud
       // capacity of the per-voxel arrays and of the table
       if (n_total > idx->vcap) {
         const size_t cap = std::max<size_t>(2 * n_total, 1024);
-        SGA_TRY(grow(ctx, idx->vmean64, 3 * static_cast<size_t>(n_old), 3 * cap));
-        SGA_TRY(grow(ctx, idx->vcov64, 6 * static_cast<size_t>(n_old), 6 * cap));
+        const bool flat = idx->kind == SGA_INDEX_FLATMAP;
+        if (flat) {
+          SGA_TRY(grow(ctx, idx->fpts64, 3 * kFlatCap * static_cast<size_t>(n_old), 3 * kFlatCap * cap));
+          SGA_TRY(grow(ctx, idx->fcov64, 6 * kFlatCap * static_cast<size_t>(n_old), 6 * kFlatCap * cap));
+        } else {
+          SGA_TRY(grow(ctx, idx->vmean64, 3 * static_cast<size_t>(n_old), 3 * cap));
+          SGA_TRY(grow(ctx, idx->vcov64, 6 * static_cast<size_t>(n_old), 6 * cap));
+        }
         SGA_TRY(grow(ctx, idx->vcounts, n_old, cap));
         SGA_TRY(grow(ctx, idx->vlru, n_old, cap));
         SGA_TRY(grow(ctx, idx->vcoords, 3 * static_cast<size_t>(n_old), 3 * cap));
-        SGA_TRY(grow(ctx, idx->pts, 0, cap));
-        SGA_TRY(grow(ctx, idx->cov, 0, cap));
+        SGA_TRY(grow(ctx, idx->pts, 0, flat ? kFlatCap * cap : cap));
+        SGA_TRY(grow(ctx, idx->cov, 0, flat ? kFlatCap * cap : cap));
         idx->vcap = cap;
       }
       if (idx->hkeys.n == 0 || 2 * n_total > idx->hkeys.n) SGA_TRY(rebuild_hash(ctx, idx, n_total));
       if (n_new > 0) hipLaunchKernelGGL(ivm_assign_kernel, dim3((n_new + 255) / 256), block, 0, ctx->stream, n_new, seg_by_rank.p, n_old, seg_vid.p);
-      hipLaunchKernelGGL(
-        ivm_update_kernel, sgrid, block, 0, ctx->stream, nseg, seg_start.p, seg_vid.p, static_cast<uint32_t>(n), keys_sorted.p, order.p, cloud->pts.p, cloud->cov.p, T, n_old, idx->lru_counter, idx->vmean64.p, idx->vcov64.p,
-        idx->vcounts.p, idx->vlru.p, idx->vcoords.p, idx->hkeys.p, idx->hvals.p, idx->hmask);
+      if (idx->kind == SGA_INDEX_FLATMAP)
+        hipLaunchKernelGGL(
+          fvm_update_kernel, sgrid, block, 0, ctx->stream, nseg, seg_start.p, seg_vid.p, static_cast<uint32_t>(n), keys_sorted.p, order.p, cloud->pts.p, cloud->cov.p, T, n_old, idx->lru_counter, idx->flat_max, idx->flat_min_sq,
+          idx->fpts64.p, idx->fcov64.p, idx->vcounts.p, idx->vlru.p, idx->vcoords.p, idx->hkeys.p, idx->hvals.p, idx->hmask);
+      else
+        hipLaunchKernelGGL(
+          ivm_update_kernel, sgrid, block, 0, ctx->stream, nseg, seg_start.p, seg_vid.p, static_cast<uint32_t>(n), keys_sorted.p, order.p, cloud->pts.p, cloud->cov.p, T, n_old, idx->lru_counter, idx->vmean64.p, idx->vcov64.p,
+          idx->vcounts.p, idx->vlru.p, idx->vcoords.p, idx->hkeys.p, idx->hvals.p, idx->hmask);
       SGA_HIP(hipGetLastError());
       idx->n = n_total;
     }
@@ -345,16 +507,25 @@ int sga_voxelmap_insert(sga_context* ctx, sga_index* idx, const sga_cloud* cloud
       DevBuf<double> m2, c2;
       DevBuf<uint32_t> cnt2, lru2;
       DevBuf<int> co2;
-      SGA_TRY(m2.alloc(3 * idx->vcap));
-      SGA_TRY(c2.alloc(6 * idx->vcap));
+      const bool flat = idx->kind == SGA_INDEX_FLATMAP;
+      SGA_TRY(m2.alloc((flat ? 3 * kFlatCap : 3) * idx->vcap));
+      SGA_TRY(c2.alloc((flat ? 6 * kFlatCap : 6) * idx->vcap));
       SGA_TRY(cnt2.alloc(idx->vcap));
       SGA_TRY(lru2.alloc(idx->vcap));
       SGA_TRY(co2.alloc(3 * idx->vcap));
-      hipLaunchKernelGGL(ivm_compact_kernel, dim3((nv + 255) / 256), dim3(256), 0, ctx->stream, nv, keep.p, pos.p, idx->vmean64.p, idx->vcov64.p, idx->vcounts.p, idx->vlru.p, idx->vcoords.p, m2.p, c2.p, cnt2.p, lru2.p, co2.p);
+      if (flat)
+        hipLaunchKernelGGL(fvm_compact_kernel, dim3((nv + 255) / 256), dim3(256), 0, ctx->stream, nv, keep.p, pos.p, idx->fpts64.p, idx->fcov64.p, idx->vcounts.p, idx->vlru.p, idx->vcoords.p, m2.p, c2.p, cnt2.p, lru2.p, co2.p);
+      else
+        hipLaunchKernelGGL(ivm_compact_kernel, dim3((nv + 255) / 256), dim3(256), 0, ctx->stream, nv, keep.p, pos.p, idx->vmean64.p, idx->vcov64.p, idx->vcounts.p, idx->vlru.p, idx->vcoords.p, m2.p, c2.p, cnt2.p, lru2.p, co2.p);
       SGA_HIP(hipGetLastError());
       SGA_HIP(hipStreamSynchronize(ctx->stream));
-      idx->vmean64.swap(m2);
-      idx->vcov64.swap(c2);
+      if (flat) {
+        idx->fpts64.swap(m2);
+        idx->fcov64.swap(c2);
+      } else {
+        idx->vmean64.swap(m2);
+        idx->vcov64.swap(c2);
+      }
       idx->vcounts.swap(cnt2);
       idx->vlru.swap(lru2);
       idx->vcoords.swap(co2);
@@ -362,7 +533,12 @@ int sga_voxelmap_insert(sga_context* ctx, sga_index* idx, const sga_cloud* cloud
       SGA_TRY(rebuild_hash(ctx, idx, kept));
     }
   }
-  if (idx->n > 0) hipLaunchKernelGGL(ivm_export_kernel, dim3((idx->n + 255) / 256), dim3(256), 0, ctx->stream, static_cast<uint32_t>(idx->n), idx->vmean64.p, idx->vcov64.p, idx->pts.p, idx->cov.p);
+  if (idx->n > 0) {
+    if (idx->kind == SGA_INDEX_FLATMAP)
+      hipLaunchKernelGGL(fvm_export_kernel, dim3((idx->n * kFlatCap + 255) / 256), dim3(256), 0, ctx->stream, static_cast<uint32_t>(idx->n), idx->vcounts.p, idx->fpts64.p, idx->fcov64.p, idx->pts.p, idx->cov.p);
+    else
+      hipLaunchKernelGGL(ivm_export_kernel, dim3((idx->n + 255) / 256), dim3(256), 0, ctx->stream, static_cast<uint32_t>(idx->n), idx->vmean64.p, idx->vcov64.p, idx->pts.p, idx->cov.p);
+  }
   SGA_HIP(hipGetLastError());
   SGA_HIP(hipStreamSynchronize(ctx->stream));
   return SGA_OK;

@@ -55,7 +55,10 @@ class ModelOdometry:
     GaussianVoxelMap accumulating every registered scan (incremental insert with the estimated pose + LRU removal of voxels the
     sensor has left behind); each new scan is registered against it starting from the previous pose, then inserted."""
 
-    def __init__(self, downsampling_resolution=0.25, num_neighbors=20, voxel_resolution=1.0, max_correspondence_distance=1.0, ctx=None):
+    def __init__(self, downsampling_resolution=0.25, num_neighbors=20, voxel_resolution=1.0, max_correspondence_distance=1.0, ctx=None, model="gaussian"):
+        """model = "gaussian": GaussianVoxelMap / VGICP (odometry_benchmark_small_vgicp_model_omp.cpp); "flat": IncrementalVoxelMap<
+        FlatContainerCov> / GICP against the stored points (odometry_benchmark_small_gicp_model_omp.cpp)."""
+        self.model = model
         self.res = downsampling_resolution
         self.k = num_neighbors
         self.voxel_resolution = voxel_resolution
@@ -73,7 +76,7 @@ class ModelOdometry:
         t1 = time.perf_counter()
         api.estimate_covariances(cloud, None, self.k)
         if self.voxelmap is None:  # the very first frame
-            self.voxelmap = api.GaussianVoxelMap(self.voxel_resolution, ctx=self.ctx)
+            self.voxelmap = (api.IncrementalVoxelMapCov if self.model == "flat" else api.GaussianVoxelMap)(self.voxel_resolution, ctx=self.ctx)
             self.voxelmap.insert(cloud)
         else:
             res = api.Problem(self.voxelmap, cloud, self.T_world).align(self.setting, self.T_world)

@@ -80,6 +80,15 @@ int main(int argc, char** argv) {
       s.type = RegistrationSetting::VGICP;
       report("VGICP", align(*voxelmap, *source, Isometry3d::Identity(), s));
     }
+    {
+      // scan-to-model GICP target (odometry_benchmark_small_gicp_model_omp.cpp:24-40)
+      IncrementalVoxelMap<FlatContainerCov> model(1.0);
+      model.set_search_offsets(7);
+      model.insert(*target);
+      std::printf("MODEL_VOXELS %zu\n", model.size());
+      Registration<GICPFactor, ParallelReductionHIP> reg;
+      report("MODEL_GICP", reg.align(model, *source, model));
+    }
     // 3. accessors
     const auto p0 = target->point(0);
     const auto c0 = target->cov(0);

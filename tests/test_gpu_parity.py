@@ -418,6 +418,14 @@ def test_cpp_header_layer(tmp_path, c1_raw, c1_gold):
         dt, dr = pose_error(cases[name]["T"], T_gt)
         assert dt < 0.1 and dr < 0.03, (name, dt, dr)
     # RestrictDoF: roll/pitch and z stay (softly) frozen
+    # scan-to-model target through the C++ layer == the same calls through ctypes
+    fm = sga.IncrementalVoxelMapCov(1.0)
+    fm.set_search_offsets(7)
+    tgt_c, _ = sga.preprocess_points(c1_raw[0], 0.25, 10)
+    src_c, _ = sga.preprocess_points(c1_raw[1], 0.25, 10)
+    fm.insert(tgt_c)
+    rm = sga.Problem(fm, src_c).align(sga.make_setting("GICP"))
+    assert np.abs(rm.T_target_source - cases["MODEL_GICP"]["T"]).max() < 1e-9 and rm.iterations == cases["MODEL_GICP"]["iterations"]
     Tr = cases["RESTRICT_GICP"]["T"]
     assert abs(Tr[2, 3]) < 2e-3 and abs(Tr[2, 0]) < 1e-3 and abs(Tr[2, 1]) < 1e-3  # soft constraints (general_factor.hpp:42)
 
@@ -713,4 +721,70 @@ def test_scan_to_model_odometry_matches_oracle(orc):
             vm.insert(cloud, T)
         dt, dr = pose_error(r["estimated"][f], T)
         assert dt < 2e-4 and dr < 2e-4, (f, dt, dr)  # the chain feeds every pose into the next map: twice the single-registration tolerance
+    assert abs(r["num_voxels"] - len(vm)) <= 2
+
+
+@pytest.mark.parametrize("offsets", [1, 7, 27])
+def test_flat_voxelmap_matches_oracle(orc, c1_f32, gpu_c1, offsets):
+    """IncrementalVoxelMap<FlatContainerCov> on the device against the oracle (pinned to the reference in
+    tests/test_oracle_vs_reference.py::test_incremental_flat_voxelmap): the per-cell acceptance rule in insertion order, LRU,
+    creation order, and GICP against the stored points over 1 / 7 / 27 voxels."""
+    d = c1_f32
+    tgt, src, _ = gpu_c1
+    ot, os_ = orc.Cloud(d["tp"], d["tn"], d["tc"]), orc.Cloud(d["sp"], d["sn"], d["sc"])
+    gv, ov = sga.IncrementalVoxelMapCov(1.0), orc.FlatMap(1.0)
+    for m in (gv, ov):
+        m.set_lru(2, 3)
+        m.set_search_offsets(offsets)
+    sizes = []
+    for step in range(7):
+        T = se3([0.1, 0.2, 1.0], 0.02 * step, [5.0 * step, -2.0 * step, 0.1 * step])
+        g, o = (tgt, ot) if step % 2 == 0 else (src, os_)
+        gv.insert(g, T)
+        ov.insert(o, T)
+        gc, gn, gp, g6 = gv.download()
+        oc, on, op, ocv = ov.get()
+        assert gv.size() == len(ov) and (gc == oc).all() and (gn == on).all(), step
+        scale = max(1.0, float(np.abs(op).max()))
+        assert np.abs(gp - op).max() <= 2e-7 * scale and np.abs(sga.api.mats_from_sym6(g6.astype(np.float64)) - ocv).max() <= 2e-7, step
+        sizes.append(gv.size())
+    assert min(np.diff(sizes)) < 0
+    st = sga.make_setting("GICP")
+    T0 = se3([0.1, 0.2, 1.0], 0.02 * 6 + 0.004, [30.0 + 0.1, -12.0 - 0.05, 0.6])
+    pb = sga.Problem(gv, src, T0)
+    res = pb.align(st, T0)
+    ores = orc.align(ov, os_, orc.default_setting(factor_kind=orc.GICP, num_threads=1), T0)
+    dt, dr = pose_error(res.T_target_source, ores.T_target_source)
+    assert dt < POSE_TOL_T and dr < POSE_TOL_R and res.iterations == ores.iterations and abs(int(res.num_inliers) - int(ores.num_inliers)) <= 2, (dt, dr)
+    # fixed-pose accumulators and the exported correspondences ((voxel << 32) | point)
+    fac = orc.Factors(len(d["sp"]))
+    oH, ob, oe, on_ = orc.linearize(ov, os_, orc.default_setting(factor_kind=orc.GICP, num_threads=1), T0, fac)
+    gH, gb, ge, gn_ = pb.linearize(st.factor, T0)
+    assert abs(int(gn_) - int(on_)) <= 2 and abs(ge - oe) <= 1e-4 * oe and np.abs(gH - oH).max() <= 1e-4 * np.abs(oH).max()
+    gi = pb.factors()[0]
+    oi = fac.get(2)[0]
+    assert (gi == oi).mean() > 0.999
+
+
+def test_scan_to_model_gicp_odometry_matches_oracle(orc):
+    """odometry_benchmark_small_gicp_model_omp.cpp (GICP against IncrementalVoxelMap<FlatContainerCov>) on the synthetic sequence."""
+    from small_gicp_amd import odometry
+
+    frames = 6
+    r = odometry.run_synthetic_model(frames, model="flat")
+    vm = None
+    T = np.eye(4)
+    for f in range(frames):
+        pts, _ = sga.synthetic.kitti_like_scan(f)
+        cloud = orc.Cloud(orc.voxelgrid_sampling(pts, 0.25))
+        cloud.estimate_normals_covariances(20, 4)
+        if vm is None:
+            vm = orc.FlatMap(1.0)
+            vm.insert(cloud)
+        else:
+            res = orc.align(vm, cloud, orc.default_setting(factor_kind=orc.GICP, num_threads=4), T)
+            T = res.T_target_source
+            vm.insert(cloud, T)
+        dt, dr = pose_error(r["estimated"][f], T)
+        assert dt < 2e-4 and dr < 2e-4, (f, dt, dr)
     assert abs(r["num_voxels"] - len(vm)) <= 2

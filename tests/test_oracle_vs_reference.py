@@ -125,3 +125,37 @@ def test_incremental_voxelmap(orc, clouds):
         assert np.abs(rm - om).max() < 1e-12 and np.abs(rcv - ocv).max() < 1e-13, step
         sizes.append(len(ov))
     assert min(np.diff(sizes)) < 0  # the sweep did remove voxels at some step
+
+
+@pytest.mark.parametrize("offsets", [1, 7, 27])
+def test_incremental_flat_voxelmap(orc, clouds, offsets):
+    """IncrementalVoxelMap<FlatContainerCov> (scan-to-model GICP target): insert sequence with poses and LRU, the per-cell
+    acceptance rule (max points, minimum distance), the offset patterns of the search, and a registration against the map
+    (flat_container.hpp:33-93, incremental_voxelmap.hpp:55-190, odometry_benchmark_small_gicp_model_omp.cpp:33-36)."""
+    rv, ov = ref.FlatMap(1.0), orc.FlatMap(1.0)
+    for m in (rv, ov):
+        m.set_lru(2, 3)
+        m.set_search_offsets(offsets)
+    pairs = []
+    for o in (clouds["ot"], clouds["os"]):
+        p, n, c = o.get()
+        pairs.append((ref.Cloud(p, n, c, tree=False), o))
+    sizes = []
+    for step in range(7):
+        T = _se3([0.1, 0.2, 1.0], 0.02 * step, [5.0 * step, -2.0 * step, 0.1 * step])
+        r, o = pairs[step % 2]
+        rv.insert(r, T)
+        ov.insert(o, T)
+        rc, rn, rp, rcv = rv.get()
+        oc, on, op, ocv = ov.get()
+        assert len(rv) == len(ov) and (rc == oc).all() and (rn == on).all(), step
+        assert rn.max() <= 10 and np.abs(rp - op).max() < 1e-12 and np.abs(rcv - ocv).max() < 1e-13, step
+        sizes.append(len(ov))
+    assert min(np.diff(sizes)) < 0
+    # register the other cloud against the accumulated model from a nearby pose
+    T0 = _se3([0.1, 0.2, 1.0], 0.02 * 6 + 0.004, [30.0 + 0.1, -12.0 - 0.05, 0.6])
+    rr = rv.align(pairs[1][0], T0, num_threads=1)
+    orr = orc.align(ov, pairs[1][1], orc.default_setting(factor_kind=orc.GICP, num_threads=1), T0)
+    dt, dr = pose_error(rr.T_target_source, orr.T_target_source)
+    assert dt < 1e-8 and dr < 1e-8 and rr.iterations == orr.iterations and rr.num_inliers == orr.num_inliers
+    assert abs(rr.error - orr.error) <= 1e-8 * abs(rr.error)
