@@ -47,22 +47,36 @@ __global__ void ds_starts_kernel(const uint32_t* __restrict__ flags, const uint3
   if (flags[i]) seg_start[seg_id[i]] = static_cast<uint32_t>(i);
 }
 
+// Eight lanes per voxel: a LiDAR scan has a few voxels with hundreds of points next to the sensor, and one lane walking such a
+// segment alone was the tail of the whole kernel.  Lane g sums the points g, g+8, ... of the segment in fp64, then the eight partial
+// sums are added in a fixed order (bit-reproducible; the grouping differs from a serial sum by rounding of the last bit at most).
 __global__ void ds_mean_kernel(const uint32_t* __restrict__ seg_start, uint32_t nseg, const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ order, size_t n, const float4* __restrict__ pts, float4* __restrict__ out) {
-  const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= nseg) return;
-  const uint32_t s = seg_start[v];
-  const unsigned long long key = keys[s];
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t v = t >> 3, g = t & 7u;
+  const bool valid = v < nseg;
   double sx = 0, sy = 0, sz = 0;
   uint32_t cnt = 0;
-  for (size_t i = s; i < n && keys[i] == key; ++i) {
-    const float4 p = pts[order[i]];
-    sx += p.x;
-    sy += p.y;
-    sz += p.z;
-    cnt++;
+  if (valid) {
+    const uint32_t s = seg_start[v];
+    const unsigned long long key = keys[s];
+    for (size_t i = s + g; i < n && keys[i] == key; i += 8) {
+      const float4 p = pts[order[i]];
+      sx += p.x;
+      sy += p.y;
+      sz += p.z;
+      cnt++;
+    }
   }
-  const double inv = 1.0 / cnt;
-  out[v] = make_float4(static_cast<float>(sx * inv), static_cast<float>(sy * inv), static_cast<float>(sz * inv), __uint_as_float(v));
+  for (int off = 1; off < 8; off <<= 1) {  // lanes of one voxel are adjacent: butterfly inside the group of 8
+    sx += __shfl_xor(sx, off);
+    sy += __shfl_xor(sy, off);
+    sz += __shfl_xor(sz, off);
+    cnt += __shfl_xor(cnt, off);
+  }
+  if (valid && g == 0) {
+    const double inv = 1.0 / cnt;
+    out[v] = make_float4(static_cast<float>(sx * inv), static_cast<float>(sy * inv), static_cast<float>(sz * inv), __uint_as_float(v));
+  }
 }
 
 // ---- 3x3 symmetric eigen-decomposition (Eigen 3.4.0 computeDirect, restated), fp64 -------------------------------------------------
@@ -329,7 +343,7 @@ int sga_voxelgrid_sampling(sga_context* ctx, const sga_cloud* in, double leaf, s
     SGA_TRY(seg_start.alloc(nseg));
     SGA_TRY(res->pts.alloc(nseg));
     hipLaunchKernelGGL(ds_starts_kernel, grid, block, 0, ctx->stream, flags.p, seg_id.p, n, seg_start.p);
-    hipLaunchKernelGGL(ds_mean_kernel, dim3((nseg + 127) / 128), dim3(128), 0, ctx->stream, seg_start.p, nseg, keys_sorted.p, order.p, n, in->pts.p, res->pts.p);
+    hipLaunchKernelGGL(ds_mean_kernel, dim3((static_cast<size_t>(nseg) * 8 + 255) / 256), dim3(256), 0, ctx->stream, seg_start.p, nseg, keys_sorted.p, order.p, n, in->pts.p, res->pts.p);
     SGA_HIP(hipGetLastError());
     SGA_HIP(hipStreamSynchronize(ctx->stream));
   }

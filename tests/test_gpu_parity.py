@@ -788,3 +788,44 @@ def test_scan_to_model_gicp_odometry_matches_oracle(orc):
         dt, dr = pose_error(r["estimated"][f], T)
         assert dt < 2e-4 and dr < 2e-4, (f, dt, dr)
     assert abs(r["num_voxels"] - len(vm)) <= 2
+
+
+def test_incremental_maps_edge_cases():
+    """Empty and out-of-range inserts, argument checking of the scan-to-model maps."""
+    pts = np.array([[0.1, 0.2, 0.3], [0.15, 0.25, 0.35], [5.0, 5.0, 5.0], [1e9, 0.0, 0.0], [np.nan, 0.0, 0.0]], np.float32)
+    c6 = np.tile(np.array([1, 0, 0, 1, 0, 1], np.float32) * 0.01, (len(pts), 1))
+    cloud = sga.PointCloud(pts, covs=c6)
+    for cls in (sga.GaussianVoxelMap, sga.IncrementalVoxelMapCov):
+        m = cls(1.0)
+        assert m.size() == 0
+        m.insert(sga.PointCloud(np.zeros((0, 3), np.float32), covs=np.zeros((0, 6), np.float32)))
+        assert m.size() == 0
+        m.insert(cloud)  # the far and the NaN point fall outside the +-2^20 cell range and are dropped
+        assert m.size() == 2
+        with pytest.raises(sga.SgaError):
+            m.insert(sga.PointCloud(pts))  # no covariances
+        with pytest.raises(sga.SgaError):
+            m.set_lru(10, 0)
+    g = sga.GaussianVoxelMap(1.0)
+    with pytest.raises(sga.SgaError):
+        sga._lib.check(sga._lib.load().sga_voxelmap_set_search_offsets(g.h, 7))
+    f = sga.IncrementalVoxelMapCov(1.0)
+    for bad in (0, 5, 28):
+        with pytest.raises(sga.SgaError):
+            f.set_search_offsets(bad)
+    with pytest.raises(sga.SgaError):
+        f.set_setting(0.01, 17)
+    f.set_setting(0.0, 1)  # one point per cell
+    f.insert(cloud)
+    assert f.download()[1].tolist() == [1, 1]
+    with pytest.raises(sga.SgaError):
+        f.set_setting(0.01, 10)  # after the first insert
+    # a voxel that receives more than max points keeps the first ones, at least min distance apart
+    rng = np.random.default_rng(0)
+    dense = rng.uniform(0.0, 1.0, (500, 3)).astype(np.float32)
+    h = sga.IncrementalVoxelMapCov(1.0)
+    h.insert(sga.PointCloud(dense, covs=np.tile(c6[:1], (500, 1))))
+    coords, counts, p, _ = h.download()
+    assert len(coords) == 1 and counts[0] == 10 and (p[0] == dense[0]).all()
+    dmin = min(np.linalg.norm(p[i] - p[j]) for i in range(10) for j in range(i))
+    assert dmin >= 0.1 - 1e-6
