@@ -122,10 +122,10 @@ __device__ __forceinline__ KdBest kd_nearest(const KdView& t, float qx, float qy
         const float diff = qa - nd.x;
         const float cut = diff * diff;
         depth++;
-        if (cut < best.d2) {  // a far side at distance >= best cannot hold a closer point
-          stack[sp * STRIDE + tid] = kd_pack(cut, depth);
-          sp++;
-        }
+        // a far side at distance >= best cannot hold a closer point: the entry is written unconditionally (no branch) and only
+        // kept, i.e. the stack pointer advanced, if it can
+        stack[sp * STRIDE + tid] = kd_pack(cut, depth);
+        sp += cut < best.d2 ? 1 : 0;
         node = 2 * node + (diff < 0.f ? 0u : 1u);
       }
       if (depth < D) {
@@ -136,10 +136,8 @@ __device__ __forceinline__ KdBest kd_nearest(const KdView& t, float qx, float qy
         const float diff = qa - thr;
         const float cut = diff * diff;
         depth++;
-        if (cut < best.d2) {
-          stack[sp * STRIDE + tid] = kd_pack(cut, depth);
-          sp++;
-        }
+        stack[sp * STRIDE + tid] = kd_pack(cut, depth);
+        sp += cut < best.d2 ? 1 : 0;
         node = 2 * node + (diff < 0.f ? 0u : 1u);
       }
     }
