@@ -106,6 +106,30 @@ __device__ __forceinline__ KdBest kd_nearest(const KdView& t, float qx, float qy
   const int D = t.depth;
   int sp = 0, depth = 0;
   uint32_t node = 1;
+  // Wave-uniform top of the first descent.  The 64 queries of a wave are neighbours (the source is sorted by target leaf), so
+  // they take the same branches for the first ~12 levels: as long as a ballot says so, the node is read ONCE per wave through the
+  // scalar cache and each lane only evaluates its own plane distance (for the push test).  The first disagreement hands over to
+  // the per-lane walk below at the node reached.
+  {
+    const unsigned long long active = __ballot(true);
+    uint32_t unode = 1;
+    while (depth < D) {
+      const uint32_t un = __builtin_amdgcn_readfirstlane(unode);
+      const float2 nd = t.nodes[un];  // uniform address: scalar load
+      const int axis = __builtin_amdgcn_readfirstlane(__float_as_int(nd.y));
+      const float thr = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(nd.x)));
+      const float qa = axis == 0 ? qx : (axis == 1 ? qy : qz);
+      const float diff = qa - thr;
+      const unsigned long long right = __ballot(!(diff < 0.f));
+      if (right != 0ull && right != active) break;  // the lanes part ways here
+      const float cut = diff * diff;
+      depth++;
+      stack[sp * STRIDE + tid] = kd_pack(cut, depth);
+      sp += cut < best.d2 ? 1 : 0;
+      unode = 2 * un + (right != 0ull ? 1u : 0u);
+    }
+    node = unode;
+  }
   for (;;) {
     while (depth < D) {
       // one pair record covers the node itself (if it is of even depth) and the child the walk continues into; it is fetched with
