@@ -163,26 +163,28 @@ __global__ void kd_init_box_kernel(int* __restrict__ seg_box, uint32_t nseg) {
 __device__ __forceinline__ float float_from_ordered(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
 
 // keys for the sort of one level: (segment, coordinate along the segment's split axis)
-__global__ void kd_keys_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ perm, uint32_t n, int d, const int* __restrict__ axis_of_seg, unsigned long long* __restrict__ keys) {
+__device__ __forceinline__ int kd_longest_axis(const int* __restrict__ box6) {
+  float v[3];
+  for (int a = 0; a < 3; a++) v[a] = float_from_ordered(box6[3 + a]) - float_from_ordered(box6[a]);
+  return v[0] >= v[1] ? (v[0] >= v[2] ? 0 : 2) : (v[1] >= v[2] ? 1 : 2);
+}
+
+// split axis of every segment = longest extent of its box (each lane derives it from the six box words; the first lane of a
+// segment records it for kd_nodes_kernel) + the sort key of every point
+__global__ void kd_keys_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ perm, uint32_t n, int d, const int* __restrict__ seg_box, int* __restrict__ axis_of_seg, unsigned long long* __restrict__ keys) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t seg = kd_segment_of(i, n, d);
-  const int axis = axis_of_seg[seg];
+  const int axis = kd_longest_axis(seg_box + 6 * seg);
+  if (i == kd_bound_d(n, d, seg)) axis_of_seg[seg] = axis;
   const float4 p = pts[perm[i]];
   const float c = axis == 0 ? p.x : (axis == 1 ? p.y : p.z);
   const uint32_t oc = static_cast<uint32_t>(ordered_from_float(c)) ^ 0x80000000u;  // unsigned order
   keys[i] = (static_cast<unsigned long long>(seg) << 32) | oc;
 }
 
-__global__ void kd_choose_axis_kernel(const int* __restrict__ seg_box, uint32_t nseg, int* __restrict__ axis_of_seg) {
-  const uint32_t seg = blockIdx.x * blockDim.x + threadIdx.x;
-  if (seg >= nseg) return;
-  float v[3];
-  for (int a = 0; a < 3; a++) v[a] = float_from_ordered(seg_box[6 * seg + 3 + a]) - float_from_ordered(seg_box[6 * seg + a]);
-  axis_of_seg[seg] = v[0] >= v[1] ? (v[0] >= v[2] ? 0 : 2) : (v[1] >= v[2] ? 1 : 2);
-}
-
-__global__ void kd_nodes_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ perm, uint32_t n, int d, const int* __restrict__ axis_of_seg, float2* __restrict__ nodes) {
+// thresholds of level d; also resets the boxes of the 2^(d+1) segments of the next level (nobody reads this level's boxes any more)
+__global__ void kd_nodes_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ perm, uint32_t n, int d, const int* __restrict__ axis_of_seg, float2* __restrict__ nodes, int* __restrict__ next_box) {
   const uint32_t seg = blockIdx.x * blockDim.x + threadIdx.x;
   if (seg >= (1u << d)) return;
   const int axis = axis_of_seg[seg];
@@ -194,6 +196,12 @@ __global__ void kd_nodes_kernel(const float4* __restrict__ pts, const uint32_t* 
     thr = axis == 0 ? p.x : (axis == 1 ? p.y : p.z);
   }
   nodes[(1u << d) + seg] = make_float2(thr, __int_as_float(axis));
+  if (next_box != nullptr)
+    for (uint32_t c = 2 * seg; c < 2 * seg + 2; c++)
+      for (int k = 0; k < 3; k++) {
+        next_box[6 * c + k] = 0x7f800000;                                       // +inf
+        next_box[6 * c + 3 + k] = static_cast<int>(0xff800000u) ^ 0x7fffffff;  // -inf
+      }
 }
 
 // ---- bottom levels of the build inside LDS ----------------------------------------------------------------------------------------
@@ -262,7 +270,7 @@ __global__ __launch_bounds__(kFinishThreads) void kd_finish_kernel(const float4*
     for (uint32_t j = tid; j < nsub; j += kFinishThreads) {
       float v[3];
       for (int a = 0; a < 3; a++) v[a] = float_from_ordered(box[j][3 + a]) - float_from_ordered(box[j][a]);
-      axis_of[j] = v[0] >= v[1] ? (v[0] >= v[2] ? 0 : 2) : (v[1] >= v[2] ? 1 : 2);  // same rule as kd_choose_axis_kernel
+      axis_of[j] = v[0] >= v[1] ? (v[0] >= v[2] ? 0 : 2) : (v[1] >= v[2] ? 1 : 2);  // same rule as kd_longest_axis
     }
     __syncthreads();
     for (uint32_t pos = tid; pos < m; pos += kFinishThreads) {
@@ -437,13 +445,12 @@ static int build_kdtree(sga_context* ctx, const sga_cloud* cloud, sga_index* idx
     const uint32_t nseg = 1u << d;
     const dim3 sgrid((nseg + 255) / 256);
     const unsigned end_bit = 32 + (d > 0 ? d : 1);
-    hipLaunchKernelGGL(kd_init_box_kernel, sgrid, block, 0, ctx->stream, seg_box.p, nseg);
+    if (d == 0) hipLaunchKernelGGL(kd_init_box_kernel, sgrid, block, 0, ctx->stream, seg_box.p, nseg);  // later levels: reset by kd_nodes_kernel
     hipLaunchKernelGGL(kd_segment_box_kernel, dim3((n + 1023) / 1024), dim3(1024), 0, ctx->stream, cloud->pts.p, cur, static_cast<uint32_t>(n), d, seg_box.p);
-    hipLaunchKernelGGL(kd_choose_axis_kernel, sgrid, block, 0, ctx->stream, seg_box.p, nseg, axis_of_seg.p);
-    hipLaunchKernelGGL(kd_keys_kernel, grid, block, 0, ctx->stream, cloud->pts.p, cur, static_cast<uint32_t>(n), d, axis_of_seg.p, keys.p);
+    hipLaunchKernelGGL(kd_keys_kernel, grid, block, 0, ctx->stream, cloud->pts.p, cur, static_cast<uint32_t>(n), d, seg_box.p, axis_of_seg.p, keys.p);
     SGA_HIP(rocprim::radix_sort_pairs(ctx->d_temp.p, tb, keys.p, keys2.p, cur, nxt, n, 0, end_bit, ctx->stream));
     std::swap(cur, nxt);
-    hipLaunchKernelGGL(kd_nodes_kernel, sgrid, block, 0, ctx->stream, cloud->pts.p, cur, static_cast<uint32_t>(n), d, axis_of_seg.p, idx->kd_nodes.p);
+    hipLaunchKernelGGL(kd_nodes_kernel, sgrid, block, 0, ctx->stream, cloud->pts.p, cur, static_cast<uint32_t>(n), d, axis_of_seg.p, idx->kd_nodes.p, d + 1 < dA ? seg_box.p : static_cast<int*>(nullptr));
   }
   if (dA < D) {
     if (cap == kFinishCap)
