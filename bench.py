@@ -215,6 +215,11 @@ def main():
                 "launches_timed": kms["linearize_calls"],
                 "nn_search_kernel_avg_us": kms["search_ms"] * 1e3,
                 "linearize_kernel_avg_us": (kms["linearize_ms"] - kms["search_ms"]) * 1e3,
+                "cold_pass_avg_us": kms["cold_ms"] * 1e3,
+                "cold_passes_timed": kms["cold_calls"],
+                "warm_pass_avg_us": kms["warm_ms"] * 1e3,
+                "warm_passes_timed": kms["warm_calls"],
+                "pass_stats": problem.pass_stats(),
                 "error_kernel_avg_us": err_us,
                 "error_kernel_achieved_GBs": (ALG_BYTES_PER_POINT["error_gicp"] * n) / (err_us * 1e-6) / 1e9 if err_us > 0 else None,
             },

@@ -17,7 +17,15 @@ namespace sga {
 int ensure_temp(sga_context* ctx, size_t bytes);
 
 // ---- bounding box --------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bbox_kernel(const float4* __restrict__ pts, size_t n, float* __restrict__ out6 /* min xyz (init +inf), max xyz (init -inf) as ordered ints */) {
+// <= 256 workgroups stream the cloud; wave shuffles + one LDS stage reduce a workgroup to six values, so only six atomics per
+// workgroup reach memory (order-preserving int encoding of the floats).
+__device__ __forceinline__ int bbox_enc(float f) {
+  const int i = __float_as_int(f);
+  return i >= 0 ? i : i ^ 0x7fffffff;
+}
+
+__global__ __launch_bounds__(256) void bbox_kernel(const float4* __restrict__ pts, size_t n, int* __restrict__ out6 /* min xyz (init +inf), max xyz (init -inf), encoded */) {
+  __shared__ float sh[4][6];
   float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
   for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n; i += static_cast<size_t>(gridDim.x) * blockDim.x) {
     const float4 p = pts[i];
@@ -34,17 +42,21 @@ __global__ __launch_bounds__(256) void bbox_kernel(const float4* __restrict__ pt
       hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
     }
   }
-  if ((threadIdx.x & 63) == 0) {
-    // float atomics via the order-preserving int mapping
-    auto enc = [](float f) {
-      int i = __float_as_int(f);
-      return i >= 0 ? i : i ^ 0x7fffffff;
-    };
-    int* o = reinterpret_cast<int*>(out6);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0)
     for (int k = 0; k < 3; k++) {
-      atomicMin(&o[k], enc(lo[k]));
-      atomicMax(&o[3 + k], enc(hi[k]));
+      sh[wave][k] = lo[k];
+      sh[wave][3 + k] = hi[k];
     }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int k = threadIdx.x;
+    float v = sh[0][k];
+    for (int w = 1; w < 4; w++) v = k < 3 ? fminf(v, sh[w][k]) : fmaxf(v, sh[w][k]);
+    if (k < 3)
+      atomicMin(&out6[k], bbox_enc(v));
+    else
+      atomicMax(&out6[k], bbox_enc(v));
   }
 }
 
@@ -53,6 +65,29 @@ static inline float dec_ordered(int i) {
   float f;
   memcpy(&f, &j, 4);
   return f;
+}
+
+// bounding box of a device cloud on the host (synchronises the context's stream)
+int cloud_bbox(sga_context* ctx, const float4* pts, size_t n, float lo[3], float hi[3]) {
+  for (int k = 0; k < 3; k++) lo[k] = hi[k] = 0.f;
+  if (n == 0) {
+    SGA_HIP(hipStreamSynchronize(ctx->stream));
+    return SGA_OK;
+  }
+  DevBuf<int> d_bbox;
+  SGA_TRY(d_bbox.alloc(6));
+  const int init[6] = {0x7f800000, 0x7f800000, 0x7f800000, static_cast<int>(0xff800000u) ^ 0x7fffffff, static_cast<int>(0xff800000u) ^ 0x7fffffff, static_cast<int>(0xff800000u) ^ 0x7fffffff};
+  SGA_HIP(hipMemcpyAsync(d_bbox.p, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(bbox_kernel, dim3(std::min<size_t>(256, (n + 255) / 256)), dim3(256), 0, ctx->stream, pts, n, d_bbox.p);
+  SGA_HIP(hipGetLastError());
+  int h_bbox[6];
+  SGA_HIP(hipMemcpyAsync(h_bbox, d_bbox.p, sizeof(h_bbox), hipMemcpyDeviceToHost, ctx->stream));
+  SGA_HIP(hipStreamSynchronize(ctx->stream));
+  for (int k = 0; k < 3; k++) {
+    lo[k] = dec_ordered(h_bbox[k]);
+    hi[k] = dec_ordered(h_bbox[3 + k]);
+  }
+  return SGA_OK;
 }
 
 __global__ void gather_sorted_kernel(
@@ -583,20 +618,9 @@ int sga_index_build_kdtree(sga_context* ctx, const sga_cloud* target, sga_index*
   idx->has_normals = target->has_normals;
   idx->has_covs = target->has_covs;
   if (n > 0) {
-    DevBuf<float> d_bbox;
-    SGA_TRY(d_bbox.alloc(6));
-    const int init[6] = {0x7f800000, 0x7f800000, 0x7f800000, static_cast<int>(0xff800000u) ^ 0x7fffffff, static_cast<int>(0xff800000u) ^ 0x7fffffff, static_cast<int>(0xff800000u) ^ 0x7fffffff};
-    SGA_HIP(hipMemcpyAsync(d_bbox.p, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(bbox_kernel, dim3(std::min<size_t>(1024, (n + 255) / 256)), dim3(256), 0, ctx->stream, target->pts.p, n, d_bbox.p);
-    SGA_HIP(hipGetLastError());
-    int h_bbox[6];
-    SGA_HIP(hipMemcpyAsync(h_bbox, d_bbox.p, sizeof(h_bbox), hipMemcpyDeviceToHost, ctx->stream));
-    SGA_HIP(hipStreamSynchronize(ctx->stream));
-    for (int k = 0; k < 3; k++) {
-      idx->bbox_lo[k] = dec_ordered(h_bbox[k]);
-      idx->bbox_hi[k] = dec_ordered(h_bbox[3 + k]);
+    SGA_TRY(cloud_bbox(ctx, target->pts.p, n, idx->bbox_lo, idx->bbox_hi));
+    for (int k = 0; k < 3; k++)
       if (!std::isfinite(idx->bbox_lo[k]) || !std::isfinite(idx->bbox_hi[k])) return fail(SGA_ERR_INVALID, "target cloud contains non-finite coordinates");
-    }
     SGA_TRY(build_kdtree(ctx, target, idx.get()));
   }
   *out = idx.release();

@@ -47,7 +47,8 @@ inline KdView make_kd_view(const sga_index* idx) {
 
 struct KdBest {
   float d2;
-  int idx;  // position in the kd-ordered target, -1 = none
+  int idx;   // position in the kd-ordered target, -1 = none
+  float r2;  // exclusion bound: every target point other than `idx` has a computed squared distance >= r2 (see kd_nearest)
 };
 
 __host__ __device__ __forceinline__ uint32_t kd_bound(uint32_t n, int d, uint32_t k) { return static_cast<uint32_t>((static_cast<unsigned long long>(k) * n) >> d); }
@@ -70,11 +71,13 @@ __host__ __device__ __forceinline__ uint32_t kd_pair_count(int D) { return D == 
 __device__ __forceinline__ uint32_t kd_pack(float cut, int depth) { return ((__float_as_uint(cut) >> 4) << 5) | static_cast<uint32_t>(depth); }
 __device__ __forceinline__ float kd_cut(uint32_t e) { return __uint_as_float((e >> 5) << 4); }
 
-// stack: LDS, D * STRIDE words (STRIDE = threads per workgroup); this lane uses stack[level * STRIDE + tid].
-// bound2: only points with d2 < bound2 can win (pass max_sq nudged up by one ulp so that d2 == max_sq is still found).
-// seed:   kd position of a target point believed to be close to the query (the neighbour found for this source point at the
-//         previous pose) or -1.  Its distance only tightens the pruning bound from the first descent on — far sides that cannot
-//         beat it are never pushed — the result is still the exact nearest neighbour.
+// THE squared distance of the search: every kernel that compares distances of target points to a query (the walk, the
+// certificate check of the warm pass) evaluates exactly this expression, so they agree bit for bit.
+__device__ __forceinline__ float kd_dist2(float cx, float cy, float cz, float qx, float qy, float qz) {
+  const float dx = cx - qx, dy = cy - qy, dz = cz - qz;
+  return fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+}
+
 // Squared distance from the query to the tight bounding box of `node`, evaluated with the same operations (and rounding) as a
 // point distance: it never exceeds the distance to any point inside the box.  The split planes alone are a weak bound on
 // surface-like data — a cell reaches far beyond the points it holds — so a pending far side that passed the plane test is opened
@@ -88,15 +91,28 @@ __device__ __forceinline__ float kd_box_dist2(const KdView& t, uint32_t node, fl
   return fmaf(dx, dx, fmaf(dy, dy, dz * dz));
 }
 
+// Exact nearest neighbour of (qx, qy, qz): the target point minimising (kd_dist2, kd position) lexicographically among the points
+// with kd_dist2 < bound2 — a canonical rule (equidistant points: the lowest kd position wins), so the result depends on the
+// tree and the query only, never on the traversal order, the seed or earlier calls.  Sub-trees at a distance EQUAL to the best
+// are therefore still opened (they could hold an equidistant point of lower position); that costs nothing on real data.
+// stack:  LDS, D * STRIDE words (STRIDE = threads per workgroup); this lane uses stack[level * STRIDE + tid].
+// bound2: only points with d2 < bound2 can win (pass max_sq nudged up by one ulp so that d2 == max_sq is still found).
+// seed:   kd position of a target point believed to be close to the query (the neighbour found for this source point at the
+//         previous pose) or -1.  Its distance only tightens the pruning bound from the first descent on.
+// Besides the neighbour the walk returns, for free, an EXCLUSION BOUND r2: the minimum over (a) the distances of all scanned
+// points other than the winner and (b) the lower bounds (plane cut or box distance) of every sub-tree it discarded.  Every
+// target point except the winner is at computed squared distance >= r2.  The warm linearization pass (linearize.hip) uses it as a
+// certificate: after the query has moved by delta, the winner is still the exact nearest neighbour if its new distance is
+// below sqrt(r2) - delta.
 template <int STRIDE>
 __device__ __forceinline__ KdBest kd_nearest(const KdView& t, float qx, float qy, float qz, float bound2, int seed, uint32_t* __restrict__ stack, int tid) {
   KdBest best;
   best.d2 = bound2;
   best.idx = -1;
+  best.r2 = INFINITY;
   if (seed >= 0 && static_cast<uint32_t>(seed) < t.n) {
     const float4 c = t.pts[seed];
-    const float dx = c.x - qx, dy = c.y - qy, dz = c.z - qz;
-    const float d2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+    const float d2 = kd_dist2(c.x, c.y, c.z, qx, qy, qz);
     if (d2 < bound2) {
       best.d2 = d2;
       best.idx = seed;
@@ -125,7 +141,9 @@ __device__ __forceinline__ KdBest kd_nearest(const KdView& t, float qx, float qy
       const float cut = diff * diff;
       depth++;
       stack[sp * STRIDE + tid] = kd_pack(cut, depth);
-      sp += cut < best.d2 ? 1 : 0;
+      const bool keep = cut <= best.d2;
+      sp += keep ? 1 : 0;
+      best.r2 = keep ? best.r2 : fminf(best.r2, cut);  // discarded at once: everything beyond this plane is at >= cut
       unode = 2 * un + (right != 0ull ? 1u : 0u);
     }
     node = unode;
@@ -146,10 +164,12 @@ __device__ __forceinline__ KdBest kd_nearest(const KdView& t, float qx, float qy
         const float diff = qa - nd.x;
         const float cut = diff * diff;
         depth++;
-        // a far side at distance >= best cannot hold a closer point: the entry is written unconditionally (no branch) and only
+        // a far side beyond the best cannot hold a closer point: the entry is written unconditionally (no branch) and only
         // kept, i.e. the stack pointer advanced, if it can
         stack[sp * STRIDE + tid] = kd_pack(cut, depth);
-        sp += cut < best.d2 ? 1 : 0;
+        const bool keep = cut <= best.d2;
+        sp += keep ? 1 : 0;
+        best.r2 = keep ? best.r2 : fminf(best.r2, cut);
         node = 2 * node + (diff < 0.f ? 0u : 1u);
       }
       if (depth < D) {
@@ -161,38 +181,47 @@ __device__ __forceinline__ KdBest kd_nearest(const KdView& t, float qx, float qy
         const float cut = diff * diff;
         depth++;
         stack[sp * STRIDE + tid] = kd_pack(cut, depth);
-        sp += cut < best.d2 ? 1 : 0;
+        const bool keep = cut <= best.d2;
+        sp += keep ? 1 : 0;
+        best.r2 = keep ? best.r2 : fminf(best.r2, cut);
         node = 2 * node + (diff < 0.f ? 0u : 1u);
       }
     }
     {
       // Leaf scan, branch-free.  The 8 slots starting at the leaf's first point are read unconditionally: a leaf with fewer points
       // spills into its right neighbour (real target points, harmless candidates) and the array is padded with 8 points at
-      // infinity behind the last leaf.  Strict '<' in ascending position order: the lowest position wins ties inside a leaf.
+      // infinity behind the last leaf.  The loser of every comparison lowers the exclusion bound; a point that is scanned twice
+      // (the seed, a spilled neighbour) must not count as its own runner-up.
       const uint32_t k = node - (1u << D);
       const uint32_t first = kd_bound(t.n, D, k);
       const float4* __restrict__ lp = t.pts + first;
       float4 p[kKdLeafMax];
 #pragma unroll
       for (int i = 0; i < kKdLeafMax; i++) p[i] = lp[i];
-      int slot = -1;
 #pragma unroll
       for (int i = 0; i < kKdLeafMax; i++) {
-        const float dx = p[i].x - qx, dy = p[i].y - qy, dz = p[i].z - qz;
-        const float d2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
-        const bool closer = d2 < best.d2;
+        const float d2 = kd_dist2(p[i].x, p[i].y, p[i].z, qx, qy, qz);
+        const int pos = static_cast<int>(first) + i;
+        const bool same = pos == best.idx;
+        const bool closer = d2 < best.d2 || (d2 == best.d2 && pos < best.idx);  // best.idx == -1: only d2 < bound2 wins
+        const float loser = closer ? (best.idx >= 0 ? best.d2 : INFINITY) : d2;
+        best.r2 = same ? best.r2 : fminf(best.r2, loser);
         best.d2 = closer ? d2 : best.d2;
-        slot = closer ? i : slot;
+        best.idx = closer ? pos : best.idx;
       }
-      best.idx = slot >= 0 ? static_cast<int>(first) + slot : best.idx;
     }
-    // next pending far side that can still hold a closer point: plane test on the stored cut, then the box test
+    // next pending far side that can still hold a closer (or equidistant) point: plane test on the stored cut, then the box test
     uint32_t e = 0;
     bool found = false;
     while (sp > 0 && !found) {
       sp--;
       e = stack[sp * STRIDE + tid];
-      if (kd_cut(e) < best.d2) found = kd_box_dist2(t, (node >> (D - static_cast<int>(e & 31u))) ^ 1u, qx, qy, qz) < best.d2;
+      float lb = kd_cut(e);
+      if (lb <= best.d2) {
+        lb = kd_box_dist2(t, (node >> (D - static_cast<int>(e & 31u))) ^ 1u, qx, qy, qz);
+        found = lb <= best.d2;
+      }
+      best.r2 = found ? best.r2 : fminf(best.r2, lb);  // discarded: nothing in there is closer than lb
     }
     if (!found) break;
     depth = static_cast<int>(e & 31u);

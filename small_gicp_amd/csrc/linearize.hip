@@ -21,9 +21,10 @@ namespace sga {
 int comm_allreduce_sum(sga_context* ctx, double* d_buf, size_t count);
 
 constexpr int kTile = 256;           // threads per workgroup = source points per tile
-constexpr int kRow = 32;             // doubles per partial row (28 used + inliers)
+constexpr int kRow = 32;             // doubles per partial row (28 used + inliers + certificate failures)
 constexpr int kSearchBlock = 64;      // K1a: one wave per workgroup
 constexpr int kMaxBlocks = 2048;     // K1b / K2: 8 workgroups per CU, the whole grid is resident
+constexpr int kMaxSparseBlocks = 4096;  // warm pass: one-wave workgroups of the fallback kernel (one partial row each)
 
 template <typename Real>
 struct LinParams {
@@ -38,10 +39,14 @@ struct LinParams {
   VoxelView vox;
   FlatView flat;
   int* __restrict__ corr;
-  const int* __restrict__ hint;  // nearest neighbour per source point from nn_search_kernel (kd position) or -1
+  int* __restrict__ hint;  // exact nearest neighbour per source point at the last linearization pose (kd position) or -1
+  float* __restrict__ rex;  // its certificate: every OTHER target point was farther than rex[i] from the query at that pose
+  unsigned long long* __restrict__ fail_mask;  // warm pass: one word per 64 source points, bit = certificate failed, search again
   Real* __restrict__ maha;  // n*6
   Rigid<Real> T;
+  Rigid<Real> T_prev;  // pose of the previous linearization (warm pass)
   float max_sq;  // INFINITY = no rejector
+  float bound2;  // search bound of the nearest-neighbour search (max_sq nudged up, or INFINITY)
   int robust_kind;
   Real robust_c;
   double* __restrict__ partials;
@@ -72,19 +77,24 @@ __device__ __forceinline__ Sym3<Real> load_sym(const Cov8* __restrict__ c, int i
   return {Real(a.x), Real(a.y), Real(a.z), Real(a.w), Real(b.x), Real(b.y)};
 }
 
-// K1a: nearest neighbour of every transformed source point (kd_search.hpp); writes its kd position (or -1 when nothing lies
-// within the search bound) to nn[i].  One wave per workgroup (a finished wave frees its slot and its 4 KB of stack at once; the
-// hardware dispatcher balances the uneven walks), and without the per-pair algebra the kernel fits 8 waves per SIMD, which the
-// latency-bound walk needs.  K1b (linearize_kernel) evaluates the factors over nn[].
+// exclusion radius stored per point: sqrt of the walk's exclusion bound, rounded down
+__device__ __forceinline__ float rex_from_r2(float r2) { return sqrtf(r2) * 0.9999995f; }
+
+// K1a (cold pass): nearest neighbour of every transformed source point (kd_search.hpp); writes its kd position (or -1 when
+// nothing lies within the search bound) to nn[i] and the walk's exclusion radius to rex[i].  One wave per workgroup (a finished
+// wave frees its slot and its 4 KB of stack at once; the hardware dispatcher balances the uneven walks), and without the per-pair
+// algebra the kernel fits 8 waves per SIMD, which the latency-bound walk needs.  K1b (linearize_kernel) evaluates the factors
+// over nn[].
 template <typename Real>
 struct NNParams {
   const float4* __restrict__ src_pts;
   int n;
   KdView kd;
   Rigid<Real> T;
-  float max_sq;
+  float bound2;
   int use_seed;  // nn[] holds the neighbours found at the previous pose (or -1)
   int* __restrict__ nn;
+  float* __restrict__ rex;
 };
 
 template <typename Real, int BLOCK>
@@ -99,12 +109,80 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
   const float4 ps = p.src_pts[i];
   Real x, y, z;
   transform_point<Real>(p.T, ps.x, ps.y, ps.z, x, y, z);
-  const float bound2 = p.max_sq < 3.0e38f ? p.max_sq * 1.0000002f : INFINITY;  // d2 == max_sq must still be found (strict '>' rejector)
-  const KdBest nb = kd_nearest<BLOCK>(p.kd, static_cast<float>(x), static_cast<float>(y), static_cast<float>(z), bound2, p.use_seed ? p.nn[i] : -1, kd_stack, threadIdx.x);
+  const KdBest nb = kd_nearest<BLOCK>(p.kd, static_cast<float>(x), static_cast<float>(y), static_cast<float>(z), p.bound2, p.use_seed ? p.nn[i] : -1, kd_stack, threadIdx.x);
   p.nn[i] = nb.idx;
+  p.rex[i] = rex_from_r2(nb.r2);
 }
 
-template <typename Real, int FACTOR, int TARGET>  // TARGET: 0 kd-tree (neighbours from nn_search_kernel), 1 Gaussian voxel map, 2 flat voxel map
+// One correspondence (source point i at q = T p, target candidate j at t): rejector, fused mahalanobis, robust weight, the 28
+// values of the pair's system.  Returns whether the pair is an inlier; caches the mahalanobis (GICP).
+template <typename Real, int FACTOR>
+__device__ __forceinline__ bool pair_factor(const LinParams<Real>& p, int i, int j, bool within_bound, Real px, Real py, Real pz, Real qx, Real qy, Real qz, Real tx, Real ty, Real tz, Real* vals) {
+  const Real rx = tx - qx, ry = ty - qy, rz = tz - qz;
+  const Real d2 = rx * rx + ry * ry + rz * rz;
+  const bool inlier = (j >= 0) && within_bound && !(d2 > static_cast<Real>(p.max_sq));
+  if (inlier) {
+    Sym3<Real> M;
+    if constexpr (FACTOR == SGA_GICP) {
+      const Sym3<Real> Cs = load_sym<Real>(p.src_cov, i);
+      const Sym3<Real> Ct = load_sym<Real>(p.tgt_cov, j);
+      const Sym3<Real> RCR = rotate_sym(p.T.r, Cs);
+      M = inverse_sym<Real>({Ct.xx + RCR.xx, Ct.xy + RCR.xy, Ct.xz + RCR.xz, Ct.yy + RCR.yy, Ct.yz + RCR.yz, Ct.zz + RCR.zz});
+      Real* m = p.maha + static_cast<size_t>(i) * 6;
+      m[0] = M.xx;
+      m[1] = M.xy;
+      m[2] = M.xz;
+      m[3] = M.yy;
+      m[4] = M.yz;
+      m[5] = M.zz;
+    } else if constexpr (FACTOR == SGA_PLANE_ICP) {
+      const float4 nn = p.tgt_nrm[j];
+      M = {Real(nn.x) * Real(nn.x), Real(0), Real(0), Real(nn.y) * Real(nn.y), Real(0), Real(nn.z) * Real(nn.z)};
+    } else {
+      M = {Real(1), Real(0), Real(0), Real(1), Real(0), Real(1)};
+    }
+    Real w = Real(1);
+    if (p.robust_kind != SGA_ROBUST_NONE) {
+      const Real vx = M.xx * rx + M.xy * ry + M.xz * rz, vy = M.xy * rx + M.yy * ry + M.yz * rz, vz = M.xz * rx + M.yz * ry + M.zz * rz;
+      w = robust_weight<Real>(p.robust_kind, p.robust_c, Real(0.5) * (rx * vx + ry * vy + rz * vz));
+    }
+    pair_system<Real>(p.T.r, px, py, pz, rx, ry, rz, M, w, vals);
+  }
+  return inlier;
+}
+
+// fold one tile's per-lane values into the wave's fp64 accumulator row (acc_row: 32 doubles in LDS, owned by this wave)
+template <typename Real>
+__device__ __forceinline__ void accumulate_wave(const Real* vals, bool inlier, double* acc_row, int lane) {
+  const unsigned long long inl_mask = __ballot(inlier);
+  if (inl_mask == 0ull) return;  // wave-uniform
+  if constexpr (sizeof(Real) == 4) {
+#pragma unroll
+    for (int k = 0; k < 27; k++) {
+      const float s = wave_sum_to_lane63(vals[k]);
+      if (lane == 63) acc_row[k] += static_cast<double>(s);
+    }
+    const double e = wave_sum_f64(static_cast<double>(vals[27]));
+    if (lane == 63) acc_row[27] += e;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 28; k++) {
+      const double s = wave_sum_f64(vals[k]);
+      if (lane == 63) acc_row[k] += s;
+    }
+  }
+  if (lane == 63) acc_row[28] += static_cast<double>(__popcll(inl_mask));
+}
+
+// K1b.  TARGET: 0 kd-tree, 1 Gaussian voxel map, 2 flat voxel map (the lookup of a voxel target happens right here).
+// PHASE (kd-tree targets): 0 = cold pass, the neighbours come from nn_search_kernel.
+//                          1 = warm pass: NO search.  hint[i] is the exact nearest neighbour found at the previous linearization
+// pose and rex[i] its exclusion radius (every other target point was farther than rex[i] from the query then).  The query has
+// moved by delta = |T p - T_prev p| since; if the old neighbour is now closer than rex[i] - delta, no other point can be closer
+// (triangle inequality) and it is still the exact nearest neighbour: the lane evaluates its factor at once and shrinks the
+// radius by delta.  Otherwise its bit is set in fail_mask and sparse_search_linearize_kernel searches again.  A small relative
+// margin covers the rounding of the fp32 distances; it only ever sends a lane to the search, never changes a result.
+template <typename Real, int FACTOR, int TARGET, int PHASE>
 __global__ __launch_bounds__(kTile) void linearize_kernel(const LinParams<Real> p) {
   __shared__ double sh_acc[kTile / 64][kRow];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -129,6 +207,7 @@ __global__ __launch_bounds__(kTile) void linearize_kernel(const LinParams<Real> 
     }
     int j = -1;
     Real tx = 0, ty = 0, tz = 0;
+    bool within = true, failed = false;
     if constexpr (TARGET == 2) {
       if (active) {
         float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -149,68 +228,39 @@ __global__ __launch_bounds__(kTile) void linearize_kernel(const LinParams<Real> 
       }
     } else {
       if (active) {
-        j = p.hint[i];  // nearest neighbour found by nn_search_kernel (kd position) or -1
+        j = p.hint[i];
+        const float fx = static_cast<float>(qx), fy = static_cast<float>(qy), fz = static_cast<float>(qz);
+        float d2f = INFINITY;
         if (j >= 0) {
           const float4 m = p.tgt_pts[j];
           tx = m.x;
           ty = m.y;
           tz = m.z;
+          d2f = kd_dist2(m.x, m.y, m.z, fx, fy, fz);
+        }
+        within = d2f < p.bound2;  // what the search itself would have returned at this pose
+        if constexpr (PHASE == 1) {
+          Real ox, oy, oz;
+          transform_point(p.T_prev, px, py, pz, ox, oy, oz);
+          const float moved = sqrtf(kd_dist2(static_cast<float>(ox), static_cast<float>(oy), static_cast<float>(oz), fx, fy, fz)) * 1.000001f;
+          const float lim = p.rex[i] - moved;
+          const float lim2 = lim > 0.f ? lim * lim * 0.999995f : -1.f;
+          const bool ok = j >= 0 ? d2f < lim2 : lim2 > p.bound2;  // no neighbour within the bound before: still none
+          failed = !ok;
+          if (ok) p.rex[i] = lim * 0.9999995f;
         }
       }
     }
-    if (active) {
-      const Real rx = tx - qx, ry = ty - qy, rz = tz - qz;
-      const Real d2 = rx * rx + ry * ry + rz * rz;
-      inlier = (j >= 0) && !(d2 > static_cast<Real>(p.max_sq));
-      if (inlier) {
-        Sym3<Real> M;
-        if constexpr (FACTOR == SGA_GICP) {
-          const Sym3<Real> Cs = load_sym<Real>(p.src_cov, i);
-          const Sym3<Real> Ct = load_sym<Real>(p.tgt_cov, j);
-          const Sym3<Real> RCR = rotate_sym(p.T.r, Cs);
-          M = inverse_sym<Real>({Ct.xx + RCR.xx, Ct.xy + RCR.xy, Ct.xz + RCR.xz, Ct.yy + RCR.yy, Ct.yz + RCR.yz, Ct.zz + RCR.zz});
-          Real* m = p.maha + static_cast<size_t>(i) * 6;
-          m[0] = M.xx;
-          m[1] = M.xy;
-          m[2] = M.xz;
-          m[3] = M.yy;
-          m[4] = M.yz;
-          m[5] = M.zz;
-        } else if constexpr (FACTOR == SGA_PLANE_ICP) {
-          const float4 nn = p.tgt_nrm[j];
-          M = {Real(nn.x) * Real(nn.x), Real(0), Real(0), Real(nn.y) * Real(nn.y), Real(0), Real(nn.z) * Real(nn.z)};
-        } else {
-          M = {Real(1), Real(0), Real(0), Real(1), Real(0), Real(1)};
-        }
-        Real w = Real(1);
-        if (p.robust_kind != SGA_ROBUST_NONE) {
-          const Real vx = M.xx * rx + M.xy * ry + M.xz * rz, vy = M.xy * rx + M.yy * ry + M.yz * rz, vz = M.xz * rx + M.yz * ry + M.zz * rz;
-          w = robust_weight<Real>(p.robust_kind, p.robust_c, Real(0.5) * (rx * vx + ry * vy + rz * vz));
-        }
-        pair_system<Real>(p.T.r, px, py, pz, rx, ry, rz, M, w, vals);
-      }
+    if constexpr (PHASE == 1) {
+      const unsigned long long fmask = __ballot(failed);
+      if (lane == 0) p.fail_mask[static_cast<size_t>(tile) * (kTile / 64) + wave] = fmask;
+      if (lane == 63 && fmask != 0ull) sh_acc[wave][29] += static_cast<double>(__popcll(fmask));
+    }
+    if (active && !failed) {
+      inlier = pair_factor<Real, FACTOR>(p, i, j, within, px, py, pz, qx, qy, qz, tx, ty, tz, vals);
       p.corr[i] = inlier ? j : -1;
     }
-    // ---- wave reduction of this tile ----
-    const unsigned long long inl_mask = __ballot(inlier);
-    if (inl_mask != 0ull) {  // wave-uniform
-      if constexpr (sizeof(Real) == 4) {
-#pragma unroll
-        for (int k = 0; k < 27; k++) {
-          const float s = wave_sum_to_lane63(vals[k]);
-          if (lane == 63) sh_acc[wave][k] += static_cast<double>(s);
-        }
-        const double e = wave_sum_f64(static_cast<double>(vals[27]));
-        if (lane == 63) sh_acc[wave][27] += e;
-      } else {
-#pragma unroll
-        for (int k = 0; k < 28; k++) {
-          const double s = wave_sum_f64(vals[k]);
-          if (lane == 63) sh_acc[wave][k] += s;
-        }
-      }
-      if (lane == 63) sh_acc[wave][28] += static_cast<double>(__popcll(inl_mask));
-    }
+    accumulate_wave<Real>(vals, inlier, sh_acc[wave], lane);
   }
   __syncthreads();
   if (threadIdx.x < kRow) {
@@ -219,6 +269,64 @@ __global__ __launch_bounds__(kTile) void linearize_kernel(const LinParams<Real> 
     for (int w = 0; w < kTile / 64; w++) s += sh_acc[w][threadIdx.x];
     p.partials[static_cast<size_t>(blockIdx.x) * kRow + threadIdx.x] = s;
   }
+}
+
+// Warm pass, second kernel: the source points whose certificate failed (fail_mask) are searched again — the exact walk of
+// kd_search.hpp, seeded with the old neighbour, which usually IS the answer, so the walk is a short verification — and their
+// factors are evaluated right here (a few per cent of the points: occupancy does not matter, one launch less).  One wave per
+// workgroup; a wave owns `S` consecutive 64-point groups (a "span"), gathers the failed points of its span into LDS in ascending
+// order (deterministic, and neighbours in the sorted source stay neighbours in the wave) and walks them 64 at a time.
+// Every workgroup writes one partial row (zeros if it found nothing to do).
+template <typename Real, int FACTOR>
+__global__ __launch_bounds__(kSearchBlock) void sparse_search_linearize_kernel(const LinParams<Real> p, int S, int num_spans, int num_groups, double* __restrict__ rows) {
+  extern __shared__ uint32_t sparse_smem[];  // S * 64 point ids, then tree depth x 64 stack slots
+  __shared__ double sh_acc[kRow];
+  uint32_t* list = sparse_smem;
+  uint32_t* stack = sparse_smem + static_cast<size_t>(S) * 64;
+  const int lane = threadIdx.x;
+  if (lane < kRow) sh_acc[lane] = 0.0;
+  const int nblk = gridDim.x, per_xcd = nblk >> 3, b = blockIdx.x;
+  const bool one_each = nblk == num_spans;  // one span per workgroup: XCD-aware order like the dense kernels
+  int span = one_each ? (b < 8 * per_xcd ? (b & 7) * per_xcd + (b >> 3) : b) : b;
+  for (; span < num_spans; span += one_each ? num_spans : nblk) {
+    int total = 0;
+    for (int g = 0; g < S; g++) {
+      const int gi = span * S + g;
+      const unsigned long long m = gi < num_groups ? p.fail_mask[gi] : 0ull;  // wave-uniform
+      if ((m >> lane) & 1ull) list[total + __popcll(m & ((1ull << lane) - 1ull))] = static_cast<uint32_t>(gi * 64 + lane);
+      total += __popcll(m);
+    }
+    __syncthreads();
+    for (int c0 = 0; c0 < total; c0 += 64) {
+      const bool act = c0 + lane < total;
+      Real vals[28];
+#pragma unroll
+      for (int k = 0; k < 28; k++) vals[k] = Real(0);
+      bool inlier = false;
+      if (act) {
+        const int i = static_cast<int>(list[c0 + lane]);
+        const float4 ps4 = p.src_pts[i];
+        const Real px = ps4.x, py = ps4.y, pz = ps4.z;
+        Real qx, qy, qz;
+        transform_point(p.T, px, py, pz, qx, qy, qz);
+        const KdBest nb = kd_nearest<kSearchBlock>(p.kd, static_cast<float>(qx), static_cast<float>(qy), static_cast<float>(qz), p.bound2, p.hint[i], stack, lane);
+        p.hint[i] = nb.idx;
+        p.rex[i] = rex_from_r2(nb.r2);
+        Real tx = 0, ty = 0, tz = 0;
+        if (nb.idx >= 0) {
+          const float4 m = p.tgt_pts[nb.idx];
+          tx = m.x;
+          ty = m.y;
+          tz = m.z;
+        }
+        inlier = pair_factor<Real, FACTOR>(p, i, nb.idx, true, px, py, pz, qx, qy, qz, tx, ty, tz, vals);
+        p.corr[i] = inlier ? nb.idx : -1;
+      }
+      accumulate_wave<Real>(vals, inlier, sh_acc, lane);
+    }
+    __syncthreads();  // the list is rewritten by the next span
+  }
+  if (lane < kRow) rows[static_cast<size_t>(blockIdx.x) * kRow + lane] = sh_acc[lane];
 }
 
 template <typename Real>
@@ -340,10 +448,39 @@ static void launch_reduce(sga_context* ctx, const double* partials, int nrows, i
 
 static int grid_blocks(int num_tiles) { return num_tiles < kMaxBlocks ? (num_tiles < 1 ? 1 : num_tiles) : kMaxBlocks; }
 
-template <typename Real, int FACTOR, int TARGET>
+template <typename Real, int FACTOR, int TARGET, int PHASE = 0>
 static void launch_linearize(hipStream_t st, const LinParams<Real>& p, int blocks) {
-  hipLaunchKernelGGL((linearize_kernel<Real, FACTOR, TARGET>), dim3(blocks), dim3(kTile), 0, st, p);
+  hipLaunchKernelGGL((linearize_kernel<Real, FACTOR, TARGET, PHASE>), dim3(blocks), dim3(kTile), 0, st, p);
 }
+
+// Largest displacement |Ta p - Tb p| over the box [lo, hi] (column-major 4x4 poses): the norm of an affine map is convex, so the
+// maximum sits at a corner.
+static double max_displacement(const double Ta[16], const double Tb[16], const float lo[3], const float hi[3]) {
+  double best = 0.0;
+  for (int c = 0; c < 8; c++) {
+    const double x = (c & 1) ? hi[0] : lo[0], y = (c & 2) ? hi[1] : lo[1], z = (c & 4) ? hi[2] : lo[2];
+    double s = 0.0;
+    for (int r = 0; r < 3; r++) {
+      const double d = (Ta[r] - Tb[r]) * x + (Ta[4 + r] - Tb[4 + r]) * y + (Ta[8 + r] - Tb[8 + r]) * z + (Ta[12 + r] - Tb[12 + r]);
+      s += d * d;
+    }
+    best = std::max(best, s);
+  }
+  return std::sqrt(best);
+}
+
+// Tunables of the warm pass (metres of source-point motion since the previous linearization): above the warm limit the
+// certificates are hopeless and the pass runs cold (full search); below the dense limit nearly all of them hold and the fallback
+// kernel gathers the failures of 8 wave tiles into one wave, in between of 2.  Defaults can be overridden by the environment
+// (SGA_WARM_DELTA, SGA_WARM_DENSE_DELTA) or at run time with sga_set_warm_limits (a negative warm limit disables warm passes).
+static double env_double(const char* name, double dflt) {
+  const char* v = getenv(name);
+  return v ? atof(v) : dflt;
+}
+static double g_warm_delta = env_double("SGA_WARM_DELTA", 0.02);
+static double g_warm_dense_delta = env_double("SGA_WARM_DENSE_DELTA", 0.003);
+static double warm_delta() { return g_warm_delta; }
+static double warm_dense_delta() { return g_warm_dense_delta; }
 
 template <typename Real>
 static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, const double T[16], double* d_out30, double* host, unsigned long long seq) {
@@ -379,6 +516,8 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
   }
   p.corr = pb->corr.p;
   p.hint = pb->hint.p;
+  p.rex = pb->rex.p;
+  p.fail_mask = pb->fail_mask.p;
   if constexpr (sizeof(Real) == 4) {
     p.maha = pb->maha.p;
   } else {
@@ -387,31 +526,45 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
   }
   p.T = rigid_from_colmajor<Real>(T);
   p.max_sq = fp->max_dist_sq < 0 ? INFINITY : static_cast<float>(fp->max_dist_sq);
+  p.bound2 = p.max_sq < 3.0e38f ? p.max_sq * 1.0000002f : INFINITY;  // d2 == max_sq must still be found (strict '>' rejector)
   p.robust_kind = fp->robust_kind;
   p.robust_c = static_cast<Real>(fp->robust_c);
   p.partials = pb->partials.p;
   const int blocks = grid_blocks(p.num_tiles);
+  int rows = p.n > 0 ? blocks : 0;
+
+  // warm pass?  Only against a kd-tree, with certificates from a previous pass in the same arithmetic, and only while no source
+  // point can have moved farther than the certificates can possibly cover.
+  const int math = sizeof(Real) == 4 ? SGA_MATH_FP32 : SGA_MATH_FP64;
+  double moved = 0.0;
+  bool warm = false;
+  if (!voxel && p.n > 0 && pb->prev_valid && pb->prev_math == math) {
+    moved = max_displacement(T, pb->T_prev, pb->bbox_lo, pb->bbox_hi);
+    warm = moved <= warm_delta();
+  }
 
   const bool timed = ctx->profiling && (ctx->lin_seq++ % ctx->profile_period) == 0;  // sampled: event records cost ~7 us each
   if (timed) {
     sga_profile_collect_pending(ctx);
     (void)hipEventRecord(ctx->ev0, ctx->stream);
+    ctx->pending_warm = warm;
   }
-  if (p.n > 0 && !voxel) {
+  if (p.n > 0 && !voxel && !warm) {
     NNParams<Real> q{};
     q.src_pts = pb->pts.p;
     q.n = p.n;
     q.kd = p.kd;
     q.T = p.T;
-    q.max_sq = p.max_sq;
+    q.bound2 = p.bound2;
     q.nn = pb->hint.p;
+    q.rex = pb->rex.p;
     q.use_seed = 1;
     const size_t words = static_cast<size_t>(std::max(p.kd.depth, 1));
     hipLaunchKernelGGL((nn_search_kernel<Real, kSearchBlock>), dim3((p.n + kSearchBlock - 1) / kSearchBlock), dim3(kSearchBlock), words * kSearchBlock * sizeof(uint32_t), ctx->stream, q);
-    if (timed) {
-      (void)hipEventRecord(ctx->ev_mid, ctx->stream);
-      ctx->mid_recorded = true;
-    }
+  }
+  if (timed && !voxel && p.n > 0 && !warm) {
+    (void)hipEventRecord(ctx->ev_mid, ctx->stream);
+    ctx->mid_recorded = true;
   }
   if (p.n > 0) {
     if (flat) {
@@ -424,20 +577,50 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
         launch_linearize<Real, SGA_GICP, 1>(ctx->stream, p, blocks);
       else
         launch_linearize<Real, SGA_ICP, 1>(ctx->stream, p, blocks);
-    } else {
+    } else if (!warm) {
       switch (fp->factor_kind) {
         case SGA_GICP: launch_linearize<Real, SGA_GICP, 0>(ctx->stream, p, blocks); break;
         case SGA_PLANE_ICP: launch_linearize<Real, SGA_PLANE_ICP, 0>(ctx->stream, p, blocks); break;
         default: launch_linearize<Real, SGA_ICP, 0>(ctx->stream, p, blocks); break;
       }
+    } else {
+      p.T_prev = rigid_from_colmajor<Real>(pb->T_prev);
+      switch (fp->factor_kind) {
+        case SGA_GICP: launch_linearize<Real, SGA_GICP, 0, 1>(ctx->stream, p, blocks); break;
+        case SGA_PLANE_ICP: launch_linearize<Real, SGA_PLANE_ICP, 0, 1>(ctx->stream, p, blocks); break;
+        default: launch_linearize<Real, SGA_ICP, 0, 1>(ctx->stream, p, blocks); break;
+      }
+      const int S = moved <= warm_dense_delta() ? 8 : 2;
+      const int num_groups = p.num_tiles * (kTile / 64);
+      const int num_spans = (num_groups + S - 1) / S;
+      const int sblocks = std::min(num_spans, kMaxSparseBlocks);
+      const size_t shmem = (static_cast<size_t>(S) * 64 + static_cast<size_t>(std::max(p.kd.depth, 1)) * kSearchBlock) * sizeof(uint32_t);
+      double* srows = pb->partials.p + static_cast<size_t>(rows) * kRow;
+      switch (fp->factor_kind) {
+        case SGA_GICP: hipLaunchKernelGGL((sparse_search_linearize_kernel<Real, SGA_GICP>), dim3(sblocks), dim3(kSearchBlock), shmem, ctx->stream, p, S, num_spans, num_groups, srows); break;
+        case SGA_PLANE_ICP: hipLaunchKernelGGL((sparse_search_linearize_kernel<Real, SGA_PLANE_ICP>), dim3(sblocks), dim3(kSearchBlock), shmem, ctx->stream, p, S, num_spans, num_groups, srows); break;
+        default: hipLaunchKernelGGL((sparse_search_linearize_kernel<Real, SGA_ICP>), dim3(sblocks), dim3(kSearchBlock), shmem, ctx->stream, p, S, num_spans, num_groups, srows); break;
+      }
+      rows += sblocks;
     }
   }
   if (timed) {
     (void)hipEventRecord(ctx->ev1, ctx->stream);
     ctx->pending |= 1;
   }
-  launch_reduce(ctx, pb->partials.p, p.n > 0 ? blocks : 0, 29, kRow, pb->partials.p + static_cast<size_t>(kMaxBlocks) * kRow, d_out30, SGA_ACCUM_DOUBLES, host, seq);
+  launch_reduce(ctx, pb->partials.p, rows, 30, kRow, pb->partials.p + static_cast<size_t>(kMaxBlocks + kMaxSparseBlocks) * kRow, d_out30, SGA_ACCUM_DOUBLES, host, seq);
   SGA_HIP(hipGetLastError());
+  pb->last_math = math;
+  if (!voxel) {
+    memcpy(pb->T_prev, T, sizeof(pb->T_prev));
+    pb->prev_valid = true;
+    pb->prev_math = math;
+    if (warm)
+      pb->warm_passes++;
+    else
+      pb->cold_passes++;
+    pb->last_pass_warm = warm;
+  }
   return SGA_OK;
 }
 
@@ -480,12 +663,12 @@ static int error_dispatch(sga_context* ctx, sga_problem* pb, const sga_factor_pa
     (void)hipEventRecord(ctx->ev3, ctx->stream);
     ctx->pending |= 2;
   }
-  launch_reduce(ctx, pb->partials.p, p.n > 0 ? blocks : 0, 1, 1, pb->partials.p + static_cast<size_t>(kMaxBlocks) * kRow, d_out1, 1, host, seq);
+  launch_reduce(ctx, pb->partials.p, p.n > 0 ? blocks : 0, 1, 1, pb->partials.p + static_cast<size_t>(kMaxBlocks + kMaxSparseBlocks) * kRow, d_out1, 1, host, seq);
   SGA_HIP(hipGetLastError());
   return SGA_OK;
 }
 
-int problem_partials_rows() { return kMaxBlocks + kReduceGroups; }  // K1/K2 partial rows + the stage-1 rows of the reduction
+int problem_partials_rows() { return kMaxBlocks + kMaxSparseBlocks + kReduceGroups; }  // K1/K2 partial rows + the stage-1 rows of the reduction
 
 // Hand `count` doubles to the host after an all-reduce (see reduce_rows_kernel for the protocol).
 __global__ void publish_kernel(const double* __restrict__ src, int count, double* __restrict__ host, unsigned long long seq) {
@@ -538,6 +721,13 @@ void sga_profile_collect_pending(sga_context* ctx) {
     if (hipEventSynchronize(ctx->ev1) == hipSuccess && hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) {
       ctx->lin_ms += ms;
       ctx->lin_calls++;
+      if (ctx->pending_warm) {
+        ctx->warm_ms += ms;
+        ctx->warm_calls++;
+      } else {
+        ctx->cold_ms += ms;
+        ctx->cold_calls++;
+      }
       if (ctx->mid_recorded && hipEventElapsedTime(&ms, ctx->ev0, ctx->ev_mid) == hipSuccess) {
         ctx->search_ms += ms;
         ctx->search_calls++;
@@ -574,6 +764,16 @@ void sga_unpack_accumulator(const double acc[SGA_ACCUM_DOUBLES], double H[36], d
   if (num_inliers) *num_inliers = static_cast<uint64_t>(acc[28] + 0.5);
 }
 
+void sga_set_warm_limits(double warm_delta_m, double dense_delta_m) {
+  g_warm_delta = warm_delta_m;
+  g_warm_dense_delta = dense_delta_m;
+}
+
+void sga_get_warm_limits(double* warm_delta_m, double* dense_delta_m) {
+  if (warm_delta_m) *warm_delta_m = g_warm_delta;
+  if (dense_delta_m) *dense_delta_m = g_warm_dense_delta;
+}
+
 int sga_linearize_async(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, const double T[16], double* d_out30) {
   SGA_TRY(check_args(ctx, pb, fp, T));
   if (!d_out30) return fail(SGA_ERR_INVALID, "null output");
@@ -599,6 +799,7 @@ int sga_linearize(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp
   SGA_TRY(comm_allreduce_sum(ctx, ctx->d_accum.p, SGA_ACCUM_DOUBLES));  // source sharded over ranks: sum the shards' systems
   SGA_TRY(fetch_result(ctx, ctx->d_accum.p, SGA_ACCUM_DOUBLES, seq, direct));
   sga_unpack_accumulator(ctx->h_accum, H, b, e, num_inliers);
+  if (pb->last_pass_warm) pb->fallback_points += static_cast<uint64_t>(ctx->h_accum[29] + 0.5);
   return SGA_OK;
 }
 

@@ -251,7 +251,10 @@ int sga_align_problem(sga_context* ctx, sga_problem* problem, const double init_
   if (problem->target->n <= 10) std::fprintf(stderr, "warning: target point cloud is too small. |target|=%zu\n", problem->target->n);
   if (problem->n <= 10) std::fprintf(stderr, "warning: source point cloud is too small. |source|=%zu\n", problem->n);
   // every registration starts without search hints: its result must not depend on earlier calls on the same problem
+  // (with the canonical tie rule of kd_search.hpp they could not change it anyway; what this guarantees is that no search work is
+  // carried over from one registration to the next)
   if (problem->n > 0) SGA_HIP(hipMemsetAsync(problem->hint.p, 0xff, problem->n * sizeof(int), ctx->stream));
+  problem->prev_valid = false;
   GpuReduction g{ctx, problem, &setting->factor};
   return optimize_impl(*setting, init_T ? init_T : I16, gpu_linearize, gpu_error, &g, out);
 }

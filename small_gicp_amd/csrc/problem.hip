@@ -14,6 +14,7 @@ namespace sga {
 
 int ensure_temp(sga_context* ctx, size_t bytes);
 int problem_partials_rows();
+int cloud_bbox(sga_context* ctx, const float4* pts, size_t n, float lo[3], float hi[3]);
 
 __device__ __forceinline__ unsigned long long spread3(unsigned long long v) {
   v &= 0x1fffffull;
@@ -177,6 +178,8 @@ int sga_problem_create(sga_context* ctx, const sga_index* target, const sga_clou
     if (source->has_covs) SGA_TRY(pb->cov.alloc(n));
     SGA_TRY(pb->corr.alloc(n));
     SGA_TRY(pb->hint.alloc(n));
+    SGA_TRY(pb->rex.alloc(n));
+    SGA_TRY(pb->fail_mask.alloc((n + 255) / 256 * 4));  // one word per 64 points, whole 256-point tiles
     SGA_TRY(pb->maha.alloc(n * 6));
     SGA_HIP(hipMemsetAsync(pb->corr.p, 0xff, n * sizeof(int), ctx->stream));
     SGA_HIP(hipMemsetAsync(pb->hint.p, 0xff, n * sizeof(int), ctx->stream));
@@ -210,7 +213,7 @@ int sga_problem_create(sga_context* ctx, const sga_index* target, const sga_clou
     SGA_HIP(rocprim::radix_sort_pairs(ctx->d_temp.p, tb, keys.p, keys_sorted.p, vals.p, order.p, n, 0, 63, ctx->stream));
     hipLaunchKernelGGL(gather_source_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, order.p, n, source->pts.p, source->cov.p, pb->pts.p, pb->cov.p);
     SGA_HIP(hipGetLastError());
-    SGA_HIP(hipStreamSynchronize(ctx->stream));
+    SGA_TRY(cloud_bbox(ctx, source->pts.p, n, pb->bbox_lo, pb->bbox_hi));  // synchronises the stream
   }
   *out = pb.release();
   return SGA_OK;
@@ -224,6 +227,14 @@ int sga_problem_destroy(sga_problem* problem) {
   return SGA_OK;
 }
 
+int sga_problem_get_pass_stats(const sga_problem* pb, uint64_t* cold_passes, uint64_t* warm_passes, uint64_t* fallback_points) {
+  if (!pb) return fail(SGA_ERR_INVALID, "null argument");
+  if (cold_passes) *cold_passes = pb->cold_passes;
+  if (warm_passes) *warm_passes = pb->warm_passes;
+  if (fallback_points) *fallback_points = pb->fallback_points;
+  return SGA_OK;
+}
+
 int sga_problem_get_factors(sga_context* ctx, const sga_problem* pb, int64_t* target_index, float* mahalanobis6) {
   if (!ctx || !pb) return fail(SGA_ERR_INVALID, "null argument");
   const size_t n = pb->n;
@@ -233,7 +244,12 @@ int sga_problem_get_factors(sga_context* ctx, const sga_problem* pb, int64_t* ta
   DevBuf<float> d_m;
   if (target_index) SGA_TRY(d_idx.alloc(n));
   if (mahalanobis6) SGA_TRY(d_m.alloc(n * 6));
-  hipLaunchKernelGGL((export_factors_kernel<float>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, pb->pts.p, pb->corr.p, pb->maha.p, n, pb->target->kind != SGA_INDEX_KDTREE ? pb->target->pts.p : pb->target->kd_pts.p, pb->target->kind == SGA_INDEX_FLATMAP ? 1 : 0, d_idx.p, d_m.p);
+  const float4* tpts = pb->target->kind != SGA_INDEX_KDTREE ? pb->target->pts.p : pb->target->kd_pts.p;
+  const int is_flat = pb->target->kind == SGA_INDEX_FLATMAP ? 1 : 0;
+  if (pb->last_math == SGA_MATH_FP64 && pb->maha64.p != nullptr)  // the last linearize cached its mahalanobis in fp64
+    hipLaunchKernelGGL((export_factors_kernel<double>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, pb->pts.p, pb->corr.p, pb->maha64.p, n, tpts, is_flat, d_idx.p, d_m.p);
+  else
+    hipLaunchKernelGGL((export_factors_kernel<float>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, pb->pts.p, pb->corr.p, pb->maha.p, n, tpts, is_flat, d_idx.p, d_m.p);
   SGA_HIP(hipGetLastError());
   if (target_index) SGA_HIP(hipMemcpyAsync(target_index, d_idx.p, n * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
   if (mahalanobis6) SGA_HIP(hipMemcpyAsync(mahalanobis6, d_m.p, n * 6 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));

@@ -1,0 +1,133 @@
+"""Warm linearization passes (certified neighbours, linearize.hip) give the same correspondences and the same sums as cold passes
+(full search of every source point) — on a real MI355X through the C-ABI.
+
+The warm pass never searches: it keeps the exact neighbour of the previous linearization as long as its certificate holds (new
+distance < exclusion radius - motion) and re-searches only the points whose certificate fails.  Exactness is by construction; these
+tests check it on whole pose chains shaped like a registration (large steps first, then ever smaller ones), on tie-heavy lattices,
+with the rejector on and off, for every factor, and with the limits forced so that nearly every certificate fails.
+"""
+import numpy as np
+import pytest
+
+import small_gicp_amd as sga
+from conftest import pose_error
+
+pytestmark = pytest.mark.gpu
+
+
+def se3(axis, ang, t):
+    from scipy.spatial.transform import Rotation
+
+    T = np.eye(4)
+    T[:3, :3] = Rotation.from_rotvec(np.asarray(axis, dtype=np.float64) / np.linalg.norm(axis) * ang).as_matrix()
+    T[:3, 3] = t
+    return T
+
+
+def pose_chain(T_goal, fractions=(0.0, 0.55, 0.9, 0.985, 0.998, 0.9997, 0.99996, 1.0, 1.0)):
+    """Poses approaching T_goal like an LM run: screw interpolation at the given fractions (steps shrink by ~an order each)."""
+    from scipy.spatial.transform import Rotation
+
+    rv = Rotation.from_matrix(T_goal[:3, :3]).as_rotvec()
+    out = []
+    for f in fractions:
+        T = np.eye(4)
+        T[:3, :3] = Rotation.from_rotvec(rv * f).as_matrix()
+        T[:3, 3] = T_goal[:3, 3] * f
+        out.append(T)
+    return out
+
+
+@pytest.fixture(autouse=True)
+def restore_limits():
+    lim = sga.get_warm_limits()
+    yield
+    sga.set_warm_limits(*lim)
+
+
+def run_chain(tree, src, setting, poses, limits, rel):
+    """linearize along `poses` on two problems: one with warm passes (limits), one cold only; everything must agree."""
+    pw, pc = sga.Problem(tree, src), sga.Problem(tree, src)
+    for k, T in enumerate(poses):
+        sga.set_warm_limits(*limits)
+        Hw, bw, ew, nw = pw.linearize(setting.factor, T)
+        e2w = pw.error(setting.factor, T)
+        cw, mw = pw.factors()
+        sga.set_warm_limits(-1.0, 0.0)
+        Hc, bc, ec, nc = pc.linearize(setting.factor, T)
+        cc, mc = pc.factors()
+        assert (cw == cc).all(), (k, int((cw != cc).sum()))
+        assert nw == nc, (k, nw, nc)
+        scale = max(np.abs(Hc).max(), 1e-30)
+        assert np.abs(Hw - Hc).max() <= rel * scale and np.abs(bw - bc).max() <= rel * max(np.abs(bc).max(), scale * 1e-3), k
+        assert abs(ew - ec) <= rel * max(abs(ec), 1e-30) and abs(e2w - ew) <= 1e-5 * max(abs(ew), 1e-30), k
+        assert np.allclose(mw, mc, rtol=1e-5, atol=1e-30), k  # the cached mahalanobis: same pairs, same arithmetic
+    sw, sc = pw.pass_stats(), pc.pass_stats()
+    assert sc["warm_passes"] == 0 and sc["cold_passes"] == len(poses)
+    return sw
+
+
+@pytest.mark.parametrize("kind", ["GICP", "PLANE_ICP", "ICP"])
+@pytest.mark.parametrize("mode", ["fp32", "fp64"])
+def test_warm_equals_cold_on_c1(c1_f32, kind, mode):
+    d = c1_f32
+    tgt = sga.PointCloud(d["tp"], d["tn"], d["tc"])
+    src = sga.PointCloud(d["sp"], d["sn"], d["sc"])
+    tree = sga.KdTree(tgt)
+    st = sga.make_setting(kind, math_mode=mode)
+    goal = se3([0.1, 0.2, 1.0], np.deg2rad(0.7), [0.49, 0.12, -0.02])
+    stats = run_chain(tree, src, st, pose_chain(goal), sga.get_warm_limits(), 1e-6 if mode == "fp32" else 1e-12)
+    assert stats["warm_passes"] >= 4, stats  # the small steps of the chain ran without a search
+    assert stats["fallback_points"] < 0.2 * len(d["sp"]) * stats["warm_passes"], stats
+
+
+def test_warm_with_every_certificate_failing(c1_f32):
+    """Limits forced wide open: every pass after the first is 'warm' although the points move by decimetres, so nearly every
+    certificate fails and the fallback kernel does the whole search (both packings) — still the same answer."""
+    d = c1_f32
+    tgt = sga.PointCloud(d["tp"], d["tn"], d["tc"])
+    src = sga.PointCloud(d["sp"], d["sn"], d["sc"])
+    tree = sga.KdTree(tgt)
+    goal = se3([0.3, -0.2, 1.0], np.deg2rad(3.0), [0.6, -0.3, 0.1])
+    for limits in ((100.0, 0.0), (100.0, 100.0)):  # 2 resp. 8 wave tiles per fallback wave
+        for st in (sga.make_setting("GICP"), sga.make_setting("GICP", max_correspondence_distance=-1.0), sga.make_setting("ICP", max_correspondence_distance=0.3)):
+            stats = run_chain(tree, src, st, pose_chain(goal, (0.0, 0.3, 0.6, 0.8, 0.9, 1.0)), limits, 1e-6)
+            assert stats["warm_passes"] == 5 and stats["fallback_points"] > 0.5 * len(d["sp"]), stats
+
+
+def test_warm_on_lattice_ties():
+    """Integer-lattice target (every query has equidistant candidates, kdtree_synthetic_test.cpp:26-76 style) and sub-millimetre
+    steps: the canonical tie rule (lowest kd position) makes warm and cold agree on every correspondence."""
+    g = np.arange(-6, 7, dtype=np.float32)
+    lattice = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    rng = np.random.default_rng(3)
+    src_pts = np.concatenate([lattice[rng.choice(len(lattice), 800, replace=False)] + 0.5, lattice[:500] + np.float32(0.25), rng.uniform(-6, 6, (700, 3)).astype(np.float32)]).astype(np.float32)
+    tree = sga.KdTree(sga.PointCloud(lattice))
+    src = sga.PointCloud(src_pts)
+    st = sga.make_setting("ICP", max_correspondence_distance=2.0)
+    poses = [np.eye(4)] + [se3([0, 0, 1], 1e-5 * k, [2e-4 * k, -1e-4 * k, 0.0]) for k in range(1, 6)] + [np.eye(4)]
+    stats = run_chain(tree, src, st, poses, (0.02, 0.003), 1e-6)
+    assert stats["warm_passes"] == len(poses) - 1
+
+
+def test_warm_registration_matches_cold_registration_100k():
+    """Whole registrations (LM from the identity to convergence) on the synthetic 100k pair: identical iteration count, inliers and
+    final correspondences; poses equal to rounding of the fp64 sums."""
+    target, source, T_gt = sga.synthetic.registration_pair(100_000)
+    tgt, src = sga.PointCloud(target), sga.PointCloud(source)
+    sga.estimate_covariances(tgt, None, 20)
+    sga.estimate_covariances(src, None, 20)
+    tree = sga.KdTree(tgt)
+    st = sga.make_setting("GICP", max_correspondence_distance=1.0)
+    pw, pc = sga.Problem(tree, src), sga.Problem(tree, src)
+    rw = pw.align(st)
+    sga.set_warm_limits(-1.0, 0.0)
+    rc = pc.align(st)
+    assert rw.iterations == rc.iterations and rw.num_inliers == rc.num_inliers and rw.converged == rc.converged
+    dt, dr = pose_error(rw.T_target_source, rc.T_target_source)
+    assert dt < 1e-9 and dr < 1e-9, (dt, dr)
+    assert (pw.factors()[0] == pc.factors()[0]).all()
+    sw = pw.pass_stats()
+    assert sw["warm_passes"] >= 1 and sw["cold_passes"] >= 1, sw
+    dt, dr = pose_error(rw.T_target_source, T_gt)
+    assert dt < 2e-2 and dr < 2e-3
