@@ -134,7 +134,7 @@ int sga_linearize(sga_context* ctx, sga_problem* problem, const sga_factor_param
 /* Sum_i e_i at T with the correspondences and mahalanobis cached by the last sga_linearize (gicp_factor.hpp:80-89). */
 int sga_error(sga_context* ctx, sga_problem* problem, const sga_factor_params* params, const double T[16], double* e);
 /* Enqueue-only forms for multi-GPU: results stay in device memory so they can be all-reduced (RCCL) on the same stream before
- * the host reads them.  d_out30: [0..20] upper triangle of H row-wise, [21..26] b, [27] e, [28] num_inliers (as double), [29] source points re-searched by a warm pass (diagnostic).
+ * the host reads them.  d_out30: [0..20] upper triangle of H row-wise, [21..26] b, [27] e, [28] num_inliers (as double), [29] 0.
  * d_out1: e.  Both must be device pointers valid on the context's device; no host synchronisation is performed. */
 #define SGA_ACCUM_DOUBLES 30
 int sga_linearize_async(sga_context* ctx, sga_problem* problem, const sga_factor_params* params, const double T[16], double* d_out30);
@@ -156,17 +156,17 @@ int sga_context_set_profiling(sga_context* ctx, int enabled);
 int sga_context_get_kernel_ms(sga_context* ctx, double* linearize_ms, uint64_t* linearize_calls, double* error_ms, uint64_t* error_calls);
 /* The part of a COLD pass's time spent in the nearest-neighbour search kernel (the rest: factor evaluation + block reduction). */
 int sga_context_get_search_ms(sga_context* ctx, double* search_ms, uint64_t* search_calls);
-/* linearize_ms split by kind of pass against a kd-tree: cold = full nearest-neighbour search (kdtree.hpp:193-233 for every source
- * point) + factors; warm = no search: the neighbour of the previous linearization is certified still exact (exclusion radius minus
- * the point's motion, triangle inequality), only the points whose certificate fails are searched again.  Same results either way. */
-int sga_context_get_pass_ms(sga_context* ctx, double* cold_ms, uint64_t* cold_calls, double* warm_ms, uint64_t* warm_calls);
-/* Process-wide limits of the warm pass: a pass runs warm while no source point can have moved farther than warm_delta_m metres
- * since the previous linearization (negative: never, i.e. every pass searches in full); dense_delta_m only tunes how the re-searched
- * points are packed into waves.  Results do not depend on these numbers, only speed does. */
-void sga_set_warm_limits(double warm_delta_m, double dense_delta_m);
-void sga_get_warm_limits(double* warm_delta_m, double* dense_delta_m);
-/* Passes of each kind since the problem was created, and the number of source points re-searched in the warm passes. */
-int sga_problem_get_pass_stats(const sga_problem* problem, uint64_t* cold_passes, uint64_t* warm_passes, uint64_t* fallback_points);
+/* linearize_ms split by kind of pass against a kd-tree.  cold = the exact nearest-neighbour walk (kdtree.hpp:193-233) for every source
+ * point; warm = the neighbour of the previous linearization is kept wherever it is certified still exact (its exclusion radius minus
+ * the point's motion since, triangle inequality) and only the other points walk.  Same results either way, bit for bit in the
+ * correspondences.  warm_search_ms: the part of warm_ms spent in the search kernel. */
+int sga_context_get_pass_ms(sga_context* ctx, double* cold_ms, uint64_t* cold_calls, double* warm_ms, uint64_t* warm_calls, double* warm_search_ms);
+/* A pass runs warm while no source point can have moved farther than warm_delta_m metres since the previous linearization (default
+ * 0.1; negative: never, i.e. every pass walks in full).  Process-wide; results do not depend on it, only speed does. */
+void sga_set_warm_limit(double warm_delta_m);
+double sga_get_warm_limit(void);
+/* Passes of each kind since the problem was created, and the number of source points that had to walk in the warm passes. */
+int sga_problem_get_pass_stats(sga_context* ctx, const sga_problem* problem, uint64_t* cold_passes, uint64_t* warm_passes, uint64_t* walked_points);
 
 /* ---- the driver: Registration<>::align + optimizers (registration/registration.hpp:33-54, optimizer.hpp:24-149) -------- */
 typedef struct sga_registration_setting {

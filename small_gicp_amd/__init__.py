@@ -19,8 +19,8 @@ from .api import (  # noqa: F401
     estimate_covariances,
     estimate_normals,
     estimate_normals_covariances,
-    get_warm_limits,
-    set_warm_limits,
+    get_warm_limit,
+    set_warm_limit,
     make_setting,
     optimize,
     preprocess_points,

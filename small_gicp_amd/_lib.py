@@ -106,10 +106,10 @@ SYMBOLS = [
     ("sga_context_set_profiling", C.c_int, [_vp, C.c_int]),
     ("sga_context_get_kernel_ms", C.c_int, [_vp, _dp, C.POINTER(C.c_uint64), _dp, C.POINTER(C.c_uint64)]),
     ("sga_context_get_search_ms", C.c_int, [_vp, _dp, C.POINTER(C.c_uint64)]),
-    ("sga_context_get_pass_ms", C.c_int, [_vp, _dp, C.POINTER(C.c_uint64), _dp, C.POINTER(C.c_uint64)]),
-    ("sga_set_warm_limits", None, [C.c_double, C.c_double]),
-    ("sga_get_warm_limits", None, [_dp, _dp]),
-    ("sga_problem_get_pass_stats", C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    ("sga_context_get_pass_ms", C.c_int, [_vp, _dp, C.POINTER(C.c_uint64), _dp, C.POINTER(C.c_uint64), _dp]),
+    ("sga_set_warm_limit", None, [C.c_double]),
+    ("sga_get_warm_limit", C.c_double, []),
+    ("sga_problem_get_pass_stats", C.c_int, [_vp, _vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("sga_registration_setting_default", None, [C.POINTER(RegistrationSettingC)]),
     ("sga_align", C.c_int, [_vp, _vp, _vp, _dp, C.POINTER(RegistrationSettingC), C.POINTER(ResultC)]),
     ("sga_align_problem", C.c_int, [_vp, _vp, _dp, C.POINTER(RegistrationSettingC), C.POINTER(ResultC)]),

@@ -69,9 +69,10 @@ class Context:
         check(load().sga_context_get_search_ms(self.h, C.byref(sm), C.byref(sc)))
         cm, wm = C.c_double(), C.c_double()
         cc, wc = C.c_uint64(), C.c_uint64()
-        check(load().sga_context_get_pass_ms(self.h, C.byref(cm), C.byref(cc), C.byref(wm), C.byref(wc)))
+        wf = C.c_double()
+        check(load().sga_context_get_pass_ms(self.h, C.byref(cm), C.byref(cc), C.byref(wm), C.byref(wc), C.byref(wf)))
         return {"linearize_ms": lm.value, "linearize_calls": lc.value, "error_ms": em.value, "error_calls": ec.value, "search_ms": sm.value, "search_calls": sc.value,
-                "cold_ms": cm.value, "cold_calls": cc.value, "warm_ms": wm.value, "warm_calls": wc.value}
+                "cold_ms": cm.value, "cold_calls": cc.value, "warm_ms": wm.value, "warm_calls": wc.value, "warm_search_ms": wf.value}
 
 
 _DEFAULT_CTX = None
@@ -443,20 +444,17 @@ class Problem:
         """Linearization passes since creation by kind (cold = full search, warm = certified neighbours) and the source points
         the warm passes had to search again."""
         c, w, f = C.c_uint64(), C.c_uint64(), C.c_uint64()
-        check(load().sga_problem_get_pass_stats(self.h, C.byref(c), C.byref(w), C.byref(f)))
-        return {"cold_passes": c.value, "warm_passes": w.value, "fallback_points": f.value}
+        check(load().sga_problem_get_pass_stats(self.ctx.h, self.h, C.byref(c), C.byref(w), C.byref(f)))
+        return {"cold_passes": c.value, "warm_passes": w.value, "walked_points": f.value}
 
 
-def set_warm_limits(warm_delta_m, dense_delta_m=None):
-    """sga_set_warm_limits: a negative warm limit makes every linearization pass search in full (used by tests to compare the two kinds of pass)."""
-    cur = get_warm_limits()
-    load().sga_set_warm_limits(float(warm_delta_m), float(cur[1] if dense_delta_m is None else dense_delta_m))
+def set_warm_limit(warm_delta_m):
+    """sga_set_warm_limit: a negative limit makes every linearization pass walk in full (used by tests to compare the two kinds of pass)."""
+    load().sga_set_warm_limit(float(warm_delta_m))
 
 
-def get_warm_limits():
-    a, b = C.c_double(), C.c_double()
-    load().sga_get_warm_limits(C.byref(a), C.byref(b))
-    return a.value, b.value
+def get_warm_limit():
+    return float(load().sga_get_warm_limit())
 
 
 def unpack_accumulator(acc30):

@@ -109,6 +109,7 @@ struct sga_context {
   uint64_t lin_calls = 0, err_calls = 0;
   bool pending_warm = false;  // the pending linearize pair brackets a warm pass
   double warm_ms = 0.0, cold_ms = 0.0;  // the same samples split by kind of pass
+  double warm_first_ms = 0.0;           // warm passes: the certificate + factor kernel alone (the rest: fallback search)
   uint64_t warm_calls = 0, cold_calls = 0;
   int num_cus = 256;
   // multi-GPU (comm.hip): RCCL communicator over the ranks that share one registration, or null
@@ -177,16 +178,13 @@ struct sga_problem {
   sga::DevBuf<int> corr;         // kd position of the matched target point / voxel id (voxelmap); -1 = outlier
   sga::DevBuf<int> hint;         // exact nearest neighbour per source point at the last linearization pose, rejected or not (kd targets)
   sga::DevBuf<float> rex;        // its exclusion radius (kd_search.hpp): the certificate of the warm pass
-  sga::DevBuf<unsigned long long> fail_mask;  // warm pass: one word per 64 source points, bit = certificate failed
+  sga::DevBuf<uint32_t> walked;  // statistics, one counter per 64 source points: lanes of warm passes that had to walk
   double T_prev[16] = {0};       // pose of the last linearization (column-major), valid iff prev_valid
   bool prev_valid = false;
   int prev_math = 0;
   int last_math = 0;             // arithmetic of the last linearize of any kind (which mahalanobis cache is current)
   float bbox_lo[3] = {0, 0, 0}, bbox_hi[3] = {0, 0, 0};  // bounding box of the source (source frame): bounds the motion between two poses
-  // statistics of the passes against a kd-tree since the problem was created
-  uint64_t cold_passes = 0, warm_passes = 0;
-  uint64_t fallback_points = 0;  // certificate failures summed over the warm passes whose result was read back (sga_linearize)
-  bool last_pass_warm = false;
+  uint64_t cold_passes = 0, warm_passes = 0;  // passes against a kd-tree since the problem was created
   sga::DevBuf<float> maha;       // n*6 (fp32 mode) — fused mahalanobis of the last linearize
   sga::DevBuf<double> maha64;    // n*6 (fp64 mode, allocated on first use)
   // reduction scratch

@@ -261,7 +261,7 @@ int sga_context_set_profiling(sga_context* ctx, int enabled) {
   ctx->lin_calls = ctx->err_calls = 0;
   ctx->search_ms = 0.0;
   ctx->search_calls = 0;
-  ctx->warm_ms = ctx->cold_ms = 0.0;
+  ctx->warm_ms = ctx->cold_ms = ctx->warm_first_ms = 0.0;
   ctx->warm_calls = ctx->cold_calls = 0;
   ctx->pending = 0;
   return SGA_OK;
@@ -277,13 +277,14 @@ int sga_context_get_kernel_ms(sga_context* ctx, double* lin_ms, uint64_t* lin_ca
   return SGA_OK;
 }
 
-int sga_context_get_pass_ms(sga_context* ctx, double* cold_ms, uint64_t* cold_calls, double* warm_ms, uint64_t* warm_calls) {
+int sga_context_get_pass_ms(sga_context* ctx, double* cold_ms, uint64_t* cold_calls, double* warm_ms, uint64_t* warm_calls, double* warm_search_ms) {
   if (!ctx) return fail(SGA_ERR_INVALID, "null context");
   sga_profile_collect_pending(ctx);
   if (cold_ms) *cold_ms = ctx->cold_calls ? ctx->cold_ms / ctx->cold_calls : 0.0;
   if (cold_calls) *cold_calls = ctx->cold_calls;
   if (warm_ms) *warm_ms = ctx->warm_calls ? ctx->warm_ms / ctx->warm_calls : 0.0;
   if (warm_calls) *warm_calls = ctx->warm_calls;
+  if (warm_search_ms) *warm_search_ms = ctx->warm_calls ? ctx->warm_first_ms / ctx->warm_calls : 0.0;
   return SGA_OK;
 }
 

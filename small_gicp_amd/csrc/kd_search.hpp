@@ -49,6 +49,7 @@ struct KdBest {
   float d2;
   int idx;   // position in the kd-ordered target, -1 = none
   float r2;  // exclusion bound: every target point other than `idx` has a computed squared distance >= r2 (see kd_nearest)
+  int leaves;  // leaves scanned (a measure of the walk's length)
 };
 
 __host__ __device__ __forceinline__ uint32_t kd_bound(uint32_t n, int d, uint32_t k) { return static_cast<uint32_t>((static_cast<unsigned long long>(k) * n) >> d); }
@@ -91,63 +92,69 @@ __device__ __forceinline__ float kd_box_dist2(const KdView& t, uint32_t node, fl
   return fmaf(dx, dx, fmaf(dy, dy, dz * dz));
 }
 
-// Exact nearest neighbour of (qx, qy, qz): the target point minimising (kd_dist2, kd position) lexicographically among the points
-// with kd_dist2 < bound2 — a canonical rule (equidistant points: the lowest kd position wins), so the result depends on the
-// tree and the query only, never on the traversal order, the seed or earlier calls.  Sub-trees at a distance EQUAL to the best
-// are therefore still opened (they could hold an equidistant point of lower position); that costs nothing on real data.
-// stack:  LDS, D * STRIDE words (STRIDE = threads per workgroup); this lane uses stack[level * STRIDE + tid].
-// bound2: only points with d2 < bound2 can win (pass max_sq nudged up by one ulp so that d2 == max_sq is still found).
-// seed:   kd position of a target point believed to be close to the query (the neighbour found for this source point at the
-//         previous pose) or -1.  Its distance only tightens the pruning bound from the first descent on.
-// Besides the neighbour the walk returns, for free, an EXCLUSION BOUND r2: the minimum over (a) the distances of all scanned
-// points other than the winner and (b) the lower bounds (plane cut or box distance) of every sub-tree it discarded.  Every
-// target point except the winner is at computed squared distance >= r2.  The warm linearization pass (linearize.hip) uses it as a
-// certificate: after the query has moved by delta, the winner is still the exact nearest neighbour if its new distance is
-// below sqrt(r2) - delta.
-template <int STRIDE>
-__device__ __forceinline__ KdBest kd_nearest(const KdView& t, float qx, float qy, float qz, float bound2, int seed, uint32_t* __restrict__ stack, int tid) {
+// ---- exact nearest neighbour ---------------------------------------------------------------------------------------------------
+// The target point minimising (kd_dist2, kd position) lexicographically among the points with kd_dist2 < bound2 — a canonical
+// rule (equidistant points: the lowest kd position wins), so the result depends on the tree and the query only, never on the
+// traversal order, the seed or earlier calls.  Sub-trees at a distance EQUAL to the best are therefore still opened (they could
+// hold an equidistant point of lower position); that costs nothing on real data.
+//
+// The walk keeps the two smallest distances it has seen — the winner as a 64-bit key (distance bits, position), the runner-up
+// as a float (one v_med3 per scanned point) — and the smallest lower bound (plane cut or box distance) of the sub-trees it
+// discarded.  The minimum of the runner-up and that bound is an EXCLUSION BOUND r2: every target point except the winner is at
+// computed squared distance >= r2.  The warm linearization pass (linearize.hip) uses it as a certificate: after the query has
+// moved by delta, the winner is still the exact nearest neighbour if its new distance is below sqrt(r2) - delta.
+struct KdState {
+  unsigned long long win;  // (distance bits << 32) | position of the nearest point seen (start: +inf, no point); distances are >= 0, so bit order = value order
+  float second;            // distance of the runner-up
+  float dropped;           // smallest lower bound of a discarded sub-tree
+  float prune0;            // nothing at or beyond this distance can win (search bound, or the seed's distance + 1 ulp)
+  float prune;             // = min(prune0, distance of the winner)
+  int leaves;              // leaves scanned so far
+};
+
+__device__ __forceinline__ KdState kd_state(float prune0) { return {(0x7f800000ull << 32) | 0xffffffffull, INFINITY, INFINITY, prune0, prune0, 0}; }
+
+__device__ __forceinline__ KdBest kd_result(const KdState& s, float bound2) {
   KdBest best;
-  best.d2 = bound2;
-  best.idx = -1;
-  best.r2 = INFINITY;
-  if (seed >= 0 && static_cast<uint32_t>(seed) < t.n) {
-    const float4 c = t.pts[seed];
-    const float d2 = kd_dist2(c.x, c.y, c.z, qx, qy, qz);
-    if (d2 < bound2) {
-      best.d2 = d2;
-      best.idx = seed;
-    }
+  const float wd2 = __uint_as_float(static_cast<uint32_t>(s.win >> 32));
+  const bool hit = wd2 < bound2;  // else: the nearest point seen lies beyond the search bound — no neighbour, and it is a runner-up like the others
+  best.idx = hit ? static_cast<int>(static_cast<uint32_t>(s.win)) : -1;
+  best.d2 = hit ? wd2 : bound2;
+  best.r2 = fminf(fminf(s.second, s.dropped), hit ? INFINITY : wd2);
+  best.leaves = s.leaves;
+  return best;
+}
+
+// Leaf scan, branch-free: 8 slots are read unconditionally (the array is padded with 8 points at infinity behind the last
+// leaf); the slots behind the leaf's own points belong to its right neighbour and are masked out, so that no point is ever
+// scanned twice (it would become its own runner-up).  Per point: the distance, one v_med3 for the runner-up, one 64-bit
+// compare + select for the winner.
+__device__ __forceinline__ void kd_scan_leaf(const KdView& t, uint32_t leaf_node, float qx, float qy, float qz, KdState& s) {
+  const uint32_t k = leaf_node - (1u << t.depth);
+  const uint32_t first = kd_bound(t.n, t.depth, k);
+  const uint32_t count = kd_bound(t.n, t.depth, k + 1) - first;
+  const float4* __restrict__ lp = t.pts + first;
+  float4 p[kKdLeafMax];
+#pragma unroll
+  for (int i = 0; i < kKdLeafMax; i++) p[i] = lp[i];
+#pragma unroll
+  for (int i = 0; i < kKdLeafMax; i++) {
+    float d2 = kd_dist2(p[i].x, p[i].y, p[i].z, qx, qy, qz);
+    d2 = static_cast<uint32_t>(i) < count ? d2 : INFINITY;
+    s.second = __builtin_amdgcn_fmed3f(__uint_as_float(static_cast<uint32_t>(s.win >> 32)), s.second, d2);
+    const unsigned long long key = (static_cast<unsigned long long>(__float_as_uint(d2)) << 32) | (first + static_cast<uint32_t>(i));
+    s.win = key < s.win ? key : s.win;
   }
-  if (t.n == 0) return best;
+  s.prune = fminf(s.prune0, __uint_as_float(static_cast<uint32_t>(s.win >> 32)));
+  s.leaves++;
+}
+
+// The reference's recursion (descend to the near side; visit the far side iff it can hold a closer point, kdtree.hpp:207-230)
+// on an explicit stack, continued from `node` at `depth` with `sp` entries already pending, until the stack is empty.
+// stack: LDS, D * STRIDE words (STRIDE = threads per workgroup); this lane uses stack[level * STRIDE + tid].
+template <int STRIDE>
+__device__ __forceinline__ void kd_walk(const KdView& t, float qx, float qy, float qz, KdState& s, uint32_t node, int depth, int sp, uint32_t* __restrict__ stack, int tid) {
   const int D = t.depth;
-  int sp = 0, depth = 0;
-  uint32_t node = 1;
-  // Wave-uniform top of the first descent.  The 64 queries of a wave are neighbours (the source is sorted by target leaf), so
-  // they take the same branches for the first ~12 levels: as long as a ballot says so, the node is read ONCE per wave through the
-  // scalar cache and each lane only evaluates its own plane distance (for the push test).  The first disagreement hands over to
-  // the per-lane walk below at the node reached.
-  {
-    const unsigned long long active = __ballot(true);
-    uint32_t unode = 1;
-    while (depth < D) {
-      const uint32_t un = __builtin_amdgcn_readfirstlane(unode);
-      const float2 nd = t.nodes[un];  // uniform address: scalar load
-      const int axis = __builtin_amdgcn_readfirstlane(__float_as_int(nd.y));
-      const float thr = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(nd.x)));
-      const float qa = axis == 0 ? qx : (axis == 1 ? qy : qz);
-      const float diff = qa - thr;
-      const unsigned long long right = __ballot(!(diff < 0.f));
-      if (right != 0ull && right != active) break;  // the lanes part ways here
-      const float cut = diff * diff;
-      depth++;
-      stack[sp * STRIDE + tid] = kd_pack(cut, depth);
-      const bool keep = cut <= best.d2;
-      sp += keep ? 1 : 0;
-      best.r2 = keep ? best.r2 : fminf(best.r2, cut);  // discarded at once: everything beyond this plane is at >= cut
-      unode = 2 * un + (right != 0ull ? 1u : 0u);
-    }
-    node = unode;
-  }
   for (;;) {
     while (depth < D) {
       // one pair record covers the node itself (if it is of even depth) and the child the walk continues into; it is fetched with
@@ -165,11 +172,11 @@ __device__ __forceinline__ KdBest kd_nearest(const KdView& t, float qx, float qy
         const float cut = diff * diff;
         depth++;
         // a far side beyond the best cannot hold a closer point: the entry is written unconditionally (no branch) and only
-        // kept, i.e. the stack pointer advanced, if it can
+        // kept, i.e. the stack pointer advanced, if it can; a discarded one lowers the exclusion bound
         stack[sp * STRIDE + tid] = kd_pack(cut, depth);
-        const bool keep = cut <= best.d2;
+        const bool keep = cut <= s.prune;
         sp += keep ? 1 : 0;
-        best.r2 = keep ? best.r2 : fminf(best.r2, cut);
+        s.dropped = fminf(s.dropped, keep ? INFINITY : cut);
         node = 2 * node + (diff < 0.f ? 0u : 1u);
       }
       if (depth < D) {
@@ -181,35 +188,13 @@ __device__ __forceinline__ KdBest kd_nearest(const KdView& t, float qx, float qy
         const float cut = diff * diff;
         depth++;
         stack[sp * STRIDE + tid] = kd_pack(cut, depth);
-        const bool keep = cut <= best.d2;
+        const bool keep = cut <= s.prune;
         sp += keep ? 1 : 0;
-        best.r2 = keep ? best.r2 : fminf(best.r2, cut);
+        s.dropped = fminf(s.dropped, keep ? INFINITY : cut);
         node = 2 * node + (diff < 0.f ? 0u : 1u);
       }
     }
-    {
-      // Leaf scan, branch-free.  The 8 slots starting at the leaf's first point are read unconditionally: a leaf with fewer points
-      // spills into its right neighbour (real target points, harmless candidates) and the array is padded with 8 points at
-      // infinity behind the last leaf.  The loser of every comparison lowers the exclusion bound; a point that is scanned twice
-      // (the seed, a spilled neighbour) must not count as its own runner-up.
-      const uint32_t k = node - (1u << D);
-      const uint32_t first = kd_bound(t.n, D, k);
-      const float4* __restrict__ lp = t.pts + first;
-      float4 p[kKdLeafMax];
-#pragma unroll
-      for (int i = 0; i < kKdLeafMax; i++) p[i] = lp[i];
-#pragma unroll
-      for (int i = 0; i < kKdLeafMax; i++) {
-        const float d2 = kd_dist2(p[i].x, p[i].y, p[i].z, qx, qy, qz);
-        const int pos = static_cast<int>(first) + i;
-        const bool same = pos == best.idx;
-        const bool closer = d2 < best.d2 || (d2 == best.d2 && pos < best.idx);  // best.idx == -1: only d2 < bound2 wins
-        const float loser = closer ? (best.idx >= 0 ? best.d2 : INFINITY) : d2;
-        best.r2 = same ? best.r2 : fminf(best.r2, loser);
-        best.d2 = closer ? d2 : best.d2;
-        best.idx = closer ? pos : best.idx;
-      }
-    }
+    kd_scan_leaf(t, node, qx, qy, qz, s);
     // next pending far side that can still hold a closer (or equidistant) point: plane test on the stored cut, then the box test
     uint32_t e = 0;
     bool found = false;
@@ -217,17 +202,64 @@ __device__ __forceinline__ KdBest kd_nearest(const KdView& t, float qx, float qy
       sp--;
       e = stack[sp * STRIDE + tid];
       float lb = kd_cut(e);
-      if (lb <= best.d2) {
+      if (lb <= s.prune) {
         lb = kd_box_dist2(t, (node >> (D - static_cast<int>(e & 31u))) ^ 1u, qx, qy, qz);
-        found = lb <= best.d2;
+        found = lb <= s.prune;
       }
-      best.r2 = found ? best.r2 : fminf(best.r2, lb);  // discarded: nothing in there is closer than lb
+      s.dropped = fminf(s.dropped, found ? INFINITY : lb);  // discarded: nothing in there is closer than lb
     }
     if (!found) break;
     depth = static_cast<int>(e & 31u);
     node = (node >> (D - depth)) ^ 1u;  // sibling of the current leaf's ancestor at that depth
   }
-  return best;
+}
+
+__device__ __forceinline__ float kd_next_up(float d2) { return __uint_as_float(__float_as_uint(d2) + 1u); }  // the next float above a finite d2 >= 0
+
+// Top-down search (cold pass).
+// bound2: only points with d2 < bound2 can win (pass max_sq nudged up by one ulp so that d2 == max_sq is still found).
+// seed:   kd position of a target point believed to be close to the query (the neighbour found for this source point at the
+//         previous pose) or -1.  Its distance (+ 1 ulp, so that the seed itself stays in reach) only tightens the pruning bound from
+//         the first descent on; the seed is found again by the walk like any other point.
+template <int STRIDE>
+__device__ __forceinline__ KdBest kd_nearest(const KdView& t, float qx, float qy, float qz, float bound2, int seed, uint32_t* __restrict__ stack, int tid) {
+  if (t.n == 0) return {bound2, -1, INFINITY, 0};
+  float prune0 = bound2;
+  if (seed >= 0 && static_cast<uint32_t>(seed) < t.n) {
+    const float4 c = t.pts[seed];
+    const float d2 = kd_dist2(c.x, c.y, c.z, qx, qy, qz);
+    prune0 = d2 < prune0 ? kd_next_up(d2) : prune0;
+  }
+  KdState s = kd_state(prune0);
+  const int D = t.depth;
+  int sp = 0, depth = 0;
+  uint32_t node = 1;
+  // Wave-uniform top of the first descent.  The 64 queries of a wave are neighbours (the source is sorted by target leaf), so
+  // they take the same branches for the first ~12 levels: as long as a ballot says so, the node is read ONCE per wave through the
+  // scalar cache and each lane only evaluates its own plane distance (for the push test).  The first disagreement hands over to
+  // the per-lane walk at the node reached.
+  {
+    const unsigned long long active = __ballot(true);
+    while (depth < D) {
+      const uint32_t un = __builtin_amdgcn_readfirstlane(node);
+      const float2 nd = t.nodes[un];  // uniform address: scalar load
+      const int axis = __builtin_amdgcn_readfirstlane(__float_as_int(nd.y));
+      const float thr = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(nd.x)));
+      const float qa = axis == 0 ? qx : (axis == 1 ? qy : qz);
+      const float diff = qa - thr;
+      const unsigned long long right = __ballot(!(diff < 0.f));
+      if (right != 0ull && right != active) break;  // the lanes part ways here
+      const float cut = diff * diff;
+      depth++;
+      stack[sp * STRIDE + tid] = kd_pack(cut, depth);
+      const bool keep = cut <= s.prune;
+      sp += keep ? 1 : 0;
+      s.dropped = fminf(s.dropped, keep ? INFINITY : cut);  // discarded at once: everything beyond this plane is at >= cut
+      node = 2 * un + (right != 0ull ? 1u : 0u);
+    }
+  }
+  kd_walk<STRIDE>(t, qx, qy, qz, s, node, depth, sp, stack, tid);
+  return kd_result(s, bound2);
 }
 
 // ---- k nearest neighbours (traits::knn_search; normal / covariance estimation) -----------------------------------------------------

@@ -21,10 +21,9 @@ namespace sga {
 int comm_allreduce_sum(sga_context* ctx, double* d_buf, size_t count);
 
 constexpr int kTile = 256;           // threads per workgroup = source points per tile
-constexpr int kRow = 32;             // doubles per partial row (28 used + inliers + certificate failures)
+constexpr int kRow = 32;             // doubles per partial row (28 used + inliers)
 constexpr int kSearchBlock = 64;      // K1a: one wave per workgroup
 constexpr int kMaxBlocks = 2048;     // K1b / K2: 8 workgroups per CU, the whole grid is resident
-constexpr int kMaxSparseBlocks = 4096;  // warm pass: one-wave workgroups of the fallback kernel (one partial row each)
 
 template <typename Real>
 struct LinParams {
@@ -39,14 +38,11 @@ struct LinParams {
   VoxelView vox;
   FlatView flat;
   int* __restrict__ corr;
-  int* __restrict__ hint;  // exact nearest neighbour per source point at the last linearization pose (kd position) or -1
-  float* __restrict__ rex;  // its certificate: every OTHER target point was farther than rex[i] from the query at that pose
-  unsigned long long* __restrict__ fail_mask;  // warm pass: one word per 64 source points, bit = certificate failed, search again
+  const int* __restrict__ hint;  // exact nearest neighbour per source point at this pose (kd position) or -1, from nn_search_kernel
   Real* __restrict__ maha;  // n*6
   Rigid<Real> T;
-  Rigid<Real> T_prev;  // pose of the previous linearization (warm pass)
   float max_sq;  // INFINITY = no rejector
-  float bound2;  // search bound of the nearest-neighbour search (max_sq nudged up, or INFINITY)
+  float bound2;  // a neighbour counts only if kd_dist2 < bound2 (max_sq nudged up by an ulp, or INFINITY); the walks reach a little farther
   int robust_kind;
   Real robust_c;
   double* __restrict__ partials;
@@ -80,22 +76,47 @@ __device__ __forceinline__ Sym3<Real> load_sym(const Cov8* __restrict__ c, int i
 // exclusion radius stored per point: sqrt of the walk's exclusion bound, rounded down
 __device__ __forceinline__ float rex_from_r2(float r2) { return sqrtf(r2) * 0.9999995f; }
 
-// K1a (cold pass): nearest neighbour of every transformed source point (kd_search.hpp); writes its kd position (or -1 when
-// nothing lies within the search bound) to nn[i] and the walk's exclusion radius to rex[i].  One wave per workgroup (a finished
-// wave frees its slot and its 4 KB of stack at once; the hardware dispatcher balances the uneven walks), and without the per-pair
-// algebra the kernel fits 8 waves per SIMD, which the latency-bound walk needs.  K1b (linearize_kernel) evaluates the factors
-// over nn[].
+// The walks search a little farther than the rejector reaches: a source point without a neighbour inside max_dist then carries the
+// certificate "nothing within max_dist * (1 + margin)" and stays settled while it moves by less than the margin — without it those
+// points (isolated clutter: the longest walks there are) would be searched again in every pass.
+constexpr float kSearchMargin = 0.05f;
+
+// K1a: exact nearest neighbour of every transformed source point: nn[i] = its kd position (or -1 when nothing lies within the
+// search bound), rex[i] = the exclusion radius the walk certifies (kd_search.hpp: every OTHER target point is farther than rex[i]).
+//
+// COLD pass (check = 0): the full walk for every point, seeded with the previous neighbour.
+// WARM pass (check = 1): nn[] / rex[] describe the previous linearization pose T_prev.  The query has moved by
+// delta = |T p - T_prev p| since; if the old neighbour is now closer than rex[i] - delta, no other point can be closer (triangle
+// inequality): it is still the exact nearest neighbour, the lane shrinks the radius by delta and is done — no tree access at all.
+// Only the lanes whose certificate fails walk (seeded with the old neighbour, which usually is the answer).  A small relative margin
+// covers the rounding of the fp32 distances; it only ever sends a lane into the walk, never changes a result.  Late LM iterations
+// move the points by micrometres: their passes are a stream over 40 bytes per point.
+//
+// One wave per workgroup (a finished wave frees its slot and its 4 KB of stack at once; the hardware dispatcher balances the uneven
+// walks), and without the per-pair algebra the kernel fits 8 waves per SIMD, which the walk needs.  K1b (linearize_kernel)
+// evaluates the factors over nn[].
 template <typename Real>
 struct NNParams {
   const float4* __restrict__ src_pts;
   int n;
   KdView kd;
   Rigid<Real> T;
-  float bound2;
-  int use_seed;  // nn[] holds the neighbours found at the previous pose (or -1)
+  float bound2;      // the walks find neighbours with kd_dist2 < bound2 (the rejector's reach + kSearchMargin)
+  float within2;     // a neighbour counts for the rejector only if kd_dist2 < within2
   int* __restrict__ nn;
   float* __restrict__ rex;
+  int check;         // warm pass
+  Rigid<Real> T_prev;
+  uint32_t* __restrict__ walked;  // statistics, one counter per wave tile: lanes of warm passes that had to walk
 };
+
+// Returns the shrunken radius (relative to the new pose) or a negative value if the certificate fails.
+__device__ __forceinline__ float certify(float rex, float moved, bool has_neighbour, float d2_new, float within2) {
+  const float lim = rex - moved * 1.000001f;
+  const float lim2 = lim > 0.f ? lim * lim * 0.999995f : -1.f;
+  const bool ok = has_neighbour ? d2_new < lim2 : lim2 > within2;  // no neighbour within reach before: still none
+  return ok ? lim * 0.9999995f : -1.f;
+}
 
 template <typename Real, int BLOCK>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void nn_search_kernel(const NNParams<Real> p) {
@@ -109,7 +130,26 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
   const float4 ps = p.src_pts[i];
   Real x, y, z;
   transform_point<Real>(p.T, ps.x, ps.y, ps.z, x, y, z);
-  const KdBest nb = kd_nearest<BLOCK>(p.kd, static_cast<float>(x), static_cast<float>(y), static_cast<float>(z), p.bound2, p.use_seed ? p.nn[i] : -1, kd_stack, threadIdx.x);
+  const float fx = static_cast<float>(x), fy = static_cast<float>(y), fz = static_cast<float>(z);
+  const int seed = p.nn[i];
+  if (p.check) {
+    Real ox, oy, oz;
+    transform_point<Real>(p.T_prev, ps.x, ps.y, ps.z, ox, oy, oz);
+    const float moved = sqrtf(kd_dist2(static_cast<float>(ox), static_cast<float>(oy), static_cast<float>(oz), fx, fy, fz));
+    float d2 = INFINITY;
+    if (seed >= 0) {
+      const float4 c = p.kd.pts[seed];
+      d2 = kd_dist2(c.x, c.y, c.z, fx, fy, fz);
+    }
+    const float r = certify(p.rex[i], moved, seed >= 0, d2, p.within2);
+    if (r >= 0.f) {
+      p.rex[i] = r;
+      return;
+    }
+    const unsigned long long walking = __ballot(true);
+    if (threadIdx.x == __ffsll(static_cast<long long>(walking)) - 1) p.walked[tile] += static_cast<uint32_t>(__popcll(walking));  // the tile belongs to this wave: no atomic
+  }
+  const KdBest nb = kd_nearest<BLOCK>(p.kd, fx, fy, fz, p.bound2, seed, kd_stack, threadIdx.x);
   p.nn[i] = nb.idx;
   p.rex[i] = rex_from_r2(nb.r2);
 }
@@ -174,15 +214,9 @@ __device__ __forceinline__ void accumulate_wave(const Real* vals, bool inlier, d
   if (lane == 63) acc_row[28] += static_cast<double>(__popcll(inl_mask));
 }
 
-// K1b.  TARGET: 0 kd-tree, 1 Gaussian voxel map, 2 flat voxel map (the lookup of a voxel target happens right here).
-// PHASE (kd-tree targets): 0 = cold pass, the neighbours come from nn_search_kernel.
-//                          1 = warm pass: NO search.  hint[i] is the exact nearest neighbour found at the previous linearization
-// pose and rex[i] its exclusion radius (every other target point was farther than rex[i] from the query then).  The query has
-// moved by delta = |T p - T_prev p| since; if the old neighbour is now closer than rex[i] - delta, no other point can be closer
-// (triangle inequality) and it is still the exact nearest neighbour: the lane evaluates its factor at once and shrinks the
-// radius by delta.  Otherwise its bit is set in fail_mask and sparse_search_linearize_kernel searches again.  A small relative
-// margin covers the rounding of the fp32 distances; it only ever sends a lane to the search, never changes a result.
-template <typename Real, int FACTOR, int TARGET, int PHASE>
+// K1b.  TARGET: 0 kd-tree (the neighbours come from nn_search_kernel), 1 Gaussian voxel map, 2 flat voxel map (the lookup of a
+// voxel target happens right here).  Streaming + two gathers; per-pair values reduced with DPP inside a wave, fp64 across waves.
+template <typename Real, int FACTOR, int TARGET>
 __global__ __launch_bounds__(kTile) void linearize_kernel(const LinParams<Real> p) {
   __shared__ double sh_acc[kTile / 64][kRow];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -207,7 +241,7 @@ __global__ __launch_bounds__(kTile) void linearize_kernel(const LinParams<Real> 
     }
     int j = -1;
     Real tx = 0, ty = 0, tz = 0;
-    bool within = true, failed = false;
+    bool within = true;
     if constexpr (TARGET == 2) {
       if (active) {
         float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -229,34 +263,18 @@ __global__ __launch_bounds__(kTile) void linearize_kernel(const LinParams<Real> 
     } else {
       if (active) {
         j = p.hint[i];
-        const float fx = static_cast<float>(qx), fy = static_cast<float>(qy), fz = static_cast<float>(qz);
-        float d2f = INFINITY;
         if (j >= 0) {
           const float4 m = p.tgt_pts[j];
           tx = m.x;
           ty = m.y;
           tz = m.z;
-          d2f = kd_dist2(m.x, m.y, m.z, fx, fy, fz);
-        }
-        within = d2f < p.bound2;  // what the search itself would have returned at this pose
-        if constexpr (PHASE == 1) {
-          Real ox, oy, oz;
-          transform_point(p.T_prev, px, py, pz, ox, oy, oz);
-          const float moved = sqrtf(kd_dist2(static_cast<float>(ox), static_cast<float>(oy), static_cast<float>(oz), fx, fy, fz)) * 1.000001f;
-          const float lim = p.rex[i] - moved;
-          const float lim2 = lim > 0.f ? lim * lim * 0.999995f : -1.f;
-          const bool ok = j >= 0 ? d2f < lim2 : lim2 > p.bound2;  // no neighbour within the bound before: still none
-          failed = !ok;
-          if (ok) p.rex[i] = lim * 0.9999995f;
+          // the search reaches a little beyond the rejector (kSearchMargin) and a certified neighbour may have drifted out of
+          // reach: a neighbour counts only inside the reach of a plain search, whichever way it was found
+          within = kd_dist2(m.x, m.y, m.z, static_cast<float>(qx), static_cast<float>(qy), static_cast<float>(qz)) < p.bound2;
         }
       }
     }
-    if constexpr (PHASE == 1) {
-      const unsigned long long fmask = __ballot(failed);
-      if (lane == 0) p.fail_mask[static_cast<size_t>(tile) * (kTile / 64) + wave] = fmask;
-      if (lane == 63 && fmask != 0ull) sh_acc[wave][29] += static_cast<double>(__popcll(fmask));
-    }
-    if (active && !failed) {
+    if (active) {
       inlier = pair_factor<Real, FACTOR>(p, i, j, within, px, py, pz, qx, qy, qz, tx, ty, tz, vals);
       p.corr[i] = inlier ? j : -1;
     }
@@ -269,64 +287,6 @@ __global__ __launch_bounds__(kTile) void linearize_kernel(const LinParams<Real> 
     for (int w = 0; w < kTile / 64; w++) s += sh_acc[w][threadIdx.x];
     p.partials[static_cast<size_t>(blockIdx.x) * kRow + threadIdx.x] = s;
   }
-}
-
-// Warm pass, second kernel: the source points whose certificate failed (fail_mask) are searched again — the exact walk of
-// kd_search.hpp, seeded with the old neighbour, which usually IS the answer, so the walk is a short verification — and their
-// factors are evaluated right here (a few per cent of the points: occupancy does not matter, one launch less).  One wave per
-// workgroup; a wave owns `S` consecutive 64-point groups (a "span"), gathers the failed points of its span into LDS in ascending
-// order (deterministic, and neighbours in the sorted source stay neighbours in the wave) and walks them 64 at a time.
-// Every workgroup writes one partial row (zeros if it found nothing to do).
-template <typename Real, int FACTOR>
-__global__ __launch_bounds__(kSearchBlock) void sparse_search_linearize_kernel(const LinParams<Real> p, int S, int num_spans, int num_groups, double* __restrict__ rows) {
-  extern __shared__ uint32_t sparse_smem[];  // S * 64 point ids, then tree depth x 64 stack slots
-  __shared__ double sh_acc[kRow];
-  uint32_t* list = sparse_smem;
-  uint32_t* stack = sparse_smem + static_cast<size_t>(S) * 64;
-  const int lane = threadIdx.x;
-  if (lane < kRow) sh_acc[lane] = 0.0;
-  const int nblk = gridDim.x, per_xcd = nblk >> 3, b = blockIdx.x;
-  const bool one_each = nblk == num_spans;  // one span per workgroup: XCD-aware order like the dense kernels
-  int span = one_each ? (b < 8 * per_xcd ? (b & 7) * per_xcd + (b >> 3) : b) : b;
-  for (; span < num_spans; span += one_each ? num_spans : nblk) {
-    int total = 0;
-    for (int g = 0; g < S; g++) {
-      const int gi = span * S + g;
-      const unsigned long long m = gi < num_groups ? p.fail_mask[gi] : 0ull;  // wave-uniform
-      if ((m >> lane) & 1ull) list[total + __popcll(m & ((1ull << lane) - 1ull))] = static_cast<uint32_t>(gi * 64 + lane);
-      total += __popcll(m);
-    }
-    __syncthreads();
-    for (int c0 = 0; c0 < total; c0 += 64) {
-      const bool act = c0 + lane < total;
-      Real vals[28];
-#pragma unroll
-      for (int k = 0; k < 28; k++) vals[k] = Real(0);
-      bool inlier = false;
-      if (act) {
-        const int i = static_cast<int>(list[c0 + lane]);
-        const float4 ps4 = p.src_pts[i];
-        const Real px = ps4.x, py = ps4.y, pz = ps4.z;
-        Real qx, qy, qz;
-        transform_point(p.T, px, py, pz, qx, qy, qz);
-        const KdBest nb = kd_nearest<kSearchBlock>(p.kd, static_cast<float>(qx), static_cast<float>(qy), static_cast<float>(qz), p.bound2, p.hint[i], stack, lane);
-        p.hint[i] = nb.idx;
-        p.rex[i] = rex_from_r2(nb.r2);
-        Real tx = 0, ty = 0, tz = 0;
-        if (nb.idx >= 0) {
-          const float4 m = p.tgt_pts[nb.idx];
-          tx = m.x;
-          ty = m.y;
-          tz = m.z;
-        }
-        inlier = pair_factor<Real, FACTOR>(p, i, nb.idx, true, px, py, pz, qx, qy, qz, tx, ty, tz, vals);
-        p.corr[i] = inlier ? nb.idx : -1;
-      }
-      accumulate_wave<Real>(vals, inlier, sh_acc, lane);
-    }
-    __syncthreads();  // the list is rewritten by the next span
-  }
-  if (lane < kRow) rows[static_cast<size_t>(blockIdx.x) * kRow + lane] = sh_acc[lane];
 }
 
 template <typename Real>
@@ -448,9 +408,9 @@ static void launch_reduce(sga_context* ctx, const double* partials, int nrows, i
 
 static int grid_blocks(int num_tiles) { return num_tiles < kMaxBlocks ? (num_tiles < 1 ? 1 : num_tiles) : kMaxBlocks; }
 
-template <typename Real, int FACTOR, int TARGET, int PHASE = 0>
+template <typename Real, int FACTOR, int TARGET>
 static void launch_linearize(hipStream_t st, const LinParams<Real>& p, int blocks) {
-  hipLaunchKernelGGL((linearize_kernel<Real, FACTOR, TARGET, PHASE>), dim3(blocks), dim3(kTile), 0, st, p);
+  hipLaunchKernelGGL((linearize_kernel<Real, FACTOR, TARGET>), dim3(blocks), dim3(kTile), 0, st, p);
 }
 
 // Largest displacement |Ta p - Tb p| over the box [lo, hi] (column-major 4x4 poses): the norm of an affine map is convex, so the
@@ -469,18 +429,10 @@ static double max_displacement(const double Ta[16], const double Tb[16], const f
   return std::sqrt(best);
 }
 
-// Tunables of the warm pass (metres of source-point motion since the previous linearization): above the warm limit the
-// certificates are hopeless and the pass runs cold (full search); below the dense limit nearly all of them hold and the fallback
-// kernel gathers the failures of 8 wave tiles into one wave, in between of 2.  Defaults can be overridden by the environment
-// (SGA_WARM_DELTA, SGA_WARM_DENSE_DELTA) or at run time with sga_set_warm_limits (a negative warm limit disables warm passes).
-static double env_double(const char* name, double dflt) {
-  const char* v = getenv(name);
-  return v ? atof(v) : dflt;
-}
-static double g_warm_delta = env_double("SGA_WARM_DELTA", 0.02);
-static double g_warm_dense_delta = env_double("SGA_WARM_DENSE_DELTA", 0.003);
-static double warm_delta() { return g_warm_delta; }
-static double warm_dense_delta() { return g_warm_dense_delta; }
+// A pass runs warm (certified neighbours skip the walk) while no source point can have moved farther than this since the previous
+// linearization; beyond it hardly any certificate holds and checking them is wasted work.  Environment override SGA_WARM_DELTA
+// (metres), run-time override sga_set_warm_limit; negative = never.  Results do not depend on it.
+static double g_warm_delta = getenv("SGA_WARM_DELTA") ? atof(getenv("SGA_WARM_DELTA")) : 0.1;
 
 template <typename Real>
 static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, const double T[16], double* d_out30, double* host, unsigned long long seq) {
@@ -516,8 +468,6 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
   }
   p.corr = pb->corr.p;
   p.hint = pb->hint.p;
-  p.rex = pb->rex.p;
-  p.fail_mask = pb->fail_mask.p;
   if constexpr (sizeof(Real) == 4) {
     p.maha = pb->maha.p;
   } else {
@@ -531,17 +481,11 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
   p.robust_c = static_cast<Real>(fp->robust_c);
   p.partials = pb->partials.p;
   const int blocks = grid_blocks(p.num_tiles);
-  int rows = p.n > 0 ? blocks : 0;
 
-  // warm pass?  Only against a kd-tree, with certificates from a previous pass in the same arithmetic, and only while no source
-  // point can have moved farther than the certificates can possibly cover.
+  // warm pass?  Only with certificates from a previous pass in the same arithmetic (the queries must be bit-identical), and only
+  // while no source point can have moved farther than the certificates can possibly cover.
   const int math = sizeof(Real) == 4 ? SGA_MATH_FP32 : SGA_MATH_FP64;
-  double moved = 0.0;
-  bool warm = false;
-  if (!voxel && p.n > 0 && pb->prev_valid && pb->prev_math == math) {
-    moved = max_displacement(T, pb->T_prev, pb->bbox_lo, pb->bbox_hi);
-    warm = moved <= warm_delta();
-  }
+  const bool warm = !voxel && p.n > 0 && pb->prev_valid && pb->prev_math == math && max_displacement(T, pb->T_prev, pb->bbox_lo, pb->bbox_hi) <= g_warm_delta;
 
   const bool timed = ctx->profiling && (ctx->lin_seq++ % ctx->profile_period) == 0;  // sampled: event records cost ~7 us each
   if (timed) {
@@ -549,22 +493,25 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
     (void)hipEventRecord(ctx->ev0, ctx->stream);
     ctx->pending_warm = warm;
   }
-  if (p.n > 0 && !voxel && !warm) {
+  if (p.n > 0 && !voxel) {
     NNParams<Real> q{};
     q.src_pts = pb->pts.p;
     q.n = p.n;
     q.kd = p.kd;
     q.T = p.T;
-    q.bound2 = p.bound2;
+    q.within2 = p.bound2;
+    q.bound2 = p.bound2 * (1.f + kSearchMargin) * (1.f + kSearchMargin);
     q.nn = pb->hint.p;
     q.rex = pb->rex.p;
-    q.use_seed = 1;
+    q.check = warm ? 1 : 0;
+    if (warm) q.T_prev = rigid_from_colmajor<Real>(pb->T_prev);
+    q.walked = pb->walked.p;
     const size_t words = static_cast<size_t>(std::max(p.kd.depth, 1));
     hipLaunchKernelGGL((nn_search_kernel<Real, kSearchBlock>), dim3((p.n + kSearchBlock - 1) / kSearchBlock), dim3(kSearchBlock), words * kSearchBlock * sizeof(uint32_t), ctx->stream, q);
-  }
-  if (timed && !voxel && p.n > 0 && !warm) {
-    (void)hipEventRecord(ctx->ev_mid, ctx->stream);
-    ctx->mid_recorded = true;
+    if (timed) {
+      (void)hipEventRecord(ctx->ev_mid, ctx->stream);
+      ctx->mid_recorded = true;
+    }
   }
   if (p.n > 0) {
     if (flat) {
@@ -577,38 +524,19 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
         launch_linearize<Real, SGA_GICP, 1>(ctx->stream, p, blocks);
       else
         launch_linearize<Real, SGA_ICP, 1>(ctx->stream, p, blocks);
-    } else if (!warm) {
+    } else {
       switch (fp->factor_kind) {
         case SGA_GICP: launch_linearize<Real, SGA_GICP, 0>(ctx->stream, p, blocks); break;
         case SGA_PLANE_ICP: launch_linearize<Real, SGA_PLANE_ICP, 0>(ctx->stream, p, blocks); break;
         default: launch_linearize<Real, SGA_ICP, 0>(ctx->stream, p, blocks); break;
       }
-    } else {
-      p.T_prev = rigid_from_colmajor<Real>(pb->T_prev);
-      switch (fp->factor_kind) {
-        case SGA_GICP: launch_linearize<Real, SGA_GICP, 0, 1>(ctx->stream, p, blocks); break;
-        case SGA_PLANE_ICP: launch_linearize<Real, SGA_PLANE_ICP, 0, 1>(ctx->stream, p, blocks); break;
-        default: launch_linearize<Real, SGA_ICP, 0, 1>(ctx->stream, p, blocks); break;
-      }
-      const int S = moved <= warm_dense_delta() ? 8 : 2;
-      const int num_groups = p.num_tiles * (kTile / 64);
-      const int num_spans = (num_groups + S - 1) / S;
-      const int sblocks = std::min(num_spans, kMaxSparseBlocks);
-      const size_t shmem = (static_cast<size_t>(S) * 64 + static_cast<size_t>(std::max(p.kd.depth, 1)) * kSearchBlock) * sizeof(uint32_t);
-      double* srows = pb->partials.p + static_cast<size_t>(rows) * kRow;
-      switch (fp->factor_kind) {
-        case SGA_GICP: hipLaunchKernelGGL((sparse_search_linearize_kernel<Real, SGA_GICP>), dim3(sblocks), dim3(kSearchBlock), shmem, ctx->stream, p, S, num_spans, num_groups, srows); break;
-        case SGA_PLANE_ICP: hipLaunchKernelGGL((sparse_search_linearize_kernel<Real, SGA_PLANE_ICP>), dim3(sblocks), dim3(kSearchBlock), shmem, ctx->stream, p, S, num_spans, num_groups, srows); break;
-        default: hipLaunchKernelGGL((sparse_search_linearize_kernel<Real, SGA_ICP>), dim3(sblocks), dim3(kSearchBlock), shmem, ctx->stream, p, S, num_spans, num_groups, srows); break;
-      }
-      rows += sblocks;
     }
   }
   if (timed) {
     (void)hipEventRecord(ctx->ev1, ctx->stream);
     ctx->pending |= 1;
   }
-  launch_reduce(ctx, pb->partials.p, rows, 30, kRow, pb->partials.p + static_cast<size_t>(kMaxBlocks + kMaxSparseBlocks) * kRow, d_out30, SGA_ACCUM_DOUBLES, host, seq);
+  launch_reduce(ctx, pb->partials.p, p.n > 0 ? blocks : 0, 29, kRow, pb->partials.p + static_cast<size_t>(kMaxBlocks) * kRow, d_out30, SGA_ACCUM_DOUBLES, host, seq);
   SGA_HIP(hipGetLastError());
   pb->last_math = math;
   if (!voxel) {
@@ -619,7 +547,6 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
       pb->warm_passes++;
     else
       pb->cold_passes++;
-    pb->last_pass_warm = warm;
   }
   return SGA_OK;
 }
@@ -663,12 +590,12 @@ static int error_dispatch(sga_context* ctx, sga_problem* pb, const sga_factor_pa
     (void)hipEventRecord(ctx->ev3, ctx->stream);
     ctx->pending |= 2;
   }
-  launch_reduce(ctx, pb->partials.p, p.n > 0 ? blocks : 0, 1, 1, pb->partials.p + static_cast<size_t>(kMaxBlocks + kMaxSparseBlocks) * kRow, d_out1, 1, host, seq);
+  launch_reduce(ctx, pb->partials.p, p.n > 0 ? blocks : 0, 1, 1, pb->partials.p + static_cast<size_t>(kMaxBlocks) * kRow, d_out1, 1, host, seq);
   SGA_HIP(hipGetLastError());
   return SGA_OK;
 }
 
-int problem_partials_rows() { return kMaxBlocks + kMaxSparseBlocks + kReduceGroups; }  // K1/K2 partial rows + the stage-1 rows of the reduction
+int problem_partials_rows() { return kMaxBlocks + kReduceGroups; }  // K1/K2 partial rows + the stage-1 rows of the reduction
 
 // Hand `count` doubles to the host after an all-reduce (see reduce_rows_kernel for the protocol).
 __global__ void publish_kernel(const double* __restrict__ src, int count, double* __restrict__ host, unsigned long long seq) {
@@ -731,6 +658,7 @@ void sga_profile_collect_pending(sga_context* ctx) {
       if (ctx->mid_recorded && hipEventElapsedTime(&ms, ctx->ev0, ctx->ev_mid) == hipSuccess) {
         ctx->search_ms += ms;
         ctx->search_calls++;
+        if (ctx->pending_warm) ctx->warm_first_ms += ms;
       }
     }
     ctx->mid_recorded = false;
@@ -764,15 +692,8 @@ void sga_unpack_accumulator(const double acc[SGA_ACCUM_DOUBLES], double H[36], d
   if (num_inliers) *num_inliers = static_cast<uint64_t>(acc[28] + 0.5);
 }
 
-void sga_set_warm_limits(double warm_delta_m, double dense_delta_m) {
-  g_warm_delta = warm_delta_m;
-  g_warm_dense_delta = dense_delta_m;
-}
-
-void sga_get_warm_limits(double* warm_delta_m, double* dense_delta_m) {
-  if (warm_delta_m) *warm_delta_m = g_warm_delta;
-  if (dense_delta_m) *dense_delta_m = g_warm_dense_delta;
-}
+void sga_set_warm_limit(double warm_delta_m) { g_warm_delta = warm_delta_m; }
+double sga_get_warm_limit(void) { return g_warm_delta; }
 
 int sga_linearize_async(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, const double T[16], double* d_out30) {
   SGA_TRY(check_args(ctx, pb, fp, T));
@@ -799,7 +720,6 @@ int sga_linearize(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp
   SGA_TRY(comm_allreduce_sum(ctx, ctx->d_accum.p, SGA_ACCUM_DOUBLES));  // source sharded over ranks: sum the shards' systems
   SGA_TRY(fetch_result(ctx, ctx->d_accum.p, SGA_ACCUM_DOUBLES, seq, direct));
   sga_unpack_accumulator(ctx->h_accum, H, b, e, num_inliers);
-  if (pb->last_pass_warm) pb->fallback_points += static_cast<uint64_t>(ctx->h_accum[29] + 0.5);
   return SGA_OK;
 }
 

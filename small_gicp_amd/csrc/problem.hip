@@ -173,13 +173,14 @@ int sga_problem_create(sga_context* ctx, const sga_index* target, const sga_clou
   const size_t n = source->n;
   pb->max_blocks = problem_partials_rows();
   SGA_TRY(pb->partials.alloc(static_cast<size_t>(pb->max_blocks) * 32));
+  SGA_TRY(pb->walked.alloc(n / 64 + 1));
+  SGA_HIP(hipMemsetAsync(pb->walked.p, 0, (n / 64 + 1) * sizeof(uint32_t), ctx->stream));
   if (n > 0) {
     SGA_TRY(pb->pts.alloc(n));
     if (source->has_covs) SGA_TRY(pb->cov.alloc(n));
     SGA_TRY(pb->corr.alloc(n));
     SGA_TRY(pb->hint.alloc(n));
     SGA_TRY(pb->rex.alloc(n));
-    SGA_TRY(pb->fail_mask.alloc((n + 255) / 256 * 4));  // one word per 64 points, whole 256-point tiles
     SGA_TRY(pb->maha.alloc(n * 6));
     SGA_HIP(hipMemsetAsync(pb->corr.p, 0xff, n * sizeof(int), ctx->stream));
     SGA_HIP(hipMemsetAsync(pb->hint.p, 0xff, n * sizeof(int), ctx->stream));
@@ -227,11 +228,19 @@ int sga_problem_destroy(sga_problem* problem) {
   return SGA_OK;
 }
 
-int sga_problem_get_pass_stats(const sga_problem* pb, uint64_t* cold_passes, uint64_t* warm_passes, uint64_t* fallback_points) {
-  if (!pb) return fail(SGA_ERR_INVALID, "null argument");
+int sga_problem_get_pass_stats(sga_context* ctx, const sga_problem* pb, uint64_t* cold_passes, uint64_t* warm_passes, uint64_t* walked_points) {
+  if (!ctx || !pb) return fail(SGA_ERR_INVALID, "null argument");
   if (cold_passes) *cold_passes = pb->cold_passes;
   if (warm_passes) *warm_passes = pb->warm_passes;
-  if (fallback_points) *fallback_points = pb->fallback_points;
+  if (walked_points) {
+    std::vector<uint32_t> w(pb->walked.n);
+    SGA_HIP(hipSetDevice(ctx->device));
+    SGA_HIP(hipMemcpyAsync(w.data(), pb->walked.p, w.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    SGA_HIP(hipStreamSynchronize(ctx->stream));
+    uint64_t sum = 0;
+    for (uint32_t v : w) sum += v;
+    *walked_points = sum;
+  }
   return SGA_OK;
 }
 

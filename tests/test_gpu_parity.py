@@ -312,13 +312,14 @@ def test_c3_properties(c3):
     pb = sga.Problem(c3["tree"], c3["src"])
     T = se3([0.2, 0.3, 0.93], np.deg2rad(1.0), [0.1, -0.1, 0.0])
     H, b, e, n = pb.linearize(st.factor, T)  # cold pass: full search
-    # the second and third call at the same pose are warm passes (every certificate holds: no search at all)
+    # the second and third call at the same pose are warm passes (every certificate holds: no tree walk at all)
     H2, b2, e2, n2 = pb.linearize(st.factor, T)
     H3, b3, e3, n3 = pb.linearize(st.factor, T)
-    assert pb.pass_stats() == {"cold_passes": 1, "warm_passes": 2, "fallback_points": 0}
+    ps = pb.pass_stats()
+    assert ps["cold_passes"] == 1 and ps["warm_passes"] == 2 and ps["walked_points"] < 2000, ps  # only near-ties (runner-up within 1e-5) walk again
     # determinism: same launch, bit-identical sums; warm vs cold: the same pairs, sums equal to fp64 rounding
     assert (H2 == H3).all() and (b2 == b3).all() and e2 == e3 and n2 == n3
-    assert np.abs(H - H2).max() <= 1e-10 * np.abs(H).max() and abs(e - e2) <= 1e-10 * e and n == n2
+    assert (H == H2).all() and (b == b2).all() and e == e2 and n == n2  # same neighbours -> the same factor kernel over the same inputs  # the few re-searched points regroup fp32 wave sums
     # idempotence of the cached state: the error pass at the linearization point reproduces e
     assert abs(pb.error(st.factor, T) - e) <= 1e-6 * e
     # additivity over source shards (what the multi-GPU all-reduce relies on): halves sum to the whole

@@ -1,10 +1,10 @@
 """Warm linearization passes (certified neighbours, linearize.hip) give the same correspondences and the same sums as cold passes
-(full search of every source point) — on a real MI355X through the C-ABI.
+(the full walk for every source point) — on a real MI355X through the C-ABI.
 
-The warm pass never searches: it keeps the exact neighbour of the previous linearization as long as its certificate holds (new
-distance < exclusion radius - motion) and re-searches only the points whose certificate fails.  Exactness is by construction; these
-tests check it on whole pose chains shaped like a registration (large steps first, then ever smaller ones), on tie-heavy lattices,
-with the rejector on and off, for every factor, and with the limits forced so that nearly every certificate fails.
+A warm pass keeps the exact neighbour of the previous linearization wherever its certificate holds (new distance < exclusion
+radius - motion) and walks the tree only for the other points.  Exactness is by construction; these tests check it on whole pose
+chains shaped like a registration (large steps first, then ever smaller ones), on tie-heavy lattices, with the rejector on and
+off, for every factor, and with the limit forced so that nearly every certificate fails.
 """
 import numpy as np
 import pytest
@@ -40,20 +40,20 @@ def pose_chain(T_goal, fractions=(0.0, 0.55, 0.9, 0.985, 0.998, 0.9997, 0.99996,
 
 @pytest.fixture(autouse=True)
 def restore_limits():
-    lim = sga.get_warm_limits()
+    lim = sga.get_warm_limit()
     yield
-    sga.set_warm_limits(*lim)
+    sga.set_warm_limit(lim)
 
 
-def run_chain(tree, src, setting, poses, limits, rel):
+def run_chain(tree, src, setting, poses, limit, rel):
     """linearize along `poses` on two problems: one with warm passes (limits), one cold only; everything must agree."""
     pw, pc = sga.Problem(tree, src), sga.Problem(tree, src)
     for k, T in enumerate(poses):
-        sga.set_warm_limits(*limits)
+        sga.set_warm_limit(limit)
         Hw, bw, ew, nw = pw.linearize(setting.factor, T)
         e2w = pw.error(setting.factor, T)
         cw, mw = pw.factors()
-        sga.set_warm_limits(-1.0, 0.0)
+        sga.set_warm_limit(-1.0)
         Hc, bc, ec, nc = pc.linearize(setting.factor, T)
         cc, mc = pc.factors()
         assert (cw == cc).all(), (k, int((cw != cc).sum()))
@@ -61,7 +61,7 @@ def run_chain(tree, src, setting, poses, limits, rel):
         scale = max(np.abs(Hc).max(), 1e-30)
         assert np.abs(Hw - Hc).max() <= rel * scale and np.abs(bw - bc).max() <= rel * max(np.abs(bc).max(), scale * 1e-3), k
         assert abs(ew - ec) <= rel * max(abs(ec), 1e-30) and abs(e2w - ew) <= 1e-5 * max(abs(ew), 1e-30), k
-        assert np.allclose(mw, mc, rtol=1e-5, atol=1e-30), k  # the cached mahalanobis: same pairs, same arithmetic
+        assert np.abs(mw - mc).max(axis=1).max() <= 0 or (np.abs(mw - mc).max(axis=1) <= 1e-4 * np.abs(mc).max(axis=1)).all(), k  # the cached mahalanobis: same pairs (the two kernels may round the 3x3 inverse differently)
     sw, sc = pw.pass_stats(), pc.pass_stats()
     assert sc["warm_passes"] == 0 and sc["cold_passes"] == len(poses)
     return sw
@@ -76,23 +76,22 @@ def test_warm_equals_cold_on_c1(c1_f32, kind, mode):
     tree = sga.KdTree(tgt)
     st = sga.make_setting(kind, math_mode=mode)
     goal = se3([0.1, 0.2, 1.0], np.deg2rad(0.7), [0.49, 0.12, -0.02])
-    stats = run_chain(tree, src, st, pose_chain(goal), sga.get_warm_limits(), 1e-6 if mode == "fp32" else 1e-12)
-    assert stats["warm_passes"] >= 4, stats  # the small steps of the chain ran without a search
-    assert stats["fallback_points"] < 0.2 * len(d["sp"]) * stats["warm_passes"], stats
+    stats = run_chain(tree, src, st, pose_chain(goal), sga.get_warm_limit(), 1e-6 if mode == "fp32" else 1e-12)
+    assert stats["warm_passes"] >= 4, stats  # the small steps of the chain
+    assert stats["walked_points"] < 0.3 * len(d["sp"]) * stats["warm_passes"], stats  # and most of their points kept their neighbour without a walk
 
 
 def test_warm_with_every_certificate_failing(c1_f32):
-    """Limits forced wide open: every pass after the first is 'warm' although the points move by decimetres, so nearly every
-    certificate fails and the fallback kernel does the whole search (both packings) — still the same answer."""
+    """Limit forced wide open: every pass after the first is 'warm' although the points move by decimetres, so nearly every
+    certificate fails and nearly every point walks — still the same answer."""
     d = c1_f32
     tgt = sga.PointCloud(d["tp"], d["tn"], d["tc"])
     src = sga.PointCloud(d["sp"], d["sn"], d["sc"])
     tree = sga.KdTree(tgt)
     goal = se3([0.3, -0.2, 1.0], np.deg2rad(3.0), [0.6, -0.3, 0.1])
-    for limits in ((100.0, 0.0), (100.0, 100.0)):  # 2 resp. 8 wave tiles per fallback wave
-        for st in (sga.make_setting("GICP"), sga.make_setting("GICP", max_correspondence_distance=-1.0), sga.make_setting("ICP", max_correspondence_distance=0.3)):
-            stats = run_chain(tree, src, st, pose_chain(goal, (0.0, 0.3, 0.6, 0.8, 0.9, 1.0)), limits, 1e-6)
-            assert stats["warm_passes"] == 5 and stats["fallback_points"] > 0.5 * len(d["sp"]), stats
+    for st in (sga.make_setting("GICP"), sga.make_setting("GICP", max_correspondence_distance=-1.0), sga.make_setting("ICP", max_correspondence_distance=0.3)):
+        stats = run_chain(tree, src, st, pose_chain(goal, (0.0, 0.3, 0.6, 0.8, 0.9, 1.0)), 100.0, 1e-6)
+        assert stats["warm_passes"] == 5 and stats["walked_points"] > 0.5 * len(d["sp"]), stats
 
 
 def test_warm_on_lattice_ties():
@@ -106,7 +105,7 @@ def test_warm_on_lattice_ties():
     src = sga.PointCloud(src_pts)
     st = sga.make_setting("ICP", max_correspondence_distance=2.0)
     poses = [np.eye(4)] + [se3([0, 0, 1], 1e-5 * k, [2e-4 * k, -1e-4 * k, 0.0]) for k in range(1, 6)] + [np.eye(4)]
-    stats = run_chain(tree, src, st, poses, (0.02, 0.003), 1e-6)
+    stats = run_chain(tree, src, st, poses, 0.1, 1e-6)
     assert stats["warm_passes"] == len(poses) - 1
 
 
@@ -118,10 +117,10 @@ def test_warm_registration_matches_cold_registration_100k():
     sga.estimate_covariances(tgt, None, 20)
     sga.estimate_covariances(src, None, 20)
     tree = sga.KdTree(tgt)
-    st = sga.make_setting("GICP", max_correspondence_distance=1.0)
+    st = sga.make_setting("GICP", max_correspondence_distance=1.0, translation_eps=1e-7, rotation_eps=1e-8)  # iterate on into the small steps
     pw, pc = sga.Problem(tree, src), sga.Problem(tree, src)
     rw = pw.align(st)
-    sga.set_warm_limits(-1.0, 0.0)
+    sga.set_warm_limit(-1.0)
     rc = pc.align(st)
     assert rw.iterations == rc.iterations and rw.num_inliers == rc.num_inliers and rw.converged == rc.converged
     dt, dr = pose_error(rw.T_target_source, rc.T_target_source)
