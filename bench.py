@@ -1,27 +1,34 @@
 #!/usr/bin/env python3
 """bench.py — registration-iterations/s of the GICP hot path on MI355X (BASELINE.json metric, config C3).
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W            (N > 1 without WORLD_SIZE in the environment: spawns its own N ranks)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Workload (config.workload = "C3"): GICP with per-point covariances (k = 20), 1M target points <-> 1M source points PER GPU,
-synthetic planar scene (small_gicp_amd/synthetic.py, frozen in SURVEY.md §8d), max correspondence distance 1.0 m.
-One STEP = one outer Levenberg-Marquardt iteration of Registration<GICPFactor>::align (registration/optimizer.hpp:100-144 of
-the reference): 1x linearize (transform + exact NN + per-pair H/b/e + reduction) + the LM trial(s) (1x error pass each, normally
-one) + the 6x6 solve on the host.  Registrations are restarted from the identity every 10 steps so the search workload stays
-the real one.  Inputs (clouds, covariances, search index) are resident in HBM before the timed region.
+Workload (config.workload = "C3"): GICP with per-point covariances (k = 20), 1M target points <-> 1M source points, synthetic
+planar scene (small_gicp_amd/synthetic.py, frozen in SURVEY.md §8d), max correspondence distance 1.0 m.
+One STEP = one outer Levenberg-Marquardt iteration of Registration<GICPFactor>::align (registration/optimizer.hpp:100-144 of the
+reference): 1x linearize (transform + exact NN + per-pair H/b/e + reduction) + the LM trial(s) (1x error pass each, normally one) +
+the 6x6 solve on the host.  Registrations restart from the identity every 10 steps (and from a cold search state: no neighbour is
+carried over from one registration to the next).  Inputs (clouds, covariances, search index) are resident in HBM before the timed
+region.
 
-Multi-GPU (weak scaling): the target + index are replicated, every rank owns an independent 1M-point source shard of an
-N x 1M-point source cloud, the 30-double accumulator (21 H, 6 b, e, inliers) is all-reduced with RCCL once per linearize and
-one double per error pass; every rank runs the same host LM on the reduced numbers.  value = N x steps / time, i.e. 1M-point
-registration iterations per second summed over ranks ("iters_per_sec_job" is the plain iteration rate of the N x 1M job).
+Multi-GPU, --scaling strong (default): ONE 1M <-> 1M registration; the source cloud (registration/reduction_omp.hpp:32-58 is the
+loop being partitioned) is split into N spatially contiguous shards, the target + its index are replicated, the 30-double
+accumulator (21 H, 6 b, e, inliers) is all-reduced with RCCL once per linearization and one double per error pass on the library's
+stream; every rank runs the same host LM on the reduced numbers.  value = iterations/s of that one job.  Rank 0 also runs the
+unsharded registration and the bench asserts that the N-rank pose equals it to 1e-9.  --scaling weak: every rank owns an independent
+1M-point source (value = N x the job's iteration rate), as in round 1.
 
-Extra objects on the JSON line: "roofline" (K1, algorithmic bytes / HIP-event time vs 8 TB/s) and "cpu_baseline" (the CPU oracle
-— a restatement of the reference's OpenMP path, oracle/ — timed on this box's host cores on the same clouds; rank 0, N = 1 only).
+Extra objects on the JSON line: "roofline" (K1 = search + factor kernel of one linearize pass, algorithmic bytes / HIP-event time vs
+8 TB/s), "cpu_baseline" (the unmodified reference code, oracle/_ref, timed on this box's host cores on the same clouds; rank 0, N = 1
+only), "parity_vs_reference" (the same 10 LM iterations on the GPU against that reference run), "fp64" (the headline with fp64
+per-pair math), "vgicp_c4", "kitti_odom" (C5; with N > 1 the scan's source points are sharded like the headline).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -41,19 +48,64 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--points", type=int, default=1_000_000, help="points per cloud per GPU (C3 = 1M)")
+    ap.add_argument("--points", type=int, default=1_000_000, help="points per cloud (C3 = 1M)")
     ap.add_argument("--neighbors", type=int, default=20)
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="multi-GPU: strong = one job, source sharded; weak = one 1M source per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=10, help="outer LM iterations of the CPU baseline sample")
     ap.add_argument("--math", default="fp32", choices=["fp32", "fp64"])
     ap.add_argument("--odom-frames", type=int, default=12, help="frames of the KITTI-shaped scan-to-scan odometry leg (config C5); 0 = skip")
     ap.add_argument("--no-vgicp", action="store_true", help="skip the VGICP (config C4) leg")
+    ap.add_argument("--no-fp64", action="store_true", help="skip the fp64-math repetition of the headline")
+    ap.add_argument("--sustain-s", type=float, default=3.0, help="extra (reported separately) sustained run of the same steps for this many seconds; 0 = skip")
     ap.add_argument("--force-dist", action="store_true", help="use the torch.distributed/RCCL path even at world size 1 (validation)")
+    ap.add_argument("--oversubscribe", action="store_true", help="testing only: place ranks on device rank %% visible devices")
     return ap.parse_args()
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run, one per GPU."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MASTER_ADDR"] = "127.0.0.1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus, "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def morton_order(points):
+    """Spatial (Morton) order of a cloud on the host: contiguous slices of it are compact source shards."""
+    p = np.asarray(points, dtype=np.float64)
+    lo, hi = p.min(0), p.max(0)
+    q = np.clip(((p - lo) / np.maximum(hi - lo, 1e-9).max() * 1023.0), 0, 1023).astype(np.uint64)
+
+    def spread(v):
+        v = (v | (v << np.uint64(16))) & np.uint64(0x030000FF)
+        v = (v | (v << np.uint64(8))) & np.uint64(0x0300F00F)
+        v = (v | (v << np.uint64(4))) & np.uint64(0x030C30C3)
+        v = (v | (v << np.uint64(2))) & np.uint64(0x09249249)
+        return v
+
+    key = spread(q[:, 0]) | (spread(q[:, 1]) << np.uint64(1)) | (spread(q[:, 2]) << np.uint64(2))
+    return np.argsort(key, kind="stable")
+
+
+def pose_error(A, B):
+    E = np.linalg.inv(A) @ B
+    return float(np.linalg.norm(E[:3, 3])), float(np.arccos(min(1.0, max(-1.0, (np.trace(E[:3, :3]) - 1) / 2))))
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -69,36 +121,58 @@ def main():
         import torch  # must precede loading the HIP library: one HIP runtime per process
         import torch.distributed as dist
 
+        ndev = torch.cuda.device_count()
+        if args.oversubscribe and ndev > 0:
+            local_rank = local_rank % ndev
+        if local_rank >= ndev:
+            raise SystemExit("bench: rank %d needs GPU %d but only %d are visible" % (rank, local_rank, ndev))
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.oversubscribe:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     import small_gicp_amd as sga
 
     n = args.points
-    # ---- data: identical target on every rank, an independent source resample per rank ----
+    strong = args.scaling == "strong"
+    # ---- data: identical target on every rank; strong: the rank's shard of ONE source, weak: an independent source per rank ----
     T_gt = sga.synthetic.gt_transform()
     target = sga.synthetic.scene(n, 1)
-    src_world = sga.synthetic.scene(n, 2 + rank).astype(np.float64)
+    src_world = sga.synthetic.scene(n, 2 + (0 if strong else rank)).astype(np.float64)
     Ti = np.linalg.inv(T_gt)
     source = (src_world @ Ti[:3, :3].T + Ti[:3, 3]).astype(np.float32)
+    if strong and world > 1:
+        source = source[morton_order(source)]
 
-    if use_dist:
+    if use_dist and not args.oversubscribe:
         stream = torch.cuda.current_stream().cuda_stream
         ctx = sga.Context(local_rank, stream=stream)
     else:
-        ctx = sga.Context(0)
+        ctx = sga.Context(local_rank if use_dist else 0)
 
     # ---- preprocessing on the GPU (untimed): covariances k = 20, search index, spatially sorted source ----
     t0 = time.perf_counter()
     tgt = sga.PointCloud(target, ctx=ctx)
-    src = sga.PointCloud(source, ctx=ctx)
+    src_full = sga.PointCloud(source, ctx=ctx)
     sga.estimate_covariances(tgt, None, args.neighbors)
-    sga.estimate_covariances(src, None, args.neighbors)
+    sga.estimate_covariances(src_full, None, args.neighbors)  # over the whole source on every rank: a shard's covariances need its neighbours
     tree = sga.KdTree(tgt)
+    if strong and world > 1:
+        lo, hi = rank * n // world, (rank + 1) * n // world
+        src = src_full.slice(lo, hi - lo)
+    else:
+        src = src_full
     problem = sga.Problem(tree, src, np.eye(4))
     ctx.synchronize()
     prep_s = time.perf_counter() - t0
 
-    setting = sga.make_setting("GICP", max_correspondence_distance=1.0, max_iterations=ITERS_PER_ALIGN, rotation_eps=0.0, translation_eps=0.0, math_mode=args.math)
+    def setting_for(max_iters, math):
+        return sga.make_setting("GICP", max_correspondence_distance=1.0, max_iterations=max_iters, rotation_eps=0.0, translation_eps=0.0, math_mode=math)
+
+    # the unsharded registration of the same job (before the communicator exists): what the sharded run must reproduce
+    ref_pose = None
+    if strong and world > 1 and rank == 0:
+        ref_pose = sga.Problem(tree, src_full, np.eye(4)).align(setting_for(ITERS_PER_ALIGN, args.math)).T_target_source
 
     native_comm = False
     if use_dist:
@@ -112,74 +186,111 @@ def main():
         except Exception as ex:  # noqa: BLE001
             print("bench: native RCCL communicator unavailable (%r); falling back to torch.distributed callbacks" % (ex,), file=sys.stderr)
 
+    host_tensors = args.oversubscribe  # gloo fallback reduces on the host
     if use_dist and not native_comm:
         acc = torch.zeros(sga._lib.ACCUM_DOUBLES, dtype=torch.float64, device="cuda")
         acc1 = torch.zeros(1, dtype=torch.float64, device="cuda")
 
+        def reduce_(t):
+            if not host_tensors:
+                dist.all_reduce(t)
+                return t.cpu().numpy()
+            h = t.cpu()
+            dist.all_reduce(h)
+            return h.numpy()
+
         def lin_cb(T):
-            problem.linearize_async(setting.factor, T, acc.data_ptr())
-            dist.all_reduce(acc)
-            return sga.unpack_accumulator(acc.cpu().numpy())
+            problem.linearize_async(setting_for(1, args.math).factor, T, acc.data_ptr())
+            ctx.synchronize()
+            return sga.unpack_accumulator(reduce_(acc))
 
         def err_cb(T):
-            problem.error_async(setting.factor, T, acc1.data_ptr())
-            dist.all_reduce(acc1)
-            return float(acc1.cpu()[0])
+            problem.error_async(setting_for(1, args.math).factor, T, acc1.data_ptr())
+            ctx.synchronize()
+            return float(reduce_(acc1)[0])
 
-        def run_align(max_iters):
-            s = sga.make_setting("GICP", max_correspondence_distance=1.0, max_iterations=max_iters, rotation_eps=0.0, translation_eps=0.0, math_mode=args.math)
-            return sga.optimize(s, np.eye(4), lin_cb, err_cb)
+        def run_align(max_iters, math=args.math):
+            return sga.optimize(setting_for(max_iters, math), np.eye(4), lin_cb, err_cb)
 
     else:
 
-        def run_align(max_iters):
-            s = sga.make_setting("GICP", max_correspondence_distance=1.0, max_iterations=max_iters, rotation_eps=0.0, translation_eps=0.0, math_mode=args.math)
-            return problem.align(s, np.eye(4))
+        def run_align(max_iters, math=args.math):
+            return problem.align(setting_for(max_iters, math), np.eye(4))
 
-    def run_steps(k):
+    def run_steps(k, math=args.math):
         done = 0
         last = None
         while done < k:
-            last = run_align(min(ITERS_PER_ALIGN, k - done))
+            last = run_align(min(ITERS_PER_ALIGN, k - done), math)
             done += last.iterations + 1
         return done, last
 
     def barrier():
         if use_dist:
             dist.barrier()
-            torch.cuda.synchronize()
+            if not args.oversubscribe:
+                torch.cuda.synchronize()
         ctx.synchronize()
+
+    def timed(k, math=args.math):
+        barrier()
+        t0 = time.perf_counter()
+        done, last = run_steps(k, math)
+        barrier()
+        el = time.perf_counter() - t0
+        if use_dist:
+            tmax = torch.tensor([el], dtype=torch.float64, device="cpu" if host_tensors else "cuda")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            el = float(tmax.cpu()[0])
+        return done, last, el
 
     run_steps(args.warmup)
     ctx.set_profiling(PROFILE_PERIOD)  # HIP events around every PROFILE_PERIOD-th pass, inside the timed region
-    barrier()
-    t0 = time.perf_counter()
-    steps_done, last = run_steps(args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    steps_done, last, elapsed = timed(args.steps)
     kms = ctx.kernel_ms()
+    stats = problem.pass_stats()
     ctx.set_profiling(False)
-    if use_dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.cpu()[0])
 
     # sanity: the pose the timed registrations converge to
-    E = np.linalg.inv(last.T_target_source) @ T_gt
-    pose_err_t = float(np.linalg.norm(E[:3, 3]))
-    pose_err_r = float(np.arccos(min(1.0, max(-1.0, (np.trace(E[:3, :3]) - 1) / 2))))
+    pose_err_t, pose_err_r = pose_error(last.T_target_source, T_gt)
 
+    shard_check = None
+    if strong and world > 1:
+        full = run_align(ITERS_PER_ALIGN)  # a complete registration of the sharded job
+        if rank == 0:
+            dt, dr = pose_error(full.T_target_source, ref_pose)
+            shard_check = {"dt_m": dt, "dr_rad": dr, "tolerance": 1e-9}
+            assert dt <= 1e-9 and dr <= 1e-9, "sharded registration differs from the unsharded one: %r" % (shard_check,)
+
+    sustained = None
+    if args.sustain_s > 0:
+        k = max(args.steps, int(args.sustain_s * steps_done / max(elapsed, 1e-6)))
+        d2, _, e2 = timed(k)
+        sustained = {"steps": d2, "seconds": e2, "iterations_per_s": d2 / e2 * (1 if strong else world)}
+
+    fp64 = None
+    if not args.no_fp64 and args.math == "fp32":
+        run_steps(ITERS_PER_ALIGN, "fp64")
+        d3, l3, e3 = timed(max(40, min(args.steps, 200)), "fp64")
+        t3, r3 = pose_error(l3.T_target_source, T_gt)
+        fp64 = {"iterations_per_s": d3 / e3 * (1 if strong else world), "ms_per_step": 1e3 * e3 / d3, "steps": d3, "final_pose_error": {"trans_m": t3, "rot_rad": r3},
+                "note": "the same steps with fp64 per-pair arithmetic (SGA_MATH_FP64); data in HBM stays fp32"}
+
+    out = None
     if rank == 0:
-        iters_per_sec_job = steps_done / elapsed
-        value = iters_per_sec_job * world
+        job_rate = steps_done / elapsed
+        value = job_rate * (1 if strong else world)
         lin_us = kms["linearize_ms"] * 1e3
         err_us = kms["error_ms"] * 1e3
-        achieved = (ALG_BYTES_PER_POINT["linearize_gicp"] * n) / (lin_us * 1e-6) / 1e9 if lin_us > 0 else None
-        traffic = None
+        n_rank = src.size()
+        achieved = (ALG_BYTES_PER_POINT["linearize_gicp"] * n_rank) / (lin_us * 1e-6) / 1e9 if lin_us > 0 else None
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "k1_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get("hbm_bytes_per_launch")
+                traffic_source = "profiles/k1_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/profile_gpu.sh, commit %s): a constant from that session, not measured in this run" % tj.get("commit", "?")
             except Exception:  # noqa: BLE001
                 traffic = None
         out = {
@@ -191,26 +302,29 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / steps_done,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32" if args.math == "fp32" else "f64",
             "data": "synthetic",
             "config": {
-                "workload": "C3: GICP, per-point covariances k=20, %d target <-> %d source points per GPU, max_corr_dist 1.0 m" % (n, n),
-                "step": "1 outer LM iteration = linearize + error pass(es) + host 6x6 solve; restart from identity every %d steps" % ITERS_PER_ALIGN,
-                "parallelism": ("source sharded x%d, target index replicated, RCCL all-reduce of 30 doubles per linearize + 1 per error pass (%s)" % (world, "native ncclAllReduce on the library stream" if native_comm else "torch.distributed callbacks")) if use_dist else "single GPU",
-                "source_points_total": n * world,
+                "workload": "C3: GICP, per-point covariances k=20, %d target <-> %d source points%s, max_corr_dist 1.0 m" % (n, n, "" if strong else " per GPU"),
+                "step": "1 outer LM iteration = linearize + error pass(es) + host 6x6 solve; restart from identity (and a cold search state) every %d steps" % ITERS_PER_ALIGN,
+                "parallelism": ("%s scaling: source %s x%d, target index replicated, RCCL all-reduce of 30 doubles per linearize + 1 per error pass (%s)"
+                                % (args.scaling, "sharded (contiguous Morton ranges of one cloud)" if strong else "one independent cloud per rank", world, "native ncclAllReduce on the library stream" if native_comm else "torch.distributed callbacks")) if use_dist else "single GPU",
+                "source_points_total": n * (1 if strong else world),
+                "source_points_per_gpu": n_rank,
             },
-            "iters_per_sec_job": iters_per_sec_job,
+            "iters_per_sec_job": job_rate,
             "roofline": {
-                "kernel": "K1 = nn_search_kernel<float> + linearize_kernel<float, GICP> (the two back-to-back launches of one linearize pass)",
+                "kernel": "K1 = nn_search_kernel<float> + linearize_kernel<float, GICP> (the two back-to-back launches of one linearize pass), average over the passes of whole registrations: cold (full walk) and warm (certified neighbours skip the walk)",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                 "traffic": traffic,
-                "alg_bytes_per_launch": ALG_BYTES_PER_POINT["linearize_gicp"] * n,
+                "traffic_source": traffic_source,
+                "alg_bytes_per_launch": ALG_BYTES_PER_POINT["linearize_gicp"] * n_rank,
                 "avg_launch_us": lin_us,
                 "launches_timed": kms["linearize_calls"],
                 "nn_search_kernel_avg_us": kms["search_ms"] * 1e3,
@@ -218,26 +332,61 @@ def main():
                 "cold_pass_avg_us": kms["cold_ms"] * 1e3,
                 "cold_passes_timed": kms["cold_calls"],
                 "warm_pass_avg_us": kms["warm_ms"] * 1e3,
+                "warm_pass_search_avg_us": kms["warm_search_ms"] * 1e3,
                 "warm_passes_timed": kms["warm_calls"],
-                "pass_stats": problem.pass_stats(),
+                "pass_stats": stats,
                 "error_kernel_avg_us": err_us,
-                "error_kernel_achieved_GBs": (ALG_BYTES_PER_POINT["error_gicp"] * n) / (err_us * 1e-6) / 1e9 if err_us > 0 else None,
+                "error_kernel_achieved_GBs": (ALG_BYTES_PER_POINT["error_gicp"] * n_rank) / (err_us * 1e-6) / 1e9 if err_us > 0 else None,
             },
             "preprocess_s": prep_s,
             "final_pose_error": {"trans_m": pose_err_t, "rot_rad": pose_err_r},
         }
-        if world == 1 and not use_dist and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sga, tgt, src, n, args)
+        if shard_check is not None:
+            out["sharded_vs_unsharded"] = shard_check
+        if sustained is not None:
+            out["sustained"] = sustained
+        if fp64 is not None:
+            out["fp64"] = fp64
+        single = world == 1 and not use_dist
+        if single and not args.no_cpu_baseline:
+            out["cpu_baseline"], ref_result = cpu_baseline(sga, tgt, src, n, args)
             if out["cpu_baseline"] and out["cpu_baseline"].get("value"):
                 out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
-        if world == 1 and not use_dist and not args.no_vgicp:
+            if ref_result is not None:
+                out["parity_vs_reference"] = parity_vs_reference(problem, ref_result, setting_for(args.cpu_iters, "fp32"), setting_for(args.cpu_iters, "fp64"), out["cpu_baseline"]["kind"])
+        if single and not args.no_vgicp:
             out["vgicp_c4"] = vgicp_leg(sga, ctx, tgt, src, args)
-        if world == 1 and not use_dist and args.odom_frames > 1:
-            out["kitti_odom"] = odometry_leg(sga, args)
+        if single and args.odom_frames > 1:
+            out["kitti_odom"] = odometry_leg(sga, args, None)
+    if use_dist and native_comm and world > 1 and args.odom_frames > 1:
+        r = odometry_leg(sga, args, (rank, world, ctx))
+        if rank == 0:
+            out["kitti_odom"] = r
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def parity_vs_reference(problem, ref, st32, st64, kind):
+    """The GPU against the CPU run of the same registration (same clouds and covariances, identity start, the same fixed number of LM
+    iterations): pose, iteration count, inliers, final H / error."""
+    out = {}
+    for name, st in (("fp32", st32), ("fp64", st64)):
+        r = problem.align(st, np.eye(4))
+        dt, dr = pose_error(r.T_target_source, ref.T_target_source)
+        out[name] = {
+            "dt_m": dt,
+            "dr_rad": dr,
+            "iterations": [int(r.iterations), int(ref.iterations)],
+            "num_inliers": [int(r.num_inliers), int(ref.num_inliers)],
+            "rel_err_H": float(np.abs(r.H - ref.H).max() / np.abs(ref.H).max()),
+            "rel_err_e": float(abs(r.error - ref.error) / abs(ref.error)),
+        }
+    out["against"] = ("oracle/_ref: registration_helper.cpp align() = Registration<GICPFactor, ParallelReductionOMP> of the unmodified reference (double), registration_helper.cpp:81-137"
+                      if kind == "reference" else "oracle/ restatement (the compiled reference did not travel with the repository)")
+    return out
 
 
 def vgicp_leg(sga, ctx, tgt, src, args):
@@ -269,12 +418,21 @@ def vgicp_leg(sga, ctx, tgt, src, args):
         return {"error": repr(ex)}
 
 
-def odometry_leg(sga, args):
+def odometry_leg(sga, args, shard):
     """Second half of the BASELINE metric: ms/scan of scan-to-scan GICP odometry on the KITTI-shaped synthetic stream (C5), GPU vs
-    the CPU oracle following the same protocol (downsample 0.25 m -> covariances k = 20 -> GICP against the previous scan)."""
+    the CPU oracle following the same protocol (downsample 0.25 m -> covariances k = 20 -> GICP against the previous scan).
+    shard = (rank, world, ctx): BASELINE config 5 — every rank preprocesses the scan, registers its contiguous shard of the source and
+    the accumulators are all-reduced once per linearization / error pass."""
     try:
         from small_gicp_amd import odometry
 
+        if shard is not None:
+            rank, world, ctx = shard
+            r = odometry.run_synthetic(args.odom_frames, ctx=ctx, shard=(rank, world))
+            out = {k: v for k, v in r.items() if k not in ("estimated", "ground_truth")}
+            out["unit"] = "ms/scan"
+            out["sharding"] = "source points of every scan split into %d contiguous shards, target index and preprocessing replicated, 30-double all-reduce per linearization" % world
+            return out
         r = odometry.run_synthetic(args.odom_frames)
         out = {k: v for k, v in r.items() if k not in ("estimated", "ground_truth")}
         out["unit"] = "ms/scan"
@@ -306,6 +464,7 @@ def odometry_leg(sga, args):
                 prev = cloud
             out["cpu_registration_ms_per_scan"] = float(np.mean(reg_ms[1:])) if len(reg_ms) > 1 else None
             out["cpu_threads"] = threads
+            out["cpu_kind"] = "port (oracle/ restatement, -O3 -fopenmp)"
         return out
     except Exception as ex:  # noqa: BLE001
         return {"error": repr(ex)}
@@ -315,7 +474,7 @@ def cpu_baseline(sga, tgt, src, n, args):
     """CPU baseline on the SAME clouds and covariances, all host threads, timed region = the optimizer loop only (index build
     excluded, as on the GPU side).  kind "reference": the unmodified reference code (registration_helper.cpp align ->
     Registration<GICPFactor, ParallelReductionOMP>) from oracle/_ref, when that library travelled with the repository;
-    kind "port": the oracle's restatement of the same path (oracle/), otherwise."""
+    kind "port": the oracle's restatement of the same path (oracle/), otherwise.  Returns (json object, CPU result or None)."""
     try:
         from oracle import orc, ref
 
@@ -348,7 +507,9 @@ def cpu_baseline(sga, tgt, src, n, args):
             if best is None or ips > best[0]:
                 best = (ips, threads, r)
         ips, threads, r = best
-        what = "unmodified reference code (oracle/_ref: registration_helper.cpp align, Registration<GICPFactor, ParallelReductionOMP>, built over an Eigen stand-in)" if use_ref else "oracle/ restatement of ParallelReductionOMP + KdTree + GICPFactor + LM"
+        what = ("unmodified reference code (oracle/_ref: registration_helper.cpp align, Registration<GICPFactor, ParallelReductionOMP>) compiled -O3 without -march=native over a scalar, "
+                "un-vectorised Eigen stand-in (oracle/ref/eigen_shim): the reference's algorithm and memory behaviour, not Eigen's SIMD kernels — a stated baseline, probably slower than a build against real Eigen"
+                ) if use_ref else "oracle/ restatement of ParallelReductionOMP + KdTree + GICPFactor + LM"
         return {
             "value": ips,
             "unit": "iterations/s",
@@ -357,9 +518,9 @@ def cpu_baseline(sga, tgt, src, n, args):
             "sample": "%s; full C3 pair (%d<->%d), %d outer LM iterations from identity, OpenMP schedule(guided,8); kd-tree build %.2fs excluded; iterations/s by thread count: %s"
             % (what, n, n, r.iterations + 1, build_s, json.dumps(tried)),
             "host_threads_available": ncpu,
-        }
+        }, r
     except Exception as ex:  # noqa: BLE001
-        return {"value": None, "unit": "iterations/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (ex,)}
+        return {"value": None, "unit": "iterations/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (ex,)}, None
 
 
 if __name__ == "__main__":

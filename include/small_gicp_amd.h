@@ -64,6 +64,9 @@ void* sga_context_stream(sga_context* ctx); /* the hipStream_t */
 int sga_cloud_create_f32(sga_context* ctx, const float* xyz, const float* normals, const float* cov6, size_t n, sga_cloud** out);
 /* Reference PointCloud layout (points/point_cloud.hpp:69-71): xyzw n*4 doubles, normals n*4 doubles or NULL, covs n*16 doubles (4x4) or NULL */
 int sga_cloud_create_f64(sga_context* ctx, const double* xyzw, const double* normals4, const double* cov4x4, size_t n, sga_cloud** out);
+/* A new cloud holding points [first, first + count) of `cloud` with their normals / covariances (device copy): the source shard of one
+ * rank when a registration is spread over GPUs (reduction_omp.hpp:32-58 is the loop being partitioned). */
+int sga_cloud_slice(sga_context* ctx, const sga_cloud* cloud, size_t first, size_t count, sga_cloud** out);
 int sga_cloud_destroy(sga_cloud* cloud);
 int sga_cloud_size(const sga_cloud* cloud, size_t* n);
 int sga_cloud_has(const sga_cloud* cloud, int* has_normals, int* has_covs);

@@ -71,6 +71,7 @@ SYMBOLS = [
     ("sga_context_stream", _vp, [_vp]),
     ("sga_cloud_create_f32", C.c_int, [_vp, _fp, _fp, _fp, C.c_size_t, _pvp]),
     ("sga_cloud_create_f64", C.c_int, [_vp, _dp, _dp, _dp, C.c_size_t, _pvp]),
+    ("sga_cloud_slice", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _pvp]),
     ("sga_cloud_destroy", C.c_int, [_vp]),
     ("sga_cloud_size", C.c_int, [_vp, C.POINTER(C.c_size_t)]),
     ("sga_cloud_has", C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

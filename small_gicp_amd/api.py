@@ -133,6 +133,13 @@ class PointCloud:
 
     __len__ = size
 
+    def slice(self, first, count):
+        """A new device cloud holding points [first, first + count) with their normals / covariances (sga_cloud_slice): the source
+        shard of one rank when a registration is spread over GPUs."""
+        h = C.c_void_p()
+        check(load().sga_cloud_slice(self.ctx.h, self.h, int(first), int(count), C.byref(h)))
+        return PointCloud(ctx=self.ctx, _handle=h)
+
     def empty(self):
         return self.size() == 0
 

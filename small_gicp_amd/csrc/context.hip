@@ -162,6 +162,16 @@ __global__ void unpack_cloud_kernel(const float4* __restrict__ pts, const float4
   }
 }
 
+__global__ void slice_cloud_kernel(const float4* __restrict__ pts, const float4* __restrict__ nrm, const Cov8* __restrict__ cov, size_t first, size_t count, float4* __restrict__ opts, float4* __restrict__ onrm, Cov8* __restrict__ ocov) {
+  const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
+  if (i >= count) return;
+  float4 p = pts[first + i];
+  p.w = __uint_as_float(static_cast<uint32_t>(i));  // indices of the slice start at 0
+  opts[i] = p;
+  if (nrm) onrm[i] = nrm[first + i];
+  if (cov) ocov[i] = cov[first + i];
+}
+
 int ensure_temp(sga_context* ctx, size_t bytes) { return ctx->d_temp.reserve(bytes); }
 
 }  // namespace sga
@@ -358,6 +368,36 @@ int sga_cloud_create_f64(sga_context* ctx, const double* xyzw, const double* nor
     }
   }
   return sga_cloud_create_f32(ctx, xyz.data(), normals4 ? nrm.data() : nullptr, cov4x4 ? cov.data() : nullptr, n, out);
+}
+
+int sga_cloud_slice(sga_context* ctx, const sga_cloud* cloud, size_t first, size_t count, sga_cloud** out) {
+  if (!ctx || !cloud || !out) return fail(SGA_ERR_INVALID, "null argument");
+  if (first > cloud->n || count > cloud->n - first) return fail(SGA_ERR_INVALID, "slice [%zu, %zu) outside a cloud of %zu points", first, first + count, cloud->n);
+  if (cloud->device != ctx->device) return fail(SGA_ERR_INVALID, "cloud lives on another device");
+  *out = nullptr;
+  SGA_HIP(hipSetDevice(ctx->device));
+  auto* c = new sga_cloud;
+  c->device = ctx->device;
+  c->n = count;
+  c->has_normals = cloud->has_normals;
+  c->has_covs = cloud->has_covs;
+  int rc = c->pts.alloc(count);
+  if (rc == SGA_OK && cloud->has_normals) rc = c->nrm.alloc(count);
+  if (rc == SGA_OK && cloud->has_covs) rc = c->cov.alloc(count);
+  if (rc != SGA_OK) {
+    delete c;
+    return rc;
+  }
+  if (count > 0) {
+    hipLaunchKernelGGL(slice_cloud_kernel, dim3((count + 255) / 256), dim3(256), 0, ctx->stream, cloud->pts.p, cloud->has_normals ? cloud->nrm.p : nullptr, cloud->has_covs ? cloud->cov.p : nullptr, first, count, c->pts.p, c->nrm.p, c->cov.p);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+      delete c;
+      return fail(SGA_ERR_HIP, "slice kernel: %s", hipGetErrorString(e));
+    }
+  }
+  *out = c;
+  return SGA_OK;
 }
 
 int sga_cloud_destroy(sga_cloud* cloud) {

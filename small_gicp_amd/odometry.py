@@ -16,7 +16,13 @@ from . import api
 
 
 class OnlineOdometry:
-    def __init__(self, downsampling_resolution=0.25, num_neighbors=20, max_correspondence_distance=1.0, ctx=None):
+    """shard = (rank, world): multi-GPU form (BASELINE config C5).  Every rank preprocesses the whole scan (voxel grid, index,
+    covariances: replicated), registers only its contiguous shard of the source against the replicated target
+    and the context's RCCL communicator (Context.comm_init) sums the shards' systems once per linearization / error pass, so every rank
+    computes the same pose."""
+
+    def __init__(self, downsampling_resolution=0.25, num_neighbors=20, max_correspondence_distance=1.0, ctx=None, shard=None):
+        self.shard = shard
         self.res = downsampling_resolution
         self.k = num_neighbors
         self.setting = api.make_setting("GICP", max_correspondence_distance=max_correspondence_distance)
@@ -39,7 +45,13 @@ class OnlineOdometry:
         api.estimate_covariances(cloud, tree, self.k)
         if self.target is not None:
             tgt_cloud, tgt_tree = self.target
-            res = api.Problem(tgt_tree, cloud, np.eye(4)).align(self.setting, np.eye(4))
+            src = cloud
+            if self.shard is not None:
+                rank, world = self.shard
+                n = cloud.size()
+                lo, hi = rank * n // world, (rank + 1) * n // world
+                src = cloud.slice(lo, hi - lo)
+            res = api.Problem(tgt_tree, src, np.eye(4)).align(self.setting, np.eye(4))
             self.T_world = self.T_world @ res.T_target_source
             self.iterations.append(res.iterations + 1)
         self.ctx.synchronize()
