@@ -1,0 +1,175 @@
+// The reference-side binding, compiled and run: Registration<Factor, ParallelReductionHIP> (include/small_gicp/registration/
+// reduction_hip.hpp) instantiated from the UNMODIFIED reference headers (/root/reference/include, over the Eigen stand-in of
+// oracle/ref/eigen_shim) and linked against libsmall_gicp_amd.so, next to the reference's own Registration<Factor,
+// ParallelReductionOMP> on the same clouds.  Built by oracle/ref/Makefile into oracle/_ref/test_reduction_hip (git-ignored, travels
+// to the GPU box); driven by tests/test_integration_policy.py.
+//
+//   test_reduction_hip <target.bin> <source.bin>      (raw float32 xyz triples)
+// Prints one "CASE {json}" line per case and exits non-zero if any check fails.
+#include <cmath>
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include <small_gicp/ann/kdtree.hpp>
+#include <small_gicp/ann/kdtree_omp.hpp>
+#include <small_gicp/factors/gicp_factor.hpp>
+#include <small_gicp/factors/icp_factor.hpp>
+#include <small_gicp/factors/plane_icp_factor.hpp>
+#include <small_gicp/factors/robust_kernel.hpp>
+#include <small_gicp/points/point_cloud.hpp>
+#include <small_gicp/registration/reduction_omp.hpp>
+#include <small_gicp/registration/registration.hpp>
+#include <small_gicp/util/downsampling.hpp>
+#include <small_gicp/util/normal_estimation_omp.hpp>
+
+#include <small_gicp/registration/reduction_hip.hpp>
+
+using namespace small_gicp;
+
+static std::vector<Eigen::Vector4d> read_xyz(const char* path) {
+  std::ifstream f(path, std::ios::binary | std::ios::ate);
+  if (!f) {
+    std::fprintf(stderr, "cannot read %s\n", path);
+    std::exit(2);
+  }
+  const size_t bytes = static_cast<size_t>(f.tellg());
+  f.seekg(0);
+  std::vector<float> raw(bytes / 4);
+  f.read(reinterpret_cast<char*>(raw.data()), bytes);
+  std::vector<Eigen::Vector4d> pts(raw.size() / 3);
+  for (size_t i = 0; i < pts.size(); i++) pts[i] = Eigen::Vector4d(raw[3 * i], raw[3 * i + 1], raw[3 * i + 2], 1.0);
+  return pts;
+}
+
+static std::shared_ptr<PointCloud> preprocess(const std::vector<Eigen::Vector4d>& pts) {
+  auto cloud = std::make_shared<PointCloud>(pts);
+  auto down = voxelgrid_sampling(*cloud, 0.25);  // serial: deterministic order (util/downsampling.hpp:23-78)
+  auto tree = std::make_shared<KdTree<PointCloud>>(down, KdTreeBuilderOMP(4));
+  estimate_normals_covariances_omp(*down, *tree, 10, 4);
+  // the device stores fp32: round the host copy the same way so that both reductions see identical inputs
+  for (size_t i = 0; i < down->size(); i++) {
+    for (int k = 0; k < 3; k++) down->point(i)[k] = static_cast<float>(down->point(i)[k]);
+    for (int k = 0; k < 3; k++) down->normal(i)[k] = static_cast<float>(down->normal(i)[k]);
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) down->cov(i)(r, c) = static_cast<float>(down->cov(i)(r, c));
+  }
+  return down;
+}
+
+static void pose_error(const Eigen::Isometry3d& A, const Eigen::Isometry3d& B, double* dt, double* dr) {
+  const Eigen::Isometry3d E = A.inverse() * B;
+  *dt = E.translation().norm();
+  const double c = (E.linear()(0, 0) + E.linear()(1, 1) + E.linear()(2, 2) - 1.0) / 2.0;
+  *dr = std::acos(std::min(1.0, std::max(-1.0, c)));
+}
+
+static int failures = 0;
+
+template <typename Factor>
+static void run_case(const char* name, const PointCloud& target, const PointCloud& source, const KdTree<PointCloud>& tree, Registration<Factor, ParallelReductionHIP>& hip, const Eigen::Isometry3d& init) {
+  Registration<Factor, ParallelReductionOMP> cpu;
+  cpu.reduction.num_threads = 4;
+  cpu.rejector.max_dist_sq = hip.rejector.max_dist_sq;
+  cpu.point_factor = hip.point_factor;
+  const RegistrationResult rc = cpu.align(target, source, tree, init);
+  const RegistrationResult rh = hip.align(target, source, tree, init);
+  double dt, dr;
+  pose_error(rc.T_target_source, rh.T_target_source, &dt, &dr);
+  double dH = 0.0, mH = 0.0;
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < 6; j++) {
+      dH = std::max(dH, std::abs(rc.H(i, j) - rh.H(i, j)));
+      mH = std::max(mH, std::abs(rc.H(i, j)));
+    }
+  const double relH = dH / mH;
+  const bool ok = dt < 1e-4 && dr < 1e-4 && rc.iterations == rh.iterations && rc.converged == rh.converged && std::llabs(static_cast<long long>(rc.num_inliers) - static_cast<long long>(rh.num_inliers)) <= 2 &&
+                  rh.num_inliers == hip.reduction.num_inliers && relH < 1e-4;
+  std::printf(
+    "CASE {\"name\": \"%s\", \"ok\": %s, \"dt\": %.3e, \"dr\": %.3e, \"iterations\": [%zu, %zu], \"num_inliers\": [%zu, %zu], \"reduction_num_inliers\": %zu, \"rel_err_H\": %.3e, \"uploads\": %llu}\n", name, ok ? "true" : "false", dt, dr,
+    rh.iterations, rc.iterations, rh.num_inliers, rc.num_inliers, hip.reduction.num_inliers, relH, static_cast<unsigned long long>(hip.reduction.generation()));
+  if (!ok) failures++;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 3) {
+    std::fprintf(stderr, "usage: %s target.bin source.bin\n", argv[0]);
+    return 2;
+  }
+  auto target = preprocess(read_xyz(argv[1]));
+  auto source = preprocess(read_xyz(argv[2]));
+  KdTree<PointCloud> tree(target, KdTreeBuilderOMP(4));
+  const Eigen::Isometry3d I = Eigen::Isometry3d::Identity();
+
+  {
+    Registration<GICPFactor, ParallelReductionHIP> reg;
+    run_case("GICP", *target, *source, tree, reg, I);
+    const auto uploads = reg.reduction.generation();
+    run_case("GICP again (cached uploads)", *target, *source, tree, reg, I);
+    if (reg.reduction.generation() != uploads) {
+      std::printf("CASE {\"name\": \"unchanged clouds were uploaded again\", \"ok\": false}\n");
+      failures++;
+    }
+    // an odometry loop refills the same objects: move the source in place — the policy must notice and upload it again
+    Eigen::Isometry3d M = Eigen::Isometry3d::Identity();
+    M.matrix()(0, 0) = std::cos(0.01);  // 0.01 rad about z
+    M.matrix()(0, 1) = -std::sin(0.01);
+    M.matrix()(1, 0) = std::sin(0.01);
+    M.matrix()(1, 1) = std::cos(0.01);
+    M.matrix()(0, 3) = 0.05;
+    M.matrix()(1, 3) = -0.03;
+    M.matrix()(2, 3) = 0.01;
+    for (size_t i = 0; i < source->size(); i++) {
+      Eigen::Vector4d p = M * source->point(i);
+      for (int k = 0; k < 3; k++) p[k] = static_cast<float>(p[k]);
+      source->point(i) = p;
+      Eigen::Matrix4d c = M.matrix() * source->cov(i) * M.matrix().transpose();
+      for (int r = 0; r < 4; r++)
+        for (int cc = 0; cc < 4; cc++) c(r, cc) = static_cast<float>(c(r, cc));
+      source->cov(i) = c;
+      Eigen::Vector4d nn = M.matrix() * source->normal(i);
+      for (int k = 0; k < 3; k++) nn[k] = static_cast<float>(nn[k]);
+      source->normal(i) = nn;
+    }
+    run_case("GICP after refilling the source object in place", *target, *source, tree, reg, I);
+    reg.reduction.sync_factors = false;  // fast path: the count comes from the reduction
+    Registration<GICPFactor, ParallelReductionOMP> cpu;
+    cpu.reduction.num_threads = 4;
+    const auto rc = cpu.align(*target, *source, tree, I);
+    auto rh = reg.align(*target, *source, tree, I);
+    const bool ok = rh.num_inliers == 0 && std::llabs(static_cast<long long>(reg.reduction.num_inliers) - static_cast<long long>(rc.num_inliers)) <= 2;
+    std::printf("CASE {\"name\": \"sync_factors = false: count from reduction.num_inliers\", \"ok\": %s, \"reduction_num_inliers\": %zu, \"cpu\": %zu}\n", ok ? "true" : "false", reg.reduction.num_inliers, rc.num_inliers);
+    if (!ok) failures++;
+  }
+  {
+    Registration<PointToPlaneICPFactor, ParallelReductionHIP> reg;
+    run_case("PLANE_ICP", *target, *source, tree, reg, I);
+  }
+  {
+    Registration<ICPFactor, ParallelReductionHIP> reg;
+    reg.rejector.max_dist_sq = 0.25;
+    run_case("ICP max_dist 0.5", *target, *source, tree, reg, I);
+  }
+  {
+    Registration<RobustFactor<Huber, GICPFactor>, ParallelReductionHIP> reg;
+    reg.point_factor.robust_kernel.c = 0.5;
+    run_case("Huber(0.5) GICP", *target, *source, tree, reg, I);
+  }
+  {
+    Registration<RobustFactor<Cauchy, GICPFactor>, ParallelReductionHIP, NullFactor, NullRejector> reg;
+    Registration<RobustFactor<Cauchy, GICPFactor>, ParallelReductionOMP, NullFactor, NullRejector> cpu;
+    cpu.reduction.num_threads = 4;
+    const auto rc = cpu.align(*target, *source, tree, I);
+    const auto rh = reg.align(*target, *source, tree, I);
+    double dt, dr;
+    pose_error(rc.T_target_source, rh.T_target_source, &dt, &dr);
+    const bool ok = dt < 1e-4 && dr < 1e-4 && rc.iterations == rh.iterations && rc.num_inliers == rh.num_inliers;
+    std::printf("CASE {\"name\": \"Cauchy GICP, NullRejector\", \"ok\": %s, \"dt\": %.3e, \"dr\": %.3e, \"iterations\": [%zu, %zu], \"num_inliers\": [%zu, %zu]}\n", ok ? "true" : "false", dt, dr, rh.iterations, rc.iterations, rh.num_inliers,
+                rc.num_inliers);
+    if (!ok) failures++;
+  }
+  std::printf("DONE failures=%d\n", failures);
+  return failures == 0 ? 0 : 1;
+}
