@@ -115,8 +115,12 @@ int sga_voxelmap_set_search_offsets(sga_index* voxelmap, int num_offsets);
 int sga_flatmap_download(sga_context* ctx, const sga_index* flatmap, int32_t* coords, uint32_t* counts, float* points, float* cov6);
 /* traits::knn_search / nearest_neighbor_search (ann/traits.hpp:22-57) for m host queries (m*3 floats):
  * idx m*k int64 (original target indices, -1 = none), sq_dist m*k floats ascending (inf = none).
- * max_sq_dist < 0 means unbounded.  Voxel maps support k = 1 only (own voxel, incremental_voxelmap.hpp:99-119). */
+ * max_sq_dist < 0 means unbounded.  k <= 116 for kd-trees.  Voxel maps support k = 1 only (own voxel, incremental_voxelmap.hpp:99-119). */
 int sga_index_knn(sga_context* ctx, const sga_index* index, const float* queries, size_t m, int k, double max_sq_dist, int64_t* idx, float* sq_dist);
+/* The same with the reference's types (double queries m*3, double squared distances): the search runs on the fp32 roundings of the
+ * queries, the squared distances of the neighbours found are then evaluated in double against the double queries (the reference's
+ * Python tests compare them with scipy to 1e-6 at ranges where fp32 resolves 1e-4, src/test/python_test.py:194-257). */
+int sga_index_knn_f64(sga_context* ctx, const sga_index* index, const double* queries, size_t m, int k, double max_sq_dist, int64_t* idx, double* sq_dist);
 
 /* ---- the hot path: Reduction::linearize / Reduction::error (registration/reduction_omp.hpp:24-70) ------------------------- */
 typedef struct sga_factor_params {
@@ -151,6 +155,11 @@ int sga_comm_init(sga_context* ctx, int nranks, int rank, const unsigned char id
 int sga_comm_destroy(sga_context* ctx);
 /* Expand a 30-double accumulator (host memory) into H[36], b[6], e, num_inliers. */
 void sga_unpack_accumulator(const double acc30[SGA_ACCUM_DOUBLES], double H[36], double b[6], double* e, uint64_t* num_inliers);
+/* Factor::linearize per source point, as the reference's Python binding exposes it (src/python/factors.cpp:52-101; gicp_factor.hpp:35-73,
+ * icp_factor.hpp:20-54, plane_icp_factor.hpp:19-57): runs one linearization at T, then returns for every source point (caller's order)
+ * values28 n*28 doubles = [0..20] upper triangle of H_i row-wise, [21..26] b_i, [27] e_i, and inlier n bytes (0: no correspondence, all
+ * values 0).  kd-tree targets; per-pair arithmetic in fp64.  A diagnostic / binding entry point, not the hot path. */
+int sga_linearize_per_point(sga_context* ctx, sga_problem* problem, const sga_factor_params* params, const double T[16], double* values28, unsigned char* inlier);
 /* Factor state in the caller's source order: target_index n int64 (-1 = outlier; voxel id for voxel maps), mahalanobis6 n*6 floats (GICP only). */
 int sga_problem_get_factors(sga_context* ctx, const sga_problem* problem, int64_t* target_index, float* mahalanobis6);
 /* Average device time (ms) of the linearize / error kernel chains measured with HIP events on the context's stream (0 if profiling

@@ -113,7 +113,8 @@ def _align_voxelmap(
     translation_epsilon=1e-3,
     verbose=False,
 ):
-    """align.cpp:233-263 -> registration_helper.cpp:125-137: VGICP against a GaussianVoxelMap."""
+    """align.cpp:233-263: VGICP against a GaussianVoxelMap.  Like the binding (align.cpp:246) — and unlike the C++ helper of
+    registration_helper.cpp:125-137 — this overload applies max_correspondence_distance to the rejector."""
     s = _setting("GICP", max_correspondence_distance, max_iterations, rotation_epsilon, translation_epsilon, verbose)
     return _api.Problem(target_voxelmap, source, init_T_target_source).align(s, init_T_target_source)
 
@@ -139,17 +140,12 @@ class DistanceRejector:
         self.max_dist_sq = float(dist) ** 2
 
 
-def _skew(p):
-    z = np.zeros(len(p))
-    return np.stack([np.stack([z, -p[:, 2], p[:, 1]], 1), np.stack([p[:, 2], z, -p[:, 0]], 1), np.stack([-p[:, 1], p[:, 0], z], 1)], 1)
-
-
 class _PointFactor:
     """Per-point `linearize(target, source, kdtree, T, source_index, rejector) -> (success, H 6x6, b 6, e)` (factors.cpp:52-101).
 
-    The binding evaluates one source point per call; here the first call for a given (target, source, tree, T, rejector) evaluates
-    ALL source points at once — correspondences by the GPU search (KdTree.batch_nearest_neighbor_search), the 6x6 blocks of the
-    matched pairs in numpy following the factor's formulas — and later calls with other indices are served from that batch."""
+    The binding evaluates one source point per call.  Here the first call for a given (target, source, tree, T, rejector) runs the
+    ENGINE once over all source points — sga_linearize_per_point: the GPU search + the factor kernel's per-pair algebra, exported per
+    point instead of summed — and later calls with other indices are served from that batch."""
 
     _kind = "ICP"
 
@@ -158,39 +154,11 @@ class _PointFactor:
         self._batch = None
 
     def _evaluate(self, target, source, kdtree, T, rejector):
-        T = np.asarray(T, dtype=np.float64)
-        R, t = T[:3, :3], T[:3, 3]
-        ps = source.points()[:, :3]
-        q = ps @ R.T + t
-        idx, d2 = kdtree.batch_nearest_neighbor_search(q)
-        max_sq = getattr(rejector, "max_dist_sq", np.inf)
-        ok = (idx >= 0) & ~(d2.astype(np.float64) > max_sq)
-        j = np.where(ok, idx, 0)
-        pt = target.points()[:, :3][j]
-        r = pt - q
-        n = len(ps)
-        J = np.zeros((n, 3, 6))
-        J[:, :, :3] = R[None] @ _skew(ps)   # d(residual)/d(rotation) = R skew(p_s)      (gicp_factor.hpp:56-58, icp_factor.hpp:42-44)
-        J[:, :, 3:] = -R[None]
-        if self._kind == "GICP":
-            Ct = target.covs()[:, :3, :3][j]
-            Cs = source.covs()[:, :3, :3]
-            M = np.linalg.inv(Ct + R[None] @ Cs @ R.T[None])                      # gicp_factor.hpp:60
-            H = np.transpose(J, (0, 2, 1)) @ M @ J
-            b = (np.transpose(J, (0, 2, 1)) @ M @ r[:, :, None])[:, :, 0]
-            e = 0.5 * np.einsum("ni,nij,nj->n", r, M, r)
-        elif self._kind == "PLANE_ICP":
-            nt = target.normals()[:, :3][j]
-            Jn = nt[:, :, None] * J                                                  # plane_icp_factor.hpp:44-54: elementwise weighting
-            err = nt * r
-            H = np.transpose(Jn, (0, 2, 1)) @ Jn
-            b = (np.transpose(Jn, (0, 2, 1)) @ err[:, :, None])[:, :, 0]
-            e = 0.5 * (err * err).sum(1)
-        else:
-            H = np.transpose(J, (0, 2, 1)) @ J                                       # icp_factor.hpp:34-52
-            b = (np.transpose(J, (0, 2, 1)) @ r[:, :, None])[:, :, 0]
-            e = 0.5 * (r * r).sum(1)
-        return ok, H, b, e
+        kdtree.refresh_attributes()  # the tree may have been built before the covariances / normals were estimated
+        s = _api.make_setting(self._kind)
+        max_sq = getattr(rejector, "max_dist_sq", None)
+        s.factor.max_dist_sq = -1.0 if max_sq is None or not np.isfinite(max_sq) else float(max_sq)
+        return _api.Problem(kdtree, source, T).linearize_per_point(s.factor, T)
 
     def linearize(self, target, source, kdtree, T, source_index, rejector):
         key = (id(target), id(source), id(kdtree), np.asarray(T, dtype=np.float64).tobytes(), getattr(rejector, "max_dist_sq", None))

@@ -92,6 +92,7 @@ SYMBOLS = [
     ("sga_voxelmap_set_search_offsets", C.c_int, [_vp, C.c_int]),
     ("sga_flatmap_download", C.c_int, [_vp, _vp, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), _fp, _fp]),
     ("sga_index_knn", C.c_int, [_vp, _vp, _fp, C.c_size_t, C.c_int, C.c_double, C.POINTER(C.c_int64), _fp]),
+    ("sga_index_knn_f64", C.c_int, [_vp, _vp, _dp, C.c_size_t, C.c_int, C.c_double, C.POINTER(C.c_int64), _dp]),
     ("sga_factor_params_default", None, [C.POINTER(FactorParams)]),
     ("sga_problem_create", C.c_int, [_vp, _vp, _vp, _dp, _pvp]),
     ("sga_problem_destroy", C.c_int, [_vp]),
@@ -103,6 +104,7 @@ SYMBOLS = [
     ("sga_comm_init", C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_ubyte)]),
     ("sga_comm_destroy", C.c_int, [_vp]),
     ("sga_unpack_accumulator", None, [_dp, _dp, _dp, _dp, C.POINTER(C.c_uint64)]),
+    ("sga_linearize_per_point", C.c_int, [_vp, _vp, C.POINTER(FactorParams), _dp, _dp, C.POINTER(C.c_ubyte)]),
     ("sga_problem_get_factors", C.c_int, [_vp, _vp, C.POINTER(C.c_int64), _fp]),
     ("sga_context_set_profiling", C.c_int, [_vp, C.c_int]),
     ("sga_context_get_kernel_ms", C.c_int, [_vp, _dp, C.POINTER(C.c_uint64), _dp, C.POINTER(C.c_uint64)]),

@@ -133,6 +133,16 @@ class PointCloud:
 
     __len__ = size
 
+    def point(self, i):
+        """pointcloud.cpp: the i-th point as a homogeneous 4-vector (points/point_cloud.hpp:49)."""
+        return self.points()[int(i)]
+
+    def normal(self, i):
+        return self.normals()[int(i)]
+
+    def cov(self, i):
+        return self.covs()[int(i)]
+
     def slice(self, first, count):
         """A new device cloud holding points [first, first + count) with their normals / covariances (sga_cloud_slice): the source
         shard of one rank when a registration is spread over GPUs."""
@@ -207,10 +217,12 @@ class KdTree:
         check(load().sga_index_refresh_attributes(self.ctx.h, self.h, self.cloud.h))
 
     def batch_knn_search(self, pts, k, max_sq_dist=-1.0, num_threads=1):
-        q = np.ascontiguousarray(np.asarray(pts)[:, :3], dtype=np.float32)
+        """kdtree.cpp:128-205: (indices (m,k) int64, squared distances (m,k) float64) — double distances like the reference's
+        (sga_index_knn_f64: the search runs in fp32, the distances of the neighbours found are evaluated in double)."""
+        q = np.ascontiguousarray(np.asarray(pts)[:, :3], dtype=np.float64)
         idx = np.empty((len(q), k), np.int64)
-        d2 = np.empty((len(q), k), np.float32)
-        check(load().sga_index_knn(self.ctx.h, self.h, _fp(q), len(q), int(k), float(max_sq_dist), idx.ctypes.data_as(C.POINTER(C.c_int64)), _fp(d2)))
+        d2 = np.empty((len(q), k), np.float64)
+        check(load().sga_index_knn_f64(self.ctx.h, self.h, _dp(q), len(q), int(k), float(max_sq_dist), idx.ctypes.data_as(C.POINTER(C.c_int64)), _dp(d2)))
         return idx, d2
 
     def batch_nearest_neighbor_search(self, pts, num_threads=1):
@@ -434,6 +446,19 @@ class Problem:
         t16 = _T16(T)
         check(load().sga_error_async(self.ctx.h, self.h, C.byref(factor_params), _dp(t16), C.c_void_p(int(d_out_ptr))))
 
+    def linearize_per_point(self, factor_params, T):
+        """sga_linearize_per_point: (inlier (n,) bool, H (n,6,6), b (n,6), e (n,)) for every source point in the caller's order."""
+        n = self.source.size()
+        vals = np.zeros((n, 28))
+        ok = np.zeros(n, np.uint8)
+        t16 = _T16(T)
+        check(load().sga_linearize_per_point(self.ctx.h, self.h, C.byref(factor_params), _dp(t16), _dp(vals), ok.ctypes.data_as(C.POINTER(C.c_ubyte))))
+        H = np.zeros((n, 6, 6))
+        iu = np.triu_indices(6)
+        H[:, iu[0], iu[1]] = vals[:, :21]
+        H[:, iu[1], iu[0]] = vals[:, :21]
+        return ok.astype(bool), H, vals[:, 21:27].copy(), vals[:, 27].copy()
+
     def factors(self):
         n = self.source.size()
         ti = np.empty(n, np.int64)
@@ -560,6 +585,9 @@ def align(
     align(target_voxelmap, source_cloud)              -> VGICP                                      (registration_helper.cpp:125-137)
     """
     if isinstance(target, GaussianVoxelMap):
+        # the Python binding's voxel-map overload DOES apply max_correspondence_distance (src/python/align.cpp:246), unlike the C++
+        # helper align(GaussianVoxelMap, ...) of registration_helper.cpp:125-137 (mirrored in include/small_gicp_amd.hpp), which
+        # leaves the rejector at 1.0 m^2: each layer mirrors its own counterpart
         setting = make_setting("GICP", max_correspondence_distance, max_iterations, verbose=verbose, **kw)
         return Problem(target, source, init_T_target_source).align(setting, init_T_target_source)
     if not isinstance(target, PointCloud):

@@ -289,6 +289,37 @@ __global__ __launch_bounds__(kTile) void linearize_kernel(const LinParams<Real> 
   }
 }
 
+// Per-point export of the same factors (the reference's Python binding exposes Factor::linearize per source point,
+// src/python/factors.cpp:52-101): the 28 values of every pair instead of their sum.  Runs after a linearize pass at the same pose
+// (the neighbours come from hint[]); not on the hot path.
+template <typename Real, int FACTOR>
+__global__ __launch_bounds__(256) void per_point_kernel(const LinParams<Real> p, double* __restrict__ out28, unsigned char* __restrict__ ok) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.n) return;
+  const float4 ps4 = p.src_pts[i];
+  const Real px = ps4.x, py = ps4.y, pz = ps4.z;
+  Real qx, qy, qz;
+  transform_point(p.T, px, py, pz, qx, qy, qz);
+  Real vals[28];
+#pragma unroll
+  for (int k = 0; k < 28; k++) vals[k] = Real(0);
+  const int j = p.hint[i];
+  Real tx = 0, ty = 0, tz = 0;
+  bool within = false;
+  if (j >= 0) {
+    const float4 m = p.tgt_pts[j];
+    tx = m.x;
+    ty = m.y;
+    tz = m.z;
+    within = kd_dist2(m.x, m.y, m.z, static_cast<float>(qx), static_cast<float>(qy), static_cast<float>(qz)) < p.bound2;
+  }
+  const bool inlier = pair_factor<Real, FACTOR>(p, i, j, within, px, py, pz, qx, qy, qz, tx, ty, tz, vals);
+  const uint32_t orig = __float_as_uint(ps4.w);  // the caller's source order
+  ok[orig] = inlier ? 1 : 0;
+#pragma unroll
+  for (int k = 0; k < 28; k++) out28[static_cast<size_t>(orig) * 28 + k] = static_cast<double>(vals[k]);
+}
+
 template <typename Real>
 struct ErrParams {
   const float4* __restrict__ src_pts;
@@ -690,6 +721,50 @@ void sga_unpack_accumulator(const double acc[SGA_ACCUM_DOUBLES], double H[36], d
   for (int i = 0; i < 6; i++) b[i] = acc[21 + i];
   if (e) *e = acc[27];
   if (num_inliers) *num_inliers = static_cast<uint64_t>(acc[28] + 0.5);
+}
+
+int sga_linearize_per_point(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, const double T[16], double* values28, unsigned char* inlier) {
+  SGA_TRY(check_args(ctx, pb, fp, T));
+  if (!values28 || !inlier) return fail(SGA_ERR_INVALID, "null output");
+  if (pb->target->kind != SGA_INDEX_KDTREE) return fail(SGA_ERR_UNSUPPORTED, "per-point factors need a kd-tree target");
+  double H[36], b[6], e = 0;
+  uint64_t ninl = 0;
+  sga_factor_params f32 = *fp;
+  f32.math_mode = SGA_MATH_FP64;  // the export is a diagnostic: full precision per pair
+  SGA_TRY(sga_linearize(ctx, pb, &f32, T, H, b, &e, &ninl));  // neighbours + factor state at T
+  const size_t n = pb->n;
+  if (n == 0) return SGA_OK;
+  const sga_index* idx = pb->target;
+  LinParams<double> p{};
+  p.src_pts = pb->pts.p;
+  p.src_cov = pb->cov.p;
+  p.n = static_cast<int>(n);
+  p.tgt_pts = idx->kd_pts.p;
+  p.tgt_nrm = idx->nrm.p;
+  p.tgt_cov = idx->cov.p;
+  p.corr = pb->corr.p;
+  p.hint = pb->hint.p;
+  p.maha = pb->maha64.p;
+  p.T = rigid_from_colmajor<double>(T);
+  p.max_sq = fp->max_dist_sq < 0 ? INFINITY : static_cast<float>(fp->max_dist_sq);
+  p.bound2 = p.max_sq < 3.0e38f ? p.max_sq * 1.0000002f : INFINITY;
+  p.robust_kind = fp->robust_kind;
+  p.robust_c = fp->robust_c;
+  DevBuf<double> d_vals;
+  DevBuf<unsigned char> d_ok;
+  SGA_TRY(d_vals.alloc(n * 28));
+  SGA_TRY(d_ok.alloc(n));
+  const dim3 grid((n + 255) / 256), block(256);
+  switch (fp->factor_kind) {
+    case SGA_GICP: hipLaunchKernelGGL((per_point_kernel<double, SGA_GICP>), grid, block, 0, ctx->stream, p, d_vals.p, d_ok.p); break;
+    case SGA_PLANE_ICP: hipLaunchKernelGGL((per_point_kernel<double, SGA_PLANE_ICP>), grid, block, 0, ctx->stream, p, d_vals.p, d_ok.p); break;
+    default: hipLaunchKernelGGL((per_point_kernel<double, SGA_ICP>), grid, block, 0, ctx->stream, p, d_vals.p, d_ok.p); break;
+  }
+  SGA_HIP(hipGetLastError());
+  SGA_HIP(hipMemcpyAsync(values28, d_vals.p, n * 28 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  SGA_HIP(hipMemcpyAsync(inlier, d_ok.p, n, hipMemcpyDeviceToHost, ctx->stream));
+  SGA_HIP(hipStreamSynchronize(ctx->stream));
+  return SGA_OK;
 }
 
 void sga_set_warm_limit(double warm_delta_m) { g_warm_delta = warm_delta_m; }

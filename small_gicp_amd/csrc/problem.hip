@@ -97,8 +97,11 @@ __global__ void export_factors_kernel(const float4* __restrict__ src_pts, const 
 
 // ---- standalone kNN (traits::knn_search).  One lane per query, k-best in LDS [k][64], traversal stack in LDS [level][64]. ----
 constexpr int kKnnBlock = 64;
+constexpr int kKnnMaxK = 116;  // (k * 8 + 96) * 64 bytes of LDS per workgroup must stay below 64 KB
 
-__global__ __launch_bounds__(kKnnBlock) void knn_kernel(const KdView t, const float* __restrict__ queries, size_t m, int k, float max_sq, long long* __restrict__ out_idx, float* __restrict__ out_d2) {
+// queries64 / out_d2_64 (optional): the squared distances of the neighbours found are re-evaluated in double against the double
+// query — the coordinates stored on the device are fp32, the reference returns double distances (ann/kdtree.hpp:193-233)
+__global__ __launch_bounds__(kKnnBlock) void knn_kernel(const KdView t, const float* __restrict__ queries, size_t m, int k, float max_sq, long long* __restrict__ out_idx, float* __restrict__ out_d2, const double* __restrict__ queries64, double* __restrict__ out_d2_64) {
   extern __shared__ float sh[];  // k*64 distances, k*64 indices, kKdMaxDepth*64 stack words
   float* sd = sh;
   int* si = reinterpret_cast<int*>(sh + static_cast<size_t>(k) * kKnnBlock);
@@ -117,8 +120,13 @@ __global__ __launch_bounds__(kKnnBlock) void knn_kernel(const KdView t, const fl
     const float d2 = sd[j * kKnnBlock + lane];
     const int id = si[j * kKnnBlock + lane];
     const bool ok = id >= 0 && !(d2 > max_sq);
-    out_idx[qi * k + j] = ok ? static_cast<long long>(__float_as_uint(t.pts[id].w)) : -1ll;
+    const float4 c = ok ? t.pts[id] : make_float4(0.f, 0.f, 0.f, 0.f);
+    out_idx[qi * k + j] = ok ? static_cast<long long>(__float_as_uint(c.w)) : -1ll;
     out_d2[qi * k + j] = ok ? d2 : INFINITY;
+    if (out_d2_64 != nullptr) {
+      const double dx = static_cast<double>(c.x) - queries64[3 * qi], dy = static_cast<double>(c.y) - queries64[3 * qi + 1], dz = static_cast<double>(c.z) - queries64[3 * qi + 2];
+      out_d2_64[qi * k + j] = ok ? dx * dx + dy * dy + dz * dz : INFINITY;
+    }
   }
 }
 
@@ -266,19 +274,32 @@ int sga_problem_get_factors(sga_context* ctx, const sga_problem* pb, int64_t* ta
   return SGA_OK;
 }
 
-int sga_index_knn(sga_context* ctx, const sga_index* index, const float* queries, size_t m, int k, double max_sq_dist, int64_t* idx, float* sq_dist) {
-  if (!ctx || !index || (m > 0 && (!queries || !idx || !sq_dist))) return fail(SGA_ERR_INVALID, "null argument");
+static int index_knn_impl(sga_context* ctx, const sga_index* index, const float* queries, const double* queries64, size_t m, int k, double max_sq_dist, int64_t* idx, float* sq_dist, double* sq_dist64) {
+  if (!ctx || !index || (m > 0 && ((!queries && !queries64) || !idx || (!sq_dist && !sq_dist64)))) return fail(SGA_ERR_INVALID, "null argument");
   if (k < 1 || k > 128) return fail(SGA_ERR_INVALID, "k must be in [1,128]");
   if (index->kind == SGA_INDEX_FLATMAP) return fail(SGA_ERR_UNSUPPORTED, "flat voxel maps are searched inside the registration only");
   if (index->kind == SGA_INDEX_VOXELMAP && k != 1) return fail(SGA_ERR_UNSUPPORTED, "voxel maps answer k = 1 only");
   if (m == 0) return SGA_OK;
   SGA_HIP(hipSetDevice(ctx->device));
+  std::vector<float> qf;
+  if (!queries) {  // double queries: the search itself runs on their fp32 roundings
+    qf.resize(m * 3);
+    for (size_t i = 0; i < m * 3; i++) qf[i] = static_cast<float>(queries64[i]);
+    queries = qf.data();
+  }
   DevBuf<float> d_q, d_d;
+  DevBuf<double> d_q64, d_d64;
   DevBuf<long long> d_i;
   SGA_TRY(d_q.alloc(m * 3));
   SGA_TRY(d_d.alloc(m * k));
   SGA_TRY(d_i.alloc(m * k));
   SGA_HIP(hipMemcpyAsync(d_q.p, queries, m * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  const bool want64 = sq_dist64 != nullptr && queries64 != nullptr && index->kind == SGA_INDEX_KDTREE && index->n > 0;
+  if (want64) {
+    SGA_TRY(d_q64.alloc(m * 3));
+    SGA_TRY(d_d64.alloc(m * k));
+    SGA_HIP(hipMemcpyAsync(d_q64.p, queries64, m * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  }
   const float max_sq = max_sq_dist < 0 ? INFINITY : static_cast<float>(max_sq_dist);
   if (index->kind == SGA_INDEX_VOXELMAP) {
     VoxelView v{index->hkeys.p, index->hvals.p, index->hmask, 1.0 / index->leaf};
@@ -289,15 +310,33 @@ int sga_index_knn(sga_context* ctx, const sga_index* index, const float* queries
     SGA_HIP(hipMemcpyAsync(d_d.p, inf.data(), m * k * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     SGA_HIP(hipStreamSynchronize(ctx->stream));
   } else {
+    if (k > kKnnMaxK) return fail(SGA_ERR_INVALID, "k must be <= %d for a kd-tree (LDS per workgroup)", kKnnMaxK);
     const size_t shmem = (static_cast<size_t>(k) * 8 + kKdMaxDepth * 4) * kKnnBlock;
     KdView kv = make_kd_view(index);
-    hipLaunchKernelGGL(knn_kernel, dim3((m + kKnnBlock - 1) / kKnnBlock), dim3(kKnnBlock), shmem, ctx->stream, kv, d_q.p, m, k, max_sq, d_i.p, d_d.p);
+    hipLaunchKernelGGL(knn_kernel, dim3((m + kKnnBlock - 1) / kKnnBlock), dim3(kKnnBlock), shmem, ctx->stream, kv, d_q.p, m, k, max_sq, d_i.p, d_d.p, want64 ? d_q64.p : nullptr, want64 ? d_d64.p : nullptr);
   }
   SGA_HIP(hipGetLastError());
   SGA_HIP(hipMemcpyAsync(idx, d_i.p, m * k * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
-  SGA_HIP(hipMemcpyAsync(sq_dist, d_d.p, m * k * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  std::vector<float> tmp;
+  float* dst = sq_dist;
+  if (!dst) {
+    tmp.resize(m * k);
+    dst = tmp.data();
+  }
+  SGA_HIP(hipMemcpyAsync(dst, d_d.p, m * k * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  if (want64) SGA_HIP(hipMemcpyAsync(sq_dist64, d_d64.p, m * k * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   SGA_HIP(hipStreamSynchronize(ctx->stream));
+  if (sq_dist64 && !want64)
+    for (size_t i = 0; i < m * k; i++) sq_dist64[i] = dst[i];
   return SGA_OK;
+}
+
+int sga_index_knn(sga_context* ctx, const sga_index* index, const float* queries, size_t m, int k, double max_sq_dist, int64_t* idx, float* sq_dist) {
+  return index_knn_impl(ctx, index, queries, nullptr, m, k, max_sq_dist, idx, sq_dist, nullptr);
+}
+
+int sga_index_knn_f64(sga_context* ctx, const sga_index* index, const double* queries, size_t m, int k, double max_sq_dist, int64_t* idx, double* sq_dist) {
+  return index_knn_impl(ctx, index, nullptr, queries, m, k, max_sq_dist, idx, nullptr, sq_dist);
 }
 
 }  // extern "C"

@@ -8,6 +8,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+collect_ignore_glob = ["golden/*"]  # fixtures (incl. the reference's vendored python_test.py, run by test_reference_python_suite.py), not test modules
 
 
 def pytest_configure(config):
