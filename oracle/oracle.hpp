@@ -666,6 +666,14 @@ struct OptimizerSetting {
   double lambda_factor = 10.0;
   double gn_lambda = 1e-6;
   bool verbose = false;
+  // general factor: NullFactor (restrict_lambda = 0) or RestrictDoFFactor (factors/general_factor.hpp:41-75):
+  // update_linearized_system adds restrict_lambda * |mask - 1| to the diagonal of H; update_error is a no-op (:71)
+  double restrict_lambda = 0.0;
+  double restrict_mask[6] = {1, 1, 1, 1, 1, 1};  // rx, ry, rz, tx, ty, tz: 1 = free, 0 = (softly) frozen
+  void apply_general_factor(Mat6& H) const {
+    if (restrict_lambda > 0)
+      for (int k = 0; k < 6; k++) H(k, k) += restrict_lambda * std::fabs(restrict_mask[k] - 1.0);
+  }
 };
 
 struct IterationTrace {
@@ -673,7 +681,7 @@ struct IterationTrace {
   std::vector<double> new_e;  // accepted error of each outer iteration (LM)
 };
 
-// registration/optimizer.hpp:83-149 (LM) and :24-63 (GN); general factor = NullFactor.
+// registration/optimizer.hpp:83-149 (LM) and :24-63 (GN); general factor = NullFactor or RestrictDoFFactor (OptimizerSetting).
 inline RegistrationResult optimize(
   const OptimizerSetting& opt,
   const TerminationCriteria& criteria,
@@ -690,6 +698,7 @@ inline RegistrationResult optimize(
   if (opt.type == 1) {
     for (int i = 0; i < opt.max_iterations && !result.converged; i++) {
       auto [H, b, e] = reduction.linearize(fs, target, source, max_dist_sq, result.T_target_source, factors);
+      opt.apply_general_factor(H);  // optimizer.hpp:42: general_factor.update_linearized_system
       if (trace) trace->e.push_back(e);
       Mat6 A = H;
       for (int k = 0; k < 6; k++) A(k, k) += opt.gn_lambda;
@@ -707,6 +716,7 @@ inline RegistrationResult optimize(
     double lambda = opt.init_lambda;
     for (int i = 0; i < opt.max_iterations && !result.converged; i++) {
       auto [H, b, e] = reduction.linearize(fs, target, source, max_dist_sq, result.T_target_source, factors);
+      opt.apply_general_factor(H);  // optimizer.hpp:103
       if (trace) trace->e.push_back(e);
       bool success = false;
       for (int j = 0; j < opt.max_inner_iterations; j++) {

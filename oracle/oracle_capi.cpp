@@ -52,6 +52,8 @@ struct orc_setting {
   double translation_eps;
   double rotation_eps;
   int verbose;
+  double restrict_lambda;   // RestrictDoFFactor (general_factor.hpp:41-75); 0 = NullFactor
+  double restrict_mask[6];
 };
 
 struct orc_result {
@@ -79,6 +81,8 @@ void orc_default_setting(orc_setting* s) {
   s->translation_eps = 1e-3;
   s->rotation_eps = 0.1 * M_PI / 180.0;
   s->verbose = 0;
+  s->restrict_lambda = 0.0;
+  for (int k = 0; k < 6; k++) s->restrict_mask[k] = 1.0;
 }
 
 int orc_fast_floor(double x) { return fast_floor(x); }
@@ -336,6 +340,8 @@ int orc_align(
   opt.lambda_factor = s->lambda_factor;
   opt.gn_lambda = s->gn_lambda;
   opt.verbose = s->verbose != 0;
+  opt.restrict_lambda = s->restrict_lambda;
+  for (int k = 0; k < 6; k++) opt.restrict_mask[k] = s->restrict_mask[k];
   TerminationCriteria crit;
   crit.translation_eps = s->translation_eps;
   crit.rotation_eps = s->rotation_eps;

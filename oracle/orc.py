@@ -33,6 +33,8 @@ class Setting(C.Structure):
         ("translation_eps", C.c_double),
         ("rotation_eps", C.c_double),
         ("verbose", C.c_int),
+        ("restrict_lambda", C.c_double),
+        ("restrict_mask", C.c_double * 6),
     ]
 
 
@@ -129,7 +131,11 @@ def default_setting(**kw):
     for k, v in kw.items():
         if not hasattr(s, k):
             raise AttributeError(k)
-        setattr(s, k, v)
+        if k == "restrict_mask":
+            for i in range(6):
+                s.restrict_mask[i] = float(v[i])
+        else:
+            setattr(s, k, v)
     return s
 
 

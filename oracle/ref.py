@@ -51,6 +51,7 @@ def lib():
         L.ref_knn.argtypes = [vp, dp, C.c_size_t, C.c_int, C.POINTER(C.c_int64), dp]
         L.ref_knn.restype = C.c_size_t
         L.ref_align.argtypes = [vp, vp, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double, C.c_double, dp, C.POINTER(Result), dp]
+        L.ref_align_general.argtypes = [vp, vp, C.c_int, C.c_double, dp, C.c_double, C.c_int, C.c_int, C.c_double, C.c_double, dp, C.POINTER(Result)]
         L.ref_linearize.argtypes = [vp, vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, dp, dp, dp, dp, dp, C.POINTER(C.c_uint64)]
         L.ref_voxelmap_size.argtypes = [vp, C.c_double]
         L.ref_voxelmap_size.restype = C.c_size_t
@@ -219,6 +220,18 @@ def align(target, source, type=GICP, voxel_resolution=1.0, max_correspondence_di
     r = _result(res)
     r.elapsed_sec = el.value
     return r
+
+
+def align_general(target, source, optimizer=0, restrict_lambda=0.0, restrict_mask=(1, 1, 1, 1, 1, 1), max_correspondence_distance=1.0, num_threads=4, max_iterations=20, rotation_eps=0.1 * np.pi / 180.0,
+                  translation_eps=1e-3, init_T=None):
+    """Registration<GICPFactor, ParallelReductionOMP, RestrictDoFFactor | NullFactor, DistanceRejector, LM (0) | GN (1)>::align."""
+    res = Result()
+    t16 = _T16(np.eye(4) if init_T is None else init_T)
+    m = np.ascontiguousarray(restrict_mask, dtype=np.float64)
+    rc = lib().ref_align_general(target.h, source.h, int(optimizer), float(restrict_lambda), _dp(m), float(max_correspondence_distance), int(num_threads), int(max_iterations), float(rotation_eps), float(translation_eps),
+                                 _dp(t16), C.byref(res))
+    assert rc == 0
+    return _result(res)
 
 
 def _result(res):

@@ -12,6 +12,7 @@
 #include <small_gicp/ann/gaussian_voxelmap.hpp>
 #include <small_gicp/ann/flat_container.hpp>
 #include <small_gicp/ann/incremental_voxelmap.hpp>
+#include <small_gicp/factors/general_factor.hpp>
 #include <small_gicp/factors/gicp_factor.hpp>
 #include <small_gicp/factors/icp_factor.hpp>
 #include <small_gicp/factors/plane_icp_factor.hpp>
@@ -65,6 +66,22 @@ static void linearize_with(const RefCloud& t, const RefCloud& s, double max_dist
   }
   *e = err;
   *inliers = std::count_if(factors.begin(), factors.end(), [](const Factor& f) { return f.inlier(); });
+}
+
+
+// (templates live outside the C linkage block)
+// Registration<GICPFactor, ParallelReductionOMP, RestrictDoFFactor | NullFactor, DistanceRejector, LM | GN> of the reference
+// (registration/registration.hpp:17-54, factors/general_factor.hpp:41-75, optimizer.hpp:24-149).
+template <typename General, typename Optimizer>
+static RegistrationResult align_general(const RefCloud& t, const RefCloud& s, double max_corr_dist, int num_threads, int max_iterations, double rotation_eps, double translation_eps, const Eigen::Isometry3d& init_T, const General& general) {
+  Registration<GICPFactor, ParallelReductionOMP, General, DistanceRejector, Optimizer> reg;
+  reg.reduction.num_threads = num_threads;
+  reg.rejector.max_dist_sq = max_corr_dist * max_corr_dist;
+  reg.criteria.rotation_eps = rotation_eps;
+  reg.criteria.translation_eps = translation_eps;
+  reg.optimizer.max_iterations = max_iterations;
+  reg.general_factor = general;
+  return reg.align(*t.cloud, *s.cloud, *t.tree, init_T);
 }
 
 
@@ -190,6 +207,30 @@ int ref_align(void* target_h, void* source_h, int type, double voxel_resolution,
     t1 = std::chrono::steady_clock::now();
   }
   fill_result(r, out, std::chrono::duration<double>(t1 - t0).count(), elapsed_sec);
+  return 0;
+}
+
+// optimizer: 0 LM, 1 GN; restrict_lambda > 0: RestrictDoFFactor with that lambda and mask (rx ry rz tx ty tz; 1 = free)
+int ref_align_general(void* target_h, void* source_h, int optimizer, double restrict_lambda, const double* mask6, double max_corr_dist, int num_threads, int max_iterations, double rotation_eps, double translation_eps,
+                      const double* init_T16, ref_result* out) {
+  auto* t = static_cast<RefCloud*>(target_h);
+  auto* s = static_cast<RefCloud*>(source_h);
+  if (!t->tree) return -1;
+  const Eigen::Isometry3d init_T = to_iso(init_T16);
+  RegistrationResult r;
+  if (restrict_lambda > 0) {
+    RestrictDoFFactor g;
+    g.lambda = restrict_lambda;
+    g.set_rotation_mask(Eigen::Array3d(mask6[0], mask6[1], mask6[2]));
+    g.set_translation_mask(Eigen::Array3d(mask6[3], mask6[4], mask6[5]));
+    r = optimizer == 1 ? align_general<RestrictDoFFactor, GaussNewtonOptimizer>(*t, *s, max_corr_dist, num_threads, max_iterations, rotation_eps, translation_eps, init_T, g)
+                       : align_general<RestrictDoFFactor, LevenbergMarquardtOptimizer>(*t, *s, max_corr_dist, num_threads, max_iterations, rotation_eps, translation_eps, init_T, g);
+  } else {
+    r = optimizer == 1 ? align_general<NullFactor, GaussNewtonOptimizer>(*t, *s, max_corr_dist, num_threads, max_iterations, rotation_eps, translation_eps, init_T, NullFactor())
+                       : align_general<NullFactor, LevenbergMarquardtOptimizer>(*t, *s, max_corr_dist, num_threads, max_iterations, rotation_eps, translation_eps, init_T, NullFactor());
+  }
+  double el = 0;
+  fill_result(r, out, 0.0, &el);
   return 0;
 }
 

@@ -174,6 +174,27 @@ def test_gauss_newton_and_null_rejector(orc, c1_f32, gpu_c1):
     assert n == no == src.size() and abs(e - eo) <= FP32_REL * eo
 
 
+@pytest.mark.parametrize("optimizer", ["LM", "GN"])
+@pytest.mark.parametrize("mode", ["fp32", "fp64"])
+def test_restrict_dof_factor_matches_oracle(orc, c1_f32, gpu_c1, optimizer, mode):
+    """RestrictDoFFactor (factors/general_factor.hpp:41-75: H += lambda |mask - 1|, update_error a no-op) under both optimizers:
+    pose within 1e-4 m / 1e-4 rad of the oracle — which equals the reference's Registration<GICPFactor, ParallelReductionOMP,
+    RestrictDoFFactor, ...> to 1e-9 (tests/test_oracle_vs_reference.py) — same iteration and inlier counts, and the frozen
+    directions (roll, pitch, z) stay frozen."""
+    tgt, src, tree = gpu_c1
+    mask = (0.0, 0.0, 1.0, 1.0, 1.0, 0.0)
+    res = sga.Problem(tree, src).align(sga.make_setting("GICP", optimizer=optimizer, math_mode=mode, restrict_dof_lambda=1e9, restrict_dof_mask=mask))
+    ref = orc.align(c1_f32["otc"], c1_f32["osc"], orc.default_setting(factor_kind=orc.GICP, num_threads=4, optimizer_type=0 if optimizer == "LM" else 1, restrict_lambda=1e9, restrict_mask=mask))
+    dt, dr = pose_error(res.T_target_source, ref.T_target_source)
+    assert dt < POSE_TOL_T and dr < POSE_TOL_R and res.iterations == ref.iterations and res.converged == ref.converged, (dt, dr, res.iterations, ref.iterations)
+    assert abs(int(res.num_inliers) - int(ref.num_inliers)) <= 2
+    T = res.T_target_source
+    assert abs(T[2, 3]) < 1e-3 and abs(T[2, 0]) < 1e-3 and abs(T[2, 1]) < 1e-3
+    # and it differs from the unrestricted optimum (the constraint is active on this pair: ground truth has z = -0.025)
+    free = sga.Problem(tree, src).align(sga.make_setting("GICP", optimizer=optimizer, math_mode=mode))
+    assert abs(free.T_target_source[2, 3]) > 5e-3
+
+
 # ---- nearest-neighbour search (kdtree_test.cpp / kdtree_synthetic_test.cpp protocols) ----------------------------------------
 def _brute(target, queries, k):
     d2 = ((queries[:, None, :].astype(np.float64) - target[None, :, :].astype(np.float64)) ** 2).sum(-1)

@@ -159,3 +159,22 @@ def test_incremental_flat_voxelmap(orc, clouds, offsets):
     dt, dr = pose_error(rr.T_target_source, orr.T_target_source)
     assert dt < 1e-8 and dr < 1e-8 and rr.iterations == orr.iterations and rr.num_inliers == orr.num_inliers
     assert abs(rr.error - orr.error) <= 1e-8 * abs(rr.error)
+
+
+@pytest.mark.parametrize("optimizer", [0, 1])
+@pytest.mark.parametrize("restrict", [False, True])
+def test_general_factor_and_optimizers_match_reference(orc, clouds, optimizer, restrict):
+    """RestrictDoFFactor (factors/general_factor.hpp:41-75) and both optimizers (optimizer.hpp:24-149): the restatement equals
+    Registration<GICPFactor, ParallelReductionOMP, RestrictDoFFactor | NullFactor, DistanceRejector, LM | GN> of the reference."""
+    rt, rs, ot, os_ = clouds["rt"], clouds["rs"], clouds["ot"], clouds["os"]
+    mask = (0.0, 0.0, 1.0, 1.0, 1.0, 0.0)  # yaw + planar translation free; roll, pitch, z softly frozen
+    lam = 1e9 if restrict else 0.0
+    r = ref.align_general(rt, rs, optimizer, lam, mask, 1.0, 1)
+    s = orc.default_setting(factor_kind=orc.GICP, num_threads=1, optimizer_type=optimizer, restrict_lambda=lam, restrict_mask=mask)
+    o = orc.align(ot, os_, s)
+    assert o.iterations == r.iterations and o.num_inliers == r.num_inliers and o.converged == r.converged
+    assert np.abs(o.T_target_source - r.T_target_source).max() < 1e-9
+    assert np.abs(o.H - r.H).max() <= 1e-9 * np.abs(r.H).max()
+    if restrict:  # the frozen directions really are frozen (softly: lambda = 1e9)
+        E = r.T_target_source
+        assert abs(E[2, 3]) < 1e-3 and abs(E[2, 0]) < 1e-3 and abs(E[2, 1]) < 1e-3
