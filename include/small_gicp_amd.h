@@ -155,6 +155,14 @@ int sga_comm_init(sga_context* ctx, int nranks, int rank, const unsigned char id
 int sga_comm_destroy(sga_context* ctx);
 /* Expand a 30-double accumulator (host memory) into H[36], b[6], e, num_inliers. */
 void sga_unpack_accumulator(const double acc30[SGA_ACCUM_DOUBLES], double H[36], double b[6], double* e, uint64_t* num_inliers);
+/* A custom CorrespondenceRejector on the host (registration/rejector.hpp:11-28 is a duck-typed functor `bool operator()(target, source, T,
+ * target_index, source_index, sq_dist)`, true = reject).  Batch form: once per linearization the callback receives, for every source
+ * point in the caller's order, the index of its nearest target point (caller's target order, -1 = the target is empty) and the
+ * squared distance, and fills reject[i] (1 = reject).  While a callback is set the search is unbounded and params->max_dist_sq is
+ * ignored, exactly as with a user-supplied rejector type in the reference.  Costs a device->host->device round trip per
+ * linearization: a correctness path, not a fast one.  fn = NULL restores the built-in DistanceRejector / NullRejector.  kd-tree targets. */
+typedef int (*sga_rejector_fn)(void* user, const double T[16], size_t n, const int64_t* target_index, const float* sq_dist, unsigned char* reject);
+int sga_problem_set_rejector(sga_problem* problem, sga_rejector_fn fn, void* user);
 /* Factor::linearize per source point, as the reference's Python binding exposes it (src/python/factors.cpp:52-101; gicp_factor.hpp:35-73,
  * icp_factor.hpp:20-54, plane_icp_factor.hpp:19-57): runs one linearization at T, then returns for every source point (caller's order)
  * values28 n*28 doubles = [0..20] upper triangle of H_i row-wise, [21..26] b_i, [27] e_i, and inlier n bytes (0: no correspondence, all

@@ -446,6 +446,29 @@ class Problem:
         t16 = _T16(T)
         check(load().sga_error_async(self.ctx.h, self.h, C.byref(factor_params), _dp(t16), C.c_void_p(int(d_out_ptr))))
 
+    def set_rejector(self, fn):
+        """A custom CorrespondenceRejector (rejector.hpp:11-28) as a batch callback: fn(T 4x4, target_index (n,) int64, sq_dist (n,)
+        float32) -> boolean array, True = reject.  None restores the built-in distance rejector."""
+        if fn is None:
+            self._rejector_cb = _lib.REJECTOR_FN()  # NULL function pointer
+        else:
+            def cb(_user, T16, n, idx_p, d2_p, rej_p):
+                try:
+                    T = np.ctypeslib.as_array(T16, (16,)).reshape(4, 4).T.copy()
+                    idx = np.ctypeslib.as_array(idx_p, (n,))
+                    d2 = np.ctypeslib.as_array(d2_p, (n,))
+                    out = np.ctypeslib.as_array(rej_p, (n,))
+                    out[:] = np.asarray(fn(T, idx, d2), dtype=bool)
+                    return 0
+                except Exception:  # noqa: BLE001
+                    import traceback
+
+                    traceback.print_exc()
+                    return 1
+
+            self._rejector_cb = _lib.REJECTOR_FN(cb)
+        check(load().sga_problem_set_rejector(self.h, self._rejector_cb, None))
+
     def linearize_per_point(self, factor_params, T):
         """sga_linearize_per_point: (inlier (n,) bool, H (n,6,6), b (n,6), e (n,)) for every source point in the caller's order."""
         n = self.source.size()

@@ -187,6 +187,10 @@ struct sga_problem {
   uint64_t cold_passes = 0, warm_passes = 0;  // passes against a kd-tree since the problem was created
   sga::DevBuf<float> maha;       // n*6 (fp32 mode) — fused mahalanobis of the last linearize
   sga::DevBuf<double> maha64;    // n*6 (fp64 mode, allocated on first use)
+  // custom CorrespondenceRejector on the host (sga_problem_set_rejector): reject flag per source point (caller's order) for the current pass
+  sga_rejector_fn rejector_fn = nullptr;
+  void* rejector_user = nullptr;
+  sga::DevBuf<unsigned char> reject;
   // reduction scratch
   sga::DevBuf<double> partials;  // nblocks * 32
   int max_blocks = 0;

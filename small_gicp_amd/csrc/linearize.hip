@@ -39,6 +39,7 @@ struct LinParams {
   FlatView flat;
   int* __restrict__ corr;
   const int* __restrict__ hint;  // exact nearest neighbour per source point at this pose (kd position) or -1, from nn_search_kernel
+  const unsigned char* __restrict__ reject;  // optional: verdict of a host rejector per source point in the CALLER's order (1 = reject)
   Real* __restrict__ maha;  // n*6
   Rigid<Real> T;
   float max_sq;  // INFINITY = no rejector
@@ -271,6 +272,7 @@ __global__ __launch_bounds__(kTile) void linearize_kernel(const LinParams<Real> 
           // the search reaches a little beyond the rejector (kSearchMargin) and a certified neighbour may have drifted out of
           // reach: a neighbour counts only inside the reach of a plain search, whichever way it was found
           within = kd_dist2(m.x, m.y, m.z, static_cast<float>(qx), static_cast<float>(qy), static_cast<float>(qz)) < p.bound2;
+          if (p.reject != nullptr) within = within && p.reject[__float_as_uint(p.src_pts[i].w)] == 0;
         }
       }
     }
@@ -439,6 +441,28 @@ static void launch_reduce(sga_context* ctx, const double* partials, int nrows, i
 
 static int grid_blocks(int num_tiles) { return num_tiles < kMaxBlocks ? (num_tiles < 1 ? 1 : num_tiles) : kMaxBlocks; }
 
+// nearest neighbour (caller's target order) and squared distance of every source point in the caller's source order: the input of a
+// host rejector callback
+template <typename Real>
+__global__ void export_neighbours_kernel(const float4* __restrict__ src_pts, const int* __restrict__ nn, int n, const float4* __restrict__ tgt_pts, Rigid<Real> T, long long* __restrict__ out_idx, float* __restrict__ out_d2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 ps = src_pts[i];
+  const uint32_t orig = __float_as_uint(ps.w);
+  const int j = nn[i];
+  long long t = -1;
+  float d2 = INFINITY;
+  if (j >= 0) {
+    Real x, y, z;
+    transform_point<Real>(T, ps.x, ps.y, ps.z, x, y, z);
+    const float4 m = tgt_pts[j];
+    t = static_cast<long long>(__float_as_uint(m.w));
+    d2 = kd_dist2(m.x, m.y, m.z, static_cast<float>(x), static_cast<float>(y), static_cast<float>(z));
+  }
+  out_idx[orig] = t;
+  out_d2[orig] = d2;
+}
+
 template <typename Real, int FACTOR, int TARGET>
 static void launch_linearize(hipStream_t st, const LinParams<Real>& p, int blocks) {
   hipLaunchKernelGGL((linearize_kernel<Real, FACTOR, TARGET>), dim3(blocks), dim3(kTile), 0, st, p);
@@ -506,7 +530,8 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
     p.maha = pb->maha64.p;
   }
   p.T = rigid_from_colmajor<Real>(T);
-  p.max_sq = fp->max_dist_sq < 0 ? INFINITY : static_cast<float>(fp->max_dist_sq);
+  const bool host_rejector = pb->rejector_fn != nullptr && !voxel;
+  p.max_sq = (fp->max_dist_sq < 0 || host_rejector) ? INFINITY : static_cast<float>(fp->max_dist_sq);  // a user rejector sees every nearest neighbour
   p.bound2 = p.max_sq < 3.0e38f ? p.max_sq * 1.0000002f : INFINITY;  // d2 == max_sq must still be found (strict '>' rejector)
   p.robust_kind = fp->robust_kind;
   p.robust_c = static_cast<Real>(fp->robust_c);
@@ -542,6 +567,26 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
     if (timed) {
       (void)hipEventRecord(ctx->ev_mid, ctx->stream);
       ctx->mid_recorded = true;
+    }
+    if (host_rejector) {  // neighbours down, verdicts up (rejector.hpp:11-28 through sga_rejector_fn)
+      const size_t n = pb->n;
+      DevBuf<long long> d_idx;
+      DevBuf<float> d_d2;
+      SGA_TRY(d_idx.alloc(n));
+      SGA_TRY(d_d2.alloc(n));
+      SGA_TRY(pb->reject.reserve(n));
+      hipLaunchKernelGGL((export_neighbours_kernel<Real>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, pb->pts.p, pb->hint.p, p.n, p.tgt_pts, p.T, d_idx.p, d_d2.p);
+      SGA_HIP(hipGetLastError());
+      std::vector<int64_t> h_idx(n);
+      std::vector<float> h_d2(n);
+      std::vector<unsigned char> h_rej(n, 0);
+      SGA_HIP(hipMemcpyAsync(h_idx.data(), d_idx.p, n * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+      SGA_HIP(hipMemcpyAsync(h_d2.data(), d_d2.p, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+      SGA_HIP(hipStreamSynchronize(ctx->stream));
+      if (pb->rejector_fn(pb->rejector_user, T, n, h_idx.data(), h_d2.data(), h_rej.data()) != 0) return fail(SGA_ERR_CALLBACK, "rejector callback failed");
+      SGA_HIP(hipMemcpyAsync(pb->reject.p, h_rej.data(), n, hipMemcpyHostToDevice, ctx->stream));
+      SGA_HIP(hipStreamSynchronize(ctx->stream));  // h_rej goes out of scope
+      p.reject = pb->reject.p;
     }
   }
   if (p.n > 0) {
@@ -764,6 +809,15 @@ int sga_linearize_per_point(sga_context* ctx, sga_problem* pb, const sga_factor_
   SGA_HIP(hipMemcpyAsync(values28, d_vals.p, n * 28 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   SGA_HIP(hipMemcpyAsync(inlier, d_ok.p, n, hipMemcpyDeviceToHost, ctx->stream));
   SGA_HIP(hipStreamSynchronize(ctx->stream));
+  return SGA_OK;
+}
+
+int sga_problem_set_rejector(sga_problem* pb, sga_rejector_fn fn, void* user) {
+  if (!pb) return fail(SGA_ERR_INVALID, "null argument");
+  if (fn && pb->target->kind != SGA_INDEX_KDTREE) return fail(SGA_ERR_UNSUPPORTED, "host rejectors need a kd-tree target");
+  pb->rejector_fn = fn;
+  pb->rejector_user = user;
+  pb->prev_valid = false;  // the search bound changes with the rejector
   return SGA_OK;
 }
 

@@ -195,6 +195,37 @@ def test_restrict_dof_factor_matches_oracle(orc, c1_f32, gpu_c1, optimizer, mode
     assert abs(free.T_target_source[2, 3]) > 5e-3
 
 
+def test_host_rejector_callback(gpu_c1):
+    """A user-supplied CorrespondenceRejector (rejector.hpp:11-28 is a duck-typed functor) through sga_problem_set_rejector: a callback
+    equivalent to DistanceRejector reproduces the built-in one exactly, one the built-in cannot express (a predicate on the target
+    index) filters exactly the pairs it names, and None restores the built-in behaviour."""
+    tgt, src, tree = gpu_c1
+    st = sga.make_setting("GICP", max_correspondence_distance=0.5)
+    st_other = sga.make_setting("GICP", max_correspondence_distance=7.0)  # ignored while a callback is installed
+    base = sga.Problem(tree, src).linearize(st.factor, np.eye(4))
+    pb = sga.Problem(tree, src)
+    seen = []
+
+    def like_distance_rejector(T, target_index, sq_dist):
+        seen.append((len(target_index), int((target_index >= 0).sum())))
+        return sq_dist > 0.25
+
+    pb.set_rejector(like_distance_rejector)
+    got = pb.linearize(st_other.factor, np.eye(4))
+    assert seen and seen[0] == (src.size(), src.size())  # the callback saw every source point with its (unbounded) nearest neighbour
+    assert got[3] == base[3] and (got[0] == base[0]).all() and got[2] == base[2]
+    r_cb = pb.align(st_other)
+    r_builtin = sga.Problem(tree, src).align(st)
+    assert r_cb.iterations == r_builtin.iterations and np.abs(r_cb.T_target_source - r_builtin.T_target_source).max() < 1e-12
+    pb.set_rejector(lambda T, target_index, sq_dist: (target_index % 2 == 1) | (sq_dist > 1.0))
+    H, b, e, n = pb.linearize(st.factor, np.eye(4))
+    corr = pb.factors()[0]
+    assert n == (corr >= 0).sum() > 1000 and (corr[corr >= 0] % 2 == 0).all()
+    pb.set_rejector(None)
+    again = pb.linearize(st.factor, np.eye(4))
+    assert again[3] == base[3] and again[2] == base[2]
+
+
 # ---- nearest-neighbour search (kdtree_test.cpp / kdtree_synthetic_test.cpp protocols) ----------------------------------------
 def _brute(target, queries, k):
     d2 = ((queries[:, None, :].astype(np.float64) - target[None, :, :].astype(np.float64)) ** 2).sum(-1)
