@@ -59,7 +59,10 @@ extern "C" {
 int sga_comm_unique_id(unsigned char id[128]) {
   if (!id) return fail(SGA_ERR_INVALID, "null argument");
   RcclApi* api = rccl();
-  if (!api) return fail(SGA_ERR_HIP, "librccl is not available: %s", dlerror() ? dlerror() : "dlopen failed");
+  if (!api) {
+    const char* why = dlerror();  // one call: the second one returns NULL
+    return fail(SGA_ERR_HIP, "librccl is not available: %s", why ? why : "dlopen failed");
+  }
   ncclUniqueId uid;
   const ncclResult_t r = api->get_unique_id(&uid);
   if (r != ncclSuccess) return fail(SGA_ERR_HIP, "ncclGetUniqueId -> %s", api->get_error_string ? api->get_error_string(r) : "error");
@@ -73,7 +76,7 @@ int sga_comm_init(sga_context* ctx, int nranks, int rank, const unsigned char id
   if (ctx->comm) return fail(SGA_ERR_INVALID, "context already has a communicator");
   RcclApi* api = rccl();
   if (!api) return fail(SGA_ERR_HIP, "librccl is not available");
-  SGA_HIP(hipSetDevice(ctx->device));
+  SGA_ENTER(ctx);
   ncclUniqueId uid;
   memcpy(&uid, id, 128);
   ncclComm_t comm = nullptr;

@@ -31,11 +31,25 @@ int fail(int code, const char* fmt, ...);
 
 // ---- device memory --------------------------------------------------------------------------------------------------------
 // hipMalloc / hipFree cost tens of microseconds each and hipFree synchronises the device; a registration of a 30k-point scan
-// allocates ~30 buffers.  Freed blocks are therefore kept per device in size-bucketed free lists (context.hip) and handed out
-// again.  Reuse is safe because every entry point that allocates runs on its context's stream and synchronises it before
-// returning; the cache is emptied when the last context is destroyed.
+// allocates ~30 buffers.  Freed blocks are therefore kept in size-bucketed free lists (context.hip) and handed out again — in
+// STREAM ORDER, because work is asynchronous (sga_linearize_async, borrowed streams, several contexts on one device):
+//   * a block freed inside an entry point (the thread's current stream, SGA_ENTER) goes to THAT stream's list and is only handed to
+//     later allocations on the same stream, which run after everything that touched it;
+//   * a block freed outside any entry point (sga_*_destroy) may still be in use by kernels in flight on any stream of its device:
+//     an event is recorded on every busy stream and the block becomes reusable once those events have completed;
+//   * the lists of a context move to the shared pool when the context is destroyed (after synchronising its stream).
 int dev_alloc(void** p, size_t bytes);
 void dev_free(void* p);
+struct StreamScope {  // the calling thread's current stream for dev_alloc / dev_free
+  explicit StreamScope(hipStream_t s);
+  ~StreamScope();
+  StreamScope(const StreamScope&) = delete;
+  StreamScope& operator=(const StreamScope&) = delete;
+  hipStream_t prev;
+};
+#define SGA_ENTER(ctx)                        \
+  SGA_HIP(hipSetDevice((ctx)->device));       \
+  ::sga::StreamScope _sga_stream_scope((ctx)->stream)
 
 // ---- device buffer -----------------------------------------------------------------------------------------------------
 template <typename T>
@@ -89,6 +103,7 @@ struct sga_context {
   int device = 0;
   hipStream_t stream = nullptr;
   bool owns_stream = false;
+  bool registered = false;  // known to the allocator (context.hip)
   // scratch
   sga::DevBuf<double> d_accum;    // SGA_ACCUM_DOUBLES
   sga::DevBuf<unsigned> d_ticket; // arrival counter of the reduction kernel (linearize.hip), zero between launches

@@ -24,12 +24,33 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 
-// ---- caching device allocator (see common.hpp) ---------------------------------------------------------------------------------
+// ---- caching device allocator, stream ordered (see common.hpp) -------------------------------------------------------------------
 namespace {
+thread_local hipStream_t g_cur_stream = nullptr;  // set by SGA_ENTER for the duration of an entry point
+
+struct FreeKey {
+  int device;
+  hipStream_t stream;  // nullptr = the shared pool: blocks nobody is using any more
+  size_t bucket;
+  bool operator<(const FreeKey& o) const {
+    if (device != o.device) return device < o.device;
+    if (stream != o.stream) return stream < o.stream;
+    return bucket < o.bucket;
+  }
+};
+struct PendingBlock {
+  void* p;
+  int device;
+  size_t bucket;
+  std::vector<hipEvent_t> events;  // one per stream that was busy when the block was freed
+};
 struct DevCache {
   std::mutex mu;
-  std::unordered_map<void*, std::pair<int, size_t>> live;             // every block handed out: device, bucket size
-  std::map<std::pair<int, size_t>, std::vector<void*>> free_blocks;   // (device, bucket size) -> cached blocks
+  std::unordered_map<void*, std::pair<int, size_t>> live;  // every block handed out: device, bucket size
+  std::map<FreeKey, std::vector<void*>> free_blocks;
+  std::vector<PendingBlock> pending;                       // freed outside an entry point: reusable once their events have completed
+  std::vector<std::pair<int, hipStream_t>> streams;        // the streams of the live contexts
+  std::vector<hipEvent_t> event_pool;
   size_t cached_bytes = 0;
   int contexts = 0;
 };
@@ -48,13 +69,58 @@ size_t bucket_bytes(size_t bytes) {
   return ((bytes + step - 1) / step) * step;
 }
 
+void recycle_events(DevCache& c, std::vector<hipEvent_t>& evs) {
+  for (hipEvent_t e : evs) c.event_pool.push_back(e);
+  evs.clear();
+}
+
+// move the pending blocks whose events have all completed into the shared pool
+void collect_pending_locked(DevCache& c) {
+  size_t w = 0;
+  for (size_t i = 0; i < c.pending.size(); i++) {
+    PendingBlock& b = c.pending[i];
+    bool done = true;
+    for (hipEvent_t e : b.events)
+      if (hipEventQuery(e) == hipErrorNotReady) {
+        done = false;
+        break;
+      }
+    if (done) {
+      recycle_events(c, b.events);
+      c.free_blocks[{b.device, nullptr, b.bucket}].push_back(b.p);
+    } else {
+      if (w != i) c.pending[w] = std::move(b);
+      w++;
+    }
+  }
+  c.pending.resize(w);
+  (void)hipGetLastError();  // hipEventQuery's hipErrorNotReady is sticky in hipGetLastError
+}
+
 void release_cached_locked(DevCache& c) {
+  for (PendingBlock& b : c.pending) {
+    for (hipEvent_t e : b.events) (void)hipEventSynchronize(e);
+    recycle_events(c, b.events);
+    (void)hipFree(b.p);
+  }
+  c.pending.clear();
   for (auto& kv : c.free_blocks)
     for (void* q : kv.second) (void)hipFree(q);
   c.free_blocks.clear();
   c.cached_bytes = 0;
 }
+
+void* take_locked(DevCache& c, const FreeKey& key) {
+  auto it = c.free_blocks.find(key);
+  if (it == c.free_blocks.end() || it->second.empty()) return nullptr;
+  void* p = it->second.back();
+  it->second.pop_back();
+  return p;
+}
 }  // namespace
+
+StreamScope::StreamScope(hipStream_t s) : prev(g_cur_stream) { g_cur_stream = s; }
+StreamScope::~StreamScope() { g_cur_stream = prev; }
 
 int dev_alloc(void** p, size_t bytes) {
   *p = nullptr;
@@ -64,10 +130,14 @@ int dev_alloc(void** p, size_t bytes) {
   const size_t bucket = bucket_bytes(bytes);
   DevCache& c = dev_cache();
   std::lock_guard<std::mutex> lock(c.mu);
-  auto it = c.free_blocks.find({device, bucket});
-  if (it != c.free_blocks.end() && !it->second.empty()) {
-    *p = it->second.back();
-    it->second.pop_back();
+  // same stream first (stream order makes the reuse safe), then blocks nobody uses, then blocks whose last users have finished
+  if (g_cur_stream != nullptr) *p = take_locked(c, {device, g_cur_stream, bucket});
+  if (!*p) *p = take_locked(c, {device, nullptr, bucket});
+  if (!*p && !c.pending.empty()) {
+    collect_pending_locked(c);
+    *p = take_locked(c, {device, nullptr, bucket});
+  }
+  if (*p) {
     c.cached_bytes -= bucket;
   } else {
     hipError_t e = hipMalloc(p, bucket);
@@ -94,27 +164,79 @@ void dev_free(void* p) {
     (void)hipFree(p);
     return;
   }
-  const std::pair<int, size_t> key = it->second;
+  const int device = it->second.first;
+  const size_t bucket = it->second.second;
   c.live.erase(it);
-  if (c.contexts == 0 || c.cached_bytes + key.second > kCacheLimitBytes) {
-    (void)hipFree(p);
+  if (c.contexts == 0 || c.cached_bytes + bucket > kCacheLimitBytes) {
+    (void)hipFree(p);  // synchronises the device: safe whatever is in flight
     return;
   }
-  c.free_blocks[key].push_back(p);
-  c.cached_bytes += key.second;
+  c.cached_bytes += bucket;
+  if (g_cur_stream != nullptr) {  // inside an entry point: only later work on the same stream may get this block
+    c.free_blocks[{device, g_cur_stream, bucket}].push_back(p);
+    return;
+  }
+  // outside an entry point (destroy functions): kernels on any stream of the device may still use the block
+  PendingBlock b{p, device, bucket, {}};
+  int cur = -1;
+  (void)hipGetDevice(&cur);
+  for (const auto& ds : c.streams) {
+    if (ds.first != device) continue;
+    if (hipStreamQuery(ds.second) != hipErrorNotReady) continue;  // idle: nothing of it can touch the block
+    if (cur != device) {
+      (void)hipSetDevice(device);
+      cur = device;
+    }
+    hipEvent_t e = nullptr;
+    if (!c.event_pool.empty()) {
+      e = c.event_pool.back();
+      c.event_pool.pop_back();
+    } else if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+      e = nullptr;
+    }
+    if (e == nullptr || hipEventRecord(e, ds.second) != hipSuccess) {
+      (void)hipStreamSynchronize(ds.second);  // cannot track it: wait for it instead
+      if (e) c.event_pool.push_back(e);
+      continue;
+    }
+    b.events.push_back(e);
+  }
+  (void)hipGetLastError();
+  if (b.events.empty())
+    c.free_blocks[{device, nullptr, bucket}].push_back(p);
+  else
+    c.pending.push_back(std::move(b));
 }
 
-static void dev_cache_context_created() {
+static void dev_cache_context_created(int device, hipStream_t stream) {
   DevCache& c = dev_cache();
   std::lock_guard<std::mutex> lock(c.mu);
   c.contexts++;
+  c.streams.push_back({device, stream});
 }
-static void dev_cache_context_destroyed() {
+// the context's stream has been synchronised: its blocks join the shared pool
+static void dev_cache_context_destroyed(int device, hipStream_t stream) {
   DevCache& c = dev_cache();
   std::lock_guard<std::mutex> lock(c.mu);
+  for (size_t i = 0; i < c.streams.size(); i++)
+    if (c.streams[i].first == device && c.streams[i].second == stream) {
+      c.streams.erase(c.streams.begin() + i);
+      break;
+    }
+  for (auto it = c.free_blocks.begin(); it != c.free_blocks.end();) {
+    if (it->first.device == device && it->first.stream == stream && stream != nullptr) {
+      auto& pool = c.free_blocks[{device, nullptr, it->first.bucket}];
+      pool.insert(pool.end(), it->second.begin(), it->second.end());
+      it = c.free_blocks.erase(it);
+    } else {
+      ++it;
+    }
+  }
   if (--c.contexts <= 0) {
     c.contexts = 0;
     release_cached_locked(c);
+    for (hipEvent_t e : c.event_pool) (void)hipEventDestroy(e);
+    c.event_pool.clear();
   }
 }
 
@@ -203,7 +325,6 @@ static int context_create_impl(int device, void* stream, bool borrow, sga_contex
   SGA_HIP(hipGetDeviceProperties(&prop, device));
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(SGA_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
   auto* ctx = new sga_context;
-  dev_cache_context_created();
   ctx->device = device;
   ctx->num_cus = prop.multiProcessorCount;
   if (borrow) {
@@ -212,11 +333,13 @@ static int context_create_impl(int device, void* stream, bool borrow, sga_contex
   } else {
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
       delete ctx;
-      dev_cache_context_destroyed();
       return fail(SGA_ERR_HIP, "hipStreamCreate failed");
     }
     ctx->owns_stream = true;
   }
+  dev_cache_context_created(device, ctx->stream);
+  ctx->registered = true;
+  StreamScope scope(ctx->stream);
   int rc = ctx->d_accum.alloc(64);
   if (rc == SGA_OK) rc = ctx->d_ticket.alloc(16);
   if (rc == SGA_OK && hipMemsetAsync(ctx->d_ticket.p, 0, 16 * sizeof(unsigned), ctx->stream) != hipSuccess) rc = fail(SGA_ERR_HIP, "hipMemsetAsync failed");
@@ -248,9 +371,15 @@ int sga_context_destroy(sga_context* ctx) {
   if (ctx->ev3) (void)hipEventDestroy(ctx->ev3);
   if (ctx->ev_mid) (void)hipEventDestroy(ctx->ev_mid);
   if (ctx->h_accum) (void)hipHostFree(ctx->h_accum);
-  if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
-  delete ctx;
-  dev_cache_context_destroyed();  // the last context gives the cached device memory back
+  const int device = ctx->device;
+  const hipStream_t stream = ctx->stream;
+  const bool registered = ctx->registered, owns = ctx->owns_stream;
+  {
+    StreamScope scope(stream);  // the context's own buffers: the stream is idle (synchronised above)
+    delete ctx;
+  }
+  if (registered) dev_cache_context_destroyed(device, stream);  // the last context gives the cached device memory back
+  if (owns && stream) (void)hipStreamDestroy(stream);
   return SGA_OK;
 }
 
@@ -310,7 +439,7 @@ int sga_cloud_create_f32(sga_context* ctx, const float* xyz, const float* normal
   if (!ctx || !out || (n > 0 && !xyz)) return fail(SGA_ERR_INVALID, "null argument");
   if (n >= (1ull << 31)) return fail(SGA_ERR_INVALID, "cloud too large (%zu points; limit 2^31-1)", n);
   *out = nullptr;
-  SGA_HIP(hipSetDevice(ctx->device));
+  SGA_ENTER(ctx);
   auto* c = new sga_cloud;
   c->device = ctx->device;
   c->n = n;
@@ -375,7 +504,7 @@ int sga_cloud_slice(sga_context* ctx, const sga_cloud* cloud, size_t first, size
   if (first > cloud->n || count > cloud->n - first) return fail(SGA_ERR_INVALID, "slice [%zu, %zu) outside a cloud of %zu points", first, first + count, cloud->n);
   if (cloud->device != ctx->device) return fail(SGA_ERR_INVALID, "cloud lives on another device");
   *out = nullptr;
-  SGA_HIP(hipSetDevice(ctx->device));
+  SGA_ENTER(ctx);
   auto* c = new sga_cloud;
   c->device = ctx->device;
   c->n = count;
@@ -427,7 +556,7 @@ int sga_cloud_download(sga_context* ctx, const sga_cloud* cloud, float* xyz, flo
   if (cov6 && !cloud->has_covs) return fail(SGA_ERR_INVALID, "cloud has no covariances");
   const size_t n = cloud->n;
   if (n == 0) return SGA_OK;
-  SGA_HIP(hipSetDevice(ctx->device));
+  SGA_ENTER(ctx);
   DevBuf<float> sx, sn, sc;
   if (xyz) SGA_TRY(sx.alloc(n * 3));
   if (normals) SGA_TRY(sn.alloc(n * 3));

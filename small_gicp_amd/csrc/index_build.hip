@@ -609,7 +609,7 @@ int sga_index_build_kdtree(sga_context* ctx, const sga_cloud* target, sga_index*
   if (!ctx || !target || !out) return fail(SGA_ERR_INVALID, "null argument");
   if (target->device != ctx->device) return fail(SGA_ERR_INVALID, "cloud lives on another device");
   *out = nullptr;
-  SGA_HIP(hipSetDevice(ctx->device));
+  SGA_ENTER(ctx);
   const size_t n = target->n;
   std::unique_ptr<sga_index> idx(new sga_index);
   idx->kind = SGA_INDEX_KDTREE;
@@ -633,7 +633,7 @@ int sga_index_build_gaussian_voxelmap(sga_context* ctx, const sga_cloud* cloud, 
   if (!cloud->has_covs) return fail(SGA_ERR_INVALID, "GaussianVoxelMap needs point covariances");
   if (cloud->device != ctx->device) return fail(SGA_ERR_INVALID, "cloud lives on another device");
   *out = nullptr;
-  SGA_HIP(hipSetDevice(ctx->device));
+  SGA_ENTER(ctx);
   const size_t n = cloud->n;
   std::unique_ptr<sga_index> idx(new sga_index);
   idx->kind = SGA_INDEX_VOXELMAP;
@@ -726,7 +726,7 @@ int sga_index_voxelmap_download(sga_context* ctx, const sga_index* index, int32_
   if (index->kind != SGA_INDEX_VOXELMAP) return fail(SGA_ERR_INVALID, "not a voxel map");
   const size_t n = index->n;
   if (n == 0) return SGA_OK;
-  SGA_HIP(hipSetDevice(ctx->device));
+  SGA_ENTER(ctx);
   std::vector<float4> hp;
   std::vector<Cov8> hc;
   if (means) {

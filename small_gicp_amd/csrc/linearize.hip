@@ -8,6 +8,7 @@
 // deterministic fp64 tree over the partial rows.  The 6x6 solve stays on the host (optimizer.cpp).
 #include <algorithm>
 #include <chrono>
+#include <thread>
 
 #include "common.hpp"
 #include "device_math.hpp"
@@ -686,12 +687,17 @@ static int wait_result(sga_context* ctx, unsigned long long seq) {
   const auto t0 = std::chrono::steady_clock::now();
   for (unsigned spins = 0;; spins++) {
     if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return SGA_OK;
+    __builtin_ia32_pause();
+    if (spins > 200000u) std::this_thread::yield();  // a result normally arrives within tens of microseconds; past ~1 ms stop hogging the core
     if ((spins & 0xfffu) == 0xfffu) {
       // the stream has drained without publishing (a fault), or this is taking implausibly long: let the runtime report it
       const hipError_t q = hipStreamQuery(ctx->stream);
       if (q != hipErrorNotReady || std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
         SGA_HIP(hipStreamSynchronize(ctx->stream));
         if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return SGA_OK;
+        // a faulted or aborted launch may have left the arrival counter of reduce_rows_kernel non-zero: the next result on this
+        // context would never be published
+        (void)hipMemsetAsync(ctx->d_ticket.p, 0, ctx->d_ticket.n * sizeof(unsigned), ctx->stream);
         return fail(SGA_ERR_HIP, "result was not published by the device");
       }
     }
@@ -772,6 +778,7 @@ int sga_linearize_per_point(sga_context* ctx, sga_problem* pb, const sga_factor_
   SGA_TRY(check_args(ctx, pb, fp, T));
   if (!values28 || !inlier) return fail(SGA_ERR_INVALID, "null output");
   if (pb->target->kind != SGA_INDEX_KDTREE) return fail(SGA_ERR_UNSUPPORTED, "per-point factors need a kd-tree target");
+  SGA_ENTER(ctx);
   double H[36], b[6], e = 0;
   uint64_t ninl = 0;
   sga_factor_params f32 = *fp;
@@ -827,21 +834,21 @@ double sga_get_warm_limit(void) { return g_warm_delta; }
 int sga_linearize_async(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, const double T[16], double* d_out30) {
   SGA_TRY(check_args(ctx, pb, fp, T));
   if (!d_out30) return fail(SGA_ERR_INVALID, "null output");
-  SGA_HIP(hipSetDevice(ctx->device));
+  SGA_ENTER(ctx);
   return fp->math_mode == SGA_MATH_FP64 ? linearize_dispatch<double>(ctx, pb, fp, T, d_out30, nullptr, 0) : linearize_dispatch<float>(ctx, pb, fp, T, d_out30, nullptr, 0);
 }
 
 int sga_error_async(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, const double T[16], double* d_out1) {
   SGA_TRY(check_args(ctx, pb, fp, T));
   if (!d_out1) return fail(SGA_ERR_INVALID, "null output");
-  SGA_HIP(hipSetDevice(ctx->device));
+  SGA_ENTER(ctx);
   return fp->math_mode == SGA_MATH_FP64 ? error_dispatch<double>(ctx, pb, fp, T, d_out1, nullptr, 0) : error_dispatch<float>(ctx, pb, fp, T, d_out1, nullptr, 0);
 }
 
 int sga_linearize(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, const double T[16], double H[36], double b[6], double* e, uint64_t* num_inliers) {
   SGA_TRY(check_args(ctx, pb, fp, T));
   if (!H || !b || !e) return fail(SGA_ERR_INVALID, "null output");
-  SGA_HIP(hipSetDevice(ctx->device));
+  SGA_ENTER(ctx);
   const unsigned long long seq = ++ctx->publish_seq;
   const bool direct = ctx->comm == nullptr;
   double* host = direct ? ctx->h_accum_dev : nullptr;
@@ -855,7 +862,7 @@ int sga_linearize(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp
 int sga_error(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, const double T[16], double* e) {
   SGA_TRY(check_args(ctx, pb, fp, T));
   if (!e) return fail(SGA_ERR_INVALID, "null output");
-  SGA_HIP(hipSetDevice(ctx->device));
+  SGA_ENTER(ctx);
   const unsigned long long seq = ++ctx->publish_seq;
   const bool direct = ctx->comm == nullptr;
   double* host = direct ? ctx->h_accum_dev : nullptr;

@@ -306,7 +306,7 @@ int sga_voxelgrid_sampling(sga_context* ctx, const sga_cloud* in, double leaf, s
   if (!(leaf > 0)) return fail(SGA_ERR_INVALID, "leaf size must be positive");
   if (in->device != ctx->device) return fail(SGA_ERR_INVALID, "cloud lives on another device");
   *out = nullptr;
-  SGA_HIP(hipSetDevice(ctx->device));
+  SGA_ENTER(ctx);
   const size_t n = in->n;
   std::unique_ptr<sga_cloud> res(new sga_cloud);
   res->device = ctx->device;
@@ -355,7 +355,7 @@ int sga_index_refresh_attributes(sga_context* ctx, sga_index* index, const sga_c
   if (!ctx || !index || !cloud) return fail(SGA_ERR_INVALID, "null argument");
   if (index->kind != SGA_INDEX_KDTREE) return fail(SGA_ERR_INVALID, "not a kd-tree index");
   if (index->n != cloud->n) return fail(SGA_ERR_INVALID, "index was built over a cloud of %zu points, got %zu", index->n, cloud->n);
-  SGA_HIP(hipSetDevice(ctx->device));
+  SGA_ENTER(ctx);
   const size_t n = index->n;
   if (cloud->has_normals && index->nrm.n < n) SGA_TRY(index->nrm.alloc(n));
   if (cloud->has_covs && index->cov.n < n) SGA_TRY(index->cov.alloc(n));
@@ -371,10 +371,10 @@ int sga_index_refresh_attributes(sga_context* ctx, sga_index* index, const sga_c
 
 int sga_estimate_normals_covariances(sga_context* ctx, sga_cloud* cloud, const sga_index* index_in, int k, int flags) {
   if (!ctx || !cloud) return fail(SGA_ERR_INVALID, "null argument");
-  if (k < 1 || k > 128) return fail(SGA_ERR_INVALID, "num_neighbors must be in [1,128]");
+  if (k < 1 || k > 116) return fail(SGA_ERR_INVALID, "num_neighbors must be in [1,116] ((k * 8 + 96) * 64 bytes of LDS per workgroup must stay below 64 KB)");
   if ((flags & 3) == 0) return SGA_OK;
   if (cloud->device != ctx->device) return fail(SGA_ERR_INVALID, "cloud lives on another device");
-  SGA_HIP(hipSetDevice(ctx->device));
+  SGA_ENTER(ctx);
   const size_t n = cloud->n;
   sga_index* index = const_cast<sga_index*>(index_in);
   sga_index* temp = nullptr;

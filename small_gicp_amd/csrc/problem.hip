@@ -169,7 +169,7 @@ int sga_problem_create(sga_context* ctx, const sga_index* target, const sga_clou
   if (!ctx || !target || !source || !out) return fail(SGA_ERR_INVALID, "null argument");
   if (target->device != ctx->device || source->device != ctx->device) return fail(SGA_ERR_INVALID, "target/source live on another device");
   *out = nullptr;
-  SGA_HIP(hipSetDevice(ctx->device));
+  SGA_ENTER(ctx);
   static const double I16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   const double* T = init_T ? init_T : I16;
   std::unique_ptr<sga_problem> pb(new sga_problem);
@@ -242,7 +242,7 @@ int sga_problem_get_pass_stats(sga_context* ctx, const sga_problem* pb, uint64_t
   if (warm_passes) *warm_passes = pb->warm_passes;
   if (walked_points) {
     std::vector<uint32_t> w(pb->walked.n);
-    SGA_HIP(hipSetDevice(ctx->device));
+    SGA_ENTER(ctx);
     SGA_HIP(hipMemcpyAsync(w.data(), pb->walked.p, w.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     SGA_HIP(hipStreamSynchronize(ctx->stream));
     uint64_t sum = 0;
@@ -256,7 +256,7 @@ int sga_problem_get_factors(sga_context* ctx, const sga_problem* pb, int64_t* ta
   if (!ctx || !pb) return fail(SGA_ERR_INVALID, "null argument");
   const size_t n = pb->n;
   if (n == 0) return SGA_OK;
-  SGA_HIP(hipSetDevice(ctx->device));
+  SGA_ENTER(ctx);
   DevBuf<long long> d_idx;
   DevBuf<float> d_m;
   if (target_index) SGA_TRY(d_idx.alloc(n));
@@ -280,7 +280,7 @@ static int index_knn_impl(sga_context* ctx, const sga_index* index, const float*
   if (index->kind == SGA_INDEX_FLATMAP) return fail(SGA_ERR_UNSUPPORTED, "flat voxel maps are searched inside the registration only");
   if (index->kind == SGA_INDEX_VOXELMAP && k != 1) return fail(SGA_ERR_UNSUPPORTED, "voxel maps answer k = 1 only");
   if (m == 0) return SGA_OK;
-  SGA_HIP(hipSetDevice(ctx->device));
+  SGA_ENTER(ctx);
   std::vector<float> qf;
   if (!queries) {  // double queries: the search itself runs on their fp32 roundings
     qf.resize(m * 3);

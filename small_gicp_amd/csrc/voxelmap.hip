@@ -351,7 +351,7 @@ int sga_flatmap_download(sga_context* ctx, const sga_index* index, int32_t* coor
   if (index->kind != SGA_INDEX_FLATMAP) return fail(SGA_ERR_INVALID, "not a flat voxel map");
   const size_t n = index->n;
   if (n == 0) return SGA_OK;
-  SGA_HIP(hipSetDevice(ctx->device));
+  SGA_ENTER(ctx);
   std::vector<float4> hp;
   std::vector<Cov8> hc;
   if (points) {
@@ -396,7 +396,7 @@ int sga_voxelmap_insert(sga_context* ctx, sga_index* idx, const sga_cloud* cloud
   if (!idx->incremental) return fail(SGA_ERR_INVALID, "not an incremental voxel map (create it with sga_voxelmap_create)");
   if (cloud->n > 0 && !cloud->has_covs) return fail(SGA_ERR_INVALID, "GaussianVoxelMap needs point covariances");
   if (cloud->device != ctx->device || idx->device != ctx->device) return fail(SGA_ERR_INVALID, "cloud / map live on another device");
-  SGA_HIP(hipSetDevice(ctx->device));
+  SGA_ENTER(ctx);
   Pose12 T;
   for (int r = 0; r < 3; r++) {
     for (int c = 0; c < 3; c++) T.r[3 * r + c] = T16 ? T16[4 * c + r] : (r == c ? 1.0 : 0.0);
