@@ -346,6 +346,7 @@ static int context_create_impl(int device, void* stream, bool borrow, sga_contex
   if (rc == SGA_OK && hipHostMalloc(reinterpret_cast<void**>(&ctx->h_accum), 128 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) rc = fail(SGA_ERR_HIP, "hipHostMalloc failed");
   if (rc == SGA_OK) {
     std::memset(ctx->h_accum, 0, 128 * sizeof(double));
+    ctx->h_scratch = reinterpret_cast<int*>(ctx->h_accum + 96);  // doubles [96, 104) of the pinned block
     if (hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->h_accum_dev), ctx->h_accum, 0) != hipSuccess) rc = fail(SGA_ERR_HIP, "hipHostGetDevicePointer failed");
   }
   if (rc == SGA_OK && (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess || hipEventCreate(&ctx->ev2) != hipSuccess || hipEventCreate(&ctx->ev3) != hipSuccess || hipEventCreate(&ctx->ev_mid) != hipSuccess)) rc = fail(SGA_ERR_HIP, "hipEventCreate failed");

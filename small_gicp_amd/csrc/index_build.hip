@@ -67,26 +67,32 @@ static inline float dec_ordered(int i) {
   return f;
 }
 
-// bounding box of a device cloud on the host (synchronises the context's stream)
-int cloud_bbox(sga_context* ctx, const float4* pts, size_t n, float lo[3], float hi[3]) {
-  for (int k = 0; k < 3; k++) lo[k] = hi[k] = 0.f;
-  if (n == 0) {
-    SGA_HIP(hipStreamSynchronize(ctx->stream));
-    return SGA_OK;
-  }
-  DevBuf<int> d_bbox;
+// bounding box of a device cloud: enqueue (the six encoded values land in pinned host memory when the stream gets there) ...
+int cloud_bbox_enqueue(sga_context* ctx, const float4* pts, size_t n, DevBuf<int>& d_bbox, int* h_bbox6_pinned) {
   SGA_TRY(d_bbox.alloc(6));
   const int init[6] = {0x7f800000, 0x7f800000, 0x7f800000, static_cast<int>(0xff800000u) ^ 0x7fffffff, static_cast<int>(0xff800000u) ^ 0x7fffffff, static_cast<int>(0xff800000u) ^ 0x7fffffff};
-  SGA_HIP(hipMemcpyAsync(d_bbox.p, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(bbox_kernel, dim3(std::min<size_t>(256, (n + 255) / 256)), dim3(256), 0, ctx->stream, pts, n, d_bbox.p);
+  for (int k = 0; k < 6; k++) h_bbox6_pinned[k] = init[k];
+  SGA_HIP(hipMemcpyAsync(d_bbox.p, h_bbox6_pinned, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+  if (n > 0) hipLaunchKernelGGL(bbox_kernel, dim3(std::min<size_t>(256, (n + 255) / 256)), dim3(256), 0, ctx->stream, pts, n, d_bbox.p);
   SGA_HIP(hipGetLastError());
-  int h_bbox[6];
-  SGA_HIP(hipMemcpyAsync(h_bbox, d_bbox.p, sizeof(h_bbox), hipMemcpyDeviceToHost, ctx->stream));
-  SGA_HIP(hipStreamSynchronize(ctx->stream));
+  SGA_HIP(hipMemcpyAsync(h_bbox6_pinned, d_bbox.p, sizeof(init), hipMemcpyDeviceToHost, ctx->stream));
+  return SGA_OK;
+}
+// ... and decode after the stream has been synchronised
+void cloud_bbox_decode(const int* h_bbox6, size_t n, float lo[3], float hi[3]) {
   for (int k = 0; k < 3; k++) {
-    lo[k] = dec_ordered(h_bbox[k]);
-    hi[k] = dec_ordered(h_bbox[3 + k]);
+    lo[k] = n ? dec_ordered(h_bbox6[k]) : 0.f;
+    hi[k] = n ? dec_ordered(h_bbox6[3 + k]) : 0.f;
   }
+}
+
+// both steps at once (synchronises the context's stream)
+int cloud_bbox(sga_context* ctx, const float4* pts, size_t n, float lo[3], float hi[3]) {
+  DevBuf<int> d_bbox;
+  int* h = ctx->h_scratch;
+  SGA_TRY(cloud_bbox_enqueue(ctx, pts, n, d_bbox, h));
+  SGA_HIP(hipStreamSynchronize(ctx->stream));
+  cloud_bbox_decode(h, n, lo, hi);
   return SGA_OK;
 }
 
@@ -353,19 +359,22 @@ __global__ __launch_bounds__(kFinishThreads) void kd_finish_kernel(const float4*
   for (uint32_t pos = tid; pos < m; pos += kFinishThreads) perm_out[B0 + pos] = gidx[ord[pos]];
 }
 
-// pair records for the 1-NN walk (kd_search.hpp): node of even depth + its two children in one 16-byte record
-__global__ void kd_pairs_kernel(const float2* __restrict__ nodes, int D, int d, float4* __restrict__ pairs) {
-  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= (1u << d)) return;
-  const uint32_t node = (1u << d) + k;
+// pair records for the 1-NN walk (kd_search.hpp): node of even depth + its two children in one 16-byte record; one launch covers
+// every even depth (record r of the level-by-level layout belongs to depth d = 2 * floor(log4(3 r + 1)))
+__global__ void kd_pairs_kernel(const float2* __restrict__ nodes, int D, uint32_t count, float4* __restrict__ pairs) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= count) return;
+  int d = 0;
+  while (d + 2 < D && kd_pair_index(d + 2, 1u << (d + 2)) <= r) d += 2;  // the records of depth d + 2 start at or before r
+  const uint32_t node = (1u << d) + (r - kd_pair_index(d, 1u << d));
   const float2 a = nodes[node];
-  float2 l = make_float2(0.f, 0.f), r = make_float2(0.f, 0.f);
+  float2 l = make_float2(0.f, 0.f), rr = make_float2(0.f, 0.f);
   if (d + 1 < D) {
     l = nodes[2 * node];
-    r = nodes[2 * node + 1];
+    rr = nodes[2 * node + 1];
   }
-  const uint32_t axes = static_cast<uint32_t>(__float_as_int(a.y)) | (static_cast<uint32_t>(__float_as_int(l.y)) << 2) | (static_cast<uint32_t>(__float_as_int(r.y)) << 4);
-  pairs[kd_pair_index(d, node)] = make_float4(a.x, l.x, r.x, __uint_as_float(axes));
+  const uint32_t axes = static_cast<uint32_t>(__float_as_int(a.y)) | (static_cast<uint32_t>(__float_as_int(l.y)) << 2) | (static_cast<uint32_t>(__float_as_int(rr.y)) << 4);
+  pairs[r] = make_float4(a.x, l.x, rr.x, __uint_as_float(axes));
 }
 
 // Tight bounding boxes of all nodes, bottom-up (kd_search.hpp: a pending far side is opened only if its box can hold a closer point).
@@ -494,7 +503,10 @@ static int build_kdtree(sga_context* ctx, const sga_cloud* cloud, sga_index* idx
       hipLaunchKernelGGL(kd_finish_kernel<kFinishCap / 2>, dim3(1u << dA), dim3(kFinishThreads), 0, ctx->stream, cloud->pts.p, cur, nxt, static_cast<uint32_t>(n), dA, D, idx->kd_nodes.p);
     std::swap(cur, nxt);
   }
-  for (int d = 0; d < D; d += 2) hipLaunchKernelGGL(kd_pairs_kernel, dim3(((1u << d) + 255) / 256), block, 0, ctx->stream, idx->kd_nodes.p, D, d, idx->kd_nodes4.p);
+  {
+    const uint32_t npairs = kd_pair_count(D);
+    hipLaunchKernelGGL(kd_pairs_kernel, dim3((npairs + 255) / 256), block, 0, ctx->stream, idx->kd_nodes.p, D, npairs, idx->kd_nodes4.p);
+  }
   SGA_HIP(hipGetLastError());
   SGA_TRY(idx->kd_pts.alloc(n + kKdLeafMax));  // + one leaf of points at infinity: leaf scans read 8 slots unconditionally
   if (cloud->has_normals) SGA_TRY(idx->nrm.alloc(n));
@@ -618,10 +630,13 @@ int sga_index_build_kdtree(sga_context* ctx, const sga_cloud* target, sga_index*
   idx->has_normals = target->has_normals;
   idx->has_covs = target->has_covs;
   if (n > 0) {
-    SGA_TRY(cloud_bbox(ctx, target->pts.p, n, idx->bbox_lo, idx->bbox_hi));
+    // the bounding box travels to the host behind the build: build_kdtree synchronises the stream once, at its end
+    DevBuf<int> d_bbox;
+    SGA_TRY(cloud_bbox_enqueue(ctx, target->pts.p, n, d_bbox, ctx->h_scratch));
+    SGA_TRY(build_kdtree(ctx, target, idx.get()));
+    cloud_bbox_decode(ctx->h_scratch, n, idx->bbox_lo, idx->bbox_hi);
     for (int k = 0; k < 3; k++)
       if (!std::isfinite(idx->bbox_lo[k]) || !std::isfinite(idx->bbox_hi[k])) return fail(SGA_ERR_INVALID, "target cloud contains non-finite coordinates");
-    SGA_TRY(build_kdtree(ctx, target, idx.get()));
   }
   *out = idx.release();
   return SGA_OK;

@@ -264,46 +264,93 @@ __device__ __forceinline__ KdBest kd_nearest(const KdView& t, float qx, float qy
 
 // ---- k nearest neighbours (traits::knn_search; normal / covariance estimation) -----------------------------------------------------
 // Same walk as kd_nearest with the k-th best distance as the pruning bound.  The k-best list lives in LDS as [k][STRIDE]
-// (lane-contiguous, conflict-free), sorted ascending by (distance, position) — KnnResult<-1>::push (ann/knn_result.hpp:80-100)
-// with a canonical tie rule.  sd / si must be initialised to +inf / -1 by the caller.  bound2: ignore points with d2 >= bound2.
+// (lane-contiguous, conflict-free) and is kept UNSORTED while the walk runs: a better candidate replaces the current worst entry
+// and the new worst is found by one sweep over the k slots — k independent LDS reads that pipeline, where a sorted insertion is
+// a chain of up to k dependent read-compare-write steps (the old form of this function spent most of its time in that chain).
+// The list is sorted once at the end, ascending by (distance, position): KnnResult<-1>::push (ann/knn_result.hpp:80-100) with a
+// canonical tie rule.  sd / si must be initialised to +inf / -1 by the caller.  bound2: ignore points with d2 >= bound2.
+// pre_first / pre_end / pre_pts (optional): a range of kd positions, staged in LDS by the caller, that is scanned up front, before
+// the walk.  Queries that are themselves
+// points of the tree (normal / covariance estimation) pass the positions around their own: kd order keeps spatial neighbours
+// close, the 64 lanes of a wave read the same candidates (one broadcast load per candidate), and the list is all but final before
+// the walk starts — which then runs with a tight bound, skips the leaves inside the range and mostly just proves that nothing
+// closer is left.  (Without it every query pays ~k/8 walk rounds of dependent loads with the whole chip waiting on a few waves.)
 template <int STRIDE>
-__device__ __forceinline__ void kd_knn(const KdView& t, float qx, float qy, float qz, int k, float bound2, float* __restrict__ sd, int* __restrict__ si, uint32_t* __restrict__ stack, int tid) {
+__device__ __forceinline__ void kd_knn(const KdView& t, float qx, float qy, float qz, int k, float bound2, float* __restrict__ sd, int* __restrict__ si, uint32_t* __restrict__ stack, int tid, bool sort_result = true,
+                                       uint32_t pre_first = 0, uint32_t pre_end = 0, const float4* __restrict__ pre_pts = nullptr /* LDS copy of pts[pre_first, pre_end) */,
+                                       uint32_t pre_own_first = 0, uint32_t pre_own_end = 0 /* the part of the range to scan first */) {
   if (t.n == 0) return;
   const int D = t.depth;
-  float worst = bound2;     // k-th best squared distance so far
+  float worst = bound2;  // admission bound: the k-th best (distance, position) once the list is full
   int worst_id = 0x7fffffff;
-  auto leaf_scan = [&](uint32_t leaf_node) {
-    const uint32_t kk = leaf_node - (1u << D);
-    const uint32_t first = kd_bound(t.n, D, kk), end = kd_bound(t.n, D, kk + 1);
+  int worst_slot = 0, count = 0;
+  auto scan_range = [&](uint32_t first, uint32_t end, bool skip_pre) {
     for (uint32_t j0 = first; j0 < end; j0 += 4) {
       float4 p[4];
 #pragma unroll
-      for (int u = 0; u < 4; u++) p[u] = t.pts[min(j0 + u, end - 1)];
+      for (int u = 0; u < 4; u++) p[u] = skip_pre ? t.pts[min(j0 + u, end - 1)] : pre_pts[min(j0 + u, end - 1) - pre_first];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         if (j0 + u >= end) continue;
+        if (skip_pre && j0 + u >= pre_first && j0 + u < pre_end) continue;  // scanned up front
         const int id = static_cast<int>(j0 + u);
-        const float dx = p[u].x - qx, dy = p[u].y - qy, dz = p[u].z - qz;
-        const float d2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+        const float d2 = kd_dist2(p[u].x, p[u].y, p[u].z, qx, qy, qz);
         if (!(d2 < worst || (d2 == worst && id < worst_id))) continue;
-        int loc = k - 1;
-        for (; loc > 0; loc--) {
-          const float pd = sd[(loc - 1) * STRIDE + tid];
-          const int pi = si[(loc - 1) * STRIDE + tid];
-          if (!(d2 < pd || (d2 == pd && (pi < 0 || id < pi)))) break;
-          sd[loc * STRIDE + tid] = pd;
-          si[loc * STRIDE + tid] = pi;
+        if (count < k) {  // filling up: any slot will do
+          sd[count * STRIDE + tid] = d2;
+          si[count * STRIDE + tid] = id;
+          count++;
+          if (count < k) continue;
+        } else {
+          sd[worst_slot * STRIDE + tid] = d2;
+          si[worst_slot * STRIDE + tid] = id;
         }
-        sd[loc * STRIDE + tid] = d2;
-        si[loc * STRIDE + tid] = id;
-        const int li = si[(k - 1) * STRIDE + tid];
-        if (li >= 0) {  // list full: the bound tightens to the k-th best
-          worst = sd[(k - 1) * STRIDE + tid];
-          worst_id = li;
+        // the list is full: its worst entry is the new admission bound.  Four slots per step: eight LDS reads in flight, one wait
+        // (slots k .. k+3 exist — the callers pad the list — and hold (+inf, -1) only until the list is full, never afterwards:
+        // they are excluded by the j + u < k test)
+        float wd = -1.f;
+        int wi = -1, ws = 0;
+        for (int j = 0; j < k; j += 4) {
+          float pd[4];
+          int pi[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            pd[u] = sd[(j + u) * STRIDE + tid];
+            pi[u] = si[(j + u) * STRIDE + tid];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const bool worse = j + u < k && (pd[u] > wd || (pd[u] == wd && pi[u] > wi));
+            wd = worse ? pd[u] : wd;
+            wi = worse ? pi[u] : wi;
+            ws = worse ? j + u : ws;
+          }
         }
+        worst = wd;
+        worst_id = wi;
+        worst_slot = ws;
       }
     }
   };
+  auto leaf_scan = [&](uint32_t leaf_node) {
+    const uint32_t kk = leaf_node - (1u << D);
+    const uint32_t first = kd_bound(t.n, D, kk), end = kd_bound(t.n, D, kk + 1);
+    if (first >= pre_first && end <= pre_end) return;  // the whole leaf was scanned up front
+    scan_range(first, end, true);
+  };
+  if (pre_end > pre_first && pre_pts != nullptr) {
+    // nearest positions first (wave-uniform order): the wave's own stretch, then chunks alternately to its right and to its left —
+    // the admission bound is tight after the first few dozen candidates and most of the rest fail the single compare
+    const uint32_t own_first = min(max(pre_own_first, pre_first), pre_end), own_end = min(max(pre_own_end, own_first), pre_end);
+    scan_range(own_first, own_end, false);
+    for (uint32_t step = 0;; step++) {
+      const uint32_t r0 = own_end + 16u * step, l1 = own_first >= 16u * step ? own_first - 16u * step : 0u;
+      const bool right = r0 < pre_end, left = l1 > pre_first;
+      if (!right && !left) break;
+      if (right) scan_range(r0, min(r0 + 16u, pre_end), false);
+      if (left) scan_range(l1 > pre_first + 16u ? l1 - 16u : pre_first, l1, false);
+    }
+  }
   int sp = 0, depth = 0;
   uint32_t node = 1;
   for (;;) {
@@ -329,6 +376,133 @@ __device__ __forceinline__ void kd_knn(const KdView& t, float qx, float qy, floa
         const int dd = static_cast<int>(e & 31u);
         const uint32_t far_node = (node >> (D - dd)) ^ 1u;
         if (kd_box_dist2(t, far_node, qx, qy, qz) <= worst) {  // plane test, then the tight box of the pending sub-tree
+          depth = dd;
+          node = far_node;
+          found = true;
+          break;
+        }
+      }
+    }
+    if (!found) break;
+  }
+  if (!sort_result) return;
+  // once, at the end: selection sort of the `count` entries, ascending by (distance, position); unused slots stay (+inf, -1)
+  for (int a = 0; a + 1 < count; a++) {
+    float bd = sd[a * STRIDE + tid];
+    int bi = si[a * STRIDE + tid], bs = a;
+    for (int j = a + 1; j < count; j++) {
+      const float pd = sd[j * STRIDE + tid];
+      const int pi = si[j * STRIDE + tid];
+      const bool better = pd < bd || (pd == bd && pi < bi);
+      bd = better ? pd : bd;
+      bi = better ? pi : bi;
+      bs = better ? j : bs;
+    }
+    if (bs != a) {
+      sd[bs * STRIDE + tid] = sd[a * STRIDE + tid];
+      si[bs * STRIDE + tid] = si[a * STRIDE + tid];
+      sd[a * STRIDE + tid] = bd;
+      si[a * STRIDE + tid] = bi;
+    }
+  }
+}
+
+// ---- k nearest neighbours of the tree's OWN points, k known at compile time (normal / covariance estimation, k = 10 / 20) -------
+// The list lives in registers, sorted ascending; an insertion is a branch-free shift network (7 VALU operations per slot), so the 64
+// lanes of a wave never serialise on each other's insertions the way the LDS list of kd_knn does (any lane inserting makes the whole
+// wave run the insertion path: with k = 20 that path ran for nearly every candidate).  Candidates first come from `window`, an LDS
+// copy of the kd positions [pre_first, pre_end) around the wave's own — kd order keeps spatial neighbours close and all lanes read
+// the same candidate (a broadcast) — nearest stretch first; the walk that follows runs with the k-th distance found so far as its
+// bound, skips what the window covered and mostly proves that nothing closer is left.  Distances tie-break by arrival order (a fixed
+// order): deterministic; only the choice among equidistant k-th candidates can differ from kd_knn's canonical rule.
+template <int K>
+struct KnnRegs {
+  float d[K];
+  int id[K];
+};
+
+template <int K>
+__device__ __forceinline__ void knn_regs_insert(KnnRegs<K>& L, float v, int vid) {
+#pragma unroll
+  for (int j = K - 1; j >= 1; j--) {
+    const bool shift = v < L.d[j - 1];        // the new element lands before slot j - 1: that one moves up
+    const bool here = !shift && v < L.d[j];   // it lands exactly here
+    L.d[j] = shift ? L.d[j - 1] : (here ? v : L.d[j]);
+    L.id[j] = shift ? L.id[j - 1] : (here ? vid : L.id[j]);
+  }
+  const bool first = v < L.d[0];
+  L.d[0] = first ? v : L.d[0];
+  L.id[0] = first ? vid : L.id[0];
+}
+
+template <int K, int STRIDE>
+__device__ __forceinline__ void kd_knn_own_points(const KdView& t, float qx, float qy, float qz, KnnRegs<K>& L, const float4* __restrict__ window, uint32_t pre_first, uint32_t pre_end, uint32_t own_first, uint32_t own_end,
+                                                  uint32_t* __restrict__ stack, int tid) {
+#pragma unroll
+  for (int j = 0; j < K; j++) {
+    L.d[j] = INFINITY;
+    L.id[j] = -1;
+  }
+  if (t.n == 0) return;
+  auto offer = [&](float4 c, int id, bool valid) {
+    const float d2 = kd_dist2(c.x, c.y, c.z, qx, qy, qz);
+    const bool take = valid && d2 < L.d[K - 1];
+    if (__ballot(take) == 0ull) return;  // wave-uniform: nobody wants this candidate
+    knn_regs_insert<K>(L, take ? d2 : INFINITY, id);
+  };
+  auto scan_window = [&](uint32_t first, uint32_t end) {
+    for (uint32_t j = first; j < end; j++) offer(window[j - pre_first], static_cast<int>(j), true);
+  };
+  scan_window(own_first, own_end);
+  for (uint32_t step = 0;; step++) {
+    const uint32_t r0 = own_end + 16u * step, l1 = own_first >= 16u * step ? own_first - 16u * step : 0u;
+    const bool right = r0 < pre_end, left = l1 > pre_first;
+    if (!right && !left) break;
+    if (right) scan_window(r0, min(r0 + 16u, pre_end));
+    if (left) scan_window(l1 > pre_first + 16u ? l1 - 16u : pre_first, l1);
+  }
+  // the walk: kd_knn's, with the register list
+  const int D = t.depth;
+  int sp = 0, depth = 0;
+  uint32_t node = 1;
+  for (;;) {
+    while (depth < D) {
+      const float2 nd = t.nodes[node];
+      const int axis = __float_as_int(nd.y);
+      const float qa = axis == 0 ? qx : (axis == 1 ? qy : qz);
+      const float diff = qa - nd.x;
+      const float cut = diff * diff;
+      depth++;
+      if (cut <= L.d[K - 1]) {
+        stack[sp * STRIDE + tid] = kd_pack(cut, depth);
+        sp++;
+      }
+      node = 2 * node + (diff < 0.f ? 0u : 1u);
+    }
+    {
+      const uint32_t kk = node - (1u << D);
+      const uint32_t first = kd_bound(t.n, D, kk), end = kd_bound(t.n, D, kk + 1);
+      if (!(first >= pre_first && end <= pre_end)) {  // not covered by the window
+        float4 p[kKdLeafMax];
+#pragma unroll
+        for (int i = 0; i < kKdLeafMax; i++) p[i] = t.pts[first + i];  // 8 slots are always readable (padding behind the last leaf)
+#pragma unroll
+        for (int i = 0; i < kKdLeafMax; i++) {
+          const uint32_t pos = first + i;
+          const bool valid = pos < end && !(pos >= pre_first && pos < pre_end);
+          const float d2 = kd_dist2(p[i].x, p[i].y, p[i].z, qx, qy, qz);
+          if (valid && d2 < L.d[K - 1]) knn_regs_insert<K>(L, d2, static_cast<int>(pos));  // rare once the window has been scanned
+        }
+      }
+    }
+    bool found = false;
+    while (sp > 0) {
+      sp--;
+      const uint32_t e = stack[sp * STRIDE + tid];
+      if (kd_cut(e) <= L.d[K - 1]) {
+        const int dd = static_cast<int>(e & 31u);
+        const uint32_t far_node = (node >> (D - dd)) ^ 1u;
+        if (kd_box_dist2(t, far_node, qx, qy, qz) <= L.d[K - 1]) {
           depth = dd;
           node = far_node;
           found = true;

@@ -193,24 +193,44 @@ __device__ __forceinline__ Eig3 eigen_sym3(const double a[3][3] /* lower triangl
 
 // ---- normals / covariances -----------------------------------------------------------------------------------------------------
 constexpr int kFeatBlock = 64;
+constexpr int kFeatWindow = 256;
 
 // One lane per point of the kd-ordered index; neighbours come from the same tree.  Results are written both to the index's
 // kd-ordered attribute arrays and, through the original index kept in pts.w, to the caller's cloud.
+template <int K>  // K > 0: k = K neighbours in registers (kd_knn_own_points); K = 0: any k, list in LDS (kd_knn)
 __global__ __launch_bounds__(kFeatBlock) void local_features_kernel(
   const KdView g, size_t n, int k, int flags, float4* __restrict__ idx_nrm, Cov8* __restrict__ idx_cov, float4* __restrict__ cloud_nrm, Cov8* __restrict__ cloud_cov) {
   extern __shared__ float sh[];
+  __shared__ float4 window[kFeatWindow];  // the kd positions around the wave's own, scanned before the walk
+  const int kpad = (k + 3) & ~3;  // kd_knn sweeps the list four slots at a time
   float* sd = sh;
-  int* si = reinterpret_cast<int*>(sh + static_cast<size_t>(k) * kFeatBlock);
-  uint32_t* stack = reinterpret_cast<uint32_t*>(sh + 2 * static_cast<size_t>(k) * kFeatBlock);
+  int* si = reinterpret_cast<int*>(sh + static_cast<size_t>(kpad) * kFeatBlock);
+  uint32_t* stack = reinterpret_cast<uint32_t*>(sh + 2 * static_cast<size_t>(kpad) * kFeatBlock);
   const int lane = threadIdx.x;
   const size_t i = blockIdx.x * static_cast<size_t>(kFeatBlock) + lane;
-  for (int j = 0; j < k; j++) {
+  for (int j = 0; j < kpad; j++) {
     sd[j * kFeatBlock + lane] = INFINITY;
     si[j * kFeatBlock + lane] = -1;
   }
+  // candidates scanned before the walk: the wave's own 64 positions and 96 on either side, fetched with four coalesced loads
+  const uint32_t base = blockIdx.x * kFeatBlock;
+  const uint32_t pre_first = base > 96u ? base - 96u : 0u;
+  const uint32_t pre_end = static_cast<uint32_t>(min(static_cast<size_t>(pre_first) + kFeatWindow, n));
+  for (uint32_t w = lane; w < pre_end - pre_first; w += kFeatBlock) window[w] = g.pts[pre_first + w];
+  __syncthreads();
   if (i >= n) return;
   const float4 p = g.pts[i];
-  kd_knn<kFeatBlock>(g, p.x, p.y, p.z, k, INFINITY, sd, si, stack, lane);
+  if constexpr (K > 0) {
+    KnnRegs<K> L;
+    kd_knn_own_points<K, kFeatBlock>(g, p.x, p.y, p.z, L, window, pre_first, pre_end, min(base, pre_end), min(base + kFeatBlock, pre_end), stack, lane);
+#pragma unroll
+    for (int j = 0; j < K; j++) {  // hand the list to the common code below
+      sd[j * kFeatBlock + lane] = L.d[j];
+      si[j * kFeatBlock + lane] = L.id[j];
+    }
+  } else {
+    kd_knn<kFeatBlock>(g, p.x, p.y, p.z, k, INFINITY, sd, si, stack, lane, false, pre_first, pre_end, window, base, base + kFeatBlock);  // unsorted: the sums below do not depend on the order
+  }
   int found = 0;
   double sp[3] = {0, 0, 0}, sc[6] = {0, 0, 0, 0, 0, 0};
   for (int j = 0; j < k; j++) {
@@ -389,12 +409,20 @@ int sga_estimate_normals_covariances(sga_context* ctx, sga_cloud* cloud, const s
   if ((flags & 1) && cloud->nrm.n < n) rc = cloud->nrm.alloc(n);
   if (rc == SGA_OK && (flags & 2) && cloud->cov.n < n) rc = cloud->cov.alloc(n);
   if (rc == SGA_OK && n > 0) {
-    const size_t shmem = (static_cast<size_t>(k) * 8 + kKdMaxDepth * 4) * kFeatBlock;
+    const size_t shmem = (static_cast<size_t>((k + 3) & ~3) * 8 + kKdMaxDepth * 4) * kFeatBlock;
     if ((flags & 1) && !temp && index->nrm.n < n) rc = index->nrm.alloc(n);
     if (rc == SGA_OK && (flags & 2) && !temp && index->cov.n < n) rc = index->cov.alloc(n);
     KdView kv = make_kd_view(index);
-    hipLaunchKernelGGL(
-      local_features_kernel, dim3((n + kFeatBlock - 1) / kFeatBlock), dim3(kFeatBlock), shmem, ctx->stream, kv, n, k, flags, temp ? nullptr : index->nrm.p, temp ? nullptr : index->cov.p, cloud->nrm.p, cloud->cov.p);
+    const dim3 fgrid((n + kFeatBlock - 1) / kFeatBlock), fblock(kFeatBlock);
+    float4* inrm = temp ? nullptr : index->nrm.p;
+    Cov8* icov = temp ? nullptr : index->cov.p;
+    // the reference's two neighbourhood sizes (registration_helper.cpp:60-61 k = 10, the benchmarks' k = 20) keep the list in registers
+    if (k == 20)
+      hipLaunchKernelGGL((local_features_kernel<20>), fgrid, fblock, shmem, ctx->stream, kv, n, k, flags, inrm, icov, cloud->nrm.p, cloud->cov.p);
+    else if (k == 10)
+      hipLaunchKernelGGL((local_features_kernel<10>), fgrid, fblock, shmem, ctx->stream, kv, n, k, flags, inrm, icov, cloud->nrm.p, cloud->cov.p);
+    else
+      hipLaunchKernelGGL((local_features_kernel<0>), fgrid, fblock, shmem, ctx->stream, kv, n, k, flags, inrm, icov, cloud->nrm.p, cloud->cov.p);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) rc = fail(SGA_ERR_HIP, "local_features_kernel: %s", hipGetErrorString(e));

@@ -103,12 +103,13 @@ constexpr int kKnnMaxK = 116;  // (k * 8 + 96) * 64 bytes of LDS per workgroup m
 // query — the coordinates stored on the device are fp32, the reference returns double distances (ann/kdtree.hpp:193-233)
 __global__ __launch_bounds__(kKnnBlock) void knn_kernel(const KdView t, const float* __restrict__ queries, size_t m, int k, float max_sq, long long* __restrict__ out_idx, float* __restrict__ out_d2, const double* __restrict__ queries64, double* __restrict__ out_d2_64) {
   extern __shared__ float sh[];  // k*64 distances, k*64 indices, kKdMaxDepth*64 stack words
+  const int kpad = (k + 3) & ~3;  // kd_knn sweeps the list four slots at a time
   float* sd = sh;
-  int* si = reinterpret_cast<int*>(sh + static_cast<size_t>(k) * kKnnBlock);
-  uint32_t* stack = reinterpret_cast<uint32_t*>(sh + 2 * static_cast<size_t>(k) * kKnnBlock);
+  int* si = reinterpret_cast<int*>(sh + static_cast<size_t>(kpad) * kKnnBlock);
+  uint32_t* stack = reinterpret_cast<uint32_t*>(sh + 2 * static_cast<size_t>(kpad) * kKnnBlock);
   const int lane = threadIdx.x;
   const size_t qi = blockIdx.x * static_cast<size_t>(kKnnBlock) + lane;
-  for (int j = 0; j < k; j++) {
+  for (int j = 0; j < kpad; j++) {
     sd[j * kKnnBlock + lane] = INFINITY;
     si[j * kKnnBlock + lane] = -1;
   }
@@ -311,7 +312,7 @@ static int index_knn_impl(sga_context* ctx, const sga_index* index, const float*
     SGA_HIP(hipStreamSynchronize(ctx->stream));
   } else {
     if (k > kKnnMaxK) return fail(SGA_ERR_INVALID, "k must be <= %d for a kd-tree (LDS per workgroup)", kKnnMaxK);
-    const size_t shmem = (static_cast<size_t>(k) * 8 + kKdMaxDepth * 4) * kKnnBlock;
+    const size_t shmem = (static_cast<size_t>((k + 3) & ~3) * 8 + kKdMaxDepth * 4) * kKnnBlock;
     KdView kv = make_kd_view(index);
     hipLaunchKernelGGL(knn_kernel, dim3((m + kKnnBlock - 1) / kKnnBlock), dim3(kKnnBlock), shmem, ctx->stream, kv, d_q.p, m, k, max_sq, d_i.p, d_d.p, want64 ? d_q64.p : nullptr, want64 ? d_d64.p : nullptr);
   }
