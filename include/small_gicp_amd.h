@@ -48,6 +48,9 @@ enum sga_math_mode { SGA_MATH_FP32 = 0, SGA_MATH_FP64 = 1 }; /* per-pair arithme
 const char* sga_last_error(void);
 /* Library version string. */
 const char* sga_version(void);
+/* Diagnostics of the library's caching device allocator: hipMalloc calls, allocations served by the calling stream's own free list, by
+ * the shared pool, by blocks whose deferred release had completed, and frees that had to be deferred behind busy streams. */
+void sga_allocator_stats(uint64_t out[5]);
 /* Number of visible HIP devices (0 when there is no GPU / no driver). */
 int sga_device_count(void);
 

@@ -65,6 +65,7 @@ SYMBOLS = [
     ("sga_last_error", C.c_char_p, []),
     ("sga_version", C.c_char_p, []),
     ("sga_device_count", C.c_int, []),
+    ("sga_allocator_stats", None, [C.POINTER(C.c_uint64)]),
     ("sga_context_create", C.c_int, [C.c_int, _pvp]),
     ("sga_context_create_on_stream", C.c_int, [C.c_int, _vp, _pvp]),
     ("sga_context_destroy", C.c_int, [_vp]),

@@ -109,6 +109,8 @@ struct sga_context {
   sga::DevBuf<unsigned> d_ticket; // arrival counter of the reduction kernel (linearize.hip), zero between launches
   double* h_accum = nullptr;      // pinned + device-mapped: [0, 64) results, word 64 = sequence number of the last published result
   double* h_accum_dev = nullptr;  // device address of h_accum
+  void* h_stage = nullptr;        // pinned staging buffer for uploads (context.hip), grow-only
+  size_t h_stage_bytes = 0;
   int* h_scratch = nullptr;       // 16 pinned ints behind h_accum: small asynchronous read-backs (bounding boxes)
   unsigned long long publish_seq = 0;
   sga::DevBuf<uint8_t> d_temp;    // rocPRIM temp storage (grow-only)

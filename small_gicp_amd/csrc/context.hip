@@ -53,6 +53,7 @@ struct DevCache {
   std::vector<hipEvent_t> event_pool;
   size_t cached_bytes = 0;
   int contexts = 0;
+  uint64_t n_malloc = 0, n_stream_hit = 0, n_pool_hit = 0, n_pending_hit = 0, n_deferred = 0;  // statistics (sga_allocator_stats)
 };
 DevCache& dev_cache() {
   static DevCache* c = new DevCache;  // never destroyed: no HIP calls during static destruction
@@ -131,15 +132,16 @@ int dev_alloc(void** p, size_t bytes) {
   DevCache& c = dev_cache();
   std::lock_guard<std::mutex> lock(c.mu);
   // same stream first (stream order makes the reuse safe), then blocks nobody uses, then blocks whose last users have finished
-  if (g_cur_stream != nullptr) *p = take_locked(c, {device, g_cur_stream, bucket});
-  if (!*p) *p = take_locked(c, {device, nullptr, bucket});
+  if (g_cur_stream != nullptr && (*p = take_locked(c, {device, g_cur_stream, bucket})) != nullptr) c.n_stream_hit++;
+  if (!*p && (*p = take_locked(c, {device, nullptr, bucket})) != nullptr) c.n_pool_hit++;
   if (!*p && !c.pending.empty()) {
     collect_pending_locked(c);
-    *p = take_locked(c, {device, nullptr, bucket});
+    if ((*p = take_locked(c, {device, nullptr, bucket})) != nullptr) c.n_pending_hit++;
   }
   if (*p) {
     c.cached_bytes -= bucket;
   } else {
+    c.n_malloc++;
     hipError_t e = hipMalloc(p, bucket);
     if (e != hipSuccess) {  // out of memory with blocks parked in the cache: give them back and retry once
       (void)hipGetLastError();
@@ -202,10 +204,12 @@ void dev_free(void* p) {
     b.events.push_back(e);
   }
   (void)hipGetLastError();
-  if (b.events.empty())
+  if (b.events.empty()) {
     c.free_blocks[{device, nullptr, bucket}].push_back(p);
-  else
+  } else {
+    c.n_deferred++;
     c.pending.push_back(std::move(b));
+  }
 }
 
 static void dev_cache_context_created(int device, hipStream_t stream) {
@@ -305,6 +309,16 @@ using namespace sga;
 extern "C" {
 
 const char* sga_last_error(void) { return g_err; }
+
+void sga_allocator_stats(uint64_t out[5]) {
+  DevCache& c = dev_cache();
+  std::lock_guard<std::mutex> lock(c.mu);
+  out[0] = c.n_malloc;
+  out[1] = c.n_stream_hit;
+  out[2] = c.n_pool_hit;
+  out[3] = c.n_pending_hit;
+  out[4] = c.n_deferred;
+}
 const char* sga_version(void) { return "small_gicp_amd 0.1.0 (gfx950)"; }
 
 int sga_device_count(void) {
@@ -372,6 +386,7 @@ int sga_context_destroy(sga_context* ctx) {
   if (ctx->ev3) (void)hipEventDestroy(ctx->ev3);
   if (ctx->ev_mid) (void)hipEventDestroy(ctx->ev_mid);
   if (ctx->h_accum) (void)hipHostFree(ctx->h_accum);
+  if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   const int device = ctx->device;
   const hipStream_t stream = ctx->stream;
   const bool registered = ctx->registered, owns = ctx->owns_stream;
@@ -436,6 +451,21 @@ int sga_context_get_search_ms(sga_context* ctx, double* search_ms, uint64_t* sea
   return SGA_OK;
 }
 
+// the context's pinned staging buffer for host -> device uploads (grow-only; the stream must be idle: uploads synchronise)
+static int ctx_pinned_stage(sga_context* ctx, size_t bytes, void** out) {
+  if (ctx->h_stage_bytes < bytes) {
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    ctx->h_stage = nullptr;
+    ctx->h_stage_bytes = 0;
+    size_t want = 1u << 20;
+    while (want < bytes) want <<= 1;
+    if (hipHostMalloc(&ctx->h_stage, want, hipHostMallocDefault) != hipSuccess) return fail(SGA_ERR_HIP, "hipHostMalloc(%zu bytes) failed", want);
+    ctx->h_stage_bytes = want;
+  }
+  *out = ctx->h_stage;
+  return SGA_OK;
+}
+
 int sga_cloud_create_f32(sga_context* ctx, const float* xyz, const float* normals, const float* cov6, size_t n, sga_cloud** out) {
   if (!ctx || !out || (n > 0 && !xyz)) return fail(SGA_ERR_INVALID, "null argument");
   if (n >= (1ull << 31)) return fail(SGA_ERR_INVALID, "cloud too large (%zu points; limit 2^31-1)", n);
@@ -458,9 +488,22 @@ int sga_cloud_create_f32(sga_context* ctx, const float* xyz, const float* normal
     return rc;
   }
   if (n > 0) {
-    hipError_t e = hipMemcpyAsync(sx.p, xyz, n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess && normals) e = hipMemcpyAsync(sn.p, normals, n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess && cov6) e = hipMemcpyAsync(sc.p, cov6, n * 6 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    // The caller's buffers are pageable: copied from there the runtime has to lock their pages first, which costs up to tens of
+    // milliseconds per fresh megabyte-sized buffer on some hosts (measured: 15-28 ms for a 1.4 MB scan).  They are staged through the
+    // context's own pinned buffer instead (a CPU memcpy at memory speed).
+    const size_t fx = n * 3, fn = normals ? n * 3 : 0, fc = cov6 ? n * 6 : 0;
+    float* stage = nullptr;
+    rc = ctx_pinned_stage(ctx, (fx + fn + fc) * sizeof(float), reinterpret_cast<void**>(&stage));
+    if (rc != SGA_OK) {
+      delete c;
+      return rc;
+    }
+    std::memcpy(stage, xyz, fx * sizeof(float));
+    if (normals) std::memcpy(stage + fx, normals, fn * sizeof(float));
+    if (cov6) std::memcpy(stage + fx + fn, cov6, fc * sizeof(float));
+    hipError_t e = hipMemcpyAsync(sx.p, stage, fx * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && normals) e = hipMemcpyAsync(sn.p, stage + fx, fn * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && cov6) e = hipMemcpyAsync(sc.p, stage + fx + fn, fc * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
       hipLaunchKernelGGL(pack_cloud_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, sx.p, sn.p, sc.p, n, c->pts.p, c->nrm.p, c->cov.p);
       e = hipGetLastError();

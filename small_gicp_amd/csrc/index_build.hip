@@ -490,7 +490,12 @@ static int build_kdtree(sga_context* ctx, const sga_cloud* cloud, sga_index* idx
     const dim3 sgrid((nseg + 255) / 256);
     const unsigned end_bit = 32 + (d > 0 ? d : 1);
     if (d == 0) hipLaunchKernelGGL(kd_init_box_kernel, sgrid, block, 0, ctx->stream, seg_box.p, nseg);  // later levels: reset by kd_nodes_kernel
-    hipLaunchKernelGGL(kd_segment_box_kernel, dim3((n + 1023) / 1024), dim3(1024), 0, ctx->stream, cloud->pts.p, cur, static_cast<uint32_t>(n), d, seg_box.p);
+    {
+      // six atomics per workgroup on a handful of addresses: large workgroups for large clouds (fewer atomics), small ones for
+      // small clouds (a 15k-point scan in 1024-thread workgroups would occupy 15 CUs)
+      const unsigned bs = n > 200000 ? 1024u : 256u;
+      hipLaunchKernelGGL(kd_segment_box_kernel, dim3((n + bs - 1) / bs), dim3(bs), 0, ctx->stream, cloud->pts.p, cur, static_cast<uint32_t>(n), d, seg_box.p);
+    }
     hipLaunchKernelGGL(kd_keys_kernel, grid, block, 0, ctx->stream, cloud->pts.p, cur, static_cast<uint32_t>(n), d, seg_box.p, axis_of_seg.p, keys.p);
     SGA_HIP(rocprim::radix_sort_pairs(ctx->d_temp.p, tb, keys.p, keys2.p, cur, nxt, n, 0, end_bit, ctx->stream));
     std::swap(cur, nxt);

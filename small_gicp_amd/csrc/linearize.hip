@@ -26,6 +26,46 @@ constexpr int kRow = 32;             // doubles per partial row (28 used + inlie
 constexpr int kSearchBlock = 64;      // K1a: one wave per workgroup
 constexpr int kMaxBlocks = 2048;     // K1b / K2: 8 workgroups per CU, the whole grid is resident
 
+// Small grids (a 15k-point scan is 60 workgroups) fold the final reduction into the producer kernel: every workgroup publishes its
+// partial row (agent-scope write-through stores), takes a ticket, and the workgroup that arrives last adds the rows in fixed order
+// and hands the result over — one launch and one dependent-launch gap less per pass.  (With the 2048 workgroups of a 1M-point pass
+// the ticket contention costs more than the launch: those keep the separate reduce_rows_kernel.)
+constexpr int kFuseMaxBlocks = 256;
+struct FusedTail {
+  int enabled;
+  unsigned* ticket;
+  double* out;        // device result (out_n doubles)
+  int out_n;
+  double* host;       // pinned, device-mapped host result or null
+  unsigned long long seq;
+};
+
+__device__ __forceinline__ void fused_tail(const FusedTail& f, const double* __restrict__ partials, int nrows, int ncols, int row_stride) {
+  __shared__ unsigned sh_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this workgroup's row has left the CU
+  __syncthreads();
+  if (threadIdx.x == 0) sh_last = __hip_atomic_fetch_add(f.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == static_cast<unsigned>(nrows - 1) ? 1u : 0u;
+  __syncthreads();
+  if (!sh_last) return;  // workgroup-uniform
+  if (threadIdx.x < 32) {
+    const int c = threadIdx.x;
+    double t = 0.0;
+    if (c < ncols)
+      for (int r = 0; r < nrows; r++) t += __hip_atomic_load(&partials[static_cast<size_t>(r) * row_stride + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (c < f.out_n) {
+      const double v = c < ncols ? t : 0.0;
+      f.out[c] = v;
+      if (f.host != nullptr) f.host[c] = v;
+    }
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(f.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch on this stream
+  if (f.host != nullptr) {
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(reinterpret_cast<unsigned long long*>(f.host + 64), f.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 template <typename Real>
 struct LinParams {
   const float4* __restrict__ src_pts;
@@ -48,6 +88,7 @@ struct LinParams {
   int robust_kind;
   Real robust_c;
   double* __restrict__ partials;
+  FusedTail tail;
 };
 
 // XCD-aware tile schedule: workgroup b runs on XCD b % 8 (observed placement; used for L2 affinity only).  Each XCD
@@ -288,8 +329,12 @@ __global__ __launch_bounds__(kTile) void linearize_kernel(const LinParams<Real> 
     double s = 0.0;
 #pragma unroll
     for (int w = 0; w < kTile / 64; w++) s += sh_acc[w][threadIdx.x];
-    p.partials[static_cast<size_t>(blockIdx.x) * kRow + threadIdx.x] = s;
+    if (p.tail.enabled)
+      __hip_atomic_store(&p.partials[static_cast<size_t>(blockIdx.x) * kRow + threadIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+      p.partials[static_cast<size_t>(blockIdx.x) * kRow + threadIdx.x] = s;
   }
+  if (p.tail.enabled) fused_tail(p.tail, p.partials, gridDim.x, 29, kRow);
 }
 
 // Per-point export of the same factors (the reference's Python binding exposes Factor::linearize per source point,
@@ -336,6 +381,7 @@ struct ErrParams {
   int robust_kind;
   Real robust_c;
   double* __restrict__ partials;
+  FusedTail tail;
 };
 
 template <typename Real, int FACTOR>
@@ -377,8 +423,12 @@ __global__ __launch_bounds__(kTile) void error_kernel(const ErrParams<Real> p) {
   if (threadIdx.x == 0) {
     double s = 0.0;
     for (int w = 0; w < kTile / 64; w++) s += sh_e[w];
-    p.partials[blockIdx.x] = s;
+    if (p.tail.enabled)
+      __hip_atomic_store(&p.partials[blockIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+      p.partials[blockIdx.x] = s;
   }
+  if (p.tail.enabled) fused_tail(p.tail, p.partials, gridDim.x, 1, 1);
 }
 
 // Deterministic fp64 sum of `nrows` partial rows of `ncols` (<= 32) doubles in ONE launch of G = 32 workgroups: workgroup g sums
@@ -538,6 +588,8 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
   p.robust_c = static_cast<Real>(fp->robust_c);
   p.partials = pb->partials.p;
   const int blocks = grid_blocks(p.num_tiles);
+  const bool fuse = p.n > 0 && blocks <= kFuseMaxBlocks;
+  p.tail = FusedTail{fuse ? 1 : 0, ctx->d_ticket.p, d_out30, SGA_ACCUM_DOUBLES, host, seq};
 
   // warm pass?  Only with certificates from a previous pass in the same arithmetic (the queries must be bit-identical), and only
   // while no source point can have moved farther than the certificates can possibly cover.
@@ -613,7 +665,7 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
     (void)hipEventRecord(ctx->ev1, ctx->stream);
     ctx->pending |= 1;
   }
-  launch_reduce(ctx, pb->partials.p, p.n > 0 ? blocks : 0, 29, kRow, pb->partials.p + static_cast<size_t>(kMaxBlocks) * kRow, d_out30, SGA_ACCUM_DOUBLES, host, seq);
+  if (!fuse) launch_reduce(ctx, pb->partials.p, p.n > 0 ? blocks : 0, 29, kRow, pb->partials.p + static_cast<size_t>(kMaxBlocks) * kRow, d_out30, SGA_ACCUM_DOUBLES, host, seq);
   SGA_HIP(hipGetLastError());
   pb->last_math = math;
   if (!voxel) {
@@ -649,6 +701,8 @@ static int error_dispatch(sga_context* ctx, sga_problem* pb, const sga_factor_pa
   p.robust_c = static_cast<Real>(fp->robust_c);
   p.partials = pb->partials.p;
   const int blocks = grid_blocks(p.num_tiles);
+  const bool fuse = p.n > 0 && blocks <= kFuseMaxBlocks;
+  p.tail = FusedTail{fuse ? 1 : 0, ctx->d_ticket.p, d_out1, 1, host, seq};
   if (fp->factor_kind == SGA_PLANE_ICP && !idx->has_normals) return fail(SGA_ERR_UNSUPPORTED, "PLANE_ICP needs target normals");
   const bool timed = ctx->profiling && (ctx->err_seq++ % ctx->profile_period) == 0;
   if (timed) {
@@ -667,7 +721,7 @@ static int error_dispatch(sga_context* ctx, sga_problem* pb, const sga_factor_pa
     (void)hipEventRecord(ctx->ev3, ctx->stream);
     ctx->pending |= 2;
   }
-  launch_reduce(ctx, pb->partials.p, p.n > 0 ? blocks : 0, 1, 1, pb->partials.p + static_cast<size_t>(kMaxBlocks) * kRow, d_out1, 1, host, seq);
+  if (!fuse) launch_reduce(ctx, pb->partials.p, p.n > 0 ? blocks : 0, 1, 1, pb->partials.p + static_cast<size_t>(kMaxBlocks) * kRow, d_out1, 1, host, seq);
   SGA_HIP(hipGetLastError());
   return SGA_OK;
 }

@@ -193,7 +193,7 @@ __device__ __forceinline__ Eig3 eigen_sym3(const double a[3][3] /* lower triangl
 
 // ---- normals / covariances -----------------------------------------------------------------------------------------------------
 constexpr int kFeatBlock = 64;
-constexpr int kFeatWindow = 256;
+constexpr int kFeatWindow = 128;
 
 // One lane per point of the kd-ordered index; neighbours come from the same tree.  Results are written both to the index's
 // kd-ordered attribute arrays and, through the original index kept in pts.w, to the caller's cloud.
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(kFeatBlock) void local_features_kernel(
   }
   // candidates scanned before the walk: the wave's own 64 positions and 96 on either side, fetched with four coalesced loads
   const uint32_t base = blockIdx.x * kFeatBlock;
-  const uint32_t pre_first = base > 96u ? base - 96u : 0u;
+  const uint32_t pre_first = base > (kFeatWindow - kFeatBlock) / 2 ? base - (kFeatWindow - kFeatBlock) / 2 : 0u;
   const uint32_t pre_end = static_cast<uint32_t>(min(static_cast<size_t>(pre_first) + kFeatWindow, n));
   for (uint32_t w = lane; w < pre_end - pre_first; w += kFeatBlock) window[w] = g.pts[pre_first + w];
   __syncthreads();
