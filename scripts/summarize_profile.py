@@ -1,36 +1,97 @@
-"""Condense rocprofv3 output (kernel stats CSV + PMC counter CSVs) into a short text + JSON summary."""
+"""Condense rocprofv3 output (kernel stats CSV + PMC counter CSVs + the odometry trace) into a short text summary and the JSON files
+bench.py / DESIGN.md cite:  summarize_profile.py <prof dir> <tag> <commit>"""
 import csv
 import glob
 import json
 import os
+import shutil
 import sys
 from collections import defaultdict
 
-out = sys.argv[1]
+out, tag, commit = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "r02"), (sys.argv[3] if len(sys.argv) > 3 else "unknown")
 
 
 def find(pattern):
     return sorted(glob.glob(os.path.join(out, pattern), recursive=True))
 
 
-summary = {}
+def short(name):
+    return name.split("(")[0][-70:]
+
+
+summary = {"commit": commit}
 for f in find("trace/**/*kernel_stats.csv"):
     rows = list(csv.DictReader(open(f)))
-    print("== kernel stats:", os.path.relpath(f, out))
+    shutil.copyfile(f, os.path.join(out, "%s_kernel_stats.csv" % tag))
+    print("== kernel stats of the bench workload (C3):", os.path.relpath(f, out))
     for r in rows[:12]:
-        name = r.get("Name", "")[:90]
-        print("%-90s calls=%s avg_ns=%s total_ns=%s pct=%s" % (name, r.get("Calls"), r.get("AverageNs"), r.get("TotalDurationNs"), r.get("Percentage")))
+        print("%-70s calls=%s avg_ns=%s total_ns=%s pct=%s" % (short(r.get("Name", "")), r.get("Calls"), r.get("AverageNs"), r.get("TotalDurationNs"), r.get("Percentage")))
         summary.setdefault("kernel_stats", []).append({"name": r.get("Name"), "calls": int(r.get("Calls", 0)), "avg_ns": float(r.get("AverageNs", 0)), "pct": float(r.get("Percentage", 0))})
-for tag in ("fetch", "write"):
-    files = find("pmc_%s/**/*counter_collection.csv" % tag)
+
+# per-dispatch durations of the K1 kernels from the trace: cold / warm split of the search kernel by duration order is not possible
+# here (the host knows the kind); report the distribution instead
+for f in find("trace/**/*kernel_trace.csv"):
+    durs = defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        kn = r.get("Kernel_Name", "")
+        for key in ("nn_search_kernel", "linearize_kernel", "error_kernel", "reduce_rows_kernel"):
+            if key in kn:
+                durs[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    print("== per-dispatch durations (us): min / median / mean / max")
+    for k, v in durs.items():
+        v.sort()
+        print("%-22s n=%d  %.1f / %.1f / %.1f / %.1f" % (k, len(v), v[0], v[len(v) // 2], sum(v) / len(v), v[-1]))
+        summary.setdefault("durations_us", {})[k] = {"n": len(v), "min": v[0], "median": v[len(v) // 2], "mean": sum(v) / len(v), "max": v[-1]}
+
+pmc = {}
+for ctr in ("fetch", "write"):
     agg = defaultdict(lambda: [0.0, 0])
-    for f in files:
+    for f in find("pmc_%s/**/*counter_collection.csv" % ctr):
         for r in csv.DictReader(open(f)):
-            k = (r.get("Kernel_Name", "")[:90], r.get("Counter_Name"))
+            k = (short(r.get("Kernel_Name", "")), r.get("Counter_Name"))
             agg[k][0] += float(r.get("Counter_Value", 0))
             agg[k][1] += 1
-    print("== PMC", tag)
+    print("== PMC", ctr)
     for (kn, cn), (v, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:8]:
-        print("%-90s %s per_launch=%.1f (n=%d)" % (kn, cn, v / max(c, 1), c))
+        print("%-70s %s per_launch=%.1f (n=%d)" % (kn, cn, v / max(c, 1), c))
         summary.setdefault("pmc", []).append({"kernel": kn, "counter": cn, "per_launch": v / max(c, 1), "launches": c})
-json.dump(summary, open(os.path.join(out, "summary.json"), "w"), indent=1)
+        pmc[(kn, cn)] = v / max(c, 1)
+
+
+def per_launch(kernel_sub, counter):
+    for (kn, cn), v in pmc.items():
+        if kernel_sub in kn and cn == counter:
+            return v
+    return None
+
+
+fs, fl = per_launch("nn_search_kernel", "FETCH_SIZE"), per_launch("linearize_kernel", "FETCH_SIZE")
+ws, wl = per_launch("nn_search_kernel", "WRITE_SIZE"), per_launch("linearize_kernel", "WRITE_SIZE")
+if None not in (fs, fl, ws, wl):
+    hbm = int((2.0 * (fs + fl) + ws + wl) * 1024)
+    traffic = {
+        "kernel": "K1 = sga::nn_search_kernel<float, 64> + sga::linearize_kernel<float, GICP, kd-tree>, config C3 1M<->1M, averaged over the passes of whole registrations (cold and warm)",
+        "source": "scripts/profile_gpu.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py",
+        "commit": commit,
+        "FETCH_SIZE_KB_per_launch_raw": {"nn_search_kernel": fs, "linearize_kernel": fl},
+        "WRITE_SIZE_KB_per_launch_raw": {"nn_search_kernel": ws, "linearize_kernel": wl},
+        "correction": "MI355X_MICROARCH.md section HBM: on gfx950 FETCH_SIZE tallies 128-B requests at 64 B -> x2 on the read side; WRITE_SIZE as reported",
+        "hbm_bytes_per_launch": hbm,
+        "algorithmic_bytes_per_launch": 100000000,
+    }
+    json.dump(traffic, open(os.path.join(out, "%s_k1_traffic.json" % tag), "w"), indent=1)
+    print("== K1 HBM traffic per pass: %.1f MB (algorithmic 100 MB) -> %.2fx" % (hbm / 1e6, hbm / 1e8))
+
+for f in find("odom/**/*kernel_stats.csv"):
+    rows = list(csv.DictReader(open(f)))
+    shutil.copyfile(f, os.path.join(out, "%s_odom_kernel_stats.csv" % tag))
+    frames = 12.0
+    calls = sum(int(r["Calls"]) for r in rows) / frames
+    total = sum(float(r["TotalDurationNs"]) for r in rows) / 1e3 / frames
+    print("== odometry leg (C5, 12 scans): %.1f launches / scan, %.1f us of kernels / scan" % (calls, total))
+    top = [{"name": short(r["Name"]), "calls_per_scan": int(r["Calls"]) / frames, "us_per_scan": float(r["TotalDurationNs"]) / 1e3 / frames} for r in rows[:12]]
+    for t in top:
+        print("%8.1f us/scan %5.1f calls/scan  %s" % (t["us_per_scan"], t["calls_per_scan"], t["name"]))
+    json.dump({"commit": commit, "frames": frames, "launches_per_scan": calls, "kernel_us_per_scan": total, "top_kernels": top, "source": "scripts/profile_gpu.sh: rocprofv3 --kernel-trace --stats of small_gicp_amd.odometry.run_synthetic(12)"},
+              open(os.path.join(out, "%s_odom_trace.json" % tag), "w"), indent=1)
+json.dump(summary, open(os.path.join(out, "%s_rocprofv3_summary.json" % tag), "w"), indent=1)

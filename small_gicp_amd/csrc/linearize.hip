@@ -47,11 +47,21 @@ __device__ __forceinline__ void fused_tail(const FusedTail& f, const double* __r
   if (threadIdx.x == 0) sh_last = __hip_atomic_fetch_add(f.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == static_cast<unsigned>(nrows - 1) ? 1u : 0u;
   __syncthreads();
   if (!sh_last) return;  // workgroup-uniform
+  // 8 slices of 32 columns: slice s adds rows s, s + 8, ... (independent loads), then the slices are added in fixed order
+  __shared__ double sh_slice[8][32];
+  {
+    const int c = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    double t = 0.0;
+    if (c < ncols && sl < 8)
+      for (int r = sl; r < nrows; r += 8) t += __hip_atomic_load(&partials[static_cast<size_t>(r) * row_stride + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (sl < 8) sh_slice[sl][c] = t;
+  }
+  __syncthreads();
   if (threadIdx.x < 32) {
     const int c = threadIdx.x;
     double t = 0.0;
-    if (c < ncols)
-      for (int r = 0; r < nrows; r++) t += __hip_atomic_load(&partials[static_cast<size_t>(r) * row_stride + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int sl = 0; sl < 8; sl++) t += sh_slice[sl][c];
     if (c < f.out_n) {
       const double v = c < ncols ? t : 0.0;
       f.out[c] = v;
