@@ -195,7 +195,8 @@ struct sga_problem {
   // factor state
   sga::DevBuf<int> corr;         // kd position of the matched target point / voxel id (voxelmap); -1 = outlier
   sga::DevBuf<int> hint;         // exact nearest neighbour per source point at the last linearization pose, rejected or not (kd targets)
-  sga::DevBuf<float> rex;        // its exclusion radius (kd_search.hpp): the certificate of the warm pass
+  sga::DevBuf<int> hint2;        // the runner-up of that search: second candidate of the warm pass's certificate
+  sga::DevBuf<float> rex;        // exclusion radius around the query (kd_search.hpp): every target point but the two candidates lies beyond it
   sga::DevBuf<uint32_t> walked;  // statistics, one counter per 64 source points: lanes of warm passes that had to walk
   double T_prev[16] = {0};       // pose of the last linearization (column-major), valid iff prev_valid
   bool prev_valid = false;

@@ -47,8 +47,9 @@ inline KdView make_kd_view(const sga_index* idx) {
 
 struct KdBest {
   float d2;
-  int idx;   // position in the kd-ordered target, -1 = none
-  float r2;  // exclusion bound: every target point other than `idx` has a computed squared distance >= r2 (see kd_nearest)
+  int idx;     // position in the kd-ordered target, -1 = none
+  int idx2;    // the runner-up (the second candidate of the warm pass's certificate), -1 = none
+  float r2;    // exclusion bound: every target point other than `idx` and `idx2` has a computed squared distance >= r2 (see kd_nearest)
   int leaves;  // leaves scanned (a measure of the walk's length)
 };
 
@@ -98,37 +99,48 @@ __device__ __forceinline__ float kd_box_dist2(const KdView& t, uint32_t node, fl
 // traversal order, the seed or earlier calls.  Sub-trees at a distance EQUAL to the best are therefore still opened (they could
 // hold an equidistant point of lower position); that costs nothing on real data.
 //
-// The walk keeps the two smallest distances it has seen — the winner as a 64-bit key (distance bits, position), the runner-up
-// as a float (one v_med3 per scanned point) — and the smallest lower bound (plane cut or box distance) of the sub-trees it
-// discarded.  The minimum of the runner-up and that bound is an EXCLUSION BOUND r2: every target point except the winner is at
-// computed squared distance >= r2.  The warm linearization pass (linearize.hip) uses it as a certificate: after the query has
-// moved by delta, the winner is still the exact nearest neighbour if its new distance is below sqrt(r2) - delta.
+// The walk keeps the two nearest points it has seen as 64-bit keys (distance bits, position), the distance of the third nearest
+// (one v_med3 per scanned point) and the smallest lower bound (plane cut or box distance) of the sub-trees it discarded.  The
+// minimum of the third distance and that bound is an EXCLUSION BOUND r2: every target point except the two candidates is at computed
+// squared distance >= r2.  The warm linearization pass (linearize.hip) uses it as a certificate: after the query has moved by delta,
+// the nearer of the two candidates is still the exact nearest neighbour if its new distance is below sqrt(r2) - delta.  (Two
+// candidates rather than one: a query with two nearly equidistant neighbours — a few per cent of all queries at millimetre motions —
+// would otherwise fail its certificate at every step.)
 struct KdState {
-  unsigned long long win;  // (distance bits << 32) | position of the nearest point seen (start: +inf, no point); distances are >= 0, so bit order = value order
-  float second;            // distance of the runner-up
-  float dropped;           // smallest lower bound of a discarded sub-tree
-  float prune0;            // nothing at or beyond this distance can win (search bound, or the seed's distance + 1 ulp)
-  float prune;             // = min(prune0, distance of the winner)
-  int leaves;              // leaves scanned so far
+  unsigned long long win;     // (distance bits << 32) | position of the nearest point seen (start: +inf, no point); distances are >= 0, so bit order = value order
+  unsigned long long second;  // the runner-up, same encoding
+  float third;                // distance of the third nearest
+  float dropped;              // smallest lower bound of a discarded sub-tree
+  float prune0;               // nothing at or beyond this distance can win (search bound, or the seed's distance + 1 ulp)
+  float prune;                // = min(prune0, distance of the winner)
+  float open;                 // sub-trees with a lower bound <= open are explored: prune, or (sqrt(prune) + slack)^2 (see kd_nearest)
+  float slack;                // exploration margin in metres (0 = the minimal search)
+  int leaves;                 // leaves scanned so far
 };
 
-__device__ __forceinline__ KdState kd_state(float prune0) { return {(0x7f800000ull << 32) | 0xffffffffull, INFINITY, INFINITY, prune0, prune0, 0}; }
+constexpr unsigned long long kKdNoPoint = (0x7f800000ull << 32) | 0xffffffffull;
+__device__ __forceinline__ float kd_open_bound(float prune, float slack) {
+  return slack > 0.f ? fmaf(slack, fmaf(2.f, sqrtf(prune), slack), prune) * 1.000001f : prune;  // (sqrt(prune) + slack)^2, rounded up
+}
+__device__ __forceinline__ KdState kd_state(float prune0, float slack = 0.f) { return {kKdNoPoint, kKdNoPoint, INFINITY, INFINITY, prune0, prune0, kd_open_bound(prune0, slack), slack, 0}; }
+__device__ __forceinline__ float kd_key_dist(unsigned long long key) { return __uint_as_float(static_cast<uint32_t>(key >> 32)); }
 
 __device__ __forceinline__ KdBest kd_result(const KdState& s, float bound2) {
   KdBest best;
-  const float wd2 = __uint_as_float(static_cast<uint32_t>(s.win >> 32));
-  const bool hit = wd2 < bound2;  // else: the nearest point seen lies beyond the search bound — no neighbour, and it is a runner-up like the others
+  const float wd2 = kd_key_dist(s.win);
+  const bool hit = wd2 < bound2;  // else: the nearest point seen lies beyond the search bound — no neighbour, and no candidates: the bound covers everything
   best.idx = hit ? static_cast<int>(static_cast<uint32_t>(s.win)) : -1;
+  best.idx2 = (hit && s.second != kKdNoPoint) ? static_cast<int>(static_cast<uint32_t>(s.second)) : -1;
   best.d2 = hit ? wd2 : bound2;
-  best.r2 = fminf(fminf(s.second, s.dropped), hit ? INFINITY : wd2);
+  best.r2 = hit ? fminf(s.third, s.dropped) : fminf(wd2, s.dropped);
   best.leaves = s.leaves;
   return best;
 }
 
 // Leaf scan, branch-free: 8 slots are read unconditionally (the array is padded with 8 points at infinity behind the last
 // leaf); the slots behind the leaf's own points belong to its right neighbour and are masked out, so that no point is ever
-// scanned twice (it would become its own runner-up).  Per point: the distance, one v_med3 for the runner-up, one 64-bit
-// compare + select for the winner.
+// scanned twice (it would become its own runner-up).  Per point: the distance, one v_med3 for the third distance, two 64-bit
+// compares + selects for the two candidates.
 __device__ __forceinline__ void kd_scan_leaf(const KdView& t, uint32_t leaf_node, float qx, float qy, float qz, KdState& s) {
   const uint32_t k = leaf_node - (1u << t.depth);
   const uint32_t first = kd_bound(t.n, t.depth, k);
@@ -141,11 +153,15 @@ __device__ __forceinline__ void kd_scan_leaf(const KdView& t, uint32_t leaf_node
   for (int i = 0; i < kKdLeafMax; i++) {
     float d2 = kd_dist2(p[i].x, p[i].y, p[i].z, qx, qy, qz);
     d2 = static_cast<uint32_t>(i) < count ? d2 : INFINITY;
-    s.second = __builtin_amdgcn_fmed3f(__uint_as_float(static_cast<uint32_t>(s.win >> 32)), s.second, d2);
+    s.third = __builtin_amdgcn_fmed3f(kd_key_dist(s.second), s.third, d2);  // third smallest of {second, third, new}: the runner-up's distance still the old one
     const unsigned long long key = (static_cast<unsigned long long>(__float_as_uint(d2)) << 32) | (first + static_cast<uint32_t>(i));
-    s.win = key < s.win ? key : s.win;
+    const bool before_win = key < s.win;
+    const unsigned long long low = key < s.second ? key : s.second;
+    s.second = before_win ? s.win : low;
+    s.win = before_win ? key : s.win;
   }
-  s.prune = fminf(s.prune0, __uint_as_float(static_cast<uint32_t>(s.win >> 32)));
+  s.prune = fminf(s.prune0, kd_key_dist(s.win));
+  s.open = kd_open_bound(s.prune, s.slack);
   s.leaves++;
 }
 
@@ -174,7 +190,7 @@ __device__ __forceinline__ void kd_walk(const KdView& t, float qx, float qy, flo
         // a far side beyond the best cannot hold a closer point: the entry is written unconditionally (no branch) and only
         // kept, i.e. the stack pointer advanced, if it can; a discarded one lowers the exclusion bound
         stack[sp * STRIDE + tid] = kd_pack(cut, depth);
-        const bool keep = cut <= s.prune;
+        const bool keep = cut <= s.open;
         sp += keep ? 1 : 0;
         s.dropped = fminf(s.dropped, keep ? INFINITY : cut);
         node = 2 * node + (diff < 0.f ? 0u : 1u);
@@ -188,7 +204,7 @@ __device__ __forceinline__ void kd_walk(const KdView& t, float qx, float qy, flo
         const float cut = diff * diff;
         depth++;
         stack[sp * STRIDE + tid] = kd_pack(cut, depth);
-        const bool keep = cut <= s.prune;
+        const bool keep = cut <= s.open;
         sp += keep ? 1 : 0;
         s.dropped = fminf(s.dropped, keep ? INFINITY : cut);
         node = 2 * node + (diff < 0.f ? 0u : 1u);
@@ -202,9 +218,9 @@ __device__ __forceinline__ void kd_walk(const KdView& t, float qx, float qy, flo
       sp--;
       e = stack[sp * STRIDE + tid];
       float lb = kd_cut(e);
-      if (lb <= s.prune) {
-        lb = kd_box_dist2(t, (node >> (D - static_cast<int>(e & 31u))) ^ 1u, qx, qy, qz);
-        found = lb <= s.prune;
+      if (lb <= s.open) {
+        lb = fmaxf(lb, kd_box_dist2(t, (node >> (D - static_cast<int>(e & 31u))) ^ 1u, qx, qy, qz));
+        found = lb <= s.open;
       }
       s.dropped = fminf(s.dropped, found ? INFINITY : lb);  // discarded: nothing in there is closer than lb
     }
@@ -221,16 +237,20 @@ __device__ __forceinline__ float kd_next_up(float d2) { return __uint_as_float(_
 // seed:   kd position of a target point believed to be close to the query (the neighbour found for this source point at the
 //         previous pose) or -1.  Its distance (+ 1 ulp, so that the seed itself stays in reach) only tightens the pruning bound from
 //         the first descent on; the seed is found again by the walk like any other point.
+// slack:  exploration margin in metres.  0 = the minimal search: a sub-tree is opened only if it can hold a closer (or equidistant)
+//         point.  > 0: everything within (nearest distance + slack) is explored as well — not needed for the answer, but it pushes
+//         the exclusion bound out to that distance, so that the certificate of the warm pass survives a motion of ~slack / 2.
+//         (The minimal search leaves, for a few per cent of the queries, an unexplored leaf just beyond the neighbour.)
 template <int STRIDE>
-__device__ __forceinline__ KdBest kd_nearest(const KdView& t, float qx, float qy, float qz, float bound2, int seed, uint32_t* __restrict__ stack, int tid) {
-  if (t.n == 0) return {bound2, -1, INFINITY, 0};
+__device__ __forceinline__ KdBest kd_nearest(const KdView& t, float qx, float qy, float qz, float bound2, int seed, uint32_t* __restrict__ stack, int tid, float slack = 0.f) {
+  if (t.n == 0) return {bound2, -1, -1, INFINITY, 0};
   float prune0 = bound2;
   if (seed >= 0 && static_cast<uint32_t>(seed) < t.n) {
     const float4 c = t.pts[seed];
     const float d2 = kd_dist2(c.x, c.y, c.z, qx, qy, qz);
     prune0 = d2 < prune0 ? kd_next_up(d2) : prune0;
   }
-  KdState s = kd_state(prune0);
+  KdState s = kd_state(prune0, slack);
   const int D = t.depth;
   int sp = 0, depth = 0;
   uint32_t node = 1;
@@ -252,7 +272,7 @@ __device__ __forceinline__ KdBest kd_nearest(const KdView& t, float qx, float qy
       const float cut = diff * diff;
       depth++;
       stack[sp * STRIDE + tid] = kd_pack(cut, depth);
-      const bool keep = cut <= s.prune;
+      const bool keep = cut <= s.open;
       sp += keep ? 1 : 0;
       s.dropped = fminf(s.dropped, keep ? INFINITY : cut);  // discarded at once: everything beyond this plane is at >= cut
       node = 2 * un + (right != 0ull ? 1u : 0u);

@@ -157,6 +157,7 @@ struct NNParams {
   float bound2;      // the walks find neighbours with kd_dist2 < bound2 (the rejector's reach + kSearchMargin)
   float within2;     // a neighbour counts for the rejector only if kd_dist2 < within2
   int* __restrict__ nn;
+  int* __restrict__ nn2;   // the runner-up of every walk: second candidate of the certificate
   float* __restrict__ rex;
   int check;         // warm pass
   Rigid<Real> T_prev;
@@ -171,7 +172,7 @@ __device__ __forceinline__ float certify(float rex, float moved, bool has_neighb
   return ok ? lim * 0.9999995f : -1.f;
 }
 
-template <typename Real, int BLOCK>
+template <typename Real, int BLOCK, bool CHECK>  // CHECK: warm pass (two instantiations: the cold one carries no certificate / margin state in registers)
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void nn_search_kernel(const NNParams<Real> p) {
   extern __shared__ uint32_t kd_stack[];  // tree depth x BLOCK traversal stack slots
   // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed placement; only speed depends on it), and the source is sorted by
@@ -184,26 +185,44 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
   Real x, y, z;
   transform_point<Real>(p.T, ps.x, ps.y, ps.z, x, y, z);
   const float fx = static_cast<float>(x), fy = static_cast<float>(y), fz = static_cast<float>(z);
-  const int seed = p.nn[i];
-  if (p.check) {
+  int seed = p.nn[i];
+  float slack = 0.f;
+  if constexpr (CHECK) {
     Real ox, oy, oz;
     transform_point<Real>(p.T_prev, ps.x, ps.y, ps.z, ox, oy, oz);
     const float moved = sqrtf(kd_dist2(static_cast<float>(ox), static_cast<float>(oy), static_cast<float>(oz), fx, fy, fz));
-    float d2 = INFINITY;
+    const int cand2 = p.nn2[i];
+    float d1 = INFINITY, d2 = INFINITY;
     if (seed >= 0) {
       const float4 c = p.kd.pts[seed];
+      d1 = kd_dist2(c.x, c.y, c.z, fx, fy, fz);
+    }
+    if (cand2 >= 0) {
+      const float4 c = p.kd.pts[cand2];
       d2 = kd_dist2(c.x, c.y, c.z, fx, fy, fz);
     }
-    const float r = certify(p.rex[i], moved, seed >= 0, d2, p.within2);
+    // the nearer of the two candidates (the canonical rule again: equidistant -> lower position)
+    const bool swap = cand2 >= 0 && (d2 < d1 || (d2 == d1 && cand2 < seed));
+    const int best = swap ? cand2 : seed;
+    const float r = certify(p.rex[i], moved, best >= 0, swap ? d2 : d1, p.within2);
     if (r >= 0.f) {
       p.rex[i] = r;
+      if (swap) {
+        p.nn[i] = cand2;
+        p.nn2[i] = seed;
+      }
       return;
     }
+    seed = best;
+    // this point's certificate did not survive: walk again, and explore a margin around the new neighbour proportional to the motion,
+    // so that the certificate survives the following (smaller) steps
+    slack = fminf(fmaxf(moved, 3e-4f), 0.02f);
     const unsigned long long walking = __ballot(true);
     if (threadIdx.x == __ffsll(static_cast<long long>(walking)) - 1) p.walked[tile] += static_cast<uint32_t>(__popcll(walking));  // the tile belongs to this wave: no atomic
   }
-  const KdBest nb = kd_nearest<BLOCK>(p.kd, fx, fy, fz, p.bound2, seed, kd_stack, threadIdx.x);
+  const KdBest nb = CHECK ? kd_nearest<BLOCK>(p.kd, fx, fy, fz, p.bound2, seed, kd_stack, threadIdx.x, slack) : kd_nearest<BLOCK>(p.kd, fx, fy, fz, p.bound2, seed, kd_stack, threadIdx.x, 0.f);
   p.nn[i] = nb.idx;
+  p.nn2[i] = nb.idx2;
   p.rex[i] = rex_from_r2(nb.r2);
 }
 
@@ -621,12 +640,17 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
     q.within2 = p.bound2;
     q.bound2 = p.bound2 * (1.f + kSearchMargin) * (1.f + kSearchMargin);
     q.nn = pb->hint.p;
+    q.nn2 = pb->hint2.p;
     q.rex = pb->rex.p;
     q.check = warm ? 1 : 0;
     if (warm) q.T_prev = rigid_from_colmajor<Real>(pb->T_prev);
     q.walked = pb->walked.p;
     const size_t words = static_cast<size_t>(std::max(p.kd.depth, 1));
-    hipLaunchKernelGGL((nn_search_kernel<Real, kSearchBlock>), dim3((p.n + kSearchBlock - 1) / kSearchBlock), dim3(kSearchBlock), words * kSearchBlock * sizeof(uint32_t), ctx->stream, q);
+    const dim3 sgrid((p.n + kSearchBlock - 1) / kSearchBlock), sblock(kSearchBlock);
+    if (warm)
+      hipLaunchKernelGGL((nn_search_kernel<Real, kSearchBlock, true>), sgrid, sblock, words * kSearchBlock * sizeof(uint32_t), ctx->stream, q);
+    else
+      hipLaunchKernelGGL((nn_search_kernel<Real, kSearchBlock, false>), sgrid, sblock, words * kSearchBlock * sizeof(uint32_t), ctx->stream, q);
     if (timed) {
       (void)hipEventRecord(ctx->ev_mid, ctx->stream);
       ctx->mid_recorded = true;

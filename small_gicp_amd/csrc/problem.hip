@@ -189,10 +189,12 @@ int sga_problem_create(sga_context* ctx, const sga_index* target, const sga_clou
     if (source->has_covs) SGA_TRY(pb->cov.alloc(n));
     SGA_TRY(pb->corr.alloc(n));
     SGA_TRY(pb->hint.alloc(n));
+    SGA_TRY(pb->hint2.alloc(n));
     SGA_TRY(pb->rex.alloc(n));
     SGA_TRY(pb->maha.alloc(n * 6));
     SGA_HIP(hipMemsetAsync(pb->corr.p, 0xff, n * sizeof(int), ctx->stream));
     SGA_HIP(hipMemsetAsync(pb->hint.p, 0xff, n * sizeof(int), ctx->stream));
+    SGA_HIP(hipMemsetAsync(pb->hint2.p, 0xff, n * sizeof(int), ctx->stream));
     SGA_HIP(hipMemsetAsync(pb->maha.p, 0, n * 6 * sizeof(float), ctx->stream));
     DevBuf<unsigned long long> keys, keys_sorted;
     DevBuf<uint32_t> vals, order;
