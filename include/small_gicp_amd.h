@@ -141,7 +141,10 @@ int sga_problem_create(sga_context* ctx, const sga_index* target, const sga_clou
 int sga_problem_destroy(sga_problem* problem);
 /* Sum_i (H_i, b_i, e_i) at T over all source points with a correspondence; refreshes the factor state. */
 int sga_linearize(sga_context* ctx, sga_problem* problem, const sga_factor_params* params, const double T[16], double H[36], double b[6], double* e, uint64_t* num_inliers);
-/* Sum_i e_i at T with the correspondences and mahalanobis cached by the last sga_linearize (gicp_factor.hpp:80-89). */
+/* Sum_i e_i at T with the correspondences and mahalanobis cached by the last sga_linearize (gicp_factor.hpp:80-89).  With those
+ * frozen the sum is a quadratic polynomial in T: sga_linearize accumulates its coefficients next to H / b (63 more sums) and this
+ * call evaluates it on the host — no pass over the cloud, no device round trip.  Robust kernels (not quadratic) and calls after
+ * sga_linearize_async run the error kernel. */
 int sga_error(sga_context* ctx, sga_problem* problem, const sga_factor_params* params, const double T[16], double* e);
 /* Enqueue-only forms for multi-GPU: results stay in device memory so they can be all-reduced (RCCL) on the same stream before
  * the host reads them.  d_out30: [0..20] upper triangle of H row-wise, [21..26] b, [27] e, [28] num_inliers (as double), [29] 0.
@@ -187,6 +190,8 @@ int sga_context_get_pass_ms(sga_context* ctx, double* cold_ms, uint64_t* cold_ca
 /* A pass runs warm while no source point can have moved farther than warm_delta_m metres since the previous linearization (default
  * 0.1; negative: never, i.e. every pass walks in full).  Process-wide; results do not depend on it, only speed does. */
 void sga_set_warm_limit(double warm_delta_m);
+/* 0: sga_error always runs the error kernel (the reference's literal procedure; tests compare the two). Default 1. */
+void sga_set_error_model(int enabled);
 double sga_get_warm_limit(void);
 /* Passes of each kind since the problem was created, and the number of source points that had to walk in the warm passes. */
 int sga_problem_get_pass_stats(sga_context* ctx, const sga_problem* problem, uint64_t* cold_passes, uint64_t* warm_passes, uint64_t* walked_points);

@@ -508,6 +508,11 @@ def set_warm_limit(warm_delta_m):
     load().sga_set_warm_limit(float(warm_delta_m))
 
 
+def set_error_model(enabled):
+    """sga_set_error_model: False makes every error pass run the error kernel instead of the quadratic model of the last linearization."""
+    load().sga_set_error_model(1 if enabled else 0)
+
+
 def get_warm_limit():
     return float(load().sga_get_warm_limit())
 

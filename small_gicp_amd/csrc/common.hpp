@@ -105,9 +105,9 @@ struct sga_context {
   bool owns_stream = false;
   bool registered = false;  // known to the allocator (context.hip)
   // scratch
-  sga::DevBuf<double> d_accum;    // SGA_ACCUM_DOUBLES
+  sga::DevBuf<double> d_accum;    // 128 doubles: a linearization result (30, or 96 with the error model)
   sga::DevBuf<unsigned> d_ticket; // arrival counter of the reduction kernel (linearize.hip), zero between launches
-  double* h_accum = nullptr;      // pinned + device-mapped: [0, 64) results, word 64 = sequence number of the last published result
+  double* h_accum = nullptr;      // pinned + device-mapped: [0, 128) a result, word 128 = sequence number of the last published result
   double* h_accum_dev = nullptr;  // device address of h_accum
   void* h_stage = nullptr;        // pinned staging buffer for uploads (context.hip), grow-only
   size_t h_stage_bytes = 0;
@@ -210,7 +210,10 @@ struct sga_problem {
   sga_rejector_fn rejector_fn = nullptr;
   void* rejector_user = nullptr;
   sga::DevBuf<unsigned char> reject;
+  // the quadratic error model of the last linearization (linearize.hip): valid for trial poses until the next linearization
+  bool model_valid = false;
+  double model[96] = {0};        // the reduced row: system + model sums
+  double model_T[16] = {0};      // its pose
   // reduction scratch
-  sga::DevBuf<double> partials;  // nblocks * 32
-  int max_blocks = 0;
+  sga::DevBuf<double> partials;  // partial rows + the stage rows of reduce_rows_kernel
 };

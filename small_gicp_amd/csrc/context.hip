@@ -354,13 +354,13 @@ static int context_create_impl(int device, void* stream, bool borrow, sga_contex
   dev_cache_context_created(device, ctx->stream);
   ctx->registered = true;
   StreamScope scope(ctx->stream);
-  int rc = ctx->d_accum.alloc(64);
+  int rc = ctx->d_accum.alloc(128);
   if (rc == SGA_OK) rc = ctx->d_ticket.alloc(16);
   if (rc == SGA_OK && hipMemsetAsync(ctx->d_ticket.p, 0, 16 * sizeof(unsigned), ctx->stream) != hipSuccess) rc = fail(SGA_ERR_HIP, "hipMemsetAsync failed");
-  if (rc == SGA_OK && hipHostMalloc(reinterpret_cast<void**>(&ctx->h_accum), 128 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) rc = fail(SGA_ERR_HIP, "hipHostMalloc failed");
+  if (rc == SGA_OK && hipHostMalloc(reinterpret_cast<void**>(&ctx->h_accum), 160 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) rc = fail(SGA_ERR_HIP, "hipHostMalloc failed");
   if (rc == SGA_OK) {
-    std::memset(ctx->h_accum, 0, 128 * sizeof(double));
-    ctx->h_scratch = reinterpret_cast<int*>(ctx->h_accum + 96);  // doubles [96, 104) of the pinned block
+    std::memset(ctx->h_accum, 0, 160 * sizeof(double));
+    ctx->h_scratch = reinterpret_cast<int*>(ctx->h_accum + 136);  // doubles [136, 144) of the pinned block
     if (hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->h_accum_dev), ctx->h_accum, 0) != hipSuccess) rc = fail(SGA_ERR_HIP, "hipHostGetDevicePointer failed");
   }
   if (rc == SGA_OK && (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess || hipEventCreate(&ctx->ev2) != hipSuccess || hipEventCreate(&ctx->ev3) != hipSuccess || hipEventCreate(&ctx->ev_mid) != hipSuccess)) rc = fail(SGA_ERR_HIP, "hipEventCreate failed");

@@ -100,8 +100,9 @@ __device__ __forceinline__ Real robust_weight(int kind, Real c, Real e) {
 //   J = [R skew(ps) | -R],  H = J^T M J,  b = J^T M r,  e = 1/2 r^T M r   (M, r in the target frame)
 // evaluated in the source frame: M' = R^T M R, w = R^T (M r):
 //   H_tt = M', H_rt = S M', H_rr = (S M') S^T, b_r = -S w, b_t = -w   with S = skew(ps).
+// Optionally hands back M' (Mp_out) and g = M' R^T r = R^T (M r) (g_out): the ingredients of the quadratic error model (linearize.hip).
 template <typename Real>
-__device__ __forceinline__ void pair_system(const Real* R, Real px, Real py, Real pz, Real rx, Real ry, Real rz, const Sym3<Real>& M, Real weight, Real* out) {
+__device__ __forceinline__ void pair_system(const Real* R, Real px, Real py, Real pz, Real rx, Real ry, Real rz, const Sym3<Real>& M, Real weight, Real* out, Sym3<Real>* Mp_out = nullptr, Real* g_out = nullptr) {
   const Real vx = M.xx * rx + M.xy * ry + M.xz * rz;
   const Real vy = M.xy * rx + M.yy * ry + M.yz * rz;
   const Real vz = M.xz * rx + M.yz * ry + M.zz * rz;
@@ -110,6 +111,12 @@ __device__ __forceinline__ void pair_system(const Real* R, Real px, Real py, Rea
   const Real w1 = R[1] * vx + R[4] * vy + R[7] * vz;
   const Real w2 = R[2] * vx + R[5] * vy + R[8] * vz;
   const Sym3<Real> Mp = rotate_sym_t(R, M);
+  if (Mp_out != nullptr) *Mp_out = Mp;
+  if (g_out != nullptr) {
+    g_out[0] = w0;
+    g_out[1] = w1;
+    g_out[2] = w2;
+  }
   // K = S M'
   const Real k00 = -pz * Mp.xy + py * Mp.xz, k01 = -pz * Mp.yy + py * Mp.yz, k02 = -pz * Mp.yz + py * Mp.zz;
   const Real k10 = pz * Mp.xx - px * Mp.xz, k11 = pz * Mp.xy - px * Mp.yz, k12 = pz * Mp.xz - px * Mp.zz;

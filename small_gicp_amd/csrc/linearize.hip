@@ -22,7 +22,10 @@ namespace sga {
 int comm_allreduce_sum(sga_context* ctx, double* d_buf, size_t count);
 
 constexpr int kTile = 256;           // threads per workgroup = source points per tile
-constexpr int kRow = 32;             // doubles per partial row (28 used + inliers)
+constexpr int kRow = 96;             // doubles per partial row: [0, 29) the system (21 H, 6 b, e, inliers), [32, 95) the quadratic error model
+constexpr int kCols = 128;           // columns the reduction kernels handle (>= kRow)
+constexpr int kModelOff = 32;        // error model: [32, 41) sum p_a g_j, [41, 59) sum p_a M'_c, [59, 95) sum p_a p_b M'_c
+constexpr int kModelCols = 95;
 constexpr int kSearchBlock = 64;      // K1a: one wave per workgroup
 constexpr int kMaxBlocks = 2048;     // K1b / K2: 8 workgroups per CU, the whole grid is resident
 
@@ -31,6 +34,7 @@ constexpr int kMaxBlocks = 2048;     // K1b / K2: 8 workgroups per CU, the whole
 // and hands the result over — one launch and one dependent-launch gap less per pass.  (With the 2048 workgroups of a 1M-point pass
 // the ticket contention costs more than the launch: those keep the separate reduce_rows_kernel.)
 constexpr int kFuseMaxBlocks = 256;
+constexpr int kSeqWord = 128;  // h_accum: [0, 128) a result, word 128 the sequence number of the last published one
 struct FusedTail {
   int enabled;
   unsigned* ticket;
@@ -47,21 +51,19 @@ __device__ __forceinline__ void fused_tail(const FusedTail& f, const double* __r
   if (threadIdx.x == 0) sh_last = __hip_atomic_fetch_add(f.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == static_cast<unsigned>(nrows - 1) ? 1u : 0u;
   __syncthreads();
   if (!sh_last) return;  // workgroup-uniform
-  // 8 slices of 32 columns: slice s adds rows s, s + 8, ... (independent loads), then the slices are added in fixed order
-  __shared__ double sh_slice[8][32];
+  // 2 slices of 128 columns: slice s adds rows s, s + 2, ... (independent loads), then the slices are added in fixed order
+  __shared__ double sh_slice[2][kCols];
   {
-    const int c = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = threadIdx.x & (kCols - 1), sl = threadIdx.x / kCols;
     double t = 0.0;
-    if (c < ncols && sl < 8)
-      for (int r = sl; r < nrows; r += 8) t += __hip_atomic_load(&partials[static_cast<size_t>(r) * row_stride + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (sl < 8) sh_slice[sl][c] = t;
+    if (c < ncols && sl < 2)
+      for (int r = sl; r < nrows; r += 2) t += __hip_atomic_load(&partials[static_cast<size_t>(r) * row_stride + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (sl < 2) sh_slice[sl][c] = t;
   }
   __syncthreads();
-  if (threadIdx.x < 32) {
+  if (threadIdx.x < kCols) {
     const int c = threadIdx.x;
-    double t = 0.0;
-#pragma unroll
-    for (int sl = 0; sl < 8; sl++) t += sh_slice[sl][c];
+    const double t = sh_slice[0][c] + sh_slice[1][c];
     if (c < f.out_n) {
       const double v = c < ncols ? t : 0.0;
       f.out[c] = v;
@@ -72,7 +74,7 @@ __device__ __forceinline__ void fused_tail(const FusedTail& f, const double* __r
   if (f.host != nullptr) {
     __threadfence_system();
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(reinterpret_cast<unsigned long long*>(f.host + 64), f.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) __hip_atomic_store(reinterpret_cast<unsigned long long*>(f.host + kSeqWord), f.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -98,6 +100,7 @@ struct LinParams {
   int robust_kind;
   Real robust_c;
   double* __restrict__ partials;
+  int model;  // also accumulate the quadratic error model (non-robust factors): kModelCols columns instead of 29
   FusedTail tail;
 };
 
@@ -229,7 +232,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
 // One correspondence (source point i at q = T p, target candidate j at t): rejector, fused mahalanobis, robust weight, the 28
 // values of the pair's system.  Returns whether the pair is an inlier; caches the mahalanobis (GICP).
 template <typename Real, int FACTOR>
-__device__ __forceinline__ bool pair_factor(const LinParams<Real>& p, int i, int j, bool within_bound, Real px, Real py, Real pz, Real qx, Real qy, Real qz, Real tx, Real ty, Real tz, Real* vals) {
+__device__ __forceinline__ bool pair_factor(const LinParams<Real>& p, int i, int j, bool within_bound, Real px, Real py, Real pz, Real qx, Real qy, Real qz, Real tx, Real ty, Real tz, Real* vals, Sym3<Real>* Mp_out = nullptr,
+                                            Real* g_out = nullptr) {
   const Real rx = tx - qx, ry = ty - qy, rz = tz - qz;
   const Real d2 = rx * rx + ry * ry + rz * rz;
   const bool inlier = (j >= 0) && within_bound && !(d2 > static_cast<Real>(p.max_sq));
@@ -258,7 +262,7 @@ __device__ __forceinline__ bool pair_factor(const LinParams<Real>& p, int i, int
       const Real vx = M.xx * rx + M.xy * ry + M.xz * rz, vy = M.xy * rx + M.yy * ry + M.yz * rz, vz = M.xz * rx + M.yz * ry + M.zz * rz;
       w = robust_weight<Real>(p.robust_kind, p.robust_c, Real(0.5) * (rx * vx + ry * vy + rz * vz));
     }
-    pair_system<Real>(p.T.r, px, py, pz, rx, ry, rz, M, w, vals);
+    pair_system<Real>(p.T.r, px, py, pz, rx, ry, rz, M, w, vals, Mp_out, g_out);
   }
   return inlier;
 }
@@ -286,13 +290,57 @@ __device__ __forceinline__ void accumulate_wave(const Real* vals, bool inlier, d
   if (lane == 63) acc_row[28] += static_cast<double>(__popcll(inl_mask));
 }
 
+// The quadratic ERROR MODEL.  Reduction::error (reduction_omp.hpp:61-70) evaluates sum_i 1/2 r_i^T M_i r_i at a trial pose with the
+// correspondences and mahalanobis matrices CACHED by the last linearization (gicp_factor.hpp:80-89): with those frozen, the sum is a
+// quadratic polynomial in the trial pose.  Writing the trial pose relative to the linearization pose T = (R, tau) as Y = [R^T R_n - I |
+// R^T (tau_n - tau)] (3 x 4) and with p_h = (p, 1), g = R^T M r, M' = R^T M R,
+//     e(T_n) = e(T) - sum_a Y[:,a] . S1[a] + 1/2 sum_ab Y[:,a]^T S2[a,b] Y[:,b],   S1[a] = sum_i p_h,a g_i,  S2[a,b] = sum_i p_h,a p_h,b M'_i.
+// S1[3] = -b_t and S2[3,3] = H_tt are part of the system already; the other 63 sums are accumulated here, next to it.  The LM trial
+// errors (1 - 10 per iteration, optimizer.hpp:107-134) then cost a few hundred flops on the host instead of a pass over the cloud each.
+// Robust kernels weight every term by a function of its own error: no such model — they keep the error kernel.
+template <typename Real>
+__device__ __forceinline__ void accumulate_model(Real px, Real py, Real pz, const Sym3<Real>& Mp, const Real* g, bool inlier, double* acc_row, int lane) {
+  if (__ballot(inlier) == 0ull) return;  // wave-uniform
+  const Real z = Real(0);
+  const Real pa[3] = {inlier ? px : z, inlier ? py : z, inlier ? pz : z};
+  const Real gg[3] = {inlier ? g[0] : z, inlier ? g[1] : z, inlier ? g[2] : z};
+  const Real m6[6] = {inlier ? Mp.xx : z, inlier ? Mp.xy : z, inlier ? Mp.xz : z, inlier ? Mp.yy : z, inlier ? Mp.yz : z, inlier ? Mp.zz : z};
+  auto add = [&](int col, Real v) {
+    if constexpr (sizeof(Real) == 4) {
+      const float s = wave_sum_to_lane63(v);
+      if (lane == 63) acc_row[col] += static_cast<double>(s);
+    } else {
+      const double s = wave_sum_f64(v);
+      if (lane == 63) acc_row[col] += s;
+    }
+  };
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) add(kModelOff + 3 * a + j, pa[a] * gg[j]);
+#pragma unroll
+    for (int c = 0; c < 6; c++) add(kModelOff + 9 + 6 * a + c, pa[a] * m6[c]);
+  }
+  int pair = 0;
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+#pragma unroll
+    for (int b = a; b < 3; b++) {
+      const Real pp = pa[a] * pa[b];
+#pragma unroll
+      for (int c = 0; c < 6; c++) add(kModelOff + 27 + 6 * pair + c, pp * m6[c]);
+      pair++;
+    }
+  }
+}
+
 // K1b.  TARGET: 0 kd-tree (the neighbours come from nn_search_kernel), 1 Gaussian voxel map, 2 flat voxel map (the lookup of a
 // voxel target happens right here).  Streaming + two gathers; per-pair values reduced with DPP inside a wave, fp64 across waves.
 template <typename Real, int FACTOR, int TARGET>
 __global__ __launch_bounds__(kTile) void linearize_kernel(const LinParams<Real> p) {
   __shared__ double sh_acc[kTile / 64][kRow];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane < kRow) sh_acc[wave][lane] = 0.0;  // each wave owns its row: no workgroup barrier needed until the end
+  for (int c = lane; c < kRow; c += 64) sh_acc[wave][c] = 0.0;  // each wave owns its row: no workgroup barrier needed until the end
 
   int tile, stride, tile_end;
   tile_schedule(p.num_tiles, tile, stride, tile_end);
@@ -347,11 +395,14 @@ __global__ __launch_bounds__(kTile) void linearize_kernel(const LinParams<Real> 
         }
       }
     }
+    Sym3<Real> Mp{};
+    Real g[3] = {Real(0), Real(0), Real(0)};
     if (active) {
-      inlier = pair_factor<Real, FACTOR>(p, i, j, within, px, py, pz, qx, qy, qz, tx, ty, tz, vals);
+      inlier = pair_factor<Real, FACTOR>(p, i, j, within, px, py, pz, qx, qy, qz, tx, ty, tz, vals, &Mp, g);
       p.corr[i] = inlier ? j : -1;
     }
     accumulate_wave<Real>(vals, inlier, sh_acc[wave], lane);
+    if (p.model) accumulate_model<Real>(px, py, pz, Mp, g, inlier, sh_acc[wave], lane);
   }
   __syncthreads();
   if (threadIdx.x < kRow) {
@@ -363,7 +414,7 @@ __global__ __launch_bounds__(kTile) void linearize_kernel(const LinParams<Real> 
     else
       p.partials[static_cast<size_t>(blockIdx.x) * kRow + threadIdx.x] = s;
   }
-  if (p.tail.enabled) fused_tail(p.tail, p.partials, gridDim.x, 29, kRow);
+  if (p.tail.enabled) fused_tail(p.tail, p.partials, gridDim.x, p.model ? kModelCols : 29, kRow);
 }
 
 // Per-point export of the same factors (the reference's Python binding exposes Factor::linearize per source point,
@@ -474,29 +525,25 @@ constexpr int kReduceGroups = 32;
 __global__ __launch_bounds__(256) void reduce_rows_kernel(
   const double* __restrict__ partials, int nrows, int ncols, int row_stride, double* __restrict__ stage, unsigned* __restrict__ ticket, double* __restrict__ out, int out_n, double* __restrict__ host,
   unsigned long long seq) {
-  __shared__ double sh[8][32];
+  __shared__ double sh[2][kCols];
   __shared__ unsigned sh_ticket;
-  const int c = threadIdx.x & 31, s = threadIdx.x >> 5;
+  const int c = threadIdx.x & (kCols - 1), s = threadIdx.x / kCols;  // 2 slices of up to 128 columns
   const int G = gridDim.x;
   double acc = 0.0;
   if (c < ncols)
-    for (int r = blockIdx.x + s * G; r < nrows; r += 8 * G) acc += partials[static_cast<size_t>(r) * row_stride + c];
+    for (int r = blockIdx.x + s * G; r < nrows; r += 2 * G) acc += partials[static_cast<size_t>(r) * row_stride + c];
   sh[s][c] = acc;
   __syncthreads();
-  if (threadIdx.x < 32) {
-    double t = 0.0;
-    for (int k = 0; k < 8; k++) t += sh[k][threadIdx.x];
-    __hip_atomic_store(&stage[blockIdx.x * 32 + threadIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  if (threadIdx.x < kCols) __hip_atomic_store(&stage[blockIdx.x * kCols + threadIdx.x], sh[0][threadIdx.x] + sh[1][threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) sh_ticket = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   if (sh_ticket != static_cast<unsigned>(G - 1)) return;  // workgroup-uniform
-  if (threadIdx.x < 32) {
+  if (threadIdx.x < kCols) {
     double v[kReduceGroups];
 #pragma unroll
-    for (int g = 0; g < kReduceGroups; g++) v[g] = g < G ? __hip_atomic_load(&stage[g * 32 + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    for (int g = 0; g < kReduceGroups; g++) v[g] = g < G ? __hip_atomic_load(&stage[g * kCols + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
     double t = 0.0;
 #pragma unroll
     for (int g = 0; g < kReduceGroups; g++) t += v[g];
@@ -510,7 +557,7 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(
   if (host != nullptr) {
     __threadfence_system();
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(reinterpret_cast<unsigned long long*>(host + 64), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) __hip_atomic_store(reinterpret_cast<unsigned long long*>(host + kSeqWord), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -570,7 +617,7 @@ static double max_displacement(const double Ta[16], const double Tb[16], const f
 static double g_warm_delta = getenv("SGA_WARM_DELTA") ? atof(getenv("SGA_WARM_DELTA")) : 0.1;
 
 template <typename Real>
-static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, const double T[16], double* d_out30, double* host, unsigned long long seq) {
+static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, const double T[16], double* d_out30, double* host, unsigned long long seq, bool with_model = false) {
   const sga_index* idx = pb->target;
   const bool voxel = idx->kind != SGA_INDEX_KDTREE;  // Gaussian or flat voxel map: the lookup happens inside the factor kernel
   const bool flat = idx->kind == SGA_INDEX_FLATMAP;
@@ -618,7 +665,9 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
   p.partials = pb->partials.p;
   const int blocks = grid_blocks(p.num_tiles);
   const bool fuse = p.n > 0 && blocks <= kFuseMaxBlocks;
-  p.tail = FusedTail{fuse ? 1 : 0, ctx->d_ticket.p, d_out30, SGA_ACCUM_DOUBLES, host, seq};
+  p.model = with_model && fp->robust_kind == SGA_ROBUST_NONE ? 1 : 0;
+  const int ncols = p.model ? kModelCols : 29, out_n = p.model ? kRow : SGA_ACCUM_DOUBLES;
+  p.tail = FusedTail{fuse ? 1 : 0, ctx->d_ticket.p, d_out30, out_n, host, seq};
 
   // warm pass?  Only with certificates from a previous pass in the same arithmetic (the queries must be bit-identical), and only
   // while no source point can have moved farther than the certificates can possibly cover.
@@ -699,7 +748,7 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
     (void)hipEventRecord(ctx->ev1, ctx->stream);
     ctx->pending |= 1;
   }
-  if (!fuse) launch_reduce(ctx, pb->partials.p, p.n > 0 ? blocks : 0, 29, kRow, pb->partials.p + static_cast<size_t>(kMaxBlocks) * kRow, d_out30, SGA_ACCUM_DOUBLES, host, seq);
+  if (!fuse) launch_reduce(ctx, pb->partials.p, p.n > 0 ? blocks : 0, ncols, kRow, pb->partials.p + static_cast<size_t>(kMaxBlocks) * kRow, d_out30, out_n, host, seq);
   SGA_HIP(hipGetLastError());
   pb->last_math = math;
   if (!voxel) {
@@ -760,18 +809,18 @@ static int error_dispatch(sga_context* ctx, sga_problem* pb, const sga_factor_pa
   return SGA_OK;
 }
 
-int problem_partials_rows() { return kMaxBlocks + kReduceGroups; }  // K1/K2 partial rows + the stage-1 rows of the reduction
+int problem_partials_doubles() { return kMaxBlocks * kRow + kReduceGroups * kCols; }  // K1/K2 partial rows + the stage-1 rows of the reduction
 
 // Hand `count` doubles to the host after an all-reduce (see reduce_rows_kernel for the protocol).
 __global__ void publish_kernel(const double* __restrict__ src, int count, double* __restrict__ host, unsigned long long seq) {
   if (static_cast<int>(threadIdx.x) < count) host[threadIdx.x] = src[threadIdx.x];
   __threadfence_system();
   __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_store(reinterpret_cast<unsigned long long*>(host + 64), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (threadIdx.x == 0) __hip_atomic_store(reinterpret_cast<unsigned long long*>(host + kSeqWord), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 static int wait_result(sga_context* ctx, unsigned long long seq) {
-  const volatile unsigned long long* flag = reinterpret_cast<const volatile unsigned long long*>(ctx->h_accum + 64);
+  const volatile unsigned long long* flag = reinterpret_cast<const volatile unsigned long long*>(ctx->h_accum + kSeqWord);
   const auto t0 = std::chrono::steady_clock::now();
   for (unsigned spins = 0;; spins++) {
     if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return SGA_OK;
@@ -795,7 +844,7 @@ static int wait_result(sga_context* ctx, unsigned long long seq) {
 // single GPU: the final reduction kernel publishes; with a communicator the all-reduce comes first
 static int fetch_result(sga_context* ctx, const double* d_src, int count, unsigned long long seq, bool published_by_kernel) {
   if (!published_by_kernel) {
-    hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, ctx->stream, d_src, count, ctx->h_accum_dev, seq);
+    hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(kCols), 0, ctx->stream, d_src, count, ctx->h_accum_dev, seq);
     SGA_HIP(hipGetLastError());
   }
   return wait_result(ctx, seq);
@@ -846,6 +895,8 @@ namespace sga {
 }  // namespace sga
 
 using namespace sga;
+
+static bool g_error_model = getenv("SGA_ERROR_MODEL") ? atoi(getenv("SGA_ERROR_MODEL")) != 0 : true;
 
 extern "C" {
 
@@ -922,6 +973,7 @@ double sga_get_warm_limit(void) { return g_warm_delta; }
 int sga_linearize_async(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, const double T[16], double* d_out30) {
   SGA_TRY(check_args(ctx, pb, fp, T));
   if (!d_out30) return fail(SGA_ERR_INVALID, "null output");
+  pb->model_valid = false;  // the cached factor state changes: the synchronous error path must not answer from an older model
   SGA_ENTER(ctx);
   return fp->math_mode == SGA_MATH_FP64 ? linearize_dispatch<double>(ctx, pb, fp, T, d_out30, nullptr, 0) : linearize_dispatch<float>(ctx, pb, fp, T, d_out30, nullptr, 0);
 }
@@ -940,16 +992,69 @@ int sga_linearize(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp
   const unsigned long long seq = ++ctx->publish_seq;
   const bool direct = ctx->comm == nullptr;
   double* host = direct ? ctx->h_accum_dev : nullptr;
-  SGA_TRY(fp->math_mode == SGA_MATH_FP64 ? linearize_dispatch<double>(ctx, pb, fp, T, ctx->d_accum.p, host, seq) : linearize_dispatch<float>(ctx, pb, fp, T, ctx->d_accum.p, host, seq));
-  SGA_TRY(comm_allreduce_sum(ctx, ctx->d_accum.p, SGA_ACCUM_DOUBLES));  // source sharded over ranks: sum the shards' systems
-  SGA_TRY(fetch_result(ctx, ctx->d_accum.p, SGA_ACCUM_DOUBLES, seq, direct));
+  // fp32 only: the 63 extra wave reductions cost ~10 us per pass in fp32 (against ~2 error passes saved per LM step), but more than
+  // they save as fp64 DPP chains
+  const bool model = fp->robust_kind == SGA_ROBUST_NONE && fp->math_mode != SGA_MATH_FP64 && g_error_model;
+  pb->model_valid = false;
+  SGA_TRY(fp->math_mode == SGA_MATH_FP64 ? linearize_dispatch<double>(ctx, pb, fp, T, ctx->d_accum.p, host, seq, model) : linearize_dispatch<float>(ctx, pb, fp, T, ctx->d_accum.p, host, seq, model));
+  const int count = model ? kRow : SGA_ACCUM_DOUBLES;
+  SGA_TRY(comm_allreduce_sum(ctx, ctx->d_accum.p, count));  // source sharded over ranks: sum the shards' systems (and error models)
+  SGA_TRY(fetch_result(ctx, ctx->d_accum.p, count, seq, direct));
   sga_unpack_accumulator(ctx->h_accum, H, b, e, num_inliers);
+  if (model) {
+    memcpy(pb->model, ctx->h_accum, sizeof(pb->model));
+    memcpy(pb->model_T, T, sizeof(pb->model_T));
+    pb->model_valid = true;
+  }
   return SGA_OK;
+}
+
+// e(T_n) from the quadratic error model of the last linearization (accumulate_model): a few hundred flops on the host
+static double evaluate_error_model(const double* acc, const double T[16], const double Tn[16]) {
+  // Y = [R^T R_n - I | R^T (tau_n - tau)], column-major 4x4 inputs
+  double Y[3][4];
+  for (int r = 0; r < 3; r++) {
+    for (int a = 0; a < 3; a++) {
+      double v = 0.0;
+      for (int k = 0; k < 3; k++) v += T[4 * r + k] * Tn[4 * a + k];  // (R^T R_n)[r][a] = sum_k R[k][r] R_n[k][a]
+      Y[r][a] = v - (r == a ? 1.0 : 0.0);
+    }
+    double v = 0.0;
+    for (int k = 0; k < 3; k++) v += T[4 * r + k] * (Tn[12 + k] - T[12 + k]);
+    Y[r][3] = v;
+  }
+  // S1[a][j] = sum p_h,a g_j; a = 3: sum g = -b_t
+  double S1[4][3];
+  for (int a = 0; a < 3; a++)
+    for (int j = 0; j < 3; j++) S1[a][j] = acc[kModelOff + 3 * a + j];
+  for (int j = 0; j < 3; j++) S1[3][j] = -acc[24 + j];
+  // S2[a][b] = sum p_h,a p_h,b M' as symmetric 3x3 (xx, xy, xz, yy, yz, zz)
+  auto S2 = [&](int a, int b) -> const double* {
+    if (a > b) std::swap(a, b);
+    if (b == 3) return a == 3 ? acc + 15 : acc + kModelOff + 9 + 6 * a;
+    static const int pair_of[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+    return acc + kModelOff + 27 + 6 * pair_of[a][b];
+  };
+  double lin = 0.0, quad = 0.0;
+  for (int a = 0; a < 4; a++) {
+    for (int j = 0; j < 3; j++) lin += Y[j][a] * S1[a][j];
+    for (int b2 = 0; b2 < 4; b2++) {
+      const double* m = S2(a, b2);
+      const double ya[3] = {Y[0][a], Y[1][a], Y[2][a]}, yb[3] = {Y[0][b2], Y[1][b2], Y[2][b2]};
+      const double mv[3] = {m[0] * yb[0] + m[1] * yb[1] + m[2] * yb[2], m[1] * yb[0] + m[3] * yb[1] + m[4] * yb[2], m[2] * yb[0] + m[4] * yb[1] + m[5] * yb[2]};
+      quad += ya[0] * mv[0] + ya[1] * mv[1] + ya[2] * mv[2];
+    }
+  }
+  return acc[27] - lin + 0.5 * quad;
 }
 
 int sga_error(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, const double T[16], double* e) {
   SGA_TRY(check_args(ctx, pb, fp, T));
   if (!e) return fail(SGA_ERR_INVALID, "null output");
+  if (pb->model_valid && fp->robust_kind == SGA_ROBUST_NONE && fp->math_mode != SGA_MATH_FP64 && g_error_model) {  // no pass over the cloud: the model of the last linearization
+    *e = evaluate_error_model(pb->model, pb->model_T, T);
+    return SGA_OK;
+  }
   SGA_ENTER(ctx);
   const unsigned long long seq = ++ctx->publish_seq;
   const bool direct = ctx->comm == nullptr;
@@ -960,5 +1065,8 @@ int sga_error(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, co
   *e = ctx->h_accum[0];
   return SGA_OK;
 }
+
+// experiments / tests: 0 = every error pass runs the error kernel (the reference's literal procedure)
+void sga_set_error_model(int enabled) { g_error_model = enabled != 0; }
 
 }  // extern "C"

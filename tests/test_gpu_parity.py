@@ -85,6 +85,32 @@ def test_linearize_and_error_match_oracle(orc, c1_f32, gpu_c1, name, kind, robus
             assert np.abs(m6[ok] - om6[ok]).max() <= 1e-4 * np.abs(om6[ok]).max()
 
 
+@pytest.mark.parametrize("name", ["GICP", "PLANE_ICP", "ICP"])
+@pytest.mark.parametrize("mode", ["fp32"])  # fp64 passes always run the error kernel
+def test_error_model_matches_error_kernel(gpu_c1, name, mode):
+    """sga_error answers from the quadratic error model accumulated by the last linearization; the error kernel (a pass over the
+    cloud with the cached correspondences / mahalanobis, Reduction::error of reduction_omp.hpp:61-70) must give the same number at
+    every trial pose, small or large."""
+    tgt, src, tree = gpu_c1
+    st = sga.make_setting(name, math_mode=mode)
+    pb = sga.Problem(tree, src)
+    rel = 1e-5 if mode == "fp32" else 1e-10
+    try:
+        for T in POSES:
+            _, _, e0, _ = pb.linearize(st.factor, T)
+            trials = [T, T @ se3([0, 0, 1], 1e-3, [1e-3, -2e-3, 5e-4]), T @ se3([1, 2, -1], 0.05, [0.3, -0.2, 0.1]), se3([0.3, 1, 0.2], 0.4, [1.0, 2.0, -0.5]) @ T]
+            sga.set_error_model(True)
+            em = [pb.error(st.factor, Tq) for Tq in trials]
+            sga.set_error_model(False)
+            ek = [pb.error(st.factor, Tq) for Tq in trials]
+            sga.set_error_model(True)
+            assert abs(em[0] - e0) <= rel * abs(e0)
+            for a, b in zip(em, ek):
+                assert abs(a - b) <= rel * max(abs(b), abs(e0)), (name, mode, a, b)
+    finally:
+        sga.set_error_model(True)
+
+
 @pytest.mark.parametrize("case", ["GICP", "PLANE_ICP", "ICP", "HUBER_GICP", "CAUCHY_GICP"])
 @pytest.mark.parametrize("mode", ["fp32", "fp64"])
 def test_align_matches_golden(c1_gold, gpu_c1, case, mode):
