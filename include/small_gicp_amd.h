@@ -192,6 +192,10 @@ int sga_context_get_pass_ms(sga_context* ctx, double* cold_ms, uint64_t* cold_ca
 void sga_set_warm_limit(double warm_delta_m);
 /* 0: sga_error always runs the error kernel (the reference's literal procedure; tests compare the two). Default 1. */
 void sga_set_error_model(int enabled);
+/* Which nearest-neighbour kernel the linearization runs (results do not depend on it; tests compare the two): 1 = the queue-fed
+ * kernel (a wave owns chunk_tiles x 64 source points and refills its lanes from a queue), 0 = one query per lane, 2 (default) =
+ * queue-fed for warm passes after a small motion, one query per lane otherwise.  chunk_tiles_* <= 0 keep the current value (4 / 4). */
+void sga_set_search_mode(int queue, int chunk_tiles_cold, int chunk_tiles_warm);
 double sga_get_warm_limit(void);
 /* Passes of each kind since the problem was created, and the number of source points that had to walk in the warm passes. */
 int sga_problem_get_pass_stats(sga_context* ctx, const sga_problem* problem, uint64_t* cold_passes, uint64_t* warm_passes, uint64_t* walked_points);

@@ -21,6 +21,7 @@ from .api import (  # noqa: F401
     estimate_normals_covariances,
     get_warm_limit,
     set_error_model,
+    set_search_mode,
     set_warm_limit,
     make_setting,
     optimize,

@@ -513,6 +513,12 @@ def set_error_model(enabled):
     load().sga_set_error_model(1 if enabled else 0)
 
 
+def set_search_mode(queue=2, chunk_tiles_cold=0, chunk_tiles_warm=0):
+    """sga_set_search_mode: 1 / True = queue-fed search kernel, 0 / False = one query per lane, 2 = automatic (default); tiles of 64
+    source points per wave of the queue-fed kernel."""
+    load().sga_set_search_mode(int(queue), int(chunk_tiles_cold), int(chunk_tiles_warm))
+
+
 def get_warm_limit():
     return float(load().sga_get_warm_limit())
 

@@ -230,6 +230,156 @@ __device__ __forceinline__ void kd_walk(const KdView& t, float qx, float qy, flo
   }
 }
 
+// ---- the walk in pieces, for the queue-fed search kernel (linearize.hip: nn_search_kernel) --------------------------------------
+// A lane of that kernel holds one query at a time and takes the next one from a queue when it is done, so the walk is cut into the
+// steps of one round: [start at a leaf | descend to a leaf] -> scan -> pop.  Same arithmetic, same canonical result as kd_walk.
+
+// Position -> leaf rank at depth D: the largest k with B(D, k) <= i.  inv = 2^D / n in double: the estimate is off by one at most.
+__device__ __forceinline__ uint32_t kd_leaf_rank(uint32_t i, uint32_t n, int d, double inv) {
+  uint32_t k = min(static_cast<uint32_t>(static_cast<double>(i) * inv), (1u << d) - 1u);
+  k += kd_bound(n, d, k + 1) <= i ? 1u : 0u;
+  k -= kd_bound(n, d, k) > i ? 1u : 0u;
+  return k;
+}
+
+// Leaf whose cell contains the query: the plain descent (no pending far sides), the top of it wave-uniform through the scalar
+// cache while the lanes of the wave agree (tile mode: the 64 queries are neighbours).
+__device__ __forceinline__ uint32_t kd_locate(const KdView& t, float qx, float qy, float qz) {
+  const int D = t.depth;
+  int depth = 0;
+  uint32_t node = 1;
+  const unsigned long long active = __ballot(true);
+  while (depth < D) {
+    const uint32_t un = __builtin_amdgcn_readfirstlane(node);
+    const float2 nd = t.nodes[un];
+    const int axis = __builtin_amdgcn_readfirstlane(__float_as_int(nd.y));
+    const float thr = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(nd.x)));
+    const float qa = axis == 0 ? qx : (axis == 1 ? qy : qz);
+    const unsigned long long right = __ballot(!(qa - thr < 0.f));
+    if (right != 0ull && right != active) break;
+    depth++;
+    node = 2 * un + (right != 0ull ? 1u : 0u);
+  }
+  while (depth < D) {
+    const float2 nd = t.nodes[node];
+    const int axis = __float_as_int(nd.y);
+    const float qa = axis == 0 ? qx : (axis == 1 ? qy : qz);
+    node = 2 * node + (qa - nd.x < 0.f ? 0u : 1u);
+    depth++;
+  }
+  return node;
+}
+
+// The far sides along the root path of `leaf` (a leaf the lane has just scanned), pushed top to bottom exactly as a descent to that
+// leaf would have pushed them — but the records of all ancestors are known from the leaf's index, so they are fetched with
+// INDEPENDENT loads, one latency for the whole path (a descent pays one per two levels), and the plane tests already use the bound
+// the leaf scan has set.  Where the query lies on the other side of an ancestor's plane than the leaf (a seed leaf next to the
+// query's cell), the sibling is the query's own side: lower bound 0, always opened.
+template <int STRIDE, int RECORDS>
+__device__ __forceinline__ void kd_push_path(const KdView& t, uint32_t leaf, int d0, float qx, float qy, float qz, KdState& s, int& sp, uint32_t* __restrict__ stack, int tid) {
+  const int D = t.depth;
+  float4 rec[RECORDS];
+#pragma unroll
+  for (int r = 0; r < RECORDS; r++) {
+    const int d = d0 + 2 * r;
+    rec[r] = t.nodes4[d < D ? kd_pair_index(d, leaf >> (D - d)) : 0u];
+  }
+#pragma unroll
+  for (int r = 0; r < RECORDS; r++) {
+    const int d = d0 + 2 * r;
+    if (d < D) {  // wave-uniform
+      const uint32_t axes = __float_as_uint(rec[r].w);
+      {
+        const uint32_t axis = axes & 3u;
+        const float qa = axis == 0 ? qx : (axis == 1 ? qy : qz);
+        const float diff = qa - rec[r].x;
+        const uint32_t path_right = (leaf >> (D - d - 1)) & 1u;
+        const float cut = ((diff < 0.f ? 0u : 1u) == path_right) ? diff * diff : 0.f;
+        stack[sp * STRIDE + tid] = kd_pack(cut, d + 1);
+        const bool keep = cut <= s.open;
+        sp += keep ? 1 : 0;
+        s.dropped = fminf(s.dropped, keep ? INFINITY : cut);
+      }
+      if (d + 1 < D) {
+        const uint32_t right = (leaf >> (D - d - 1)) & 1u;  // the child on the path
+        const uint32_t axis = (axes >> (2u + 2u * right)) & 3u;
+        const float thr = right ? rec[r].z : rec[r].y;
+        const float qa = axis == 0 ? qx : (axis == 1 ? qy : qz);
+        const float diff = qa - thr;
+        const uint32_t path_right = (leaf >> (D - d - 2)) & 1u;
+        const float cut = ((diff < 0.f ? 0u : 1u) == path_right) ? diff * diff : 0.f;
+        stack[sp * STRIDE + tid] = kd_pack(cut, d + 2);
+        const bool keep = cut <= s.open;
+        sp += keep ? 1 : 0;
+        s.dropped = fminf(s.dropped, keep ? INFINITY : cut);
+      }
+    }
+  }
+}
+
+// descend from (node, depth) to a leaf, pushing the far sides (the inner loop of kd_walk)
+template <int STRIDE>
+__device__ __forceinline__ void kd_descend(const KdView& t, float qx, float qy, float qz, KdState& s, uint32_t& node, int& depth, int& sp, uint32_t* __restrict__ stack, int tid) {
+  const int D = t.depth;
+  while (depth < D) {
+    const int odd = depth & 1;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 raw;
+    asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(raw) : "v"(t.nodes4 + kd_pair_index(depth - odd, node >> odd)) : "memory");
+    const float4 nd = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y), __uint_as_float(raw.z), __uint_as_float(raw.w));
+    const uint32_t axes = raw.w;
+    if (!odd) {
+      const uint32_t axis = axes & 3u;
+      const float qa = axis == 0 ? qx : (axis == 1 ? qy : qz);
+      const float diff = qa - nd.x;
+      const float cut = diff * diff;
+      depth++;
+      stack[sp * STRIDE + tid] = kd_pack(cut, depth);
+      const bool keep = cut <= s.open;
+      sp += keep ? 1 : 0;
+      s.dropped = fminf(s.dropped, keep ? INFINITY : cut);
+      node = 2 * node + (diff < 0.f ? 0u : 1u);
+    }
+    if (depth < D) {
+      const uint32_t right = node & 1u;
+      const uint32_t axis = (axes >> (2u + 2u * right)) & 3u;
+      const float thr = right ? nd.z : nd.y;
+      const float qa = axis == 0 ? qx : (axis == 1 ? qy : qz);
+      const float diff = qa - thr;
+      const float cut = diff * diff;
+      depth++;
+      stack[sp * STRIDE + tid] = kd_pack(cut, depth);
+      const bool keep = cut <= s.open;
+      sp += keep ? 1 : 0;
+      s.dropped = fminf(s.dropped, keep ? INFINITY : cut);
+      node = 2 * node + (diff < 0.f ? 0u : 1u);
+    }
+  }
+}
+
+// next pending far side that can still hold a closer (or equidistant) point: false = the walk is over
+template <int STRIDE>
+__device__ __forceinline__ bool kd_pop(const KdView& t, float qx, float qy, float qz, KdState& s, uint32_t& node, int& depth, int& sp, const uint32_t* __restrict__ stack, int tid) {
+  const int D = t.depth;
+  uint32_t e = 0;
+  bool found = false;
+  while (sp > 0 && !found) {
+    sp--;
+    e = stack[sp * STRIDE + tid];
+    float lb = kd_cut(e);
+    if (lb <= s.open) {
+      lb = fmaxf(lb, kd_box_dist2(t, (node >> (D - static_cast<int>(e & 31u))) ^ 1u, qx, qy, qz));
+      found = lb <= s.open;
+    }
+    s.dropped = fminf(s.dropped, found ? INFINITY : lb);
+  }
+  if (found) {
+    depth = static_cast<int>(e & 31u);
+    node = (node >> (D - depth)) ^ 1u;
+  }
+  return found;
+}
+
 __device__ __forceinline__ float kd_next_up(float d2) { return __uint_as_float(__float_as_uint(d2) + 1u); }  // the next float above a finite d2 >= 0
 
 // Top-down search (cold pass).

@@ -44,7 +44,11 @@ struct FusedTail {
   unsigned long long seq;
 };
 
-__device__ __forceinline__ void fused_tail(const FusedTail& f, const double* __restrict__ partials, int nrows, int ncols, int row_stride) {
+__host__ __device__ inline double derived_entry(int col, const double* m);
+__host__ __device__ inline bool is_derived_col(int c);
+
+// derive: the row holds a linearization in moment form — its derived columns are filled in from the totals (derived_entry)
+__device__ __forceinline__ void fused_tail(const FusedTail& f, const double* __restrict__ partials, int nrows, int ncols, int row_stride, bool derive = false) {
   __shared__ unsigned sh_last;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this workgroup's row has left the CU
   __syncthreads();
@@ -61,9 +65,15 @@ __device__ __forceinline__ void fused_tail(const FusedTail& f, const double* __r
     if (sl < 2) sh_slice[sl][c] = t;
   }
   __syncthreads();
+  if (derive) {  // workgroup-uniform
+    if (threadIdx.x < kCols) sh_slice[0][threadIdx.x] += sh_slice[1][threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x < kCols) sh_slice[1][threadIdx.x] = 0.0;
+    __syncthreads();
+  }
   if (threadIdx.x < kCols) {
     const int c = threadIdx.x;
-    const double t = sh_slice[0][c] + sh_slice[1][c];
+    const double t = (derive && is_derived_col(c)) ? derived_entry(c, sh_slice[0]) : sh_slice[0][c] + sh_slice[1][c];
     if (c < f.out_n) {
       const double v = c < ncols ? t : 0.0;
       f.out[c] = v;
@@ -100,7 +110,6 @@ struct LinParams {
   int robust_kind;
   Real robust_c;
   double* __restrict__ partials;
-  int model;  // also accumulate the quadratic error model (non-robust factors): kModelCols columns instead of 29
   FusedTail tail;
 };
 
@@ -165,6 +174,8 @@ struct NNParams {
   int check;         // warm pass
   Rigid<Real> T_prev;
   uint32_t* __restrict__ walked;  // statistics, one counter per wave tile: lanes of warm passes that had to walk
+  double inv_leaf;   // 2^depth / n (kd_leaf_rank)
+  int chunk_tiles;   // queue-fed kernel: tiles of 64 queries per wave
 };
 
 // Returns the shrunken radius (relative to the new pose) or a negative value if the certificate fails.
@@ -229,6 +240,160 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
   p.rex[i] = rex_from_r2(nb.r2);
 }
 
+// K1a, queue-fed.  The walks of neighbouring queries differ in length (one leaf for most, twenty for a few): with one query per
+// lane for the lifetime of a wave, a wave runs as long as its longest walk and most lanes idle most of the time (measured: about a
+// fifth of the VALU lanes active).  Here a wave owns a CHUNK of consecutive tiles and a small queue in LDS:
+//   stage:  a tile of 64 queries is prepared by all 64 lanes at once (coalesced loads; in a warm pass the certificate check — lanes
+//           whose certificate holds are done right there) and the queries that need a walk are appended to the queue, each with the
+//           leaf to start from: the leaf of its previous neighbour (or, for a point without one, the leaf of its own cell:
+//           remembered in nn2[] as -2 - rank, or located by a plain descent).
+//   walk:   a lane without a query takes the next one from the queue.  Its first round scans the start leaf and fetches the records
+//           of all ancestors of that leaf at once (kd_push_path: independent loads, one latency); later rounds are the usual
+//           descend -> scan -> pop.  A lane whose walk is over writes its result and is refilled in the next round.
+// The result is the canonical nearest neighbour (kd_search.hpp) whatever the order; only the exclusion radii may differ from the
+// one-query-per-lane kernel's (both are valid bounds).
+constexpr int kQueueCap = 128;        // entries; a tile is staged while at most kQueueCap - 64 are waiting
+constexpr int kPathRecords = 10;      // pair records fetched at once by kd_push_path: covers depth 20 (8 M points); deeper trees take a second batch
+
+template <typename Real, bool CHECK>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 6))) void nn_search_queue_kernel(const NNParams<Real> p) {
+  extern __shared__ uint32_t kd_stack[];  // tree depth x 64 traversal stack slots
+  __shared__ float4 q_pt[kQueueCap];      // query (x, y, z), w = exploration slack
+  __shared__ int q_idx[kQueueCap];        // source point
+  __shared__ uint32_t q_leaf[kQueueCap];  // start leaf (heap node)
+  const int lane = threadIdx.x;
+  const int D = p.kd.depth;
+  const int num_tiles = (p.n + 63) >> 6;
+  // XCD-aware chunk order (workgroup b runs on XCD b % 8): each XCD gets one contiguous eighth of the chunks
+  const int nblk = gridDim.x, per_xcd = nblk >> 3, b = blockIdx.x;
+  const int chunk = b < 8 * per_xcd ? (b & 7) * per_xcd + (b >> 3) : b;
+  int tile = chunk * p.chunk_tiles;
+  const int tile_end = min(tile + p.chunk_tiles, num_tiles);
+  int q_head = 0, q_count = 0;  // wave-uniform
+
+  bool busy = false, fresh = false;
+  float qx = 0.f, qy = 0.f, qz = 0.f;
+  int qi = -1;
+  uint32_t node = 1;
+  int depth = 0, sp = 0;
+  KdState s = kd_state(p.bound2, 0.f);
+
+  for (;;) {
+    // ---- stage tiles while the queue has room
+    while (tile < tile_end && q_count <= kQueueCap - 64) {
+      const int i = tile * 64 + lane;
+      bool need = i < p.n;
+      float fx = 0.f, fy = 0.f, fz = 0.f, slack = 0.f;
+      int seed = -1, cand2 = -1;
+      if (need) {
+        const float4 ps = p.src_pts[i];
+        Real x, y, z;
+        transform_point<Real>(p.T, ps.x, ps.y, ps.z, x, y, z);
+        fx = static_cast<float>(x), fy = static_cast<float>(y), fz = static_cast<float>(z);
+        seed = p.nn[i];
+        cand2 = p.nn2[i];
+        if constexpr (CHECK) {
+          Real ox, oy, oz;
+          transform_point<Real>(p.T_prev, ps.x, ps.y, ps.z, ox, oy, oz);
+          const float moved = sqrtf(kd_dist2(static_cast<float>(ox), static_cast<float>(oy), static_cast<float>(oz), fx, fy, fz));
+          float d1 = INFINITY, d2 = INFINITY;
+          if (seed >= 0) {
+            const float4 c = p.kd.pts[seed];
+            d1 = kd_dist2(c.x, c.y, c.z, fx, fy, fz);
+          }
+          if (cand2 >= 0) {
+            const float4 c = p.kd.pts[cand2];
+            d2 = kd_dist2(c.x, c.y, c.z, fx, fy, fz);
+          }
+          const bool swap = cand2 >= 0 && (d2 < d1 || (d2 == d1 && cand2 < seed));  // the canonical rule: equidistant -> lower position
+          const int best = swap ? cand2 : seed;
+          const float r = certify(p.rex[i], moved, best >= 0, swap ? d2 : d1, p.within2);
+          if (r >= 0.f) {
+            p.rex[i] = r;
+            if (swap) {
+              p.nn[i] = cand2;
+              p.nn2[i] = seed;
+            }
+            need = false;
+          }
+          seed = best;
+          slack = fminf(fmaxf(moved, 3e-4f), 0.02f);
+        }
+      }
+      // start leaf: the seed's; a point without a neighbour remembers the leaf of its cell; else locate it
+      uint32_t leaf = 0;
+      const bool seeded = need && seed >= 0, remembered = need && seed < 0 && cand2 <= -2;
+      if (seeded) leaf = (1u << D) + kd_leaf_rank(static_cast<uint32_t>(seed), p.kd.n, D, p.inv_leaf);
+      if (remembered) leaf = (1u << D) + min(static_cast<uint32_t>(-2 - cand2), (1u << D) - 1u);
+      if (__ballot(need && !seeded && !remembered) != 0ull) {  // wave-uniform branch
+        if (need && !seeded && !remembered) leaf = kd_locate(p.kd, fx, fy, fz);
+      }
+      const unsigned long long mask = __ballot(need);
+      if (mask != 0ull) {
+        if (need) {
+          const int rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
+          const int slot = (q_head + q_count + rank) & (kQueueCap - 1);
+          q_pt[slot] = make_float4(fx, fy, fz, slack);
+          q_idx[slot] = i;
+          q_leaf[slot] = leaf;
+        }
+        const int added = __popcll(mask);
+        if constexpr (CHECK) {
+          if (lane == 0) p.walked[tile] += static_cast<uint32_t>(added);  // the tile belongs to this wave: no atomic
+        }
+        q_count += added;
+      }
+      tile++;
+    }
+    // ---- lanes without a query take the next ones
+    const unsigned long long idle = __ballot(!busy);
+    if (q_count > 0 && idle != 0ull) {
+      const int rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(idle >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(idle), 0u));
+      if (!busy && rank < q_count) {
+        const int slot = (q_head + rank) & (kQueueCap - 1);
+        const float4 e = q_pt[slot];
+        qx = e.x, qy = e.y, qz = e.z;
+        qi = q_idx[slot];
+        node = q_leaf[slot];
+        depth = D;
+        sp = 0;
+        s = kd_state(p.bound2, CHECK ? e.w : 0.f);
+        busy = true;
+        fresh = true;
+      }
+      const int taken = min(__popcll(idle), q_count);
+      q_head = (q_head + taken) & (kQueueCap - 1);
+      q_count -= taken;
+    }
+    if (__ballot(busy) == 0ull) {
+      if (tile >= tile_end) break;
+      continue;
+    }
+    // ---- one round of the walk
+    if (busy) {
+      kd_descend<64>(p.kd, qx, qy, qz, s, node, depth, sp, kd_stack, lane);  // nothing to do for a fresh lane: it stands on its start leaf
+      kd_scan_leaf(p.kd, node, qx, qy, qz, s);
+    }
+    if (__ballot(fresh) != 0ull) {  // wave-uniform
+      if (fresh) {
+        kd_push_path<64, kPathRecords>(p.kd, node, 0, qx, qy, qz, s, sp, kd_stack, lane);
+        if (D > 2 * kPathRecords) kd_push_path<64, kKdMaxDepth / 2 - kPathRecords>(p.kd, node, 2 * kPathRecords, qx, qy, qz, s, sp, kd_stack, lane);
+        fresh = false;
+      }
+    }
+    if (busy) {
+      if (!kd_pop<64>(p.kd, qx, qy, qz, s, node, depth, sp, kd_stack, lane)) {
+        const KdBest nb = kd_result(s, p.bound2);
+        p.nn[qi] = nb.idx;
+        // no neighbour within reach: remember the leaf the walk ended on instead of a runner-up (the next pass starts there)
+        p.nn2[qi] = nb.idx >= 0 ? nb.idx2 : -2 - static_cast<int>(node - (1u << D));
+        p.rex[qi] = rex_from_r2(nb.r2);
+        busy = false;
+      }
+    }
+  }
+}
+
 // One correspondence (source point i at q = T p, target candidate j at t): rejector, fused mahalanobis, robust weight, the 28
 // values of the pair's system.  Returns whether the pair is an inlier; caches the mahalanobis (GICP).
 template <typename Real, int FACTOR>
@@ -267,154 +432,247 @@ __device__ __forceinline__ bool pair_factor(const LinParams<Real>& p, int i, int
   return inlier;
 }
 
-// fold one tile's per-lane values into the wave's fp64 accumulator row (acc_row: 32 doubles in LDS, owned by this wave)
-template <typename Real>
-__device__ __forceinline__ void accumulate_wave(const Real* vals, bool inlier, double* acc_row, int lane) {
-  const unsigned long long inl_mask = __ballot(inlier);
-  if (inl_mask == 0ull) return;  // wave-uniform
-  if constexpr (sizeof(Real) == 4) {
-#pragma unroll
-    for (int k = 0; k < 27; k++) {
-      const float s = wave_sum_to_lane63(vals[k]);
-      if (lane == 63) acc_row[k] += static_cast<double>(s);
-    }
-    const double e = wave_sum_f64(static_cast<double>(vals[27]));
-    if (lane == 63) acc_row[27] += e;
-  } else {
-#pragma unroll
-    for (int k = 0; k < 28; k++) {
-      const double s = wave_sum_f64(vals[k]);
-      if (lane == 63) acc_row[k] += s;
-    }
+// The sums of one linearization, in MOMENT form.  With M' = R^T M R and g = R^T M r of a pair (source frame, device_math.hpp) and
+// p = the source point, everything the optimizer needs is linear in
+//   sum M'            sum g            sum p_a M'          sum p_a g          sum p_a p_b M'          sum e, #inliers
+//   (6 = H_tt)        (3 = -b_t)       (18)                (9)                (36)
+// because H_rt = sum skew(p) M', H_rr = sum skew(p) M' skew(p)^T and b_r = -sum skew(p) g only recombine those (derived_entry,
+// evaluated once per pass by the reducing workgroup).  The same sums ARE the coefficients of the quadratic ERROR MODEL:
+// Reduction::error (reduction_omp.hpp:61-70) evaluates sum_i 1/2 r_i^T M_i r_i at a trial pose with the correspondences and
+// mahalanobis matrices CACHED by the last linearization (gicp_factor.hpp:80-89); with those frozen it is a quadratic polynomial in
+// Y = [R^T R_n - I | R^T (tau_n - tau)] (trial pose (R_n, tau_n) relative to the linearization pose (R, tau)):
+//   e(T_n) = e0 - sum_a Y[:,a] . S1[a] + 1/2 sum_ab Y[:,a]^T S2[a][b] Y[:,b],   S1[a] = sum p~_a g,  S2[a][b] = sum p~_a p~_b M'
+// with p~ = (p, 1).  sga_error evaluates it on the host: no pass over the cloud, no device round trip.
+// 74 sums instead of the 29 of the direct form, but a lane adds up PTS points before a value goes through the wave reduction (the
+// DPP chain is what a sum costs): 74 * (PTS + 6) / PTS instructions per point instead of 29 * 7 + the skew products.
+// Row layout: [0, 21) H, [21, 27) b, 27 e, 28 inliers, [32, 41) sum p_a g_j, [41, 59) sum p_a M'_c, [59, 95) sum p_a p_b M'_c
+// (c = xx, xy, xz, yy, yz, zz; pairs ab = 00, 01, 02, 11, 12, 22); columns [0, 15) and [21, 24) are derived.
+__host__ __device__ inline double derived_entry(int col, const double* m) {
+  const int S[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+  auto A = [&](int a, int j, int k) { return m[kModelOff + 9 + 6 * a + S[j][k]]; };                   // sum p_a M'_jk
+  auto B = [&](int a, int b, int j, int k) { return m[kModelOff + 27 + 6 * S[a][b] + S[j][k]]; };     // sum p_a p_b M'_jk
+  auto G = [&](int a, int j) { return m[kModelOff + 3 * a + j]; };                                    // sum p_a g_j
+  // K = skew(p) M': K_ik = p_i1 M'_i2,k - p_i2 M'_i1,k  (i1 = i + 1, i2 = i + 2 mod 3)
+  auto PK = [&](int l, int i, int k) { const int i1 = (i + 1) % 3, i2 = (i + 2) % 3; return B(l, i1, i2, k) - B(l, i2, i1, k); };  // sum p_l K_ik
+  if (col >= 21) {  // b_r = -sum p x g
+    const int i = col - 21, i1 = (i + 1) % 3, i2 = (i + 2) % 3;
+    return G(i2, i1) - G(i1, i2);
   }
-  if (lane == 63) acc_row[28] += static_cast<double>(__popcll(inl_mask));
+  // upper triangle of H, row-wise: row i starts at 6 i - i (i - 1) / 2
+  const int i = col < 6 ? 0 : (col < 11 ? 1 : 2);
+  const int j = col - (6 * i - i * (i - 1) / 2) + i;  // column in the 6x6
+  if (j >= 3) {  // H_rt = sum K
+    const int k = j - 3, i1 = (i + 1) % 3, i2 = (i + 2) % 3;
+    return A(i1, i2, k) - A(i2, i1, k);
+  }
+  // H_rr = sum K skew(p)^T: [i][j] = p_j1 K_i,j2 - p_j2 K_i,j1
+  const int j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+  return PK(j1, i, j2) - PK(j2, i, j1);
 }
+__host__ __device__ inline bool is_derived_col(int c) { return c < 15 || (c >= 21 && c < 24); }
 
-// The quadratic ERROR MODEL.  Reduction::error (reduction_omp.hpp:61-70) evaluates sum_i 1/2 r_i^T M_i r_i at a trial pose with the
-// correspondences and mahalanobis matrices CACHED by the last linearization (gicp_factor.hpp:80-89): with those frozen, the sum is a
-// quadratic polynomial in the trial pose.  Writing the trial pose relative to the linearization pose T = (R, tau) as Y = [R^T R_n - I |
-// R^T (tau_n - tau)] (3 x 4) and with p_h = (p, 1), g = R^T M r, M' = R^T M R,
-//     e(T_n) = e(T) - sum_a Y[:,a] . S1[a] + 1/2 sum_ab Y[:,a]^T S2[a,b] Y[:,b],   S1[a] = sum_i p_h,a g_i,  S2[a,b] = sum_i p_h,a p_h,b M'_i.
-// S1[3] = -b_t and S2[3,3] = H_tt are part of the system already; the other 63 sums are accumulated here, next to it.  The LM trial
-// errors (1 - 10 per iteration, optimizer.hpp:107-134) then cost a few hundred flops on the host instead of a pass over the cloud each.
-// Robust kernels weight every term by a function of its own error: no such model — they keep the error kernel.
-template <typename Real>
-__device__ __forceinline__ void accumulate_model(Real px, Real py, Real pz, const Sym3<Real>& Mp, const Real* g, bool inlier, double* acc_row, int lane) {
-  if (__ballot(inlier) == 0ull) return;  // wave-uniform
-  const Real z = Real(0);
-  const Real pa[3] = {inlier ? px : z, inlier ? py : z, inlier ? pz : z};
-  const Real gg[3] = {inlier ? g[0] : z, inlier ? g[1] : z, inlier ? g[2] : z};
-  const Real m6[6] = {inlier ? Mp.xx : z, inlier ? Mp.xy : z, inlier ? Mp.xz : z, inlier ? Mp.yy : z, inlier ? Mp.yz : z, inlier ? Mp.zz : z};
-  auto add = [&](int col, Real v) {
-    if constexpr (sizeof(Real) == 4) {
-      const float s = wave_sum_to_lane63(v);
-      if (lane == 63) acc_row[col] += static_cast<double>(s);
+// M' and g of one correspondence (weighted by the robust kernel), its error, and whether it is an inlier; caches the mahalanobis
+// matrix for the error pass.  (The direct form — the 28 values of pair_system — is pair_factor below; the per-point export uses it.)
+template <typename Real, int FACTOR>
+__device__ __forceinline__ bool pair_moments(const LinParams<Real>& p, int i, int j, bool within_bound, Real qx, Real qy, Real qz, Real tx, Real ty, Real tz, Sym3<Real>& Mp, Real* g, Real& e) {
+  const Real rx = tx - qx, ry = ty - qy, rz = tz - qz;
+  const Real d2 = rx * rx + ry * ry + rz * rz;
+  const bool inlier = (j >= 0) && within_bound && !(d2 > static_cast<Real>(p.max_sq));
+  Mp = Sym3<Real>{};
+  g[0] = g[1] = g[2] = Real(0);
+  e = Real(0);
+  if (inlier) {
+    Sym3<Real> M;
+    if constexpr (FACTOR == SGA_GICP) {
+      const Sym3<Real> Cs = load_sym<Real>(p.src_cov, i);
+      const Sym3<Real> Ct = load_sym<Real>(p.tgt_cov, j);
+      const Sym3<Real> RCR = rotate_sym(p.T.r, Cs);
+      M = inverse_sym<Real>({Ct.xx + RCR.xx, Ct.xy + RCR.xy, Ct.xz + RCR.xz, Ct.yy + RCR.yy, Ct.yz + RCR.yz, Ct.zz + RCR.zz});
+      Real* m = p.maha + static_cast<size_t>(i) * 6;
+      m[0] = M.xx;
+      m[1] = M.xy;
+      m[2] = M.xz;
+      m[3] = M.yy;
+      m[4] = M.yz;
+      m[5] = M.zz;
+    } else if constexpr (FACTOR == SGA_PLANE_ICP) {
+      const float4 nn = p.tgt_nrm[j];
+      M = {Real(nn.x) * Real(nn.x), Real(0), Real(0), Real(nn.y) * Real(nn.y), Real(0), Real(nn.z) * Real(nn.z)};
     } else {
-      const double s = wave_sum_f64(v);
-      if (lane == 63) acc_row[col] += s;
+      M = {Real(1), Real(0), Real(0), Real(1), Real(0), Real(1)};
     }
-  };
-#pragma unroll
-  for (int a = 0; a < 3; a++) {
-#pragma unroll
-    for (int j = 0; j < 3; j++) add(kModelOff + 3 * a + j, pa[a] * gg[j]);
-#pragma unroll
-    for (int c = 0; c < 6; c++) add(kModelOff + 9 + 6 * a + c, pa[a] * m6[c]);
+    const Real vx = M.xx * rx + M.xy * ry + M.xz * rz, vy = M.xy * rx + M.yy * ry + M.yz * rz, vz = M.xz * rx + M.yz * ry + M.zz * rz;
+    const Real e0 = Real(0.5) * (rx * vx + ry * vy + rz * vz);
+    const Real w = p.robust_kind != SGA_ROBUST_NONE ? robust_weight<Real>(p.robust_kind, p.robust_c, e0) : Real(1);
+    const Real* R = p.T.r;
+    g[0] = w * (R[0] * vx + R[3] * vy + R[6] * vz);
+    g[1] = w * (R[1] * vx + R[4] * vy + R[7] * vz);
+    g[2] = w * (R[2] * vx + R[5] * vy + R[8] * vz);
+    Mp = rotate_sym_t(R, M);
+    Mp = {w * Mp.xx, w * Mp.xy, w * Mp.xz, w * Mp.yy, w * Mp.yz, w * Mp.zz};
+    e = w * e0;
   }
-  int pair = 0;
-#pragma unroll
-  for (int a = 0; a < 3; a++) {
-#pragma unroll
-    for (int b = a; b < 3; b++) {
-      const Real pp = pa[a] * pa[b];
-#pragma unroll
-      for (int c = 0; c < 6; c++) add(kModelOff + 27 + 6 * pair + c, pp * m6[c]);
-      pair++;
-    }
-  }
+  return inlier;
 }
 
-// K1b.  TARGET: 0 kd-tree (the neighbours come from nn_search_kernel), 1 Gaussian voxel map, 2 flat voxel map (the lookup of a
-// voxel target happens right here).  Streaming + two gathers; per-pair values reduced with DPP inside a wave, fp64 across waves.
-template <typename Real, int FACTOR, int TARGET>
+// K1b.  TARGET: 0 kd-tree (the neighbours come from the search kernel), 1 Gaussian voxel map, 2 flat voxel map (the lookup of a
+// voxel target happens right here).  Streaming + two gathers; a lane handles PTS points (PTS x kTile consecutive points per
+// workgroup step), their products are added up in registers, reduced with DPP inside the wave, in fp64 across waves.
+template <typename Real, int FACTOR, int TARGET, int PTS>
 __global__ __launch_bounds__(kTile) void linearize_kernel(const LinParams<Real> p) {
   __shared__ double sh_acc[kTile / 64][kRow];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int c = lane; c < kRow; c += 64) sh_acc[wave][c] = 0.0;  // each wave owns its row: no workgroup barrier needed until the end
+  double* acc_row = sh_acc[wave];
 
   int tile, stride, tile_end;
   tile_schedule(p.num_tiles, tile, stride, tile_end);
   for (; tile < tile_end; tile += stride) {
-    const int i = tile * kTile + threadIdx.x;
-    Real vals[28];
+    Real P[PTS][3], G[PTS][3], E[PTS];
+    Sym3<Real> Mp[PTS];
+    int inliers = 0;
 #pragma unroll
-    for (int k = 0; k < 28; k++) vals[k] = Real(0);
-    bool inlier = false;
-    const bool active = i < p.n;
-    Real px = 0, py = 0, pz = 0, qx = 0, qy = 0, qz = 0;
-    if (active) {
-      const float4 ps4 = p.src_pts[i];
-      px = ps4.x;
-      py = ps4.y;
-      pz = ps4.z;
-      transform_point(p.T, px, py, pz, qx, qy, qz);
-    }
-    int j = -1;
-    Real tx = 0, ty = 0, tz = 0;
-    bool within = true;
-    if constexpr (TARGET == 2) {
+    for (int u = 0; u < PTS; u++) {
+      const int i = (tile * PTS + u) * kTile + threadIdx.x;
+      const bool active = i < p.n;
+      Real px = 0, py = 0, pz = 0, qx = 0, qy = 0, qz = 0;
       if (active) {
-        float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
-        j = flat_nearest<Real>(p.flat, p.tgt_pts, qx, qy, qz, m);
-        tx = m.x;
-        ty = m.y;
-        tz = m.z;
+        const float4 ps4 = p.src_pts[i];
+        px = ps4.x;
+        py = ps4.y;
+        pz = ps4.z;
+        transform_point(p.T, px, py, pz, qx, qy, qz);
       }
-    } else if constexpr (TARGET == 1) {
-      if (active) {
-        j = voxel_lookup(p.vox, static_cast<float>(qx), static_cast<float>(qy), static_cast<float>(qz));
-        if (j >= 0) {
-          const float4 m = p.tgt_pts[j];
+      int j = -1;
+      Real tx = 0, ty = 0, tz = 0;
+      bool within = true;
+      if constexpr (TARGET == 2) {
+        if (active) {
+          float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+          j = flat_nearest<Real>(p.flat, p.tgt_pts, qx, qy, qz, m);
           tx = m.x;
           ty = m.y;
           tz = m.z;
         }
+      } else if constexpr (TARGET == 1) {
+        if (active) {
+          j = voxel_lookup(p.vox, static_cast<float>(qx), static_cast<float>(qy), static_cast<float>(qz));
+          if (j >= 0) {
+            const float4 m = p.tgt_pts[j];
+            tx = m.x;
+            ty = m.y;
+            tz = m.z;
+          }
+        }
+      } else {
+        if (active) {
+          j = p.hint[i];
+          if (j >= 0) {
+            const float4 m = p.tgt_pts[j];
+            tx = m.x;
+            ty = m.y;
+            tz = m.z;
+            // the search reaches a little beyond the rejector (kSearchMargin) and a certified neighbour may have drifted out of
+            // reach: a neighbour counts only inside the reach of a plain search, whichever way it was found
+            within = kd_dist2(m.x, m.y, m.z, static_cast<float>(qx), static_cast<float>(qy), static_cast<float>(qz)) < p.bound2;
+            if (p.reject != nullptr) within = within && p.reject[__float_as_uint(p.src_pts[i].w)] == 0;
+          }
+        }
       }
-    } else {
+      bool inlier = false;
+      Mp[u] = Sym3<Real>{};
+      G[u][0] = G[u][1] = G[u][2] = E[u] = Real(0);
       if (active) {
-        j = p.hint[i];
-        if (j >= 0) {
-          const float4 m = p.tgt_pts[j];
-          tx = m.x;
-          ty = m.y;
-          tz = m.z;
-          // the search reaches a little beyond the rejector (kSearchMargin) and a certified neighbour may have drifted out of
-          // reach: a neighbour counts only inside the reach of a plain search, whichever way it was found
-          within = kd_dist2(m.x, m.y, m.z, static_cast<float>(qx), static_cast<float>(qy), static_cast<float>(qz)) < p.bound2;
-          if (p.reject != nullptr) within = within && p.reject[__float_as_uint(p.src_pts[i].w)] == 0;
+        inlier = pair_moments<Real, FACTOR>(p, i, j, within, qx, qy, qz, tx, ty, tz, Mp[u], G[u], E[u]);
+        p.corr[i] = inlier ? j : -1;
+      }
+      P[u][0] = px, P[u][1] = py, P[u][2] = pz;  // multiplied by zero M' / g when the point is no inlier
+      inliers += __popcll(__ballot(inlier));
+    }
+    if (inliers == 0) continue;  // wave-uniform
+    auto add = [&](int col, Real v) {
+      if constexpr (sizeof(Real) == 4) {
+        const float t = wave_sum_to_lane63(v);
+        if (lane == 63) acc_row[col] += static_cast<double>(t);
+      } else {
+        const double t = wave_sum_f64(v);
+        if (lane == 63) acc_row[col] += t;
+      }
+    };
+    auto m6 = [&](int u, int c) -> Real { return c == 0 ? Mp[u].xx : (c == 1 ? Mp[u].xy : (c == 2 ? Mp[u].xz : (c == 3 ? Mp[u].yy : (c == 4 ? Mp[u].yz : Mp[u].zz)))); };
+#pragma unroll
+    for (int c = 0; c < 6; c++) {  // H_tt
+      Real v = Real(0);
+#pragma unroll
+      for (int u = 0; u < PTS; u++) v += m6(u, c);
+      add(15 + c, v);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) {  // b_t = -sum g
+      Real v = Real(0);
+#pragma unroll
+      for (int u = 0; u < PTS; u++) v -= G[u][j];
+      add(24 + j, v);
+    }
+    {
+      double es = 0.0;
+#pragma unroll
+      for (int u = 0; u < PTS; u++) es += static_cast<double>(E[u]);
+      const double t = wave_sum_f64(es);
+      if (lane == 63) {
+        acc_row[27] += t;
+        acc_row[28] += static_cast<double>(inliers);
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        Real v = Real(0);
+#pragma unroll
+        for (int u = 0; u < PTS; u++) v += P[u][a] * G[u][j];
+        add(kModelOff + 3 * a + j, v);
+      }
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        Real v = Real(0);
+#pragma unroll
+        for (int u = 0; u < PTS; u++) v += P[u][a] * m6(u, c);
+        add(kModelOff + 9 + 6 * a + c, v);
+      }
+    }
+    {
+      int pair = 0;
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+#pragma unroll
+        for (int b = a; b < 3; b++) {
+          Real pp[PTS];
+#pragma unroll
+          for (int u = 0; u < PTS; u++) pp[u] = P[u][a] * P[u][b];
+#pragma unroll
+          for (int c = 0; c < 6; c++) {
+            Real v = Real(0);
+#pragma unroll
+            for (int u = 0; u < PTS; u++) v += pp[u] * m6(u, c);
+            add(kModelOff + 27 + 6 * pair + c, v);
+          }
+          pair++;
         }
       }
     }
-    Sym3<Real> Mp{};
-    Real g[3] = {Real(0), Real(0), Real(0)};
-    if (active) {
-      inlier = pair_factor<Real, FACTOR>(p, i, j, within, px, py, pz, qx, qy, qz, tx, ty, tz, vals, &Mp, g);
-      p.corr[i] = inlier ? j : -1;
-    }
-    accumulate_wave<Real>(vals, inlier, sh_acc[wave], lane);
-    if (p.model) accumulate_model<Real>(px, py, pz, Mp, g, inlier, sh_acc[wave], lane);
   }
   __syncthreads();
   if (threadIdx.x < kRow) {
-    double s = 0.0;
+    double t = 0.0;
 #pragma unroll
-    for (int w = 0; w < kTile / 64; w++) s += sh_acc[w][threadIdx.x];
+    for (int w = 0; w < kTile / 64; w++) t += sh_acc[w][threadIdx.x];
     if (p.tail.enabled)
-      __hip_atomic_store(&p.partials[static_cast<size_t>(blockIdx.x) * kRow + threadIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&p.partials[static_cast<size_t>(blockIdx.x) * kRow + threadIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else
-      p.partials[static_cast<size_t>(blockIdx.x) * kRow + threadIdx.x] = s;
+      p.partials[static_cast<size_t>(blockIdx.x) * kRow + threadIdx.x] = t;
   }
-  if (p.tail.enabled) fused_tail(p.tail, p.partials, gridDim.x, p.model ? kModelCols : 29, kRow);
+  if (p.tail.enabled) fused_tail(p.tail, p.partials, gridDim.x, kModelCols, kRow, true);
 }
 
 // Per-point export of the same factors (the reference's Python binding exposes Factor::linearize per source point,
@@ -524,7 +782,7 @@ constexpr int kReduceGroups = 32;
 
 __global__ __launch_bounds__(256) void reduce_rows_kernel(
   const double* __restrict__ partials, int nrows, int ncols, int row_stride, double* __restrict__ stage, unsigned* __restrict__ ticket, double* __restrict__ out, int out_n, double* __restrict__ host,
-  unsigned long long seq) {
+  unsigned long long seq, int derive) {
   __shared__ double sh[2][kCols];
   __shared__ unsigned sh_ticket;
   const int c = threadIdx.x & (kCols - 1), s = threadIdx.x / kCols;  // 2 slices of up to 128 columns
@@ -547,10 +805,16 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(
     double t = 0.0;
 #pragma unroll
     for (int g = 0; g < kReduceGroups; g++) t += v[g];
-    if (static_cast<int>(threadIdx.x) < out_n) {
-      const double r = static_cast<int>(threadIdx.x) < ncols ? t : 0.0;
-      out[threadIdx.x] = r;
-      if (host != nullptr) host[threadIdx.x] = r;
+    sh[0][threadIdx.x] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < kCols) {
+    const int c = threadIdx.x;
+    const double t = (derive && is_derived_col(c)) ? derived_entry(c, sh[0]) : sh[0][c];  // moment form: H_rr, H_rt, b_r from the totals
+    if (c < out_n) {
+      const double r = c < ncols ? t : 0.0;
+      out[c] = r;
+      if (host != nullptr) host[c] = r;
     }
   }
   if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch on this stream
@@ -561,11 +825,12 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(
   }
 }
 
-static void launch_reduce(sga_context* ctx, const double* partials, int nrows, int ncols, int row_stride, double* stage, double* out, int out_n, double* host, unsigned long long seq) {
+static void launch_reduce(sga_context* ctx, const double* partials, int nrows, int ncols, int row_stride, double* stage, double* out, int out_n, double* host, unsigned long long seq, bool derive = false) {
   const int groups = nrows > 2 * kReduceGroups ? kReduceGroups : 1;
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3(groups), dim3(256), 0, ctx->stream, partials, nrows, ncols, row_stride, stage, ctx->d_ticket.p, out, out_n, host, seq);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(groups), dim3(256), 0, ctx->stream, partials, nrows, ncols, row_stride, stage, ctx->d_ticket.p, out, out_n, host, seq, derive ? 1 : 0);
 }
 
+static int g_lin_pts_min = getenv("SGA_LIN_PTS_MIN") ? atoi(getenv("SGA_LIN_PTS_MIN")) : 131072;
 static int grid_blocks(int num_tiles) { return num_tiles < kMaxBlocks ? (num_tiles < 1 ? 1 : num_tiles) : kMaxBlocks; }
 
 // nearest neighbour (caller's target order) and squared distance of every source point in the caller's source order: the input of a
@@ -590,9 +855,17 @@ __global__ void export_neighbours_kernel(const float4* __restrict__ src_pts, con
   out_d2[orig] = d2;
 }
 
+// Points per lane and reduction (linearize_kernel's PTS): large clouds amortise the wave reductions over 4 points; small ones (a
+// 15k-point scan) keep one point per lane — they are bound by latency and want every workgroup they can get.
+constexpr int kLinPts = 4;
+static int linearize_pts(int n) { return n >= g_lin_pts_min ? kLinPts : 1; }
+
 template <typename Real, int FACTOR, int TARGET>
-static void launch_linearize(hipStream_t st, const LinParams<Real>& p, int blocks) {
-  hipLaunchKernelGGL((linearize_kernel<Real, FACTOR, TARGET>), dim3(blocks), dim3(kTile), 0, st, p);
+static void launch_linearize(hipStream_t st, const LinParams<Real>& p, int blocks, int pts) {
+  if (pts == kLinPts)
+    hipLaunchKernelGGL((linearize_kernel<Real, FACTOR, TARGET, kLinPts>), dim3(blocks), dim3(kTile), 0, st, p);
+  else
+    hipLaunchKernelGGL((linearize_kernel<Real, FACTOR, TARGET, 1>), dim3(blocks), dim3(kTile), 0, st, p);
 }
 
 // Largest displacement |Ta p - Tb p| over the box [lo, hi] (column-major 4x4 poses): the norm of an affine map is convex, so the
@@ -616,6 +889,16 @@ static double max_displacement(const double Ta[16], const double Tb[16], const f
 // (metres), run-time override sga_set_warm_limit; negative = never.  Results do not depend on it.
 static double g_warm_delta = getenv("SGA_WARM_DELTA") ? atof(getenv("SGA_WARM_DELTA")) : 0.1;
 
+// Search kernel selection (results do not depend on it).  SGA_SEARCH_QUEUE: 0 = one query per lane always (nn_search_kernel),
+// 1 = queue-fed always, 2 (default) = queue-fed for warm passes after a motion of at most SGA_QUEUE_DELTA metres.  Measured on C3
+// (1 M points): when most lanes walk (cold passes, the first warm pass) a wave per 64 queries and 8 waves per SIMD win — the walks
+// are bound by the number of memory accesses in flight and the queue-fed kernel starts each of them with 10 record fetches; when few
+// lanes walk (the later passes of a registration) the queue packs them into full waves: 124 -> 80, 87 -> 73, 68 -> 53 us.
+static int g_search_queue = getenv("SGA_SEARCH_QUEUE") ? atoi(getenv("SGA_SEARCH_QUEUE")) : 2;
+static double g_queue_delta = getenv("SGA_QUEUE_DELTA") ? atof(getenv("SGA_QUEUE_DELTA")) : 0.02;
+static int g_chunk_tiles_cold = getenv("SGA_CHUNK_COLD") ? atoi(getenv("SGA_CHUNK_COLD")) : 4;
+static int g_chunk_tiles_warm = getenv("SGA_CHUNK_WARM") ? atoi(getenv("SGA_CHUNK_WARM")) : 4;
+
 template <typename Real>
 static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, const double T[16], double* d_out30, double* host, unsigned long long seq, bool with_model = false) {
   const sga_index* idx = pb->target;
@@ -629,7 +912,8 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
   p.src_pts = pb->pts.p;
   p.src_cov = pb->cov.p;
   p.n = static_cast<int>(pb->n);
-  p.num_tiles = (p.n + kTile - 1) / kTile;
+  const int pts = linearize_pts(p.n);
+  p.num_tiles = (p.n + kTile * pts - 1) / (kTile * pts);  // steps of kTile * pts points
   p.tgt_pts = voxel ? idx->pts.p : idx->kd_pts.p;
   p.tgt_nrm = idx->nrm.p;
   p.tgt_cov = idx->cov.p;
@@ -665,14 +949,14 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
   p.partials = pb->partials.p;
   const int blocks = grid_blocks(p.num_tiles);
   const bool fuse = p.n > 0 && blocks <= kFuseMaxBlocks;
-  p.model = with_model && fp->robust_kind == SGA_ROBUST_NONE ? 1 : 0;
-  const int ncols = p.model ? kModelCols : 29, out_n = p.model ? kRow : SGA_ACCUM_DOUBLES;
+  const int ncols = kModelCols, out_n = with_model ? kRow : SGA_ACCUM_DOUBLES;  // the caller's buffer: the system, or the system + its moments
   p.tail = FusedTail{fuse ? 1 : 0, ctx->d_ticket.p, d_out30, out_n, host, seq};
 
   // warm pass?  Only with certificates from a previous pass in the same arithmetic (the queries must be bit-identical), and only
   // while no source point can have moved farther than the certificates can possibly cover.
   const int math = sizeof(Real) == 4 ? SGA_MATH_FP32 : SGA_MATH_FP64;
-  const bool warm = !voxel && p.n > 0 && pb->prev_valid && pb->prev_math == math && max_displacement(T, pb->T_prev, pb->bbox_lo, pb->bbox_hi) <= g_warm_delta;
+  const double displacement = (!voxel && p.n > 0 && pb->prev_valid && pb->prev_math == math) ? max_displacement(T, pb->T_prev, pb->bbox_lo, pb->bbox_hi) : INFINITY;
+  const bool warm = displacement <= g_warm_delta;
 
   const bool timed = ctx->profiling && (ctx->lin_seq++ % ctx->profile_period) == 0;  // sampled: event records cost ~7 us each
   if (timed) {
@@ -696,7 +980,15 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
     q.walked = pb->walked.p;
     const size_t words = static_cast<size_t>(std::max(p.kd.depth, 1));
     const dim3 sgrid((p.n + kSearchBlock - 1) / kSearchBlock), sblock(kSearchBlock);
-    if (warm)
+    if (g_search_queue == 1 || (g_search_queue == 2 && warm && displacement <= g_queue_delta)) {
+      q.inv_leaf = p.kd.n > 0 ? std::ldexp(1.0, p.kd.depth) / static_cast<double>(p.kd.n) : 0.0;
+      q.chunk_tiles = std::max(1, warm ? g_chunk_tiles_warm : g_chunk_tiles_cold);
+      const dim3 qgrid((sgrid.x + q.chunk_tiles - 1) / q.chunk_tiles);
+      if (warm)
+        hipLaunchKernelGGL((nn_search_queue_kernel<Real, true>), qgrid, sblock, words * 64 * sizeof(uint32_t), ctx->stream, q);
+      else
+        hipLaunchKernelGGL((nn_search_queue_kernel<Real, false>), qgrid, sblock, words * 64 * sizeof(uint32_t), ctx->stream, q);
+    } else if (warm)
       hipLaunchKernelGGL((nn_search_kernel<Real, kSearchBlock, true>), sgrid, sblock, words * kSearchBlock * sizeof(uint32_t), ctx->stream, q);
     else
       hipLaunchKernelGGL((nn_search_kernel<Real, kSearchBlock, false>), sgrid, sblock, words * kSearchBlock * sizeof(uint32_t), ctx->stream, q);
@@ -728,19 +1020,19 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
   if (p.n > 0) {
     if (flat) {
       if (fp->factor_kind == SGA_GICP)
-        launch_linearize<Real, SGA_GICP, 2>(ctx->stream, p, blocks);
+        launch_linearize<Real, SGA_GICP, 2>(ctx->stream, p, blocks, pts);
       else
-        launch_linearize<Real, SGA_ICP, 2>(ctx->stream, p, blocks);
+        launch_linearize<Real, SGA_ICP, 2>(ctx->stream, p, blocks, pts);
     } else if (voxel) {
       if (fp->factor_kind == SGA_GICP)
-        launch_linearize<Real, SGA_GICP, 1>(ctx->stream, p, blocks);
+        launch_linearize<Real, SGA_GICP, 1>(ctx->stream, p, blocks, pts);
       else
-        launch_linearize<Real, SGA_ICP, 1>(ctx->stream, p, blocks);
+        launch_linearize<Real, SGA_ICP, 1>(ctx->stream, p, blocks, pts);
     } else {
       switch (fp->factor_kind) {
-        case SGA_GICP: launch_linearize<Real, SGA_GICP, 0>(ctx->stream, p, blocks); break;
-        case SGA_PLANE_ICP: launch_linearize<Real, SGA_PLANE_ICP, 0>(ctx->stream, p, blocks); break;
-        default: launch_linearize<Real, SGA_ICP, 0>(ctx->stream, p, blocks); break;
+        case SGA_GICP: launch_linearize<Real, SGA_GICP, 0>(ctx->stream, p, blocks, pts); break;
+        case SGA_PLANE_ICP: launch_linearize<Real, SGA_PLANE_ICP, 0>(ctx->stream, p, blocks, pts); break;
+        default: launch_linearize<Real, SGA_ICP, 0>(ctx->stream, p, blocks, pts); break;
       }
     }
   }
@@ -748,7 +1040,7 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
     (void)hipEventRecord(ctx->ev1, ctx->stream);
     ctx->pending |= 1;
   }
-  if (!fuse) launch_reduce(ctx, pb->partials.p, p.n > 0 ? blocks : 0, ncols, kRow, pb->partials.p + static_cast<size_t>(kMaxBlocks) * kRow, d_out30, out_n, host, seq);
+  if (!fuse) launch_reduce(ctx, pb->partials.p, p.n > 0 ? blocks : 0, ncols, kRow, pb->partials.p + static_cast<size_t>(kMaxBlocks) * kRow, d_out30, out_n, host, seq, true);
   SGA_HIP(hipGetLastError());
   pb->last_math = math;
   if (!voxel) {
@@ -992,9 +1284,7 @@ int sga_linearize(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp
   const unsigned long long seq = ++ctx->publish_seq;
   const bool direct = ctx->comm == nullptr;
   double* host = direct ? ctx->h_accum_dev : nullptr;
-  // fp32 only: the 63 extra wave reductions cost ~10 us per pass in fp32 (against ~2 error passes saved per LM step), but more than
-  // they save as fp64 DPP chains
-  const bool model = fp->robust_kind == SGA_ROBUST_NONE && fp->math_mode != SGA_MATH_FP64 && g_error_model;
+  const bool model = fp->robust_kind == SGA_ROBUST_NONE && g_error_model;  // a robust kernel's error is not quadratic in the pose
   pb->model_valid = false;
   SGA_TRY(fp->math_mode == SGA_MATH_FP64 ? linearize_dispatch<double>(ctx, pb, fp, T, ctx->d_accum.p, host, seq, model) : linearize_dispatch<float>(ctx, pb, fp, T, ctx->d_accum.p, host, seq, model));
   const int count = model ? kRow : SGA_ACCUM_DOUBLES;
@@ -1051,7 +1341,7 @@ static double evaluate_error_model(const double* acc, const double T[16], const 
 int sga_error(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, const double T[16], double* e) {
   SGA_TRY(check_args(ctx, pb, fp, T));
   if (!e) return fail(SGA_ERR_INVALID, "null output");
-  if (pb->model_valid && fp->robust_kind == SGA_ROBUST_NONE && fp->math_mode != SGA_MATH_FP64 && g_error_model) {  // no pass over the cloud: the model of the last linearization
+  if (pb->model_valid && fp->robust_kind == SGA_ROBUST_NONE && g_error_model) {  // no pass over the cloud: the model of the last linearization
     *e = evaluate_error_model(pb->model, pb->model_T, T);
     return SGA_OK;
   }
@@ -1068,5 +1358,12 @@ int sga_error(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, co
 
 // experiments / tests: 0 = every error pass runs the error kernel (the reference's literal procedure)
 void sga_set_error_model(int enabled) { g_error_model = enabled != 0; }
+
+// experiments / tests: which search kernel runs (queue != 0: nn_search_queue_kernel with the given tiles per wave; <= 0 keeps a value)
+void sga_set_search_mode(int queue, int chunk_tiles_cold, int chunk_tiles_warm) {
+  g_search_queue = queue;
+  if (chunk_tiles_cold > 0) g_chunk_tiles_cold = chunk_tiles_cold;
+  if (chunk_tiles_warm > 0) g_chunk_tiles_warm = chunk_tiles_warm;
+}
 
 }  // extern "C"

@@ -130,3 +130,33 @@ def test_warm_registration_matches_cold_registration_100k():
     assert sw["warm_passes"] >= 1 and sw["cold_passes"] >= 1, sw
     dt, dr = pose_error(rw.T_target_source, T_gt)
     assert dt < 2e-2 and dr < 2e-3
+
+
+@pytest.mark.parametrize("chunk", [1, 4, 16])
+@pytest.mark.parametrize("maxd", [1.0, 0.3, None])
+def test_queue_fed_search_equals_lane_search(c1_f32, chunk, maxd):
+    """The queue-fed search kernel (a wave refills its lanes from a queue, walks start at the previous neighbour's leaf) and the
+    one-query-per-lane kernel return the same canonical neighbours along a pose chain — cold and warm passes, with and without a
+    rejector (points without a neighbour remember a leaf instead)."""
+    d = c1_f32
+    tgt = sga.PointCloud(d["tp"], d["tn"], d["tc"])
+    src = sga.PointCloud(d["sp"], d["sn"], d["sc"])
+    tree = sga.KdTree(tgt)
+    st = sga.make_setting("GICP", max_correspondence_distance=maxd if maxd is not None else 1.0)
+    if maxd is None:
+        st.factor.max_dist_sq = -1.0
+    goal = se3([0.1, 0.2, 1.0], np.deg2rad(0.7), [0.49, 0.12, -0.02])
+    pq, pl = sga.Problem(tree, src), sga.Problem(tree, src)
+    try:
+        for k, T in enumerate(pose_chain(goal) + [se3([1, 0, 0], 0.3, [2.0, 1.0, 0.5]), np.eye(4)]):
+            sga.set_search_mode(True, chunk, chunk)
+            Hq, bq, eq, nq = pq.linearize(st.factor, T)
+            cq, _ = pq.factors()
+            sga.set_search_mode(False)
+            Hl, bl, el, nl = pl.linearize(st.factor, T)
+            cl, _ = pl.factors()
+            assert (cq == cl).all(), (k, int((cq != cl).sum()))
+            assert nq == nl and np.abs(Hq - Hl).max() <= 1e-6 * np.abs(Hl).max() and abs(eq - el) <= 1e-6 * abs(el), k
+        assert pq.pass_stats()["warm_passes"] >= 4
+    finally:
+        sga.set_search_mode(2, 4, 4)
