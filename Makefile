@@ -16,9 +16,15 @@ $(OBJDIR)/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.hpp) include/small_gicp_amd.h
 $(LIB): $(OBJS)
 	@mkdir -p small_gicp_amd/lib
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+# diagnostics build: counts the loop-body executions of the kd walk (scripts/diag_trips.py); not part of the product
+TRIPS_LIB := small_gicp_amd/lib/libsmall_gicp_amd_trips.so
+trips:
+	@mkdir -p build/obj_trips
+	for f in $(SRCS); do $(HIPCC) $(HIPFLAGS) -DSGA_KD_TRIPS -c $$f -o build/obj_trips/$$(basename $$f .hip).o || exit 1; done
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(TRIPS_LIB) build/obj_trips/*.o
 oracle:
 	$(MAKE) -C oracle
 clean:
 	rm -rf build $(LIB)
 	$(MAKE) -C oracle clean
-.PHONY: all lib oracle clean
+.PHONY: all lib oracle clean trips

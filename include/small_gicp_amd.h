@@ -192,6 +192,10 @@ int sga_context_get_pass_ms(sga_context* ctx, double* cold_ms, uint64_t* cold_ca
 void sga_set_warm_limit(double warm_delta_m);
 /* 0: sga_error always runs the error kernel (the reference's literal procedure; tests compare the two). Default 1. */
 void sga_set_error_model(int enabled);
+/* Diagnostics: record, for the following linearization passes of this problem, the number of kd-tree leaves each source point's
+ * search scanned (source order of the engine, i.e. sorted); get returns the last pass's counts (n ints). */
+int sga_problem_set_search_stats(sga_context* ctx, sga_problem* pb, int enabled);
+int sga_problem_get_search_stats(sga_context* ctx, const sga_problem* pb, int* leaves_per_point);
 /* Which nearest-neighbour kernel the linearization runs (results do not depend on it; tests compare the two): 1 = the queue-fed
  * kernel (a wave owns chunk_tiles x 64 source points and refills its lanes from a queue), 0 = one query per lane, 2 (default) =
  * queue-fed for warm passes after a small motion, one query per lane otherwise.  chunk_tiles_* <= 0 keep the current value (4 / 4). */

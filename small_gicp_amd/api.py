@@ -495,6 +495,15 @@ class Problem:
         check(load().sga_align_problem(self.ctx.h, self.h, _dp(t16), C.byref(setting), C.byref(res)))
         return RegistrationResult(res)
 
+    def search_stats(self, enable=None):
+        """Diagnostics: enable / disable the per-point record of leaves scanned, or (enable=None) fetch the last pass's counts."""
+        if enable is not None:
+            check(load().sga_problem_set_search_stats(self.ctx.h, self.h, 1 if enable else 0))
+            return None
+        out = np.zeros(len(self.source), dtype=np.int32)
+        check(load().sga_problem_get_search_stats(self.ctx.h, self.h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def pass_stats(self):
         """Linearization passes since creation by kind (cold = full search, warm = certified neighbours) and the source points
         the warm passes had to search again."""

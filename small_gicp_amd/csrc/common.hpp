@@ -159,6 +159,7 @@ struct sga_index {
   sga::DevBuf<float2> kd_nodes;     // 2^kd_depth entries (index 0 unused)
   sga::DevBuf<float4> kd_nodes4;    // pair records of the even depths (kd_search.hpp)
   sga::DevBuf<float4> kd_boxes;     // tight bounding box of every node: [2 * node] = min corner, [2 * node + 1] = max corner
+  sga::DevBuf<float4> kd_groups;    // group headers of the 1-NN walk: the boxes of the (up to) 4 leaves under every node of depth kd_depth - 2
   int kd_depth = 0;
   float bbox_lo[3] = {0, 0, 0}, bbox_hi[3] = {0, 0, 0};
   // voxel map
@@ -197,6 +198,7 @@ struct sga_problem {
   sga::DevBuf<int> hint;         // exact nearest neighbour per source point at the last linearization pose, rejected or not (kd targets)
   sga::DevBuf<int> hint2;        // the runner-up of that search: second candidate of the warm pass's certificate
   sga::DevBuf<float> rex;        // exclusion radius around the query (kd_search.hpp): every target point but the two candidates lies beyond it
+  sga::DevBuf<int> dbg_leaves;   // diagnostics (sga_problem_set_search_stats): leaves scanned per source point in the last pass
   sga::DevBuf<uint32_t> walked;  // statistics, one counter per 64 source points: lanes of warm passes that had to walk
   double T_prev[16] = {0};       // pose of the last linearization (column-major), valid iff prev_valid
   bool prev_valid = false;

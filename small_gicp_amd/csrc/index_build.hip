@@ -452,6 +452,31 @@ __global__ void gather_attr_kernel(const float4* __restrict__ sorted_pts, size_t
   if (cov) ocov[i] = cov[s];
 }
 
+// Group headers (kd_search.hpp: kd_visit_group): for every node of depth D - G (G = min(2, D)) the tight boxes of its 2^G leaves,
+// as six float4 {lo.x, lo.y, lo.z, hi.x, hi.y, hi.z} with one lane per leaf, in one 128-byte line.  Missing leaves get an empty box.
+__global__ void kd_groups_kernel(const float4* __restrict__ boxes, int D, int G, float4* __restrict__ groups) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (1u << (D - G))) return;
+  const uint32_t gnode = (1u << (D - G)) + g;
+  float lo[3][4], hi[3][4];
+  for (int l = 0; l < 4; l++) {
+    float4 a = make_float4(INFINITY, INFINITY, INFINITY, 0.f), b = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.f);
+    if (l < (1 << G)) {
+      const uint32_t leaf = (gnode << G) + l;
+      a = boxes[2 * leaf];
+      b = boxes[2 * leaf + 1];
+    }
+    lo[0][l] = a.x, lo[1][l] = a.y, lo[2][l] = a.z;
+    hi[0][l] = b.x, hi[1][l] = b.y, hi[2][l] = b.z;
+  }
+  float4* h = groups + 8ull * g;
+  for (int a = 0; a < 3; a++) {
+    h[a] = make_float4(lo[a][0], lo[a][1], lo[a][2], lo[a][3]);
+    h[3 + a] = make_float4(hi[a][0], hi[a][1], hi[a][2], hi[a][3]);
+  }
+  h[6] = h[7] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 static int build_kdtree(sga_context* ctx, const sga_cloud* cloud, sga_index* idx) {
   const size_t n = cloud->n;
   idx->kd_depth = 0;
@@ -521,6 +546,11 @@ static int build_kdtree(sga_context* ctx, const sga_cloud* cloud, sga_index* idx
   for (int base = D;; base -= 8) {
     hipLaunchKernelGGL(kd_boxes_kernel, dim3(((1u << base) + 255) / 256), block, 0, ctx->stream, idx->kd_pts.p, static_cast<uint32_t>(n), D, base, idx->kd_boxes.p);
     if (base <= 8) break;
+  }
+  {
+    const int G = D < 2 ? D : 2;
+    SGA_TRY(idx->kd_groups.alloc(8ull << (D - G)));
+    hipLaunchKernelGGL(kd_groups_kernel, dim3(((1u << (D - G)) + 255) / 256), block, 0, ctx->stream, idx->kd_boxes.p, D, G, idx->kd_groups.p);
   }
   SGA_HIP(hipGetLastError());
   SGA_HIP(hipStreamSynchronize(ctx->stream));

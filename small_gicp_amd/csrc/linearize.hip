@@ -174,6 +174,7 @@ struct NNParams {
   int check;         // warm pass
   Rigid<Real> T_prev;
   uint32_t* __restrict__ walked;  // statistics, one counter per wave tile: lanes of warm passes that had to walk
+  int* __restrict__ leaves;  // diagnostics (sga_problem_set_search_stats): leaves scanned per source point in this pass, or null
   double inv_leaf;   // 2^depth / n (kd_leaf_rank)
   int chunk_tiles;   // queue-fed kernel: tiles of 64 queries per wave
 };
@@ -238,6 +239,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
   p.nn[i] = nb.idx;
   p.nn2[i] = nb.idx2;
   p.rex[i] = rex_from_r2(nb.r2);
+  if (p.leaves != nullptr) p.leaves[i] = nb.leaves;
 }
 
 // K1a, queue-fed.  The walks of neighbouring queries differ in length (one leaf for most, twenty for a few): with one query per
@@ -245,9 +247,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
 // fifth of the VALU lanes active).  Here a wave owns a CHUNK of consecutive tiles and a small queue in LDS:
 //   stage:  a tile of 64 queries is prepared by all 64 lanes at once (coalesced loads; in a warm pass the certificate check — lanes
 //           whose certificate holds are done right there) and the queries that need a walk are appended to the queue, each with the
-//           leaf to start from: the leaf of its previous neighbour (or, for a point without one, the leaf of its own cell:
+//           group (kd_search.hpp: the leaves under a node of depth D - 2) to start from: the one of its previous neighbour (or, for a
+//           point without one, the group of its own cell:
 //           remembered in nn2[] as -2 - rank, or located by a plain descent).
-//   walk:   a lane without a query takes the next one from the queue.  Its first round scans the start leaf and fetches the records
+//   walk:   a lane without a query takes the next one from the queue.  Its first round visits the start group and fetches the records
 //           of all ancestors of that leaf at once (kd_push_path: independent loads, one latency); later rounds are the usual
 //           descend -> scan -> pop.  A lane whose walk is over writes its result and is refilled in the next round.
 // The result is the canonical nearest neighbour (kd_search.hpp) whatever the order; only the exclusion radii may differ from the
@@ -260,9 +263,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 6))) void
   extern __shared__ uint32_t kd_stack[];  // tree depth x 64 traversal stack slots
   __shared__ float4 q_pt[kQueueCap];      // query (x, y, z), w = exploration slack
   __shared__ int q_idx[kQueueCap];        // source point
-  __shared__ uint32_t q_leaf[kQueueCap];  // start leaf (heap node)
+  __shared__ uint32_t q_leaf[kQueueCap];  // start group (heap node of depth gdepth)
   const int lane = threadIdx.x;
-  const int D = p.kd.depth;
+  const int D = p.kd.gdepth;  // the walk's unit is the group (kd_search.hpp)
   const int num_tiles = (p.n + 63) >> 6;
   // XCD-aware chunk order (workgroup b runs on XCD b % 8): each XCD gets one contiguous eighth of the chunks
   const int nblk = gridDim.x, per_xcd = nblk >> 3, b = blockIdx.x;
@@ -320,10 +323,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 6))) void
           slack = fminf(fmaxf(moved, 3e-4f), 0.02f);
         }
       }
-      // start leaf: the seed's; a point without a neighbour remembers the leaf of its cell; else locate it
+      // start group: the seed's; a point without a neighbour remembers the group of its cell; else locate it
       uint32_t leaf = 0;
       const bool seeded = need && seed >= 0, remembered = need && seed < 0 && cand2 <= -2;
-      if (seeded) leaf = (1u << D) + kd_leaf_rank(static_cast<uint32_t>(seed), p.kd.n, D, p.inv_leaf);
+      if (seeded) leaf = (1u << D) + (kd_leaf_rank(static_cast<uint32_t>(seed), p.kd.n, p.kd.depth, p.inv_leaf) >> p.kd.glevels);
       if (remembered) leaf = (1u << D) + min(static_cast<uint32_t>(-2 - cand2), (1u << D) - 1u);
       if (__ballot(need && !seeded && !remembered) != 0ull) {  // wave-uniform branch
         if (need && !seeded && !remembered) leaf = kd_locate(p.kd, fx, fy, fz);
@@ -371,8 +374,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 6))) void
     }
     // ---- one round of the walk
     if (busy) {
-      kd_descend<64>(p.kd, qx, qy, qz, s, node, depth, sp, kd_stack, lane);  // nothing to do for a fresh lane: it stands on its start leaf
-      kd_scan_leaf(p.kd, node, qx, qy, qz, s);
+      kd_descend<64>(p.kd, qx, qy, qz, s, node, depth, sp, kd_stack, lane);  // nothing to do for a fresh lane: it stands on its start group
+      kd_visit_group(p.kd, node, qx, qy, qz, s);
     }
     if (__ballot(fresh) != 0ull) {  // wave-uniform
       if (fresh) {
@@ -385,7 +388,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 6))) void
       if (!kd_pop<64>(p.kd, qx, qy, qz, s, node, depth, sp, kd_stack, lane)) {
         const KdBest nb = kd_result(s, p.bound2);
         p.nn[qi] = nb.idx;
-        // no neighbour within reach: remember the leaf the walk ended on instead of a runner-up (the next pass starts there)
+        // no neighbour within reach: remember the group the walk ended on instead of a runner-up (the next pass starts there)
         p.nn2[qi] = nb.idx >= 0 ? nb.idx2 : -2 - static_cast<int>(node - (1u << D));
         p.rex[qi] = rex_from_r2(nb.r2);
         busy = false;
@@ -474,7 +477,7 @@ __host__ __device__ inline bool is_derived_col(int c) { return c < 15 || (c >= 2
 // M' and g of one correspondence (weighted by the robust kernel), its error, and whether it is an inlier; caches the mahalanobis
 // matrix for the error pass.  (The direct form — the 28 values of pair_system — is pair_factor below; the per-point export uses it.)
 template <typename Real, int FACTOR>
-__device__ __forceinline__ bool pair_moments(const LinParams<Real>& p, int i, int j, bool within_bound, Real qx, Real qy, Real qz, Real tx, Real ty, Real tz, Sym3<Real>& Mp, Real* g, Real& e) {
+__device__ __forceinline__ bool pair_moments(const LinParams<Real>& p, int i, int j, bool within_bound, Real qx, Real qy, Real qz, Real tx, Real ty, Real tz, Sym3<Real>& Mp, Real* g, Real& e, Sym3<Real>& M_out) {
   const Real rx = tx - qx, ry = ty - qy, rz = tz - qz;
   const Real d2 = rx * rx + ry * ry + rz * rz;
   const bool inlier = (j >= 0) && within_bound && !(d2 > static_cast<Real>(p.max_sq));
@@ -488,13 +491,7 @@ __device__ __forceinline__ bool pair_moments(const LinParams<Real>& p, int i, in
       const Sym3<Real> Ct = load_sym<Real>(p.tgt_cov, j);
       const Sym3<Real> RCR = rotate_sym(p.T.r, Cs);
       M = inverse_sym<Real>({Ct.xx + RCR.xx, Ct.xy + RCR.xy, Ct.xz + RCR.xz, Ct.yy + RCR.yy, Ct.yz + RCR.yz, Ct.zz + RCR.zz});
-      Real* m = p.maha + static_cast<size_t>(i) * 6;
-      m[0] = M.xx;
-      m[1] = M.xy;
-      m[2] = M.xz;
-      m[3] = M.yy;
-      m[4] = M.yz;
-      m[5] = M.zz;
+      M_out = M;  // the caller caches it for the error pass (gicp_factor.hpp:80-89)
     } else if constexpr (FACTOR == SGA_PLANE_ICP) {
       const float4 nn = p.tgt_nrm[j];
       M = {Real(nn.x) * Real(nn.x), Real(0), Real(0), Real(nn.y) * Real(nn.y), Real(0), Real(nn.z) * Real(nn.z)};
@@ -531,63 +528,80 @@ __global__ __launch_bounds__(kTile) void linearize_kernel(const LinParams<Real> 
     Real P[PTS][3], G[PTS][3], E[PTS];
     Sym3<Real> Mp[PTS];
     int inliers = 0;
+    // The PTS points of a lane go through the stages TOGETHER — source point + neighbour index, neighbour point, covariances — so
+    // that the loads of a stage are in flight at once (one latency per stage, not per point); the stores (mahalanobis cache,
+    // correspondence) come after the last load, or they would pin the loads of the next point behind them.
+    float4 ps4[PTS];
+    int jn[PTS];
+    bool act[PTS];
 #pragma unroll
     for (int u = 0; u < PTS; u++) {
       const int i = (tile * PTS + u) * kTile + threadIdx.x;
-      const bool active = i < p.n;
-      Real px = 0, py = 0, pz = 0, qx = 0, qy = 0, qz = 0;
-      if (active) {
-        const float4 ps4 = p.src_pts[i];
-        px = ps4.x;
-        py = ps4.y;
-        pz = ps4.z;
-        transform_point(p.T, px, py, pz, qx, qy, qz);
-      }
-      int j = -1;
-      Real tx = 0, ty = 0, tz = 0;
-      bool within = true;
+      act[u] = i < p.n;
+      ps4[u] = act[u] ? p.src_pts[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      jn[u] = -1;
+      if constexpr (TARGET == 0) jn[u] = act[u] ? p.hint[i] : -1;
+    }
+    Real Q[PTS][3], Tg[PTS][3];
+    bool within[PTS];
+#pragma unroll
+    for (int u = 0; u < PTS; u++) {
+      P[u][0] = ps4[u].x, P[u][1] = ps4[u].y, P[u][2] = ps4[u].z;  // multiplied by zero M' / g when the point is no inlier
+      Q[u][0] = Q[u][1] = Q[u][2] = Real(0);
+      if (act[u]) transform_point(p.T, P[u][0], P[u][1], P[u][2], Q[u][0], Q[u][1], Q[u][2]);
+      Tg[u][0] = Tg[u][1] = Tg[u][2] = Real(0);
+      within[u] = true;
       if constexpr (TARGET == 2) {
-        if (active) {
+        if (act[u]) {
           float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
-          j = flat_nearest<Real>(p.flat, p.tgt_pts, qx, qy, qz, m);
-          tx = m.x;
-          ty = m.y;
-          tz = m.z;
+          jn[u] = flat_nearest<Real>(p.flat, p.tgt_pts, Q[u][0], Q[u][1], Q[u][2], m);
+          Tg[u][0] = m.x, Tg[u][1] = m.y, Tg[u][2] = m.z;
         }
       } else if constexpr (TARGET == 1) {
-        if (active) {
-          j = voxel_lookup(p.vox, static_cast<float>(qx), static_cast<float>(qy), static_cast<float>(qz));
-          if (j >= 0) {
-            const float4 m = p.tgt_pts[j];
-            tx = m.x;
-            ty = m.y;
-            tz = m.z;
-          }
-        }
-      } else {
-        if (active) {
-          j = p.hint[i];
-          if (j >= 0) {
-            const float4 m = p.tgt_pts[j];
-            tx = m.x;
-            ty = m.y;
-            tz = m.z;
+        if (act[u]) jn[u] = voxel_lookup(p.vox, static_cast<float>(Q[u][0]), static_cast<float>(Q[u][1]), static_cast<float>(Q[u][2]));
+      }
+    }
+    if constexpr (TARGET != 2) {
+      float4 m4[PTS];
+#pragma unroll
+      for (int u = 0; u < PTS; u++) m4[u] = jn[u] >= 0 ? p.tgt_pts[jn[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < PTS; u++) {
+        Tg[u][0] = m4[u].x, Tg[u][1] = m4[u].y, Tg[u][2] = m4[u].z;
+        if constexpr (TARGET == 0) {
+          if (jn[u] >= 0) {
             // the search reaches a little beyond the rejector (kSearchMargin) and a certified neighbour may have drifted out of
             // reach: a neighbour counts only inside the reach of a plain search, whichever way it was found
-            within = kd_dist2(m.x, m.y, m.z, static_cast<float>(qx), static_cast<float>(qy), static_cast<float>(qz)) < p.bound2;
-            if (p.reject != nullptr) within = within && p.reject[__float_as_uint(p.src_pts[i].w)] == 0;
+            within[u] = kd_dist2(m4[u].x, m4[u].y, m4[u].z, static_cast<float>(Q[u][0]), static_cast<float>(Q[u][1]), static_cast<float>(Q[u][2])) < p.bound2;
+            if (p.reject != nullptr) within[u] = within[u] && p.reject[__float_as_uint(ps4[u].w)] == 0;
           }
         }
       }
-      bool inlier = false;
+    }
+    Sym3<Real> Mh[PTS];  // the mahalanobis matrices, stored after the last load
+    bool inl[PTS];
+#pragma unroll
+    for (int u = 0; u < PTS; u++) {
+      const int i = (tile * PTS + u) * kTile + threadIdx.x;
+      inl[u] = false;
       Mp[u] = Sym3<Real>{};
+      Mh[u] = Sym3<Real>{};
       G[u][0] = G[u][1] = G[u][2] = E[u] = Real(0);
-      if (active) {
-        inlier = pair_moments<Real, FACTOR>(p, i, j, within, qx, qy, qz, tx, ty, tz, Mp[u], G[u], E[u]);
-        p.corr[i] = inlier ? j : -1;
+      if (act[u]) inl[u] = pair_moments<Real, FACTOR>(p, i, jn[u], within[u], Q[u][0], Q[u][1], Q[u][2], Tg[u][0], Tg[u][1], Tg[u][2], Mp[u], G[u], E[u], Mh[u]);
+      inliers += __popcll(__ballot(inl[u]));
+    }
+#pragma unroll
+    for (int u = 0; u < PTS; u++) {
+      const int i = (tile * PTS + u) * kTile + threadIdx.x;
+      if (act[u]) {
+        p.corr[i] = inl[u] ? jn[u] : -1;
+        if constexpr (FACTOR == SGA_GICP) {
+          if (inl[u]) {
+            Real* m = p.maha + static_cast<size_t>(i) * 6;
+            m[0] = Mh[u].xx, m[1] = Mh[u].xy, m[2] = Mh[u].xz, m[3] = Mh[u].yy, m[4] = Mh[u].yz, m[5] = Mh[u].zz;
+          }
+        }
       }
-      P[u][0] = px, P[u][1] = py, P[u][2] = pz;  // multiplied by zero M' / g when the point is no inlier
-      inliers += __popcll(__ballot(inlier));
     }
     if (inliers == 0) continue;  // wave-uniform
     auto add = [&](int col, Real v) {
@@ -830,6 +844,7 @@ static void launch_reduce(sga_context* ctx, const double* partials, int nrows, i
   hipLaunchKernelGGL(reduce_rows_kernel, dim3(groups), dim3(256), 0, ctx->stream, partials, nrows, ncols, row_stride, stage, ctx->d_ticket.p, out, out_n, host, seq, derive ? 1 : 0);
 }
 
+static int g_fuse_max = getenv("SGA_FUSE_MAX") ? atoi(getenv("SGA_FUSE_MAX")) : kFuseMaxBlocks;
 static int g_lin_pts_min = getenv("SGA_LIN_PTS_MIN") ? atoi(getenv("SGA_LIN_PTS_MIN")) : 131072;
 static int grid_blocks(int num_tiles) { return num_tiles < kMaxBlocks ? (num_tiles < 1 ? 1 : num_tiles) : kMaxBlocks; }
 
@@ -948,7 +963,7 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
   p.robust_c = static_cast<Real>(fp->robust_c);
   p.partials = pb->partials.p;
   const int blocks = grid_blocks(p.num_tiles);
-  const bool fuse = p.n > 0 && blocks <= kFuseMaxBlocks;
+  const bool fuse = p.n > 0 && blocks <= g_fuse_max;
   const int ncols = kModelCols, out_n = with_model ? kRow : SGA_ACCUM_DOUBLES;  // the caller's buffer: the system, or the system + its moments
   p.tail = FusedTail{fuse ? 1 : 0, ctx->d_ticket.p, d_out30, out_n, host, seq};
 
@@ -978,6 +993,8 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
     q.check = warm ? 1 : 0;
     if (warm) q.T_prev = rigid_from_colmajor<Real>(pb->T_prev);
     q.walked = pb->walked.p;
+    q.leaves = pb->dbg_leaves.n >= pb->n ? pb->dbg_leaves.p : nullptr;
+    if (q.leaves != nullptr) SGA_HIP(hipMemsetAsync(q.leaves, 0, pb->n * sizeof(int), ctx->stream));
     const size_t words = static_cast<size_t>(std::max(p.kd.depth, 1));
     const dim3 sgrid((p.n + kSearchBlock - 1) / kSearchBlock), sblock(kSearchBlock);
     if (g_search_queue == 1 || (g_search_queue == 2 && warm && displacement <= g_queue_delta)) {
@@ -1076,7 +1093,7 @@ static int error_dispatch(sga_context* ctx, sga_problem* pb, const sga_factor_pa
   p.robust_c = static_cast<Real>(fp->robust_c);
   p.partials = pb->partials.p;
   const int blocks = grid_blocks(p.num_tiles);
-  const bool fuse = p.n > 0 && blocks <= kFuseMaxBlocks;
+  const bool fuse = p.n > 0 && blocks <= g_fuse_max;
   p.tail = FusedTail{fuse ? 1 : 0, ctx->d_ticket.p, d_out1, 1, host, seq};
   if (fp->factor_kind == SGA_PLANE_ICP && !idx->has_normals) return fail(SGA_ERR_UNSUPPORTED, "PLANE_ICP needs target normals");
   const bool timed = ctx->profiling && (ctx->err_seq++ % ctx->profile_period) == 0;
@@ -1358,6 +1375,33 @@ int sga_error(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, co
 
 // experiments / tests: 0 = every error pass runs the error kernel (the reference's literal procedure)
 void sga_set_error_model(int enabled) { g_error_model = enabled != 0; }
+
+// diagnostics: record the leaves scanned per source point by the next passes (one-query-per-lane kernel); out = the last pass's
+int sga_problem_set_search_stats(sga_context* ctx, sga_problem* pb, int enabled) {
+  if (!ctx || !pb) return fail(SGA_ERR_INVALID, "null argument");
+  SGA_ENTER(ctx);
+  if (enabled) return pb->dbg_leaves.alloc(pb->n);
+  pb->dbg_leaves.release();
+  return SGA_OK;
+}
+int sga_problem_get_search_stats(sga_context* ctx, const sga_problem* pb, int* leaves_per_point) {
+  if (!ctx || !pb || !leaves_per_point) return fail(SGA_ERR_INVALID, "null argument");
+  if (pb->dbg_leaves.n < pb->n) return fail(SGA_ERR_INVALID, "search statistics are not enabled");
+  SGA_ENTER(ctx);
+  SGA_HIP(hipMemcpyAsync(leaves_per_point, pb->dbg_leaves.p, pb->n * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  SGA_HIP(hipStreamSynchronize(ctx->stream));
+  return SGA_OK;
+}
+
+#ifdef SGA_KD_TRIPS
+// diagnostics build (make trips): loop-body executions of the walk since the last call, [0, 6) per lane, [8, 14) per wave
+int sga_debug_kd_trips(unsigned long long* out16) {
+  unsigned long long zero[16] = {0};
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_kd_trips), sizeof(zero)) != hipSuccess) return SGA_ERR_HIP;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_kd_trips), zero, sizeof(zero)) != hipSuccess) return SGA_ERR_HIP;
+  return SGA_OK;
+}
+#endif
 
 // experiments / tests: which search kernel runs (queue != 0: nn_search_queue_kernel with the given tiles per wave; <= 0 keeps a value)
 void sga_set_search_mode(int queue, int chunk_tiles_cold, int chunk_tiles_warm) {
