@@ -20,7 +20,7 @@ $(LIB): $(OBJS)
 TRIPS_LIB := small_gicp_amd/lib/libsmall_gicp_amd_trips.so
 trips:
 	@mkdir -p build/obj_trips
-	for f in $(SRCS); do $(HIPCC) $(HIPFLAGS) -DSGA_KD_TRIPS -c $$f -o build/obj_trips/$$(basename $$f .hip).o || exit 1; done
+	for f in $(SRCS); do $(HIPCC) $(HIPFLAGS) -DSGA_KD_TRIPS $(TRIPS_FLAGS) -c $$f -o build/obj_trips/$$(basename $$f .hip).o || exit 1; done
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(TRIPS_LIB) build/obj_trips/*.o
 oracle:
 	$(MAKE) -C oracle

@@ -34,6 +34,15 @@ def lin(T):
     lib.sga_debug_kd_trips(buf)
     waves = (n + 63) // 64
     print("pass %d: " % k[0] + "; ".join("%s %.1f/wave (%.0f%% lanes)" % (names[b], buf[8 + b] / waves, 100.0 * buf[b] / max(1, 64 * buf[8 + b])) for b in range(6)), flush=True)
+    wt = (C.c_ulonglong * (2 * min(waves, 32768)))()
+    lib.sga_debug_kd_wave_times(wt, min(waves, 32768))
+    w = np.array(wt, dtype=np.float64).reshape(-1, 2) * 0.01  # us (100 MHz)
+    t0 = w[:, 0].min()
+    start, end = w[:, 0] - t0, w[:, 1] - t0
+    dur = end - start
+    order = np.sort(end)
+    print("        waves: duration mean %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f us | last start %.1f us, 50%% ended by %.1f, 90%% by %.1f, 99%% by %.1f, all by %.1f us"
+          % (dur.mean(), np.percentile(dur, 50), np.percentile(dur, 90), np.percentile(dur, 99), dur.max(), start.max(), order[len(order) // 2], order[int(len(order) * 0.9)], order[int(len(order) * 0.99)], order[-1]), flush=True)
     k[0] += 1
     return r
 

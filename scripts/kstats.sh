@@ -11,7 +11,7 @@ f=$(find "$OUT" -name "*kernel_stats.csv" | head -1)
 python - "$f" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-for r in rows[:14]:
+for r in rows[:int(__import__("os").environ.get("KSTATS_TOP", "14"))]:
     print("%-90s calls %5s avg %9.1f us  total %9.1f us" % (r["Name"][:90], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e3))
 PY
 find "$OUT" -name "*kernel_trace.csv" -delete

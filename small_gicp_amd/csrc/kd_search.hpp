@@ -501,7 +501,7 @@ __device__ __forceinline__ KdBest kd_nearest(const KdView& t, float qx, float qy
     }
   }
   kd_walk<STRIDE>(t, qx, qy, qz, s, node, depth, sp, stack, tid);
-#ifdef SGA_KD_TRIPS
+#if defined(SGA_KD_TRIPS) && !defined(SGA_KD_NO_COUNT)
   for (int k = 0; k < 6; k++) {
     atomicAdd(&g_kd_trips[k], static_cast<unsigned long long>(s.own[k]));
     atomicAdd(&g_kd_trips[8 + k], static_cast<unsigned long long>(s.wav[k]));

@@ -806,20 +806,24 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(
     for (int r = blockIdx.x + s * G; r < nrows; r += 2 * G) acc += partials[static_cast<size_t>(r) * row_stride + c];
   sh[s][c] = acc;
   __syncthreads();
-  if (threadIdx.x < kCols) __hip_atomic_store(&stage[blockIdx.x * kCols + threadIdx.x], sh[0][threadIdx.x] + sh[1][threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) sh_ticket = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-  if (sh_ticket != static_cast<unsigned>(G - 1)) return;  // workgroup-uniform
-  if (threadIdx.x < kCols) {
-    double v[kReduceGroups];
+  if (G == 1) {  // a single workgroup (small grids): its sums are the totals — no stage rows, no ticket (two dependent round trips less)
+    if (threadIdx.x < kCols) sh[0][threadIdx.x] += sh[1][threadIdx.x];
+  } else {
+    if (threadIdx.x < kCols) __hip_atomic_store(&stage[blockIdx.x * kCols + threadIdx.x], sh[0][threadIdx.x] + sh[1][threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) sh_ticket = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (sh_ticket != static_cast<unsigned>(G - 1)) return;  // workgroup-uniform
+    if (threadIdx.x < kCols) {
+      double v[kReduceGroups];
 #pragma unroll
-    for (int g = 0; g < kReduceGroups; g++) v[g] = g < G ? __hip_atomic_load(&stage[g * kCols + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-    double t = 0.0;
+      for (int g = 0; g < kReduceGroups; g++) v[g] = g < G ? __hip_atomic_load(&stage[g * kCols + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+      double t = 0.0;
 #pragma unroll
-    for (int g = 0; g < kReduceGroups; g++) t += v[g];
-    sh[0][threadIdx.x] = t;
+      for (int g = 0; g < kReduceGroups; g++) t += v[g];
+      sh[0][threadIdx.x] = t;
+    }
   }
   __syncthreads();
   if (threadIdx.x < kCols) {
@@ -831,7 +835,7 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(
       if (host != nullptr) host[c] = r;
     }
   }
-  if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch on this stream
+  if (G > 1 && threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch on this stream
   if (host != nullptr) {
     __threadfence_system();
     __syncthreads();
