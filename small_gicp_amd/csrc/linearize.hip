@@ -187,19 +187,11 @@ __device__ __forceinline__ float certify(float rex, float moved, bool has_neighb
   return ok ? lim * 0.9999995f : -1.f;
 }
 
+// The search of ONE source point (a lane of a one-query-per-lane kernel): certificate check (warm) or walk, results stored to nn[] /
+// nn2[] / rex[]; returns the neighbour's kd position or -1.  Called by every lane of the wave that holds a point (`i < n`), also
+// under divergence: the wave-level steps inside kd_nearest only involve the lanes that walk.
 template <typename Real, int BLOCK, bool CHECK>  // CHECK: warm pass (two instantiations: the cold one carries no certificate / margin state in registers)
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void nn_search_kernel(const NNParams<Real> p) {
-  extern __shared__ uint32_t kd_stack[];  // tree depth x BLOCK traversal stack slots
-  // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed placement; only speed depends on it), and the source is sorted by
-  // target leaf, so giving each XCD one contiguous eighth of the tiles makes its L2 hold one eighth of the target instead of all of it
-  const int nblk = gridDim.x, per_xcd = nblk >> 3, b = blockIdx.x;
-  const int tile = b < 8 * per_xcd ? (b & 7) * per_xcd + (b >> 3) : b;
-  const int i = tile * BLOCK + threadIdx.x;
-  if (i >= p.n) return;
-  const float4 ps = p.src_pts[i];
-  Real x, y, z;
-  transform_point<Real>(p.T, ps.x, ps.y, ps.z, x, y, z);
-  const float fx = static_cast<float>(x), fy = static_cast<float>(y), fz = static_cast<float>(z);
+__device__ __forceinline__ int search_lane(const NNParams<Real>& p, int tile, int i, const float4& ps, float fx, float fy, float fz, uint32_t* __restrict__ kd_stack) {
   int seed = p.nn[i];
   float slack = 0.f;
   if constexpr (CHECK) {
@@ -226,7 +218,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         p.nn[i] = cand2;
         p.nn2[i] = seed;
       }
-      return;
+      return best;
     }
     seed = best;
     // this point's certificate did not survive: walk again, and explore a margin around the new neighbour proportional to the motion,
@@ -240,6 +232,42 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
   p.nn2[i] = nb.idx2;
   p.rex[i] = rex_from_r2(nb.r2);
   if (p.leaves != nullptr) p.leaves[i] = nb.leaves;
+  return nb.idx;
+}
+
+// XCD-aware tile order: workgroup b runs on XCD b % 8 (observed placement; only speed depends on it), and the source is sorted by
+// target leaf, so giving each XCD one contiguous eighth of the tiles makes its L2 hold one eighth of the target instead of all of it
+__device__ __forceinline__ int search_tile_of_block() {
+  const int nblk = gridDim.x, per_xcd = nblk >> 3, b = blockIdx.x;
+  return b < 8 * per_xcd ? (b & 7) * per_xcd + (b >> 3) : b;
+}
+
+#ifdef SGA_KD_TRIPS
+static __device__ unsigned long long g_kd_wave_times[2 * 32768];  // diagnostics build: start / end (100 MHz wall clock) of every search wave
+#endif
+
+template <typename Real, int BLOCK, bool CHECK>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void nn_search_kernel(const NNParams<Real> p) {
+  extern __shared__ uint32_t kd_stack[];  // tree depth x BLOCK traversal stack slots
+#ifdef SGA_KD_TRIPS
+  const unsigned long long wave_t0 = wall_clock64();
+#endif
+  const int tile = search_tile_of_block();
+  const int i = tile * BLOCK + threadIdx.x;
+  if (i >= p.n) return;
+  const float4 ps = p.src_pts[i];
+  Real x, y, z;
+  transform_point<Real>(p.T, ps.x, ps.y, ps.z, x, y, z);
+  search_lane<Real, BLOCK, CHECK>(p, tile, i, ps, static_cast<float>(x), static_cast<float>(y), static_cast<float>(z), kd_stack);
+#ifdef SGA_KD_TRIPS
+  if (blockIdx.x < 32768) {
+    const unsigned long long t1 = wall_clock64();
+    if (threadIdx.x == __ffsll(static_cast<long long>(__ballot(true))) - 1) {
+      g_kd_wave_times[2 * blockIdx.x] = wave_t0;
+      g_kd_wave_times[2 * blockIdx.x + 1] = t1;
+    }
+  }
+#endif
 }
 
 // K1a, queue-fed.  The walks of neighbouring queries differ in length (one leaf for most, twenty for a few): with one query per
@@ -258,8 +286,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
 constexpr int kQueueCap = 128;        // entries; a tile is staged while at most kQueueCap - 64 are waiting
 constexpr int kPathRecords = 10;      // pair records fetched at once by kd_push_path: covers depth 20 (8 M points); deeper trees take a second batch
 
-template <typename Real, bool CHECK>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 6))) void nn_search_queue_kernel(const NNParams<Real> p) {
+template <typename Real, int FACTOR, int TARGET, int PTS, bool FRESH_NN = false>
+__device__ __forceinline__ void linearize_group(const LinParams<Real>& p, int first, int stride, int limit, double* __restrict__ acc_row, int lane);
+
+// FACTOR >= 0: when the chunk's searches are done the wave also evaluates the factors of its chunk (four tiles at a time, like
+// linearize_kernel) and writes ONE partial row per chunk — in the warm passes this kernel runs, the memory system and the VALUs are
+// mostly idle, so the factor kernel's work all but disappears inside it (and its launch, start-up and tail with it).
+template <typename Real, bool CHECK, int FACTOR = -1>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 6))) void nn_search_queue_kernel(const NNParams<Real> p, const LinParams<Real> lp) {
   extern __shared__ uint32_t kd_stack[];  // tree depth x 64 traversal stack slots
   __shared__ float4 q_pt[kQueueCap];      // query (x, y, z), w = exploration slack
   __shared__ int q_idx[kQueueCap];        // source point
@@ -395,6 +429,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 6))) void
       }
     }
   }
+  if constexpr (FACTOR >= 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the chunk's neighbours are written
+    __syncthreads();                                   // one wave: the stacks are free
+    double* row = reinterpret_cast<double*>(kd_stack);
+    for (int c = lane; c < kRow; c += 64) row[c] = 0.0;
+    __syncthreads();
+    const int limit = min(p.n, tile_end * 64);
+    for (int t0 = chunk * p.chunk_tiles; t0 < tile_end; t0 += 4) linearize_group<Real, FACTOR, 0, 4, true>(lp, t0 * 64 + lane, 64, limit, row, lane);
+    __syncthreads();
+    for (int c = lane; c < kRow; c += 64) lp.partials[static_cast<size_t>(chunk) * kRow + c] = row[c];
+  }
 }
 
 // One correspondence (source point i at q = T p, target candidate j at t): rejector, fused mahalanobis, robust weight, the 28
@@ -512,98 +557,10 @@ __device__ __forceinline__ bool pair_moments(const LinParams<Real>& p, int i, in
   return inlier;
 }
 
-// K1b.  TARGET: 0 kd-tree (the neighbours come from the search kernel), 1 Gaussian voxel map, 2 flat voxel map (the lookup of a
-// voxel target happens right here).  Streaming + two gathers; a lane handles PTS points (PTS x kTile consecutive points per
-// workgroup step), their products are added up in registers, reduced with DPP inside the wave, in fp64 across waves.
-template <typename Real, int FACTOR, int TARGET, int PTS>
-__global__ __launch_bounds__(kTile) void linearize_kernel(const LinParams<Real> p) {
-  __shared__ double sh_acc[kTile / 64][kRow];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int c = lane; c < kRow; c += 64) sh_acc[wave][c] = 0.0;  // each wave owns its row: no workgroup barrier needed until the end
-  double* acc_row = sh_acc[wave];
-
-  int tile, stride, tile_end;
-  tile_schedule(p.num_tiles, tile, stride, tile_end);
-  for (; tile < tile_end; tile += stride) {
-    Real P[PTS][3], G[PTS][3], E[PTS];
-    Sym3<Real> Mp[PTS];
-    int inliers = 0;
-    // The PTS points of a lane go through the stages TOGETHER — source point + neighbour index, neighbour point, covariances — so
-    // that the loads of a stage are in flight at once (one latency per stage, not per point); the stores (mahalanobis cache,
-    // correspondence) come after the last load, or they would pin the loads of the next point behind them.
-    float4 ps4[PTS];
-    int jn[PTS];
-    bool act[PTS];
-#pragma unroll
-    for (int u = 0; u < PTS; u++) {
-      const int i = (tile * PTS + u) * kTile + threadIdx.x;
-      act[u] = i < p.n;
-      ps4[u] = act[u] ? p.src_pts[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-      jn[u] = -1;
-      if constexpr (TARGET == 0) jn[u] = act[u] ? p.hint[i] : -1;
-    }
-    Real Q[PTS][3], Tg[PTS][3];
-    bool within[PTS];
-#pragma unroll
-    for (int u = 0; u < PTS; u++) {
-      P[u][0] = ps4[u].x, P[u][1] = ps4[u].y, P[u][2] = ps4[u].z;  // multiplied by zero M' / g when the point is no inlier
-      Q[u][0] = Q[u][1] = Q[u][2] = Real(0);
-      if (act[u]) transform_point(p.T, P[u][0], P[u][1], P[u][2], Q[u][0], Q[u][1], Q[u][2]);
-      Tg[u][0] = Tg[u][1] = Tg[u][2] = Real(0);
-      within[u] = true;
-      if constexpr (TARGET == 2) {
-        if (act[u]) {
-          float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
-          jn[u] = flat_nearest<Real>(p.flat, p.tgt_pts, Q[u][0], Q[u][1], Q[u][2], m);
-          Tg[u][0] = m.x, Tg[u][1] = m.y, Tg[u][2] = m.z;
-        }
-      } else if constexpr (TARGET == 1) {
-        if (act[u]) jn[u] = voxel_lookup(p.vox, static_cast<float>(Q[u][0]), static_cast<float>(Q[u][1]), static_cast<float>(Q[u][2]));
-      }
-    }
-    if constexpr (TARGET != 2) {
-      float4 m4[PTS];
-#pragma unroll
-      for (int u = 0; u < PTS; u++) m4[u] = jn[u] >= 0 ? p.tgt_pts[jn[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int u = 0; u < PTS; u++) {
-        Tg[u][0] = m4[u].x, Tg[u][1] = m4[u].y, Tg[u][2] = m4[u].z;
-        if constexpr (TARGET == 0) {
-          if (jn[u] >= 0) {
-            // the search reaches a little beyond the rejector (kSearchMargin) and a certified neighbour may have drifted out of
-            // reach: a neighbour counts only inside the reach of a plain search, whichever way it was found
-            within[u] = kd_dist2(m4[u].x, m4[u].y, m4[u].z, static_cast<float>(Q[u][0]), static_cast<float>(Q[u][1]), static_cast<float>(Q[u][2])) < p.bound2;
-            if (p.reject != nullptr) within[u] = within[u] && p.reject[__float_as_uint(ps4[u].w)] == 0;
-          }
-        }
-      }
-    }
-    Sym3<Real> Mh[PTS];  // the mahalanobis matrices, stored after the last load
-    bool inl[PTS];
-#pragma unroll
-    for (int u = 0; u < PTS; u++) {
-      const int i = (tile * PTS + u) * kTile + threadIdx.x;
-      inl[u] = false;
-      Mp[u] = Sym3<Real>{};
-      Mh[u] = Sym3<Real>{};
-      G[u][0] = G[u][1] = G[u][2] = E[u] = Real(0);
-      if (act[u]) inl[u] = pair_moments<Real, FACTOR>(p, i, jn[u], within[u], Q[u][0], Q[u][1], Q[u][2], Tg[u][0], Tg[u][1], Tg[u][2], Mp[u], G[u], E[u], Mh[u]);
-      inliers += __popcll(__ballot(inl[u]));
-    }
-#pragma unroll
-    for (int u = 0; u < PTS; u++) {
-      const int i = (tile * PTS + u) * kTile + threadIdx.x;
-      if (act[u]) {
-        p.corr[i] = inl[u] ? jn[u] : -1;
-        if constexpr (FACTOR == SGA_GICP) {
-          if (inl[u]) {
-            Real* m = p.maha + static_cast<size_t>(i) * 6;
-            m[0] = Mh[u].xx, m[1] = Mh[u].xy, m[2] = Mh[u].xz, m[3] = Mh[u].yy, m[4] = Mh[u].yz, m[5] = Mh[u].zz;
-          }
-        }
-      }
-    }
-    if (inliers == 0) continue;  // wave-uniform
+// Adds the moments of PTS points per lane (zero M' / g / e for the points that are no inliers) to the wave's fp64 row in LDS:
+// the lane adds its points up in registers, DPP sums across the wave, lane 63 adds to the row.
+template <typename Real, int PTS>
+__device__ __forceinline__ void accumulate_moments(const Real (&P)[PTS][3], const Sym3<Real> (&Mp)[PTS], const Real (&G)[PTS][3], const Real (&E)[PTS], int inliers, double* __restrict__ acc_row, int lane) {
     auto add = [&](int col, Real v) {
       if constexpr (sizeof(Real) == 4) {
         const float t = wave_sum_to_lane63(v);
@@ -675,6 +632,108 @@ __global__ __launch_bounds__(kTile) void linearize_kernel(const LinParams<Real> 
         }
       }
     }
+}
+
+// K1b.  TARGET: 0 kd-tree (the neighbours come from the search kernel), 1 Gaussian voxel map, 2 flat voxel map (the lookup of a
+// voxel target happens right here).  Streaming + two gathers; a lane handles PTS points (PTS x kTile consecutive points per
+// workgroup step), their products are added up in registers, reduced with DPP inside the wave, in fp64 across waves.
+// The factors of PTS points per lane — points first, first + stride, ... below `limit` — added to the wave's row.
+// FRESH_NN: hint[] was written earlier in this very kernel (by any lane of this wave): read it past the vector L1.
+template <typename Real, int FACTOR, int TARGET, int PTS, bool FRESH_NN>
+__device__ __forceinline__ void linearize_group(const LinParams<Real>& p, int first, int stride, int limit, double* __restrict__ acc_row, int lane) {
+  Real P[PTS][3], G[PTS][3], E[PTS];
+  Sym3<Real> Mp[PTS];
+  int inliers = 0;
+  // The PTS points of a lane go through the stages TOGETHER — source point + neighbour index, neighbour point, covariances — so
+  // that the loads of a stage are in flight at once (one latency per stage, not per point); the stores (mahalanobis cache,
+  // correspondence) come after the last load, or they would pin the loads of the next point behind them.
+  float4 ps4[PTS];
+  int jn[PTS];
+  bool act[PTS];
+#pragma unroll
+  for (int u = 0; u < PTS; u++) {
+    const int i = first + u * stride;
+    act[u] = i < limit;
+    ps4[u] = act[u] ? p.src_pts[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    jn[u] = -1;
+    if constexpr (TARGET == 0) jn[u] = act[u] ? (FRESH_NN ? __hip_atomic_load(&p.hint[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : p.hint[i]) : -1;
+  }
+  Real Q[PTS][3], Tg[PTS][3];
+  bool within[PTS];
+#pragma unroll
+  for (int u = 0; u < PTS; u++) {
+    P[u][0] = ps4[u].x, P[u][1] = ps4[u].y, P[u][2] = ps4[u].z;  // multiplied by zero M' / g when the point is no inlier
+    Q[u][0] = Q[u][1] = Q[u][2] = Real(0);
+    if (act[u]) transform_point(p.T, P[u][0], P[u][1], P[u][2], Q[u][0], Q[u][1], Q[u][2]);
+    Tg[u][0] = Tg[u][1] = Tg[u][2] = Real(0);
+    within[u] = true;
+    if constexpr (TARGET == 2) {
+      if (act[u]) {
+        float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+        jn[u] = flat_nearest<Real>(p.flat, p.tgt_pts, Q[u][0], Q[u][1], Q[u][2], m);
+        Tg[u][0] = m.x, Tg[u][1] = m.y, Tg[u][2] = m.z;
+      }
+    } else if constexpr (TARGET == 1) {
+      if (act[u]) jn[u] = voxel_lookup(p.vox, static_cast<float>(Q[u][0]), static_cast<float>(Q[u][1]), static_cast<float>(Q[u][2]));
+    }
+  }
+  if constexpr (TARGET != 2) {
+    float4 m4[PTS];
+#pragma unroll
+    for (int u = 0; u < PTS; u++) m4[u] = jn[u] >= 0 ? p.tgt_pts[jn[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < PTS; u++) {
+      Tg[u][0] = m4[u].x, Tg[u][1] = m4[u].y, Tg[u][2] = m4[u].z;
+      if constexpr (TARGET == 0) {
+        if (jn[u] >= 0) {
+          // the search reaches a little beyond the rejector (kSearchMargin) and a certified neighbour may have drifted out of
+          // reach: a neighbour counts only inside the reach of a plain search, whichever way it was found
+          within[u] = kd_dist2(m4[u].x, m4[u].y, m4[u].z, static_cast<float>(Q[u][0]), static_cast<float>(Q[u][1]), static_cast<float>(Q[u][2])) < p.bound2;
+          if (p.reject != nullptr) within[u] = within[u] && p.reject[__float_as_uint(ps4[u].w)] == 0;
+        }
+      }
+    }
+  }
+  Sym3<Real> Mh[PTS];  // the mahalanobis matrices, stored after the last load
+  bool inl[PTS];
+#pragma unroll
+  for (int u = 0; u < PTS; u++) {
+    const int i = first + u * stride;
+    inl[u] = false;
+    Mp[u] = Sym3<Real>{};
+    Mh[u] = Sym3<Real>{};
+    G[u][0] = G[u][1] = G[u][2] = E[u] = Real(0);
+    if (act[u]) inl[u] = pair_moments<Real, FACTOR>(p, i, jn[u], within[u], Q[u][0], Q[u][1], Q[u][2], Tg[u][0], Tg[u][1], Tg[u][2], Mp[u], G[u], E[u], Mh[u]);
+    inliers += __popcll(__ballot(inl[u]));
+  }
+#pragma unroll
+  for (int u = 0; u < PTS; u++) {
+    const int i = first + u * stride;
+    if (act[u]) {
+      p.corr[i] = inl[u] ? jn[u] : -1;
+      if constexpr (FACTOR == SGA_GICP) {
+        if (inl[u]) {
+          Real* m = p.maha + static_cast<size_t>(i) * 6;
+          m[0] = Mh[u].xx, m[1] = Mh[u].xy, m[2] = Mh[u].xz, m[3] = Mh[u].yy, m[4] = Mh[u].yz, m[5] = Mh[u].zz;
+        }
+      }
+    }
+  }
+  if (inliers == 0) return;  // wave-uniform
+  accumulate_moments<Real, PTS>(P, Mp, G, E, inliers, acc_row, lane);
+}
+
+template <typename Real, int FACTOR, int TARGET, int PTS>
+__global__ __launch_bounds__(kTile) void linearize_kernel(const LinParams<Real> p) {
+  __shared__ double sh_acc[kTile / 64][kRow];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int c = lane; c < kRow; c += 64) sh_acc[wave][c] = 0.0;  // each wave owns its row: no workgroup barrier needed until the end
+  double* acc_row = sh_acc[wave];
+
+  int tile, stride, tile_end;
+  tile_schedule(p.num_tiles, tile, stride, tile_end);
+  for (; tile < tile_end; tile += stride) {
+    linearize_group<Real, FACTOR, TARGET, PTS>(p, tile * PTS * kTile + static_cast<int>(threadIdx.x), kTile, p.n, acc_row, lane);
   }
   __syncthreads();
   if (threadIdx.x < kRow) {
@@ -687,6 +746,65 @@ __global__ __launch_bounds__(kTile) void linearize_kernel(const LinParams<Real> 
       p.partials[static_cast<size_t>(blockIdx.x) * kRow + threadIdx.x] = t;
   }
   if (p.tail.enabled) fused_tail(p.tail, p.partials, gridDim.x, kModelCols, kRow, true);
+}
+
+// K1, fused: the search wave also evaluates the factors of its own 64 source points — their neighbours are in registers, no nn[]
+// round trip, no second kernel whose start waits for the slowest search wave.  The factor algebra in moment form is lean enough
+// (42 VGPRs at one point per lane) to live inside the search kernel's 64-register budget, which the walks need for 8 waves per SIMD.
+// One partial row per wave (= per tile of 64 points, whatever workgroup took it: the row order, and with it the fp64 sum, does not
+// depend on the placement).  The row is built in the LDS the traversal stacks occupied.
+template <typename Real, int FACTOR, bool CHECK>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void search_linearize_kernel(const NNParams<Real> p, const LinParams<Real> lp) {
+  extern __shared__ uint32_t kd_stack[];  // max(tree depth, 3) x 64 words: the traversal stacks, then the wave's row of kRow doubles
+#ifdef SGA_KD_TRIPS
+  const unsigned long long wave_t0 = wall_clock64();
+#endif
+  const int lane = threadIdx.x;
+  const int tile = search_tile_of_block();
+  const int i = tile * 64 + lane;
+  const bool active = i < p.n;
+  const float4 ps = active ? p.src_pts[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  Real q[3] = {Real(0), Real(0), Real(0)};
+  int j = -1;
+  if (active) {
+    transform_point<Real>(p.T, ps.x, ps.y, ps.z, q[0], q[1], q[2]);
+    j = search_lane<Real, 64, CHECK>(p, tile, i, ps, static_cast<float>(q[0]), static_cast<float>(q[1]), static_cast<float>(q[2]), kd_stack);
+  }
+  // ---- the factors of the wave's 64 points (linearize_kernel with one point per lane)
+  Real P[1][3] = {{ps.x, ps.y, ps.z}}, G[1][3] = {{Real(0), Real(0), Real(0)}}, E[1] = {Real(0)};
+  Sym3<Real> Mp[1] = {Sym3<Real>{}};
+  Sym3<Real> Mh{};
+  bool inl = false;
+  if (j >= 0) {
+    const float4 m = lp.tgt_pts[j];
+    // the search reaches a little beyond the rejector (kSearchMargin) and a certified neighbour may have drifted out of reach: a
+    // neighbour counts only inside the reach of a plain search, whichever way it was found
+    const bool within = kd_dist2(m.x, m.y, m.z, static_cast<float>(q[0]), static_cast<float>(q[1]), static_cast<float>(q[2])) < lp.bound2;
+    inl = pair_moments<Real, FACTOR>(lp, i, j, within, q[0], q[1], q[2], Real(m.x), Real(m.y), Real(m.z), Mp[0], G[0], E[0], Mh);
+  }
+  if (active) {
+    lp.corr[i] = inl ? j : -1;
+    if constexpr (FACTOR == SGA_GICP) {
+      if (inl) {
+        Real* mm = lp.maha + static_cast<size_t>(i) * 6;
+        mm[0] = Mh.xx, mm[1] = Mh.xy, mm[2] = Mh.xz, mm[3] = Mh.yy, mm[4] = Mh.yz, mm[5] = Mh.zz;
+      }
+    }
+  }
+  const int inliers = __popcll(__ballot(inl));
+  __syncthreads();  // one wave: every lane is done with its stack
+  double* row = reinterpret_cast<double*>(kd_stack);
+  for (int c = lane; c < kRow; c += 64) row[c] = 0.0;
+  __syncthreads();
+  if (inliers > 0) accumulate_moments<Real, 1>(P, Mp, G, E, inliers, row, lane);
+  __syncthreads();
+  for (int c = lane; c < kRow; c += 64) lp.partials[static_cast<size_t>(tile) * kRow + c] = row[c];
+#ifdef SGA_KD_TRIPS
+  if (blockIdx.x < 32768 && lane == 0) {
+    g_kd_wave_times[2 * blockIdx.x] = wave_t0;
+    g_kd_wave_times[2 * blockIdx.x + 1] = wall_clock64();
+  }
+#endif
 }
 
 // Per-point export of the same factors (the reference's Python binding exposes Factor::linearize per source point,
@@ -792,7 +910,7 @@ __global__ __launch_bounds__(kTile) void error_kernel(const ErrParams<Real> p) {
 // When `host` is given the result is handed to the host right here: copied into pinned, device-mapped host memory, then a
 // sequence number is published (system-scope release) on which the host spins.  This replaces hipMemcpyAsync +
 // hipStreamSynchronize, whose fixed cost is paid twice per optimizer iteration.
-constexpr int kReduceGroups = 32;
+constexpr int kReduceGroups = 128;
 
 __global__ __launch_bounds__(256) void reduce_rows_kernel(
   const double* __restrict__ partials, int nrows, int ncols, int row_stride, double* __restrict__ stage, unsigned* __restrict__ ticket, double* __restrict__ out, int out_n, double* __restrict__ host,
@@ -815,14 +933,13 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(
     if (threadIdx.x == 0) sh_ticket = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (sh_ticket != static_cast<unsigned>(G - 1)) return;  // workgroup-uniform
-    if (threadIdx.x < kCols) {
-      double v[kReduceGroups];
-#pragma unroll
-      for (int g = 0; g < kReduceGroups; g++) v[g] = g < G ? __hip_atomic_load(&stage[g * kCols + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    {  // the last workgroup adds the G stage rows: slice s takes rows s, s + 2, ... (independent loads), fixed order
       double t = 0.0;
-#pragma unroll
-      for (int g = 0; g < kReduceGroups; g++) t += v[g];
-      sh[0][threadIdx.x] = t;
+      for (int g = s; g < G; g += 2) t += __hip_atomic_load(&stage[g * kCols + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      sh[s][c] = t;
+      __syncthreads();
+      if (threadIdx.x < kCols) sh[0][threadIdx.x] += sh[1][threadIdx.x];
     }
   }
   __syncthreads();
@@ -843,8 +960,12 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(
   }
 }
 
+// partial rows (one per workgroup of K1b / K2, or one per 64 source points when the search kernel does the factor algebra itself);
+// the stage-1 rows of the reduction follow them
+static size_t partial_rows(size_t n) { return std::max<size_t>(kMaxBlocks, (n + 63) / 64); }
+
 static void launch_reduce(sga_context* ctx, const double* partials, int nrows, int ncols, int row_stride, double* stage, double* out, int out_n, double* host, unsigned long long seq, bool derive = false) {
-  const int groups = nrows > 2 * kReduceGroups ? kReduceGroups : 1;
+  const int groups = nrows > 64 ? std::min(kReduceGroups, std::max(32, nrows / 64)) : 1;
   hipLaunchKernelGGL(reduce_rows_kernel, dim3(groups), dim3(256), 0, ctx->stream, partials, nrows, ncols, row_stride, stage, ctx->d_ticket.p, out, out_n, host, seq, derive ? 1 : 0);
 }
 
@@ -914,6 +1035,8 @@ static double g_warm_delta = getenv("SGA_WARM_DELTA") ? atof(getenv("SGA_WARM_DE
 // are bound by the number of memory accesses in flight and the queue-fed kernel starts each of them with 10 record fetches; when few
 // lanes walk (the later passes of a registration) the queue packs them into full waves: 124 -> 80, 87 -> 73, 68 -> 53 us.
 static int g_search_queue = getenv("SGA_SEARCH_QUEUE") ? atoi(getenv("SGA_SEARCH_QUEUE")) : 2;
+// 1 (default): the search waves evaluate the factors of their own tiles (search_linearize_kernel); 0: always a separate factor kernel (K1b)
+static bool g_fuse_search = getenv("SGA_FUSE_SEARCH") ? atoi(getenv("SGA_FUSE_SEARCH")) != 0 : true;
 static double g_queue_delta = getenv("SGA_QUEUE_DELTA") ? atof(getenv("SGA_QUEUE_DELTA")) : 0.02;
 static int g_chunk_tiles_cold = getenv("SGA_CHUNK_COLD") ? atoi(getenv("SGA_CHUNK_COLD")) : 4;
 static int g_chunk_tiles_warm = getenv("SGA_CHUNK_WARM") ? atoi(getenv("SGA_CHUNK_WARM")) : 4;
@@ -983,6 +1106,8 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
     (void)hipEventRecord(ctx->ev0, ctx->stream);
     ctx->pending_warm = warm;
   }
+  bool fused_search = false;  // the search kernel evaluates the factors itself ...
+  int fused_rows = 0;         // ... and leaves this many partial rows
   if (p.n > 0 && !voxel) {
     NNParams<Real> q{};
     q.src_pts = pb->pts.p;
@@ -1001,14 +1126,45 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
     if (q.leaves != nullptr) SGA_HIP(hipMemsetAsync(q.leaves, 0, pb->n * sizeof(int), ctx->stream));
     const size_t words = static_cast<size_t>(std::max(p.kd.depth, 1));
     const dim3 sgrid((p.n + kSearchBlock - 1) / kSearchBlock), sblock(kSearchBlock);
-    if (g_search_queue == 1 || (g_search_queue == 2 && warm && displacement <= g_queue_delta)) {
+    const bool queue = g_search_queue == 1 || (g_search_queue == 2 && warm && displacement <= g_queue_delta);
+    fused_search = g_fuse_search && !host_rejector && !queue && sizeof(Real) == 4;  // fp64 math: the fused kernel would spill
+    if (fused_search) {
+      // every search wave evaluates the factors of its own tile: one partial row per tile of 64 points, summed by reduce_rows_kernel
+      p.tail.enabled = 0;
+      fused_rows = static_cast<int>(sgrid.x);
+      const size_t lds = std::max<size_t>(words, 3) * 64 * sizeof(uint32_t);
+      switch (fp->factor_kind) {
+        case SGA_GICP:
+          if (warm) hipLaunchKernelGGL((search_linearize_kernel<Real, SGA_GICP, true>), sgrid, sblock, lds, ctx->stream, q, p);
+          else hipLaunchKernelGGL((search_linearize_kernel<Real, SGA_GICP, false>), sgrid, sblock, lds, ctx->stream, q, p);
+          break;
+        case SGA_PLANE_ICP:
+          if (warm) hipLaunchKernelGGL((search_linearize_kernel<Real, SGA_PLANE_ICP, true>), sgrid, sblock, lds, ctx->stream, q, p);
+          else hipLaunchKernelGGL((search_linearize_kernel<Real, SGA_PLANE_ICP, false>), sgrid, sblock, lds, ctx->stream, q, p);
+          break;
+        default:
+          if (warm) hipLaunchKernelGGL((search_linearize_kernel<Real, SGA_ICP, true>), sgrid, sblock, lds, ctx->stream, q, p);
+          else hipLaunchKernelGGL((search_linearize_kernel<Real, SGA_ICP, false>), sgrid, sblock, lds, ctx->stream, q, p);
+          break;
+      }
+    } else if (queue) {
       q.inv_leaf = p.kd.n > 0 ? std::ldexp(1.0, p.kd.depth) / static_cast<double>(p.kd.n) : 0.0;
       q.chunk_tiles = std::max(1, warm ? g_chunk_tiles_warm : g_chunk_tiles_cold);
       const dim3 qgrid((sgrid.x + q.chunk_tiles - 1) / q.chunk_tiles);
-      if (warm)
-        hipLaunchKernelGGL((nn_search_queue_kernel<Real, true>), qgrid, sblock, words * 64 * sizeof(uint32_t), ctx->stream, q);
+      const size_t lds = std::max<size_t>(words, 3) * 64 * sizeof(uint32_t);
+      fused_search = g_fuse_search && !host_rejector && warm && sizeof(Real) == 4;
+      if (fused_search) {  // the chunk's wave evaluates the factors as well: one partial row per chunk
+        p.tail.enabled = 0;
+        fused_rows = static_cast<int>(qgrid.x);
+        switch (fp->factor_kind) {
+          case SGA_GICP: hipLaunchKernelGGL((nn_search_queue_kernel<Real, true, SGA_GICP>), qgrid, sblock, lds, ctx->stream, q, p); break;
+          case SGA_PLANE_ICP: hipLaunchKernelGGL((nn_search_queue_kernel<Real, true, SGA_PLANE_ICP>), qgrid, sblock, lds, ctx->stream, q, p); break;
+          default: hipLaunchKernelGGL((nn_search_queue_kernel<Real, true, SGA_ICP>), qgrid, sblock, lds, ctx->stream, q, p); break;
+        }
+      } else if (warm)
+        hipLaunchKernelGGL((nn_search_queue_kernel<Real, true>), qgrid, sblock, lds, ctx->stream, q, p);
       else
-        hipLaunchKernelGGL((nn_search_queue_kernel<Real, false>), qgrid, sblock, words * 64 * sizeof(uint32_t), ctx->stream, q);
+        hipLaunchKernelGGL((nn_search_queue_kernel<Real, false>), qgrid, sblock, lds, ctx->stream, q, p);
     } else if (warm)
       hipLaunchKernelGGL((nn_search_kernel<Real, kSearchBlock, true>), sgrid, sblock, words * kSearchBlock * sizeof(uint32_t), ctx->stream, q);
     else
@@ -1038,7 +1194,7 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
       p.reject = pb->reject.p;
     }
   }
-  if (p.n > 0) {
+  if (p.n > 0 && !fused_search) {
     if (flat) {
       if (fp->factor_kind == SGA_GICP)
         launch_linearize<Real, SGA_GICP, 2>(ctx->stream, p, blocks, pts);
@@ -1061,7 +1217,10 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
     (void)hipEventRecord(ctx->ev1, ctx->stream);
     ctx->pending |= 1;
   }
-  if (!fuse) launch_reduce(ctx, pb->partials.p, p.n > 0 ? blocks : 0, ncols, kRow, pb->partials.p + static_cast<size_t>(kMaxBlocks) * kRow, d_out30, out_n, host, seq, true);
+  if (fused_search)
+    launch_reduce(ctx, pb->partials.p, fused_rows, ncols, kRow, pb->partials.p + partial_rows(pb->n) * kRow, d_out30, out_n, host, seq, true);
+  else if (!fuse)
+    launch_reduce(ctx, pb->partials.p, p.n > 0 ? blocks : 0, ncols, kRow, pb->partials.p + partial_rows(pb->n) * kRow, d_out30, out_n, host, seq, true);
   SGA_HIP(hipGetLastError());
   pb->last_math = math;
   if (!voxel) {
@@ -1117,12 +1276,12 @@ static int error_dispatch(sga_context* ctx, sga_problem* pb, const sga_factor_pa
     (void)hipEventRecord(ctx->ev3, ctx->stream);
     ctx->pending |= 2;
   }
-  if (!fuse) launch_reduce(ctx, pb->partials.p, p.n > 0 ? blocks : 0, 1, 1, pb->partials.p + static_cast<size_t>(kMaxBlocks) * kRow, d_out1, 1, host, seq);
+  if (!fuse) launch_reduce(ctx, pb->partials.p, p.n > 0 ? blocks : 0, 1, 1, pb->partials.p + partial_rows(pb->n) * kRow, d_out1, 1, host, seq);
   SGA_HIP(hipGetLastError());
   return SGA_OK;
 }
 
-int problem_partials_doubles() { return kMaxBlocks * kRow + kReduceGroups * kCols; }  // K1/K2 partial rows + the stage-1 rows of the reduction
+size_t problem_partials_doubles(size_t n) { return partial_rows(n) * kRow + static_cast<size_t>(kReduceGroups) * kCols; }
 
 // Hand `count` doubles to the host after an all-reduce (see reduce_rows_kernel for the protocol).
 __global__ void publish_kernel(const double* __restrict__ src, int count, double* __restrict__ host, unsigned long long seq) {
@@ -1307,8 +1466,8 @@ int sga_linearize(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp
   double* host = direct ? ctx->h_accum_dev : nullptr;
   const bool model = fp->robust_kind == SGA_ROBUST_NONE && g_error_model;  // a robust kernel's error is not quadratic in the pose
   pb->model_valid = false;
-  SGA_TRY(fp->math_mode == SGA_MATH_FP64 ? linearize_dispatch<double>(ctx, pb, fp, T, ctx->d_accum.p, host, seq, model) : linearize_dispatch<float>(ctx, pb, fp, T, ctx->d_accum.p, host, seq, model));
   const int count = model ? kRow : SGA_ACCUM_DOUBLES;
+  SGA_TRY(fp->math_mode == SGA_MATH_FP64 ? linearize_dispatch<double>(ctx, pb, fp, T, ctx->d_accum.p, host, seq, model) : linearize_dispatch<float>(ctx, pb, fp, T, ctx->d_accum.p, host, seq, model));
   SGA_TRY(comm_allreduce_sum(ctx, ctx->d_accum.p, count));  // source sharded over ranks: sum the shards' systems (and error models)
   SGA_TRY(fetch_result(ctx, ctx->d_accum.p, count, seq, direct));
   sga_unpack_accumulator(ctx->h_accum, H, b, e, num_inliers);

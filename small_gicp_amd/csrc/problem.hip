@@ -13,7 +13,7 @@
 namespace sga {
 
 int ensure_temp(sga_context* ctx, size_t bytes);
-int problem_partials_doubles();
+size_t problem_partials_doubles(size_t n);
 int cloud_bbox(sga_context* ctx, const float4* pts, size_t n, float lo[3], float hi[3]);
 
 __device__ __forceinline__ unsigned long long spread3(unsigned long long v) {
@@ -180,7 +180,7 @@ int sga_problem_create(sga_context* ctx, const sga_index* target, const sga_clou
   pb->has_normals = source->has_normals;
   pb->has_covs = source->has_covs;
   const size_t n = source->n;
-  SGA_TRY(pb->partials.alloc(static_cast<size_t>(problem_partials_doubles())));
+  SGA_TRY(pb->partials.alloc(problem_partials_doubles(n)));
   SGA_TRY(pb->walked.alloc(n / 64 + 1));
   SGA_HIP(hipMemsetAsync(pb->walked.p, 0, (n / 64 + 1) * sizeof(uint32_t), ctx->stream));
   if (n > 0) {
