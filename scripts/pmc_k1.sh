@@ -20,14 +20,15 @@ import csv, glob, sys, os
 from collections import defaultdict
 out = sys.argv[1]
 def name_of(kn):
-    if "nn_search_queue" in kn: return "K1a_queue"
-    if "nn_search" in kn: return "K1a_warm" if "true" in kn else "K1a_cold"
+    if "search_linearize" in kn: return "K1_lane_warm" if "true" in kn else "K1_lane_cold"   # search + factors, one query per lane
+    if "nn_search_queue" in kn: return "K1_queue_warm"                                        # check + queue-fed walks (+ factors)
+    if "nn_search" in kn: return "K1a_warm" if "true" in kn else "K1a_cold"                   # search only (non-fused paths)
     return "K1b" if "linearize" in kn else "K2"
 agg = defaultdict(lambda: [0.0, 0])
 for f in glob.glob(os.path.join(out, "p*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         kn = r.get("Kernel_Name", "")
-        if "linearize_kernel" not in kn and "error_kernel" not in kn and "nn_search" not in kn: continue
+        if "linearize_kernel" not in kn and "error_kernel" not in kn and "nn_search" not in kn: continue  # (search_linearize_kernel matches too)
         k = (name_of(kn), r.get("Counter_Name"))
         agg[k][0] += float(r.get("Counter_Value", 0)); agg[k][1] += 1
 dur = defaultdict(lambda: [0.0, 0])

@@ -34,53 +34,66 @@ for f in find("trace/**/*kernel_trace.csv"):
     durs = defaultdict(list)
     for r in csv.DictReader(open(f)):
         kn = r.get("Kernel_Name", "")
-        for key in ("nn_search_kernel", "linearize_kernel", "error_kernel", "reduce_rows_kernel"):
+        for key in ("search_linearize_kernel", "nn_search_queue_kernel", "nn_search_kernel", "linearize_kernel", "error_kernel", "reduce_rows_kernel"):
             if key in kn:
                 durs[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+                break
     print("== per-dispatch durations (us): min / median / mean / max")
     for k, v in durs.items():
         v.sort()
         print("%-22s n=%d  %.1f / %.1f / %.1f / %.1f" % (k, len(v), v[0], v[len(v) // 2], sum(v) / len(v), v[-1]))
         summary.setdefault("durations_us", {})[k] = {"n": len(v), "min": v[0], "median": v[len(v) // 2], "mean": sum(v) / len(v), "max": v[-1]}
 
-pmc = {}
-for ctr in ("fetch", "write"):
+K1_SEARCH = ("search_linearize_kernel", "nn_search_queue_kernel", "nn_search_kernel")  # one launch of these per linearization pass
+
+
+def k1_kind(name):
+    for k in K1_SEARCH:
+        if k in name:
+            return k
+    return "linearize_kernel" if "linearize_kernel" in name else None
+
+
+totals = {}
+for ctr, cname in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     agg = defaultdict(lambda: [0.0, 0])
     for f in find("pmc_%s/**/*counter_collection.csv" % ctr):
         for r in csv.DictReader(open(f)):
-            k = (short(r.get("Kernel_Name", "")), r.get("Counter_Name"))
+            if r.get("Counter_Name") != cname:
+                continue
+            k = k1_kind(r.get("Kernel_Name", ""))
+            if k is None:
+                continue
             agg[k][0] += float(r.get("Counter_Value", 0))
             agg[k][1] += 1
-    print("== PMC", ctr)
-    for (kn, cn), (v, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:8]:
-        print("%-70s %s per_launch=%.1f (n=%d)" % (kn, cn, v / max(c, 1), c))
-        summary.setdefault("pmc", []).append({"kernel": kn, "counter": cn, "per_launch": v / max(c, 1), "launches": c})
-        pmc[(kn, cn)] = v / max(c, 1)
+    print("== PMC", cname, "(KB per launch, raw)")
+    for k, (v, c) in sorted(agg.items()):
+        print("%-28s per_launch=%.1f (n=%d)" % (k, v / max(c, 1), c))
+        summary.setdefault("pmc", []).append({"kernel": k, "counter": cname, "per_launch": v / max(c, 1), "launches": c})
+    totals[cname] = agg
 
-
-def per_launch(kernel_sub, counter):
-    for (kn, cn), v in pmc.items():
-        if kernel_sub in kn and cn == counter:
-            return v
-    return None
-
-
-fs, fl = per_launch("nn_search_kernel", "FETCH_SIZE"), per_launch("linearize_kernel", "FETCH_SIZE")
-ws, wl = per_launch("nn_search_kernel", "WRITE_SIZE"), per_launch("linearize_kernel", "WRITE_SIZE")
-if None not in (fs, fl, ws, wl):
-    hbm = int((2.0 * (fs + fl) + ws + wl) * 1024)
-    traffic = {
-        "kernel": "K1 = sga::nn_search_kernel<float, 64> + sga::linearize_kernel<float, GICP, kd-tree>, config C3 1M<->1M, averaged over the passes of whole registrations (cold and warm)",
-        "source": "scripts/profile_gpu.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py",
-        "commit": commit,
-        "FETCH_SIZE_KB_per_launch_raw": {"nn_search_kernel": fs, "linearize_kernel": fl},
-        "WRITE_SIZE_KB_per_launch_raw": {"nn_search_kernel": ws, "linearize_kernel": wl},
-        "correction": "MI355X_MICROARCH.md section HBM: on gfx950 FETCH_SIZE tallies 128-B requests at 64 B -> x2 on the read side; WRITE_SIZE as reported",
-        "hbm_bytes_per_launch": hbm,
-        "algorithmic_bytes_per_launch": 100000000,
-    }
-    json.dump(traffic, open(os.path.join(out, "%s_k1_traffic.json" % tag), "w"), indent=1)
-    print("== K1 HBM traffic per pass: %.1f MB (algorithmic 100 MB) -> %.2fx" % (hbm / 1e6, hbm / 1e8))
+if totals.get("FETCH_SIZE") and totals.get("WRITE_SIZE"):
+    passes = sum(c for k, (v, c) in totals["FETCH_SIZE"].items() if k in K1_SEARCH)
+    fetch_kb = sum(v for v, c in totals["FETCH_SIZE"].values())
+    passes_w = sum(c for k, (v, c) in totals["WRITE_SIZE"].items() if k in K1_SEARCH)
+    write_kb = sum(v for v, c in totals["WRITE_SIZE"].values())
+    if passes > 0 and passes_w > 0:
+        hbm = int((2.0 * fetch_kb / passes + write_kb / passes_w) * 1024)
+        traffic = {
+            "kernel": "K1 = the launch(es) of one linearization pass, config C3 1M<->1M: sga::search_linearize_kernel<float, GICP> (cold passes and the first warm ones: search + factors in one launch), "
+                      "sga::nn_search_queue_kernel<float, warm, GICP> (warm passes after small motions: certificate check, queue-fed walks, factors), and on the non-fused paths "
+                      "sga::nn_search_kernel + sga::linearize_kernel; averaged over the passes of whole registrations",
+            "source": "scripts/profile_gpu.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py",
+            "commit": commit,
+            "passes": passes,
+            "FETCH_SIZE_KB_per_launch_raw": {k: v / max(c, 1) for k, (v, c) in totals["FETCH_SIZE"].items()},
+            "WRITE_SIZE_KB_per_launch_raw": {k: v / max(c, 1) for k, (v, c) in totals["WRITE_SIZE"].items()},
+            "correction": "MI355X_MICROARCH.md section HBM: on gfx950 FETCH_SIZE tallies 128-B requests at 64 B -> x2 on the read side; WRITE_SIZE as reported",
+            "hbm_bytes_per_launch": hbm,
+            "algorithmic_bytes_per_launch": 100000000,
+        }
+        json.dump(traffic, open(os.path.join(out, "%s_k1_traffic.json" % tag), "w"), indent=1)
+        print("== K1 HBM traffic per pass: %.1f MB (algorithmic 100 MB) -> %.2fx" % (hbm / 1e6, hbm / 1e8))
 
 for f in find("odom/**/*kernel_stats.csv"):
     rows = list(csv.DictReader(open(f)))

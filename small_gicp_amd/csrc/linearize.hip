@@ -910,46 +910,69 @@ __global__ __launch_bounds__(kTile) void error_kernel(const ErrParams<Real> p) {
 // When `host` is given the result is handed to the host right here: copied into pinned, device-mapped host memory, then a
 // sequence number is published (system-scope release) on which the host spins.  This replaces hipMemcpyAsync +
 // hipStreamSynchronize, whose fixed cost is paid twice per optimizer iteration.
-constexpr int kReduceGroups = 128;
+constexpr int kReduceGroups = 64;
 
-__global__ __launch_bounds__(256) void reduce_rows_kernel(
+constexpr int kReduceSlices = 8;  // 1024 threads = 8 slices of 128 columns
+__global__ __launch_bounds__(kReduceSlices * kCols) void reduce_rows_kernel(
   const double* __restrict__ partials, int nrows, int ncols, int row_stride, double* __restrict__ stage, unsigned* __restrict__ ticket, double* __restrict__ out, int out_n, double* __restrict__ host,
   unsigned long long seq, int derive) {
-  __shared__ double sh[2][kCols];
+  __shared__ double sh[kReduceSlices][kCols];
   __shared__ unsigned sh_ticket;
-  const int c = threadIdx.x & (kCols - 1), s = threadIdx.x / kCols;  // 2 slices of up to 128 columns
+  const int c = threadIdx.x & (kCols - 1), s = threadIdx.x / kCols;
   const int G = gridDim.x;
-  double acc = 0.0;
-  if (c < ncols)
-    for (int r = blockIdx.x + s * G; r < nrows; r += 2 * G) acc += partials[static_cast<size_t>(r) * row_stride + c];
-  sh[s][c] = acc;
+  // stage 1: (workgroup g, slice s) adds rows g + G * s, g + G * (s + 8), ...: four independent chains, the loads of a chain in flight together
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  if (c < ncols) {
+    const int step = G * kReduceSlices;
+    int r = blockIdx.x + G * s;
+    for (; r + 3 * step < nrows; r += 4 * step) {
+      const double v0 = partials[static_cast<size_t>(r) * row_stride + c], v1 = partials[static_cast<size_t>(r + step) * row_stride + c];
+      const double v2 = partials[static_cast<size_t>(r + 2 * step) * row_stride + c], v3 = partials[static_cast<size_t>(r + 3 * step) * row_stride + c];
+      a0 += v0, a1 += v1, a2 += v2, a3 += v3;
+    }
+    for (; r < nrows; r += step) a0 += partials[static_cast<size_t>(r) * row_stride + c];
+  }
+  sh[s][c] = (a0 + a1) + (a2 + a3);
   __syncthreads();
-  if (G == 1) {  // a single workgroup (small grids): its sums are the totals — no stage rows, no ticket (two dependent round trips less)
-    if (threadIdx.x < kCols) sh[0][threadIdx.x] += sh[1][threadIdx.x];
-  } else {
-    if (threadIdx.x < kCols) __hip_atomic_store(&stage[blockIdx.x * kCols + threadIdx.x], sh[0][threadIdx.x] + sh[1][threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  auto fold = [&]() {  // sh[0][c] = sum over the slices, fixed order
+    if (threadIdx.x < kCols) {
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < kReduceSlices; k++) t += sh[k][threadIdx.x];
+      sh[0][threadIdx.x] = t;
+    }
+    __syncthreads();
+  };
+  fold();
+  if (G > 1) {
+    if (threadIdx.x < kCols) __hip_atomic_store(&stage[blockIdx.x * kCols + threadIdx.x], sh[0][threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) sh_ticket = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (sh_ticket != static_cast<unsigned>(G - 1)) return;  // workgroup-uniform
-    {  // the last workgroup adds the G stage rows: slice s takes rows s, s + 2, ... (independent loads), fixed order
-      double t = 0.0;
-      for (int g = s; g < G; g += 2) t += __hip_atomic_load(&stage[g * kCols + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __syncthreads();
-      sh[s][c] = t;
-      __syncthreads();
-      if (threadIdx.x < kCols) sh[0][threadIdx.x] += sh[1][threadIdx.x];
+    // the last workgroup adds the G <= 64 stage rows: slice s takes rows s, s + 8, ...: at most 8 loads per thread, all in flight
+    double v[kReduceGroups / kReduceSlices];
+#pragma unroll
+    for (int k = 0; k < kReduceGroups / kReduceSlices; k++) {
+      const int g = s + k * kReduceSlices;
+      v[k] = g < G ? __hip_atomic_load(&stage[g * kCols + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
     }
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < kReduceGroups / kReduceSlices; k++) t += v[k];
+    __syncthreads();
+    sh[s][c] = t;
+    __syncthreads();
+    fold();
   }
-  __syncthreads();
   if (threadIdx.x < kCols) {
-    const int c = threadIdx.x;
-    const double t = (derive && is_derived_col(c)) ? derived_entry(c, sh[0]) : sh[0][c];  // moment form: H_rr, H_rt, b_r from the totals
-    if (c < out_n) {
-      const double r = c < ncols ? t : 0.0;
-      out[c] = r;
-      if (host != nullptr) host[c] = r;
+    const int cc = threadIdx.x;
+    const double t = (derive && is_derived_col(cc)) ? derived_entry(cc, sh[0]) : sh[0][cc];  // moment form: H_rr, H_rt, b_r from the totals
+    if (cc < out_n) {
+      const double r = cc < ncols ? t : 0.0;
+      out[cc] = r;
+      if (host != nullptr) host[cc] = r;
     }
   }
   if (G > 1 && threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch on this stream
@@ -965,8 +988,8 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(
 static size_t partial_rows(size_t n) { return std::max<size_t>(kMaxBlocks, (n + 63) / 64); }
 
 static void launch_reduce(sga_context* ctx, const double* partials, int nrows, int ncols, int row_stride, double* stage, double* out, int out_n, double* host, unsigned long long seq, bool derive = false) {
-  const int groups = nrows > 64 ? std::min(kReduceGroups, std::max(32, nrows / 64)) : 1;
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3(groups), dim3(256), 0, ctx->stream, partials, nrows, ncols, row_stride, stage, ctx->d_ticket.p, out, out_n, host, seq, derive ? 1 : 0);
+  const int groups = nrows > 256 ? std::min(kReduceGroups, std::max(8, nrows / 128)) : 1;  // <= 256 rows: one workgroup, no hand-off between workgroups
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(groups), dim3(kReduceSlices * kCols), 0, ctx->stream, partials, nrows, ncols, row_stride, stage, ctx->d_ticket.p, out, out_n, host, seq, derive ? 1 : 0);
 }
 
 static int g_fuse_max = getenv("SGA_FUSE_MAX") ? atoi(getenv("SGA_FUSE_MAX")) : kFuseMaxBlocks;
@@ -1213,14 +1236,14 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
       }
     }
   }
-  if (timed) {
-    (void)hipEventRecord(ctx->ev1, ctx->stream);
-    ctx->pending |= 1;
-  }
   if (fused_search)
     launch_reduce(ctx, pb->partials.p, fused_rows, ncols, kRow, pb->partials.p + partial_rows(pb->n) * kRow, d_out30, out_n, host, seq, true);
   else if (!fuse)
     launch_reduce(ctx, pb->partials.p, p.n > 0 ? blocks : 0, ncols, kRow, pb->partials.p + partial_rows(pb->n) * kRow, d_out30, out_n, host, seq, true);
+  if (timed) {  // the whole GPU side of the pass: search + factors + the sum of the rows
+    (void)hipEventRecord(ctx->ev1, ctx->stream);
+    ctx->pending |= 1;
+  }
   SGA_HIP(hipGetLastError());
   pb->last_math = math;
   if (!voxel) {
