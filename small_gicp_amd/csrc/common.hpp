@@ -203,6 +203,9 @@ struct sga_problem {
   double T_prev[16] = {0};       // pose of the last linearization (column-major), valid iff prev_valid
   bool prev_valid = false;
   int prev_math = 0;
+  int lin_factor = -1;           // factor kind, pose of the last linearize of any kind, and whether it stored its mahalanobis matrices
+  double lin_T[16] = {0};
+  bool maha_valid = false;
   int last_math = 0;             // arithmetic of the last linearize of any kind (which mahalanobis cache is current)
   float bbox_lo[3] = {0, 0, 0}, bbox_hi[3] = {0, 0, 0};  // bounding box of the source (source frame): bounds the motion between two poses
   uint64_t cold_passes = 0, warm_passes = 0;  // passes against a kd-tree since the problem was created

@@ -104,6 +104,7 @@ struct LinParams {
   const int* __restrict__ hint;  // exact nearest neighbour per source point at this pose (kd position) or -1, from nn_search_kernel
   const unsigned char* __restrict__ reject;  // optional: verdict of a host rejector per source point in the CALLER's order (1 = reject)
   Real* __restrict__ maha;  // n*6
+  int store_maha;  // cache the mahalanobis matrices for the error kernel (robust factors); otherwise they are recomputed if ever asked for
   Rigid<Real> T;
   float max_sq;  // INFINITY = no rejector
   float bound2;  // a neighbour counts only if kd_dist2 < bound2 (max_sq nudged up by an ulp, or INFINITY); the walks reach a little farther
@@ -785,7 +786,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   if (active) {
     lp.corr[i] = inl ? j : -1;
     if constexpr (FACTOR == SGA_GICP) {
-      if (inl) {
+      if (inl && lp.store_maha) {
         Real* mm = lp.maha + static_cast<size_t>(i) * 6;
         mm[0] = Mh.xx, mm[1] = Mh.xy, mm[2] = Mh.xz, mm[3] = Mh.yy, mm[4] = Mh.yz, mm[5] = Mh.zz;
       }
@@ -992,6 +993,7 @@ static void launch_reduce(sga_context* ctx, const double* partials, int nrows, i
   hipLaunchKernelGGL(reduce_rows_kernel, dim3(groups), dim3(kReduceSlices * kCols), 0, ctx->stream, partials, nrows, ncols, row_stride, stage, ctx->d_ticket.p, out, out_n, host, seq, derive ? 1 : 0);
 }
 
+static bool g_lazy_maha = getenv("SGA_LAZY_MAHA") ? atoi(getenv("SGA_LAZY_MAHA")) != 0 : true;
 static int g_fuse_max = getenv("SGA_FUSE_MAX") ? atoi(getenv("SGA_FUSE_MAX")) : kFuseMaxBlocks;
 static int g_lin_pts_min = getenv("SGA_LIN_PTS_MIN") ? atoi(getenv("SGA_LIN_PTS_MIN")) : 131072;
 static int grid_blocks(int num_tiles) { return num_tiles < kMaxBlocks ? (num_tiles < 1 ? 1 : num_tiles) : kMaxBlocks; }
@@ -1106,6 +1108,7 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
     p.maha = pb->maha64.p;
   }
   p.T = rigid_from_colmajor<Real>(T);
+  p.store_maha = (fp->robust_kind != SGA_ROBUST_NONE || !g_lazy_maha) ? 1 : 0;  // the error passes of a robust factor run the error kernel
   const bool host_rejector = pb->rejector_fn != nullptr && !voxel;
   p.max_sq = (fp->max_dist_sq < 0 || host_rejector) ? INFINITY : static_cast<float>(fp->max_dist_sq);  // a user rejector sees every nearest neighbour
   p.bound2 = p.max_sq < 3.0e38f ? p.max_sq * 1.0000002f : INFINITY;  // d2 == max_sq must still be found (strict '>' rejector)
@@ -1246,6 +1249,9 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
   }
   SGA_HIP(hipGetLastError());
   pb->last_math = math;
+  pb->lin_factor = fp->factor_kind;
+  memcpy(pb->lin_T, T, sizeof(pb->lin_T));
+  pb->maha_valid = p.store_maha != 0;
   if (!voxel) {
     memcpy(pb->T_prev, T, sizeof(pb->T_prev));
     pb->prev_valid = true;
@@ -1255,6 +1261,38 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
     else
       pb->cold_passes++;
   }
+  return SGA_OK;
+}
+
+// The mahalanobis matrices of the last linearization, (C_t + R C_s R^T)^-1 per accepted pair (gicp_factor.hpp:57-60), written on
+// demand: the hot loop of a non-robust registration never reads them (the error model answers the error passes), so the factor
+// kernels skip the 24-byte store per point; the error kernel and sga_problem_get_factors call this first.
+template <typename Real>
+__global__ void recompute_maha_kernel(const Cov8* __restrict__ src_cov, const Cov8* __restrict__ tgt_cov, const int* __restrict__ corr, int n, Rigid<Real> T, Real* __restrict__ maha) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int j = corr[i];
+  if (j < 0) return;
+  const Sym3<Real> Cs = load_sym<Real>(src_cov, i);
+  const Sym3<Real> Ct = load_sym<Real>(tgt_cov, j);
+  const Sym3<Real> RCR = rotate_sym(T.r, Cs);
+  const Sym3<Real> M = inverse_sym<Real>({Ct.xx + RCR.xx, Ct.xy + RCR.xy, Ct.xz + RCR.xz, Ct.yy + RCR.yy, Ct.yz + RCR.yz, Ct.zz + RCR.zz});
+  Real* m = maha + static_cast<size_t>(i) * 6;
+  m[0] = M.xx, m[1] = M.xy, m[2] = M.xz, m[3] = M.yy, m[4] = M.yz, m[5] = M.zz;
+}
+
+int problem_ensure_maha(sga_context* ctx, sga_problem* pb) {
+  if (pb->maha_valid || pb->n == 0 || pb->lin_factor != SGA_GICP) return SGA_OK;
+  const sga_index* idx = pb->target;
+  const int n = static_cast<int>(pb->n);
+  if (pb->last_math == SGA_MATH_FP64) {
+    if (pb->maha64.n < pb->n * 6) SGA_TRY(pb->maha64.alloc(pb->n * 6));
+    hipLaunchKernelGGL((recompute_maha_kernel<double>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, pb->cov.p, idx->cov.p, pb->corr.p, n, rigid_from_colmajor<double>(pb->lin_T), pb->maha64.p);
+  } else {
+    hipLaunchKernelGGL((recompute_maha_kernel<float>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, pb->cov.p, idx->cov.p, pb->corr.p, n, rigid_from_colmajor<float>(pb->lin_T), pb->maha.p);
+  }
+  SGA_HIP(hipGetLastError());
+  pb->maha_valid = true;
   return SGA_OK;
 }
 
@@ -1268,10 +1306,14 @@ static int error_dispatch(sga_context* ctx, sga_problem* pb, const sga_factor_pa
   p.tgt_pts = idx->kind != SGA_INDEX_KDTREE ? idx->pts.p : idx->kd_pts.p;
   p.tgt_nrm = idx->nrm.p;
   p.corr = pb->corr.p;
+  if (fp->factor_kind == SGA_GICP) {
+    if ((sizeof(Real) == 4) != (pb->last_math == SGA_MATH_FP32)) return fail(SGA_ERR_INVALID, "sga_error in another arithmetic than the last sga_linearize");
+    SGA_TRY(problem_ensure_maha(ctx, pb));
+  }
   if constexpr (sizeof(Real) == 4) {
     p.maha = pb->maha.p;
   } else {
-    if (pb->maha64.n < pb->n * 6) return fail(SGA_ERR_INVALID, "sga_error(fp64) before sga_linearize(fp64)");
+    if (fp->factor_kind == SGA_GICP && pb->maha64.n < pb->n * 6) return fail(SGA_ERR_INVALID, "sga_error(fp64) before sga_linearize(fp64)");
     p.maha = pb->maha64.p;
   }
   p.T = rigid_from_colmajor<Real>(T);

@@ -14,6 +14,7 @@ namespace sga {
 
 int ensure_temp(sga_context* ctx, size_t bytes);
 size_t problem_partials_doubles(size_t n);
+int problem_ensure_maha(sga_context* ctx, sga_problem* pb);
 int cloud_bbox(sga_context* ctx, const float4* pts, size_t n, float lo[3], float hi[3]);
 
 __device__ __forceinline__ unsigned long long spread3(unsigned long long v) {
@@ -263,6 +264,7 @@ int sga_problem_get_factors(sga_context* ctx, const sga_problem* pb, int64_t* ta
   DevBuf<float> d_m;
   if (target_index) SGA_TRY(d_idx.alloc(n));
   if (mahalanobis6) SGA_TRY(d_m.alloc(n * 6));
+  if (mahalanobis6) SGA_TRY(problem_ensure_maha(ctx, const_cast<sga_problem*>(pb)));  // written on demand (linearize.hip)
   const float4* tpts = pb->target->kind != SGA_INDEX_KDTREE ? pb->target->pts.p : pb->target->kd_pts.p;
   const int is_flat = pb->target->kind == SGA_INDEX_FLATMAP ? 1 : 0;
   if (pb->last_math == SGA_MATH_FP64 && pb->maha64.p != nullptr)  // the last linearize cached its mahalanobis in fp64
