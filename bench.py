@@ -106,6 +106,11 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
+    # stdout carries the ONE JSON line and nothing else: RCCL / gloo print their banners to fd 1 from native code, so fd 1 is pointed
+    # at stderr for the run and the JSON goes to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -170,9 +175,12 @@ def main():
         return sga.make_setting("GICP", max_correspondence_distance=1.0, max_iterations=max_iters, rotation_eps=0.0, translation_eps=0.0, math_mode=math)
 
     # the unsharded registration of the same job (before the communicator exists): what the sharded run must reproduce
-    ref_pose = None
+    # (fp64 per-pair arithmetic: the sharded sums then equal the unsharded ones to rounding of the fp64 row sums, 1e-9 m; in the
+    # default fp32 arithmetic the partial sums GROUP by shard — 64 / 256 points per fp32 sum — and the poses agree to ~1e-6 m)
+    ref_pose = {}
     if strong and world > 1 and rank == 0:
-        ref_pose = sga.Problem(tree, src_full, np.eye(4)).align(setting_for(ITERS_PER_ALIGN, args.math)).T_target_source
+        for m in ("fp64", "fp32"):
+            ref_pose[m] = sga.Problem(tree, src_full, np.eye(4)).align(setting_for(ITERS_PER_ALIGN, m)).T_target_source
 
     native_comm = False
     if use_dist:
@@ -199,17 +207,20 @@ def main():
             dist.all_reduce(h)
             return h.numpy()
 
+        cur_math = [args.math]
+
         def lin_cb(T):
-            problem.linearize_async(setting_for(1, args.math).factor, T, acc.data_ptr())
+            problem.linearize_async(setting_for(1, cur_math[0]).factor, T, acc.data_ptr())
             ctx.synchronize()
             return sga.unpack_accumulator(reduce_(acc))
 
         def err_cb(T):
-            problem.error_async(setting_for(1, args.math).factor, T, acc1.data_ptr())
+            problem.error_async(setting_for(1, cur_math[0]).factor, T, acc1.data_ptr())
             ctx.synchronize()
             return float(reduce_(acc1)[0])
 
         def run_align(max_iters, math=args.math):
+            cur_math[0] = math
             return sga.optimize(setting_for(max_iters, math), np.eye(4), lin_cb, err_cb)
 
     else:
@@ -256,11 +267,15 @@ def main():
 
     shard_check = None
     if strong and world > 1:
-        full = run_align(ITERS_PER_ALIGN)  # a complete registration of the sharded job
+        shard_check = {}
+        for m, tol in (("fp64", 1e-9), ("fp32", 1e-5)):
+            full = run_align(ITERS_PER_ALIGN, m)  # a complete registration of the sharded job
+            if rank == 0:
+                dt, dr = pose_error(full.T_target_source, ref_pose[m])
+                shard_check[m] = {"dt_m": dt, "dr_rad": dr, "tolerance": tol}
+                assert dt <= tol and dr <= tol, "sharded registration differs from the unsharded one: %r" % (shard_check,)
         if rank == 0:
-            dt, dr = pose_error(full.T_target_source, ref_pose)
-            shard_check = {"dt_m": dt, "dr_rad": dr, "tolerance": 1e-9}
-            assert dt <= 1e-9 and dr <= 1e-9, "sharded registration differs from the unsharded one: %r" % (shard_check,)
+            shard_check["note"] = "fp64 per-pair arithmetic: equal to the rounding of the fp64 row sums; fp32 (the timed mode): the fp32 partial sums group by shard"
 
     sustained = None
     if args.sustain_s > 0:
@@ -309,8 +324,10 @@ def main():
             "config": {
                 "workload": "C3: GICP, per-point covariances k=20, %d target <-> %d source points%s, max_corr_dist 1.0 m" % (n, n, "" if strong else " per GPU"),
                 "step": "1 outer LM iteration = one linearize pass (search + factor kernel, which also accumulates the quadratic error model) + host 6x6 solve(s) + the trial errors evaluated on the host from that model (exact for the cached correspondences; replaces the reference's error passes); restart from identity (and a cold search state) every %d steps" % ITERS_PER_ALIGN,
-                "parallelism": ("%s scaling: source %s x%d, target index replicated, RCCL all-reduce of 96 doubles per linearize (the system + the error-model moments) (%s)"
-                                % (args.scaling, "sharded (contiguous Morton ranges of one cloud)" if strong else "one independent cloud per rank", world, "native ncclAllReduce on the library stream" if native_comm else "torch.distributed callbacks")) if use_dist else "single GPU",
+                "parallelism": ("%s scaling: source %s x%d, target index replicated, %s"
+                                % (args.scaling, "sharded (contiguous Morton ranges of one cloud)" if strong else "one independent cloud per rank", world,
+                                   "RCCL all-reduce of 96 doubles per linearize (the system + the error-model moments): native ncclAllReduce on the library stream" if native_comm
+                                   else "FALLBACK (no RCCL communicator): torch.distributed all-reduce of 30 doubles per linearize + 1 per error pass through sga_linearize_async / sga_error_async callbacks")) if use_dist else "single GPU",
                 "source_points_total": n * (1 if strong else world),
                 "source_points_per_gpu": n_rank,
             },
@@ -363,7 +380,8 @@ def main():
         if rank == 0:
             out["kitti_odom"] = r
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
