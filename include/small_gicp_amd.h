@@ -196,6 +196,8 @@ void sga_set_error_model(int enabled);
  * search scanned (source order of the engine, i.e. sorted); get returns the last pass's counts (n ints). */
 int sga_problem_set_search_stats(sga_context* ctx, sga_problem* pb, int enabled);
 int sga_problem_get_search_stats(sga_context* ctx, const sga_problem* pb, int* leaves_per_point);
+/* Diagnostics: the source points in the engine's order (n x 4 floats: x, y, z, original index as bits). */
+int sga_problem_get_sorted_points(sga_context* ctx, const sga_problem* pb, float* xyzw);
 /* Which nearest-neighbour kernel the linearization runs (results do not depend on it; tests compare the two): 1 = the queue-fed
  * kernel (a wave owns chunk_tiles x 64 source points and refills its lanes from a queue), 0 = one query per lane, 2 (default) =
  * queue-fed for warm passes after a small motion, one query per lane otherwise.  chunk_tiles_* <= 0 keep the current value (4 / 4). */

@@ -36,7 +36,6 @@ def lin(T):
 
 sga.optimize(st, np.eye(4), lin, lambda T: pb.error(st.factor, T))
 
-
 def makespan(dur, order, slots=8192):
     h = [0.0] * slots
     heapq.heapify(h)
@@ -75,3 +74,19 @@ for k in range(0, min(4, len(works))):
             d = np.array(d)
             out.append("last %.0f%% in %d parts: %.0f" % (100 * frac, parts, makespan(d, np.arange(len(d)))))
     print("pass %d: natural %.0f us | %s" % (k, base, " | ".join(out)), flush=True)
+
+# static (pose-invariant) per-tile features of the sorted source: extent of the 64 points, and the same over the kd-ordered target
+sp = pb.sorted_points()[:, :3]
+m = len(sp) // 64 * 64
+tiles = sp[:m].reshape(-1, 64, 3).astype(np.float64)
+extent = np.linalg.norm(tiles.max(axis=1) - tiles.min(axis=1), axis=1)
+print("static feature: tile extent (m) p50 %.2f p90 %.2f p99 %.2f max %.2f" % tuple(np.percentile(extent, [50, 90, 99, 100])))
+for k in range(0, min(4, len(works))):
+    w = works[k]
+    dur = 10.0 + 6.0 * w
+    order = np.argsort(-extent, kind="stable")
+    print("pass %d: corr(work, extent) = %.2f, rank corr = %.2f | makespan natural %.0f, largest extent first %.0f, own work first (oracle) %.0f"
+          % (k, np.corrcoef(w, extent)[0, 1], np.corrcoef(np.argsort(np.argsort(w)), np.argsort(np.argsort(extent)))[0, 1], makespan(dur, np.arange(len(w))), makespan(dur, order),
+             makespan(dur, np.argsort(-w, kind="stable"))), flush=True)
+
+

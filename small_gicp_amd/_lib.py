@@ -117,6 +117,7 @@ SYMBOLS = [
     ("sga_set_error_model", None, [C.c_int]),
     ("sga_problem_set_search_stats", C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     ("sga_problem_get_search_stats", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("sga_problem_get_sorted_points", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("sga_set_search_mode", None, [C.c_int, C.c_int, C.c_int]),
     ("sga_get_warm_limit", C.c_double, []),
     ("sga_problem_get_pass_stats", C.c_int, [_vp, _vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),

@@ -504,6 +504,12 @@ class Problem:
         check(load().sga_problem_get_search_stats(self.ctx.h, self.h, out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def sorted_points(self):
+        """Diagnostics: the source points in the engine's order (n x 4 float32; the 4th column holds the original index as bits)."""
+        out = np.zeros((len(self.source), 4), dtype=np.float32)
+        check(load().sga_problem_get_sorted_points(self.ctx.h, self.h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def pass_stats(self):
         """Linearization passes since creation by kind (cold = full search, warm = certified neighbours) and the source points
         the warm passes had to search again."""

@@ -1612,6 +1612,15 @@ int sga_problem_set_search_stats(sga_context* ctx, sga_problem* pb, int enabled)
   pb->dbg_leaves.release();
   return SGA_OK;
 }
+// diagnostics: the source points in the engine's order (sorted by target leaf at init_T, then Morton): n x 4 floats (x, y, z, original index bits)
+int sga_problem_get_sorted_points(sga_context* ctx, const sga_problem* pb, float* xyzw) {
+  if (!ctx || !pb || !xyzw) return fail(SGA_ERR_INVALID, "null argument");
+  if (pb->n == 0) return SGA_OK;
+  SGA_ENTER(ctx);
+  SGA_HIP(hipMemcpyAsync(xyzw, pb->pts.p, pb->n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+  SGA_HIP(hipStreamSynchronize(ctx->stream));
+  return SGA_OK;
+}
 int sga_problem_get_search_stats(sga_context* ctx, const sga_problem* pb, int* leaves_per_point) {
   if (!ctx || !pb || !leaves_per_point) return fail(SGA_ERR_INVALID, "null argument");
   if (pb->dbg_leaves.n < pb->n) return fail(SGA_ERR_INVALID, "search statistics are not enabled");
