@@ -3,9 +3,19 @@
 // Replaces ParallelReductionOMP::linearize / ::error (registration/reduction_omp.hpp:24-70) fused with
 // {GICP,PointToPlaneICP,ICP}Factor::linearize / ::error (factors/*.hpp), RobustFactor (robust_kernel.hpp:70-98),
 // DistanceRejector (rejector.hpp:19-28) and the nearest-neighbour search (ann/kdtree.hpp:193-233 or
-// ann/incremental_voxelmap.hpp:99-119).  One lane per source point; tiles of 256 points; per-pair values reduced with
-// DPP inside a wave (fp32), accumulated per wave in fp64 in LDS, one 32-double partial row per workgroup, then a single
-// deterministic fp64 tree over the partial rows.  The 6x6 solve stays on the host (optimizer.cpp).
+// ann/incremental_voxelmap.hpp:99-119).  The 6x6 solve stays on the host (optimizer.hip).
+//
+// One linearization pass = ONE search + factor launch and reduce_rows_kernel:
+//   search_linearize_kernel   one query per lane, one wave per workgroup; cold passes (full walk) and warm passes after larger
+//                             motions (certificate check first); the wave then evaluates the factors of its own 64 points
+//   nn_search_queue_kernel    warm passes after small motions: certificate check per tile, the few walks fed from a queue, the
+//                             factors of the chunk (4 tiles) at the end
+//   nn_search_kernel + linearize_kernel   the same in two launches: host-rejector callback, fp64 per-pair arithmetic;
+//                             linearize_kernel alone for voxel-map targets (the lookup happens inside it)
+// Factor stage in MOMENT form (accumulate_moments / derived_entry): 74 sums per pass that are both the normal equations and the
+// coefficients of the quadratic error model sga_error answers from without a pass over the cloud; error_kernel (K2) only for robust
+// factors, the async API and tests.  Sums: DPP inside a wave (fp32), fp64 across waves, one row of 96 doubles per tile / chunk /
+// workgroup, added in fixed order by reduce_rows_kernel (no floating-point atomics: bit-reproducible).
 #include <algorithm>
 #include <chrono>
 #include <thread>
@@ -26,8 +36,8 @@ constexpr int kRow = 96;             // doubles per partial row: [0, 29) the sys
 constexpr int kCols = 128;           // columns the reduction kernels handle (>= kRow)
 constexpr int kModelOff = 32;        // error model: [32, 41) sum p_a g_j, [41, 59) sum p_a M'_c, [59, 95) sum p_a p_b M'_c
 constexpr int kModelCols = 95;
-constexpr int kSearchBlock = 64;      // K1a: one wave per workgroup
-constexpr int kMaxBlocks = 2048;     // K1b / K2: 8 workgroups per CU, the whole grid is resident
+constexpr int kSearchBlock = 64;      // search kernels: one wave per workgroup
+constexpr int kMaxBlocks = 2048;     // linearize_kernel / error_kernel: 8 workgroups per CU, the whole grid is resident
 
 // Small grids (a 15k-point scan is 60 workgroups) fold the final reduction into the producer kernel: every workgroup publishes its
 // partial row (agent-scope write-through stores), takes a ticket, and the workgroup that arrives last adds the rows in fixed order
@@ -147,7 +157,7 @@ __device__ __forceinline__ float rex_from_r2(float r2) { return sqrtf(r2) * 0.99
 // points (isolated clutter: the longest walks there are) would be searched again in every pass.
 constexpr float kSearchMargin = 0.05f;
 
-// K1a: exact nearest neighbour of every transformed source point: nn[i] = its kd position (or -1 when nothing lies within the
+// The search: exact nearest neighbour of every transformed source point: nn[i] = its kd position (or -1 when nothing lies within the
 // search bound), rex[i] = the exclusion radius the walk certifies (kd_search.hpp: every OTHER target point is farther than rex[i]).
 //
 // COLD pass (check = 0): the full walk for every point, seeded with the previous neighbour.
@@ -159,8 +169,8 @@ constexpr float kSearchMargin = 0.05f;
 // move the points by micrometres: their passes are a stream over 40 bytes per point.
 //
 // One wave per workgroup (a finished wave frees its slot and its 4 KB of stack at once; the hardware dispatcher balances the uneven
-// walks), and without the per-pair algebra the kernel fits 8 waves per SIMD, which the walk needs.  K1b (linearize_kernel)
-// evaluates the factors over nn[].
+// walks) at 8 waves per SIMD (64 VGPRs), which the walk needs.  The factor stage either follows inside the same wave
+// (search_linearize_kernel: the moment form needs 42 VGPRs at one point per lane) or runs as linearize_kernel over nn[].
 template <typename Real>
 struct NNParams {
   const float4* __restrict__ src_pts;
@@ -271,7 +281,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
 #endif
 }
 
-// K1a, queue-fed.  The walks of neighbouring queries differ in length (one leaf for most, twenty for a few): with one query per
+// The search, queue-fed.  The walks of neighbouring queries differ in length (one leaf for most, twenty for a few): with one query per
 // lane for the lifetime of a wave, a wave runs as long as its longest walk and most lanes idle most of the time (measured: about a
 // fifth of the VALU lanes active).  Here a wave owns a CHUNK of consecutive tiles and a small queue in LDS:
 //   stage:  a tile of 64 queries is prepared by all 64 lanes at once (coalesced loads; in a warm pass the certificate check — lanes
@@ -635,7 +645,7 @@ __device__ __forceinline__ void accumulate_moments(const Real (&P)[PTS][3], cons
     }
 }
 
-// K1b.  TARGET: 0 kd-tree (the neighbours come from the search kernel), 1 Gaussian voxel map, 2 flat voxel map (the lookup of a
+// The factor stage as a kernel of its own.  TARGET: 0 kd-tree (the neighbours come from the search kernel), 1 Gaussian voxel map, 2 flat voxel map (the lookup of a
 // voxel target happens right here).  Streaming + two gathers; a lane handles PTS points (PTS x kTile consecutive points per
 // workgroup step), their products are added up in registers, reduced with DPP inside the wave, in fp64 across waves.
 // The factors of PTS points per lane — points first, first + stride, ... below `limit` — added to the wave's row.
@@ -984,7 +994,7 @@ __global__ __launch_bounds__(kReduceSlices * kCols) void reduce_rows_kernel(
   }
 }
 
-// partial rows (one per workgroup of K1b / K2, or one per 64 source points when the search kernel does the factor algebra itself);
+// partial rows (one per workgroup of linearize_kernel / error_kernel, or one per 64 source points when the search kernel does the factor algebra itself);
 // the stage-1 rows of the reduction follow them
 static size_t partial_rows(size_t n) { return std::max<size_t>(kMaxBlocks, (n + 63) / 64); }
 
@@ -1060,7 +1070,7 @@ static double g_warm_delta = getenv("SGA_WARM_DELTA") ? atof(getenv("SGA_WARM_DE
 // are bound by the number of memory accesses in flight and the queue-fed kernel starts each of them with 10 record fetches; when few
 // lanes walk (the later passes of a registration) the queue packs them into full waves: 124 -> 80, 87 -> 73, 68 -> 53 us.
 static int g_search_queue = getenv("SGA_SEARCH_QUEUE") ? atoi(getenv("SGA_SEARCH_QUEUE")) : 2;
-// 1 (default): the search waves evaluate the factors of their own tiles (search_linearize_kernel); 0: always a separate factor kernel (K1b)
+// 1 (default): the search waves evaluate the factors of their own tiles (search_linearize_kernel); 0: always a separate factor kernel (linearize_kernel)
 static bool g_fuse_search = getenv("SGA_FUSE_SEARCH") ? atoi(getenv("SGA_FUSE_SEARCH")) != 0 : true;
 static double g_queue_delta = getenv("SGA_QUEUE_DELTA") ? atof(getenv("SGA_QUEUE_DELTA")) : 0.02;
 static int g_chunk_tiles_cold = getenv("SGA_CHUNK_COLD") ? atoi(getenv("SGA_CHUNK_COLD")) : 4;
