@@ -160,6 +160,7 @@ struct sga_index {
   sga::DevBuf<float4> kd_nodes4;    // pair records of the even depths (kd_search.hpp)
   sga::DevBuf<float4> kd_boxes;     // tight bounding box of every node: [2 * node] = min corner, [2 * node + 1] = max corner
   sga::DevBuf<float4> kd_groups;    // group headers of the 1-NN walk: the boxes of the (up to) 4 leaves under every node of depth kd_depth - 2
+  sga::DevBuf<float4> kd_leaf;      // leaf blocks of the 1-NN walk: per leaf x[8], y[8], z[8], original index[8] (kd_search.hpp: the fast leaf scan)
   int kd_depth = 0;
   float bbox_lo[3] = {0, 0, 0}, bbox_hi[3] = {0, 0, 0};
   // voxel map

@@ -178,4 +178,67 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
   return v;
 }
 
+// ---- transposing wave reduction: N sums over the 64 lanes in ~3 N instructions ----------------------------------------------------
+// Summing N per-lane values one at a time costs a 6-step DPP chain each.  Here every step HALVES the number of live values instead:
+// of a pair (a, b) a lane keeps the one its lane bit selects, hands the other to its partner lane and adds what the partner sends
+// (one DPP add, or one v_permlane{16,32}_swap + add across rows).  After the six steps lane l holds the wave totals of the values
+// number l and 64 + l.  Partners: lane ^ 1, lane ^ 2 (quad_perm), then rotations by 4 and by 8 inside the row of 16 (a perfect
+// matching between the lanes with the step's bit clear and set that keeps the lower bits), then the row and half-wave swaps.
+template <int CTRL, int N>
+__device__ __forceinline__ void wave_halve_dpp(const float (&v)[N], float (&o)[(N + 1) / 2], bool bit) {
+#pragma unroll
+  for (int k = 0; k < N / 2; k++) {
+    const float keep = bit ? v[2 * k + 1] : v[2 * k], send = bit ? v[2 * k] : v[2 * k + 1];
+    o[k] = keep + dpp_mov_f32<CTRL>(send);
+  }
+  if constexpr ((N & 1) != 0) o[N / 2] = v[N - 1] + dpp_mov_f32<CTRL>(v[N - 1]);  // lanes with the bit set then hold a value that does not exist (index >= N)
+}
+
+typedef unsigned int sga_u32x2 __attribute__((ext_vector_type(2)));
+template <bool HALVES>
+__device__ __forceinline__ sga_u32x2 wave_swap(unsigned a, unsigned b) {
+  if constexpr (HALVES)
+    return __builtin_amdgcn_permlane32_swap(a, b, false, false);  // upper 32 lanes of a <-> lower 32 lanes of b
+  else
+    return __builtin_amdgcn_permlane16_swap(a, b, false, false);  // odd rows of a <-> even rows of b
+}
+// After the swap both registers hold, lane by lane, partial sums of the SAME value of the pair; which one is read off a swapped
+// marker (0 = the first of the pair, 1 = the second), so nothing here depends on which rows the instruction exchanges.
+template <bool HALVES, int N>
+__device__ __forceinline__ void wave_halve_swap(const float (&v)[N], float (&o)[(N + 1) / 2], unsigned& which) {
+  which = wave_swap<HALVES>(0u, 1u).x;
+#pragma unroll
+  for (int k = 0; k < N / 2; k++) {
+    const sga_u32x2 r = wave_swap<HALVES>(__float_as_uint(v[2 * k]), __float_as_uint(v[2 * k + 1]));
+    o[k] = __uint_as_float(r.x) + __uint_as_float(r.y);
+  }
+  if constexpr ((N & 1) != 0) {
+    const sga_u32x2 r = wave_swap<HALVES>(__float_as_uint(v[N - 1]), 0u);
+    o[N / 2] = __uint_as_float(r.x) + __uint_as_float(r.y);
+  }
+}
+
+// in: N <= 128 values per lane (all 64 lanes active).  out: lane l holds the totals of value `slot` (lo) and `64 + slot` (hi); slot
+// is a permutation of the lane numbers.  Totals of values >= N are meaningless.
+template <int N>
+__device__ __forceinline__ void wave_transpose_sum(const float (&v)[N], int lane, float& lo, float& hi, int& slot) {
+  static_assert(N > 64 && N <= 128, "sized for the 72 moment sums");
+  float a[(N + 1) / 2];
+  wave_halve_dpp<0xB1>(v, a, (lane & 1) != 0);   // quad_perm [1,0,3,2]
+  float b[(N + 3) / 4];
+  wave_halve_dpp<0x4E>(a, b, (lane & 2) != 0);   // quad_perm [2,3,0,1]
+  float c[(N + 7) / 8];
+  wave_halve_dpp<0x124>(b, c, (lane & 4) != 0);  // row_ror:4
+  float d[(N + 15) / 16];
+  wave_halve_dpp<0x128>(c, d, (lane & 8) != 0);  // row_ror:8
+  float e[(N + 31) / 32];
+  unsigned m4, m5;
+  wave_halve_swap<false>(d, e, m4);
+  float f[(N + 63) / 64];
+  wave_halve_swap<true>(e, f, m5);
+  lo = f[0];
+  hi = f[1];
+  slot = (lane & 15) | static_cast<int>(m4 << 4) | static_cast<int>(m5 << 5);
+}
+
 }  // namespace sga

@@ -477,6 +477,23 @@ __global__ void kd_groups_kernel(const float4* __restrict__ boxes, int D, int G,
   h[6] = h[7] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// Leaf blocks (kd_search.hpp: the fast leaf scan): the points of every leaf as structure of arrays in one 128-byte line —
+// x[8], y[8], z[8], original index[8] — so that a lane loads the coordinates of two points into adjacent registers (packed fp32
+// arithmetic).  Slots a leaf does not fill lie far away (kKdFar): their distance is huge but finite and never wins.
+__global__ void kd_leaf_blocks_kernel(const float4* __restrict__ pts, uint32_t n, int D, float* __restrict__ blocks) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (8u << D)) return;
+  const uint32_t leaf = i >> 3, slot = i & 7u;
+  const uint32_t pos = kd_bound(n, D, leaf) + slot;
+  const bool valid = pos < kd_bound(n, D, leaf + 1);
+  const float4 p = valid ? pts[pos] : make_float4(kKdFar, kKdFar, kKdFar, 0.f);
+  float* b = blocks + 32ull * leaf;
+  b[slot] = p.x;
+  b[8 + slot] = p.y;
+  b[16 + slot] = p.z;
+  b[24 + slot] = p.w;
+}
+
 static int build_kdtree(sga_context* ctx, const sga_cloud* cloud, sga_index* idx) {
   const size_t n = cloud->n;
   idx->kd_depth = 0;
@@ -552,6 +569,8 @@ static int build_kdtree(sga_context* ctx, const sga_cloud* cloud, sga_index* idx
     SGA_TRY(idx->kd_groups.alloc(8ull << (D - G)));
     hipLaunchKernelGGL(kd_groups_kernel, dim3(((1u << (D - G)) + 255) / 256), block, 0, ctx->stream, idx->kd_boxes.p, D, G, idx->kd_groups.p);
   }
+  SGA_TRY(idx->kd_leaf.alloc(8ull << D));
+  hipLaunchKernelGGL(kd_leaf_blocks_kernel, dim3(((8u << D) + 255) / 256), block, 0, ctx->stream, idx->kd_pts.p, static_cast<uint32_t>(n), D, reinterpret_cast<float*>(idx->kd_leaf.p));
   SGA_HIP(hipGetLastError());
   SGA_HIP(hipStreamSynchronize(ctx->stream));
   return SGA_OK;

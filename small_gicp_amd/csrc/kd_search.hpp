@@ -31,6 +31,7 @@ struct KdView {
   const float4* __restrict__ nodes4;  // pair records: x = own threshold, y / z = thresholds of the left / right child, w = axes (2 bits each)
   const float4* __restrict__ boxes;   // tight bounding boxes: [2 * node] = min corner, [2 * node + 1] = max corner
   const float4* __restrict__ groups;  // group headers: 8 float4 per node of depth gdepth — the boxes of its leaves (kd_visit_group)
+  const float4* __restrict__ leafblk; // leaf blocks: 8 float4 per leaf = x[8], y[8], z[8], original index[8] (one 128-byte line; unused slots far away)
   uint32_t n;
   int depth;    // D; leaves are the 2^D ranges at depth D
   int gdepth;   // D - glevels: the 1-NN walk descends to this depth and handles the leaves below it as one group
@@ -44,6 +45,7 @@ inline KdView make_kd_view(const sga_index* idx) {
   k.nodes4 = idx->kd_nodes4.p;
   k.boxes = idx->kd_boxes.p;
   k.groups = idx->kd_groups.p;
+  k.leafblk = idx->kd_leaf.p;
   k.n = static_cast<uint32_t>(idx->n);
   k.depth = idx->kd_depth;
   k.glevels = idx->kd_depth < 2 ? idx->kd_depth : 2;
@@ -194,6 +196,74 @@ __device__ __forceinline__ void kd_scan_leaf(const KdView& t, uint32_t leaf_node
   KD_TRIP(s, 3);
 }
 
+// ---- the fast leaf scan ----------------------------------------------------------------------------------------------------------
+// A leaf scan with 64-bit (distance, position) keys costs ~190 instructions and is the largest single item of a walk.  The fast
+// state keeps the three nearest points as 32-bit keys instead: the bits of the squared distance with the low 3 bits replaced by the
+// point's slot inside its leaf, so that inserting a point into the sorted triple is v_med3_u32, v_med3_u32, v_min_u32 and the
+// eight distances of a leaf come from a structure-of-arrays leaf block with packed fp32 arithmetic (v_pk_*: two points per
+// instruction, the same operations and rounding per point as kd_dist2).  ~70 instructions per leaf.
+// Truncating 3 bits makes the ORDER of two points uncertain when their distances agree in all the remaining bits (relative
+// difference < 1e-6).  That is detected at the end of the walk (kd_result: the winner and the runner-up share their truncated
+// distance, or the winner sits within 8 ulps of the search bound) and such a query — a few per million on real data, every query
+// on a lattice — is searched again with the exact 64-bit keys.  Everything else the walk decides with these keys is conservative:
+// pruning uses the UPPER end of the winner's distance interval, the exclusion bound the LOWER end of the third's.
+constexpr float kKdFar = 1e18f;             // coordinate of an unused leaf-block slot: squared distance ~3e36, finite
+constexpr uint32_t kKdNoneKey = 0x7149f2cau;  // bits of 1e30f: keys at or above it are no points (unused slots, initial state)
+struct KdFast {
+  uint32_t w1, w2, w3;  // keys of the three nearest points seen, ascending
+  uint32_t l1, l2;      // leaf ranks of the first two
+  float dropped;        // smallest lower bound of a discarded sub-tree
+  float prune0;         // nothing at or beyond this distance can win
+  float open;           // sub-trees with a lower bound <= open are explored
+  float slack;
+  int leaves;
+#ifdef SGA_KD_TRIPS
+  int own[6], wav[6];
+#endif
+};
+__device__ __forceinline__ KdFast kd_fast_state(float prune0, float slack = 0.f) {
+  KdFast s{};
+  s.w1 = s.w2 = s.w3 = 0xffffffffu;
+  s.l1 = s.l2 = 0u;
+  s.dropped = INFINITY;
+  s.prune0 = prune0;
+  s.open = kd_open_bound(prune0, slack);
+  s.slack = slack;
+  return s;
+}
+__device__ __forceinline__ uint32_t kd_umed3(uint32_t a, uint32_t b, uint32_t c) { return max(min(a, b), min(max(a, b), c)); }  // v_med3_u32
+__device__ __forceinline__ float kd_key_hi(uint32_t key) { return key < kKdNoneKey ? __uint_as_float(key | 7u) : INFINITY; }  // >= the point's distance
+__device__ __forceinline__ float kd_key_lo(uint32_t key) { return key < kKdNoneKey ? __uint_as_float(key & ~7u) : INFINITY; }  // <= the point's distance
+
+typedef float kd_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void kd_scan_leaf(const KdView& t, uint32_t leaf_node, float qx, float qy, float qz, KdFast& s) {
+  const uint32_t k = leaf_node - (1u << t.depth);
+  const float4* __restrict__ b = t.leafblk + 8ull * k;
+  const float4 x0 = b[0], x1 = b[1], y0 = b[2], y1 = b[3], z0 = b[4], z1 = b[5];
+  const kd_f32x2 X[4] = {{x0.x, x0.y}, {x0.z, x0.w}, {x1.x, x1.y}, {x1.z, x1.w}};
+  const kd_f32x2 Y[4] = {{y0.x, y0.y}, {y0.z, y0.w}, {y1.x, y1.y}, {y1.z, y1.w}};
+  const kd_f32x2 Z[4] = {{z0.x, z0.y}, {z0.z, z0.w}, {z1.x, z1.y}, {z1.z, z1.w}};
+  const uint32_t o1 = s.w1, o2 = s.w2;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const kd_f32x2 dx = X[i] - qx, dy = Y[i] - qy, dz = Z[i] - qz;
+    const kd_f32x2 d2 = __builtin_elementwise_fma(dx, dx, __builtin_elementwise_fma(dy, dy, dz * dz));  // kd_dist2, two points at a time
+    const uint32_t k0 = (__float_as_uint(d2.x) & ~7u) | static_cast<uint32_t>(2 * i), k1 = (__float_as_uint(d2.y) & ~7u) | static_cast<uint32_t>(2 * i + 1);
+    s.w3 = kd_umed3(s.w2, s.w3, k0);
+    s.w2 = kd_umed3(s.w1, s.w2, k0);
+    s.w1 = min(s.w1, k0);
+    s.w3 = kd_umed3(s.w2, s.w3, k1);
+    s.w2 = kd_umed3(s.w1, s.w2, k1);
+    s.w1 = min(s.w1, k1);
+  }
+  // whose leaf: a key that changed came from this leaf, except a runner-up that is the old winner moved down
+  s.l2 = s.w2 != o2 ? (s.w2 == o1 ? s.l1 : k) : s.l2;
+  s.l1 = s.w1 != o1 ? k : s.l1;
+  s.open = kd_open_bound(fminf(s.prune0, kd_key_hi(s.w1)), s.slack);
+  s.leaves++;
+  KD_TRIP(s, 3);
+}
+
 // The bottom of the walk.  The leaves under a node of depth D - 2 (a GROUP: up to 4 leaves, 32 points) are not reached through two
 // more levels of splits, pushes, pops and box tests — each a dependent memory access — but through the group's header: the tight
 // boxes of its leaves in one 128-byte line.  The lane computes the four box distances at once and scans the leaves that can hold a
@@ -207,7 +277,8 @@ __device__ __forceinline__ float kd_box_dist2_vals(float lox, float loy, float l
   return fmaf(dx, dx, fmaf(dy, dy, dz * dz));  // the same operations as kd_box_dist2
 }
 
-__device__ __forceinline__ void kd_visit_group(const KdView& t, uint32_t gnode, float qx, float qy, float qz, KdState& s) {
+template <class S>
+__device__ __forceinline__ void kd_visit_group(const KdView& t, uint32_t gnode, float qx, float qy, float qz, S& s) {
   const float4* __restrict__ h = t.groups + 8ull * (gnode - (1u << t.gdepth));
   const float4 lox = h[0], loy = h[1], loz = h[2], hix = h[3], hiy = h[4], hiz = h[5];
   float lb0 = kd_box_dist2_vals(lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, qx, qy, qz);
@@ -235,8 +306,8 @@ __device__ __forceinline__ void kd_visit_group(const KdView& t, uint32_t gnode, 
 // The reference's recursion (descend to the near side; visit the far side iff it can hold a closer point, kdtree.hpp:207-230)
 // on an explicit stack, continued from `node` at `depth` (<= gdepth) with `sp` entries already pending, until the stack is empty.
 // stack: LDS, gdepth * STRIDE words (STRIDE = threads per workgroup); this lane uses stack[level * STRIDE + tid].
-template <int STRIDE>
-__device__ __forceinline__ void kd_walk(const KdView& t, float qx, float qy, float qz, KdState& s, uint32_t node, int depth, int sp, uint32_t* __restrict__ stack, int tid) {
+template <int STRIDE, class S>
+__device__ __forceinline__ void kd_walk(const KdView& t, float qx, float qy, float qz, S& s, uint32_t node, int depth, int sp, uint32_t* __restrict__ stack, int tid) {
   const int D = t.gdepth;
   for (;;) {
     KD_TRIP(s, 5);
@@ -346,8 +417,8 @@ __device__ __forceinline__ uint32_t kd_locate(const KdView& t, float qx, float q
 // fetched with INDEPENDENT loads, one latency for the whole path (a descent pays one per two levels), and the plane tests already use
 // the bound the visit has set.  Where the query lies on the other side of an ancestor's plane than the group (a seed next to the
 // query's cell), the sibling is the query's own side: lower bound 0, always opened.
-template <int STRIDE, int RECORDS>
-__device__ __forceinline__ void kd_push_path(const KdView& t, uint32_t leaf, int d0, float qx, float qy, float qz, KdState& s, int& sp, uint32_t* __restrict__ stack, int tid) {
+template <int STRIDE, int RECORDS, class S>
+__device__ __forceinline__ void kd_push_path(const KdView& t, uint32_t leaf, int d0, float qx, float qy, float qz, S& s, int& sp, uint32_t* __restrict__ stack, int tid) {
   const int D = t.gdepth;
   float4 rec[RECORDS];
 #pragma unroll
@@ -389,8 +460,8 @@ __device__ __forceinline__ void kd_push_path(const KdView& t, uint32_t leaf, int
 }
 
 // descend from (node, depth) to a group, pushing the far sides (the inner loop of kd_walk)
-template <int STRIDE>
-__device__ __forceinline__ void kd_descend(const KdView& t, float qx, float qy, float qz, KdState& s, uint32_t& node, int& depth, int& sp, uint32_t* __restrict__ stack, int tid) {
+template <int STRIDE, class S>
+__device__ __forceinline__ void kd_descend(const KdView& t, float qx, float qy, float qz, S& s, uint32_t& node, int& depth, int& sp, uint32_t* __restrict__ stack, int tid) {
   const int D = t.gdepth;
   while (depth < D) {
     const int odd = depth & 1;
@@ -429,8 +500,8 @@ __device__ __forceinline__ void kd_descend(const KdView& t, float qx, float qy, 
 }
 
 // next pending far side that can still hold a closer (or equidistant) point: false = the walk is over
-template <int STRIDE>
-__device__ __forceinline__ bool kd_pop(const KdView& t, float qx, float qy, float qz, KdState& s, uint32_t& node, int& depth, int& sp, const uint32_t* __restrict__ stack, int tid) {
+template <int STRIDE, class S>
+__device__ __forceinline__ bool kd_pop(const KdView& t, float qx, float qy, float qz, S& s, uint32_t& node, int& depth, int& sp, const uint32_t* __restrict__ stack, int tid) {
   const int D = t.gdepth;
   uint32_t e = 0;
   bool found = false;
@@ -508,6 +579,72 @@ __device__ __forceinline__ KdBest kd_nearest(const KdView& t, float qx, float qy
   }
 #endif
   return kd_result(s, bound2);
+}
+
+// The same search with the fast leaf scan (KdFast).  `ambiguous` = the truncated keys cannot tell the winner from the runner-up, or
+// the winner from the search bound: the caller repeats the search of that query with kd_nearest (exact keys).  When it is false the
+// result equals kd_nearest's canonical neighbour; the runner-up and the exclusion bound are valid but may differ.
+struct KdBestFast {
+  KdBest best;
+  bool ambiguous;
+};
+__device__ __forceinline__ KdBestFast kd_result(const KdView& t, const KdFast& s, float bound2) {
+  KdBestFast r;
+  const bool none = s.w1 >= kKdNoneKey;
+  const float lo = kd_key_lo(s.w1), hi = kd_key_hi(s.w1);
+  const bool hit = !none && hi < bound2;
+  const bool miss = none ? bound2 <= 1e30f : !(lo < bound2);
+  r.ambiguous = !(hit || miss) || (hit && ((s.w1 ^ s.w2) < 8u));
+  r.best.idx = hit ? static_cast<int>(kd_bound(t.n, t.depth, s.l1) + (s.w1 & 7u)) : -1;
+  r.best.idx2 = (hit && s.w2 < kKdNoneKey) ? static_cast<int>(kd_bound(t.n, t.depth, s.l2) + (s.w2 & 7u)) : -1;
+  r.best.d2 = hit ? lo : bound2;
+  r.best.r2 = hit ? fminf(kd_key_lo(s.w3), s.dropped) : fminf(lo, s.dropped);
+  r.best.leaves = s.leaves;
+  return r;
+}
+
+template <int STRIDE>
+__device__ __forceinline__ KdBestFast kd_nearest_fast(const KdView& t, float qx, float qy, float qz, float bound2, int seed, uint32_t* __restrict__ stack, int tid, float slack = 0.f) {
+  if (t.n == 0) return {{bound2, -1, -1, INFINITY, 0}, false};
+  float prune0 = bound2;
+  if (seed >= 0 && static_cast<uint32_t>(seed) < t.n) {
+    const float4 c = t.pts[seed];
+    const float d2 = kd_dist2(c.x, c.y, c.z, qx, qy, qz);
+    prune0 = d2 < prune0 ? kd_next_up(d2) : prune0;
+  }
+  KdFast s = kd_fast_state(prune0, slack);
+  const int D = t.gdepth;
+  int sp = 0, depth = 0;
+  uint32_t node = 1;
+  {  // wave-uniform top of the first descent (see kd_nearest)
+    const unsigned long long active = __ballot(true);
+    while (depth < D) {
+      KD_TRIP(s, 0);
+      const uint32_t un = __builtin_amdgcn_readfirstlane(node);
+      const float2 nd = t.nodes[un];
+      const int axis = __builtin_amdgcn_readfirstlane(__float_as_int(nd.y));
+      const float thr = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(nd.x)));
+      const float qa = axis == 0 ? qx : (axis == 1 ? qy : qz);
+      const float diff = qa - thr;
+      const unsigned long long right = __ballot(!(diff < 0.f));
+      if (right != 0ull && right != active) break;
+      const float cut = diff * diff;
+      depth++;
+      stack[sp * STRIDE + tid] = kd_pack(cut, depth);
+      const bool keep = cut <= s.open;
+      sp += keep ? 1 : 0;
+      s.dropped = fminf(s.dropped, keep ? INFINITY : cut);
+      node = 2 * un + (right != 0ull ? 1u : 0u);
+    }
+  }
+  kd_walk<STRIDE>(t, qx, qy, qz, s, node, depth, sp, stack, tid);
+#if defined(SGA_KD_TRIPS) && !defined(SGA_KD_NO_COUNT)
+  for (int k = 0; k < 6; k++) {
+    atomicAdd(&g_kd_trips[k], static_cast<unsigned long long>(s.own[k]));
+    atomicAdd(&g_kd_trips[8 + k], static_cast<unsigned long long>(s.wav[k]));
+  }
+#endif
+  return kd_result(t, s, bound2);
 }
 
 // ---- k nearest neighbours (traits::knn_search; normal / covariance estimation) -----------------------------------------------------

@@ -188,6 +188,7 @@ struct NNParams {
   int* __restrict__ leaves;  // diagnostics (sga_problem_set_search_stats): leaves scanned per source point in this pass, or null
   double inv_leaf;   // 2^depth / n (kd_leaf_rank)
   int chunk_tiles;   // queue-fed kernel: tiles of 64 queries per wave
+  int fast;          // one-query-per-lane kernels: walk with the fast leaf scan (exact repeat where it cannot decide)
 };
 
 // Returns the shrunken radius (relative to the new pose) or a negative value if the certificate fails.
@@ -238,7 +239,16 @@ __device__ __forceinline__ int search_lane(const NNParams<Real>& p, int tile, in
     const unsigned long long walking = __ballot(true);
     if (threadIdx.x == __ffsll(static_cast<long long>(walking)) - 1) p.walked[tile] += static_cast<uint32_t>(__popcll(walking));  // the tile belongs to this wave: no atomic
   }
-  const KdBest nb = CHECK ? kd_nearest<BLOCK>(p.kd, fx, fy, fz, p.bound2, seed, kd_stack, threadIdx.x, slack) : kd_nearest<BLOCK>(p.kd, fx, fy, fz, p.bound2, seed, kd_stack, threadIdx.x, 0.f);
+  // the walk with the fast leaf scan (kd_search.hpp); the rare query it cannot decide (two candidates within 1e-6 of each other, or
+  // of the search bound) is searched again with the exact keys
+  KdBest nb{};
+  bool exact = p.fast == 0;
+  if (!exact) {
+    const KdBestFast f = kd_nearest_fast<BLOCK>(p.kd, fx, fy, fz, p.bound2, seed, kd_stack, threadIdx.x, CHECK ? slack : 0.f);
+    nb = f.best;
+    exact = f.ambiguous;
+  }
+  if (exact) nb = kd_nearest<BLOCK>(p.kd, fx, fy, fz, p.bound2, seed, kd_stack, threadIdx.x, CHECK ? slack : 0.f);
   p.nn[i] = nb.idx;
   p.nn2[i] = nb.idx2;
   p.rex[i] = rex_from_r2(nb.r2);
@@ -568,81 +578,67 @@ __device__ __forceinline__ bool pair_moments(const LinParams<Real>& p, int i, in
   return inlier;
 }
 
-// Adds the moments of PTS points per lane (zero M' / g / e for the points that are no inliers) to the wave's fp64 row in LDS:
-// the lane adds its points up in registers, DPP sums across the wave, lane 63 adds to the row.
+// Adds the moments of PTS points per lane (zero M' / g / e for the points that are no inliers) to the wave's fp64 row in LDS.  The
+// lane adds its points up in registers; the 72 fp32 sums then go through ONE transposing wave reduction (device_math.hpp:
+// wave_transpose_sum, ~3 instructions per sum instead of a 6-step DPP chain each) that leaves the totals spread over the lanes —
+// lane l holds the sums number `slot` and 64 + slot — and every lane adds its own two to the row.  e is summed in fp64.
+// Must be called by all 64 lanes of the wave (cross-lane operations).
+// Sum number s -> row column: s < 6: H_tt (15 + s); s < 9: b_t (24 + s - 6); else the error-model block (kModelOff + s - 9).
+constexpr int kMomentSums = 72;
+__host__ __device__ constexpr int moment_column(int s) { return s < 6 ? 15 + s : (s < 9 ? 18 + s : kModelOff - 9 + s); }
+
 template <typename Real, int PTS>
 __device__ __forceinline__ void accumulate_moments(const Real (&P)[PTS][3], const Sym3<Real> (&Mp)[PTS], const Real (&G)[PTS][3], const Real (&E)[PTS], int inliers, double* __restrict__ acc_row, int lane) {
-    auto add = [&](int col, Real v) {
-      if constexpr (sizeof(Real) == 4) {
-        const float t = wave_sum_to_lane63(v);
-        if (lane == 63) acc_row[col] += static_cast<double>(t);
-      } else {
-        const double t = wave_sum_f64(v);
-        if (lane == 63) acc_row[col] += t;
-      }
-    };
-    auto m6 = [&](int u, int c) -> Real { return c == 0 ? Mp[u].xx : (c == 1 ? Mp[u].xy : (c == 2 ? Mp[u].xz : (c == 3 ? Mp[u].yy : (c == 4 ? Mp[u].yz : Mp[u].zz)))); };
+  auto m6 = [&](int u, int c) -> Real { return c == 0 ? Mp[u].xx : (c == 1 ? Mp[u].xy : (c == 2 ? Mp[u].xz : (c == 3 ? Mp[u].yy : (c == 4 ? Mp[u].yz : Mp[u].zz)))); };
+  // the s-th sum of this lane's points (s is a compile-time constant after unrolling)
+  auto moment = [&](int s) -> Real {
+    Real v = Real(0);
+    if (s < 6) {
 #pragma unroll
-    for (int c = 0; c < 6; c++) {  // H_tt
-      Real v = Real(0);
+      for (int u = 0; u < PTS; u++) v += m6(u, s);
+    } else if (s < 9) {
 #pragma unroll
-      for (int u = 0; u < PTS; u++) v += m6(u, c);
-      add(15 + c, v);
+      for (int u = 0; u < PTS; u++) v -= G[u][s - 6];
+    } else if (s < 18) {
+      const int a = (s - 9) / 3, j = (s - 9) % 3;
+#pragma unroll
+      for (int u = 0; u < PTS; u++) v += P[u][a] * G[u][j];
+    } else if (s < 36) {
+      const int a = (s - 18) / 6, c = (s - 18) % 6;
+#pragma unroll
+      for (int u = 0; u < PTS; u++) v += P[u][a] * m6(u, c);
+    } else {
+      const int pair = (s - 36) / 6, c = (s - 36) % 6;
+      const int a = pair < 3 ? 0 : (pair < 5 ? 1 : 2), b = pair < 3 ? pair : (pair < 5 ? pair - 2 : 2);
+#pragma unroll
+      for (int u = 0; u < PTS; u++) v += (P[u][a] * P[u][b]) * m6(u, c);
     }
+    return v;
+  };
+  double es = 0.0;
 #pragma unroll
-    for (int j = 0; j < 3; j++) {  // b_t = -sum g
-      Real v = Real(0);
+  for (int u = 0; u < PTS; u++) es += static_cast<double>(E[u]);
+  const double et = wave_sum_f64(es);
+  if (lane == 0) {
+    acc_row[27] += et;
+    acc_row[28] += static_cast<double>(inliers);
+  }
+  if constexpr (sizeof(Real) == 4) {
+    float v[kMomentSums];
 #pragma unroll
-      for (int u = 0; u < PTS; u++) v -= G[u][j];
-      add(24 + j, v);
+    for (int s = 0; s < kMomentSums; s++) v[s] = moment(s);
+    float lo, hi;
+    int slot;
+    wave_transpose_sum<kMomentSums>(v, lane, lo, hi, slot);
+    acc_row[moment_column(slot)] += static_cast<double>(lo);
+    if (slot + 64 < kMomentSums) acc_row[moment_column(slot + 64)] += static_cast<double>(hi);
+  } else {
+#pragma unroll
+    for (int s = 0; s < kMomentSums; s++) {
+      const double t = wave_sum_f64(moment(s));
+      if (lane == 0) acc_row[moment_column(s)] += t;
     }
-    {
-      double es = 0.0;
-#pragma unroll
-      for (int u = 0; u < PTS; u++) es += static_cast<double>(E[u]);
-      const double t = wave_sum_f64(es);
-      if (lane == 63) {
-        acc_row[27] += t;
-        acc_row[28] += static_cast<double>(inliers);
-      }
-    }
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-#pragma unroll
-      for (int j = 0; j < 3; j++) {
-        Real v = Real(0);
-#pragma unroll
-        for (int u = 0; u < PTS; u++) v += P[u][a] * G[u][j];
-        add(kModelOff + 3 * a + j, v);
-      }
-#pragma unroll
-      for (int c = 0; c < 6; c++) {
-        Real v = Real(0);
-#pragma unroll
-        for (int u = 0; u < PTS; u++) v += P[u][a] * m6(u, c);
-        add(kModelOff + 9 + 6 * a + c, v);
-      }
-    }
-    {
-      int pair = 0;
-#pragma unroll
-      for (int a = 0; a < 3; a++) {
-#pragma unroll
-        for (int b = a; b < 3; b++) {
-          Real pp[PTS];
-#pragma unroll
-          for (int u = 0; u < PTS; u++) pp[u] = P[u][a] * P[u][b];
-#pragma unroll
-          for (int c = 0; c < 6; c++) {
-            Real v = Real(0);
-#pragma unroll
-            for (int u = 0; u < PTS; u++) v += pp[u] * m6(u, c);
-            add(kModelOff + 27 + 6 * pair + c, v);
-          }
-          pair++;
-        }
-      }
-    }
+  }
 }
 
 // The factor stage as a kernel of its own.  TARGET: 0 kd-tree (the neighbours come from the search kernel), 1 Gaussian voxel map, 2 flat voxel map (the lookup of a
@@ -723,7 +719,7 @@ __device__ __forceinline__ void linearize_group(const LinParams<Real>& p, int fi
     if (act[u]) {
       p.corr[i] = inl[u] ? jn[u] : -1;
       if constexpr (FACTOR == SGA_GICP) {
-        if (inl[u]) {
+        if (inl[u] && p.store_maha) {  // only robust factors read it back (error kernel); otherwise it is recomputed on demand
           Real* m = p.maha + static_cast<size_t>(i) * 6;
           m[0] = Mh[u].xx, m[1] = Mh[u].xy, m[2] = Mh[u].xz, m[3] = Mh[u].yy, m[4] = Mh[u].yz, m[5] = Mh[u].zz;
         }
@@ -1073,6 +1069,9 @@ static int g_search_queue = getenv("SGA_SEARCH_QUEUE") ? atoi(getenv("SGA_SEARCH
 // 1 (default): the search waves evaluate the factors of their own tiles (search_linearize_kernel); 0: always a separate factor kernel (linearize_kernel)
 static bool g_fuse_search = getenv("SGA_FUSE_SEARCH") ? atoi(getenv("SGA_FUSE_SEARCH")) != 0 : true;
 static double g_queue_delta = getenv("SGA_QUEUE_DELTA") ? atof(getenv("SGA_QUEUE_DELTA")) : 0.02;
+// 1 (default): the one-query-per-lane search kernels walk with the fast leaf scan (32-bit keys, packed fp32; exact repeat of the
+// queries it cannot decide); 0: the exact 64-bit keys throughout.  Results do not depend on it.
+static int g_fast_scan = getenv("SGA_FAST_SCAN") ? atoi(getenv("SGA_FAST_SCAN")) : 1;
 static int g_chunk_tiles_cold = getenv("SGA_CHUNK_COLD") ? atoi(getenv("SGA_CHUNK_COLD")) : 4;
 static int g_chunk_tiles_warm = getenv("SGA_CHUNK_WARM") ? atoi(getenv("SGA_CHUNK_WARM")) : 4;
 
@@ -1144,6 +1143,10 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
   }
   bool fused_search = false;  // the search kernel evaluates the factors itself ...
   int fused_rows = 0;         // ... and leaves this many partial rows
+  // The search kernels rewrite hint / hint2 / rex for THIS pose: until the pass has been launched completely the certificates belong
+  // to no pose the host knows, so an early return below (allocation, rejector callback, launch error) must not leave them marked
+  // valid for T_prev.
+  if (!voxel) pb->prev_valid = false;
   if (p.n > 0 && !voxel) {
     NNParams<Real> q{};
     q.src_pts = pb->pts.p;
@@ -1156,6 +1159,7 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
     q.nn2 = pb->hint2.p;
     q.rex = pb->rex.p;
     q.check = warm ? 1 : 0;
+    q.fast = g_fast_scan;
     if (warm) q.T_prev = rigid_from_colmajor<Real>(pb->T_prev);
     q.walked = pb->walked.p;
     q.leaves = pb->dbg_leaves.n >= pb->n ? pb->dbg_leaves.p : nullptr;
@@ -1543,8 +1547,14 @@ int sga_linearize(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp
   pb->model_valid = false;
   const int count = model ? kRow : SGA_ACCUM_DOUBLES;
   SGA_TRY(fp->math_mode == SGA_MATH_FP64 ? linearize_dispatch<double>(ctx, pb, fp, T, ctx->d_accum.p, host, seq, model) : linearize_dispatch<float>(ctx, pb, fp, T, ctx->d_accum.p, host, seq, model));
-  SGA_TRY(comm_allreduce_sum(ctx, ctx->d_accum.p, count));  // source sharded over ranks: sum the shards' systems (and error models)
-  SGA_TRY(fetch_result(ctx, ctx->d_accum.p, count, seq, direct));
+  {
+    int rc = comm_allreduce_sum(ctx, ctx->d_accum.p, count);  // source sharded over ranks: sum the shards' systems (and error models)
+    if (rc == SGA_OK) rc = fetch_result(ctx, ctx->d_accum.p, count, seq, direct);
+    if (rc != SGA_OK) {
+      pb->prev_valid = false;  // the pass did not complete: its certificates are not to be trusted
+      return rc;
+    }
+  }
   sga_unpack_accumulator(ctx->h_accum, H, b, e, num_inliers);
   if (model) {
     memcpy(pb->model, ctx->h_accum, sizeof(pb->model));
