@@ -28,3 +28,8 @@ clean:
 	rm -rf build $(LIB)
 	$(MAKE) -C oracle clean
 .PHONY: all lib oracle clean trips
+# experiment builds: the library with other compile-time settings, e.g.  make variant V=w6 VFLAGS=-DSGA_SEARCH_WAVES=6
+variant:
+	@mkdir -p build/obj_$(V) small_gicp_amd/lib
+	for f in $(SRCS); do o=build/obj_$(V)/$$(basename $$f .hip).o; if [ $$(basename $$f) = linearize.hip ] || [ ! -f $$o ]; then $(HIPCC) $(HIPFLAGS) $(VFLAGS) -c $$f -o $$o || exit 1; fi; done
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o small_gicp_amd/lib/libsmall_gicp_amd_$(V).so build/obj_$(V)/*.o

@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <chrono>
 #include <thread>
+#include <utility>
 
 #include "common.hpp"
 #include "device_math.hpp"
@@ -587,34 +588,41 @@ __device__ __forceinline__ bool pair_moments(const LinParams<Real>& p, int i, in
 constexpr int kMomentSums = 72;
 __host__ __device__ constexpr int moment_column(int s) { return s < 6 ? 15 + s : (s < 9 ? 18 + s : kModelOff - 9 + s); }
 
+// the S-th sum of one lane's PTS points (S is a template parameter: every index below is a compile-time constant, so the 72 values
+// live in registers — a run-time-indexed array of them would be placed in scratch memory)
+template <typename Real, int PTS, int S>
+__device__ __forceinline__ Real moment_sum(const Real (&P)[PTS][3], const Sym3<Real> (&Mp)[PTS], const Real (&G)[PTS][3]) {
+  auto m6 = [&](int u, int c) -> Real { return c == 0 ? Mp[u].xx : (c == 1 ? Mp[u].xy : (c == 2 ? Mp[u].xz : (c == 3 ? Mp[u].yy : (c == 4 ? Mp[u].yz : Mp[u].zz)))); };
+  Real v = Real(0);
+  if constexpr (S < 6) {
+#pragma unroll
+    for (int u = 0; u < PTS; u++) v += m6(u, S);
+  } else if constexpr (S < 9) {
+#pragma unroll
+    for (int u = 0; u < PTS; u++) v -= G[u][S - 6];
+  } else if constexpr (S < 18) {
+    constexpr int a = (S - 9) / 3, j = (S - 9) % 3;
+#pragma unroll
+    for (int u = 0; u < PTS; u++) v += P[u][a] * G[u][j];
+  } else if constexpr (S < 36) {
+    constexpr int a = (S - 18) / 6, c = (S - 18) % 6;
+#pragma unroll
+    for (int u = 0; u < PTS; u++) v += P[u][a] * m6(u, c);
+  } else {
+    constexpr int pair = (S - 36) / 6, c = (S - 36) % 6;
+    constexpr int a = pair < 3 ? 0 : (pair < 5 ? 1 : 2), b = pair < 3 ? pair : (pair < 5 ? pair - 2 : 2);
+#pragma unroll
+    for (int u = 0; u < PTS; u++) v += (P[u][a] * P[u][b]) * m6(u, c);
+  }
+  return v;
+}
+template <typename Real, int PTS, int... S>
+__device__ __forceinline__ void moment_sums(const Real (&P)[PTS][3], const Sym3<Real> (&Mp)[PTS], const Real (&G)[PTS][3], Real (&v)[sizeof...(S)], std::integer_sequence<int, S...>) {
+  ((v[S] = moment_sum<Real, PTS, S>(P, Mp, G)), ...);
+}
+
 template <typename Real, int PTS>
 __device__ __forceinline__ void accumulate_moments(const Real (&P)[PTS][3], const Sym3<Real> (&Mp)[PTS], const Real (&G)[PTS][3], const Real (&E)[PTS], int inliers, double* __restrict__ acc_row, int lane) {
-  auto m6 = [&](int u, int c) -> Real { return c == 0 ? Mp[u].xx : (c == 1 ? Mp[u].xy : (c == 2 ? Mp[u].xz : (c == 3 ? Mp[u].yy : (c == 4 ? Mp[u].yz : Mp[u].zz)))); };
-  // the s-th sum of this lane's points (s is a compile-time constant after unrolling)
-  auto moment = [&](int s) -> Real {
-    Real v = Real(0);
-    if (s < 6) {
-#pragma unroll
-      for (int u = 0; u < PTS; u++) v += m6(u, s);
-    } else if (s < 9) {
-#pragma unroll
-      for (int u = 0; u < PTS; u++) v -= G[u][s - 6];
-    } else if (s < 18) {
-      const int a = (s - 9) / 3, j = (s - 9) % 3;
-#pragma unroll
-      for (int u = 0; u < PTS; u++) v += P[u][a] * G[u][j];
-    } else if (s < 36) {
-      const int a = (s - 18) / 6, c = (s - 18) % 6;
-#pragma unroll
-      for (int u = 0; u < PTS; u++) v += P[u][a] * m6(u, c);
-    } else {
-      const int pair = (s - 36) / 6, c = (s - 36) % 6;
-      const int a = pair < 3 ? 0 : (pair < 5 ? 1 : 2), b = pair < 3 ? pair : (pair < 5 ? pair - 2 : 2);
-#pragma unroll
-      for (int u = 0; u < PTS; u++) v += (P[u][a] * P[u][b]) * m6(u, c);
-    }
-    return v;
-  };
   double es = 0.0;
 #pragma unroll
   for (int u = 0; u < PTS; u++) es += static_cast<double>(E[u]);
@@ -623,10 +631,9 @@ __device__ __forceinline__ void accumulate_moments(const Real (&P)[PTS][3], cons
     acc_row[27] += et;
     acc_row[28] += static_cast<double>(inliers);
   }
+  Real v[kMomentSums];
+  moment_sums<Real, PTS>(P, Mp, G, v, std::make_integer_sequence<int, kMomentSums>{});
   if constexpr (sizeof(Real) == 4) {
-    float v[kMomentSums];
-#pragma unroll
-    for (int s = 0; s < kMomentSums; s++) v[s] = moment(s);
     float lo, hi;
     int slot;
     wave_transpose_sum<kMomentSums>(v, lane, lo, hi, slot);
@@ -635,7 +642,7 @@ __device__ __forceinline__ void accumulate_moments(const Real (&P)[PTS][3], cons
   } else {
 #pragma unroll
     for (int s = 0; s < kMomentSums; s++) {
-      const double t = wave_sum_f64(moment(s));
+      const double t = wave_sum_f64(v[s]);
       if (lane == 0) acc_row[moment_column(s)] += t;
     }
   }
@@ -731,7 +738,7 @@ __device__ __forceinline__ void linearize_group(const LinParams<Real>& p, int fi
 }
 
 template <typename Real, int FACTOR, int TARGET, int PTS>
-__global__ __launch_bounds__(kTile) void linearize_kernel(const LinParams<Real> p) {
+__global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(4))) void linearize_kernel(const LinParams<Real> p) {
   __shared__ double sh_acc[kTile / 64][kRow];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int c = lane; c < kRow; c += 64) sh_acc[wave][c] = 0.0;  // each wave owns its row: no workgroup barrier needed until the end
@@ -1172,7 +1179,8 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
       // every search wave evaluates the factors of its own tile: one partial row per tile of 64 points, summed by reduce_rows_kernel
       p.tail.enabled = 0;
       fused_rows = static_cast<int>(sgrid.x);
-      const size_t lds = std::max<size_t>(words, 3) * 64 * sizeof(uint32_t);
+      static const size_t lds_pad = getenv("SGA_LDS_PAD") ? static_cast<size_t>(atoi(getenv("SGA_LDS_PAD"))) : 0;  // experiments: bytes of unused LDS per wave (lowers the occupancy)
+      const size_t lds = std::max<size_t>(words, 3) * 64 * sizeof(uint32_t) + lds_pad;
       switch (fp->factor_kind) {
         case SGA_GICP:
           if (warm) hipLaunchKernelGGL((search_linearize_kernel<Real, SGA_GICP, true>), sgrid, sblock, lds, ctx->stream, q, p);
@@ -1656,6 +1664,12 @@ int sga_debug_kd_trips(unsigned long long* out16) {
   unsigned long long zero[16] = {0};
   if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_kd_trips), sizeof(zero)) != hipSuccess) return SGA_ERR_HIP;
   if (hipMemcpyToSymbol(HIP_SYMBOL(g_kd_trips), zero, sizeof(zero)) != hipSuccess) return SGA_ERR_HIP;
+  return SGA_OK;
+}
+// diagnostics build: start / end (100 MHz wall clock) of the first `waves` search waves of the last fused search launch
+int sga_debug_kd_wave_times(unsigned long long* out, int waves) {
+  if (waves > 32768) waves = 32768;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_kd_wave_times), sizeof(unsigned long long) * 2 * static_cast<size_t>(waves)) != hipSuccess) return SGA_ERR_HIP;
   return SGA_OK;
 }
 #endif
