@@ -159,6 +159,19 @@ int sga_error_async(sga_context* ctx, sga_problem* problem, const sga_factor_par
 int sga_comm_unique_id(unsigned char id[128]);
 int sga_comm_init(sga_context* ctx, int nranks, int rank, const unsigned char id[128]);
 int sga_comm_destroy(sga_context* ctx);
+/* The same protocol with the sum over ranks supplied by the caller: wherever the RCCL form runs ncclAllReduce (same place in the
+ * stream order: behind the row reduction, before the result is handed to the host), the library copies the accumulator to the host,
+ * calls fn(user, values, count) — which must replace values[0..count) by their sum over all ranks (MPI_Allreduce, gloo, a pipe) and
+ * return 0 — and copies the sums back.  For transports other than RCCL, and for running the N-rank code path on a single device
+ * (tests/test_distributed_gpu.py).  count is 96 (system + error-model moments) or 30 / 1 (robust factors). */
+typedef int (*sga_allreduce_fn)(void* user, double* values, size_t count);
+int sga_comm_init_callback(sga_context* ctx, int nranks, int rank, sga_allreduce_fn fn, void* user);
+/* Host only (no device): the error at trial pose T from the 96-double accumulator of a linearization at T_lin — what sga_error answers
+ * from after sga_linearize.  acc96: [0, 30) the system (SGA_ACCUM_DOUBLES layout), [32, 95) the moments sum p_a g (9), sum p_a M' (18),
+ * sum p_a p_b M' (36) with M' = R^T M R, g = R^T M r in the source frame; sums over ranks of such accumulators are
+ * accumulators. */
+#define SGA_MODEL_DOUBLES 96
+int sga_error_model_eval(const double acc96[SGA_MODEL_DOUBLES], const double T_lin[16], const double T[16], double* e);
 /* Expand a 30-double accumulator (host memory) into H[36], b[6], e, num_inliers. */
 void sga_unpack_accumulator(const double acc30[SGA_ACCUM_DOUBLES], double H[36], double b[6], double* e, uint64_t* num_inliers);
 /* A custom CorrespondenceRejector on the host (registration/rejector.hpp:11-28 is a duck-typed functor `bool operator()(target, source, T,

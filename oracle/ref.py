@@ -23,8 +23,23 @@ class Result(C.Structure):
     _fields_ = [("T", C.c_double * 16), ("converged", C.c_int), ("iterations", C.c_uint64), ("num_inliers", C.c_uint64), ("H", C.c_double * 36), ("b", C.c_double * 6), ("error", C.c_double)]
 
 
+LIB_PATH_V3 = os.path.join(_HERE, "_ref", "libsmall_gicp_ref_v3.so")  # the same sources compiled with -march=x86-64-v3
+
+
 def available():
     return os.path.exists(LIB_PATH)
+
+
+def select(variant=None):
+    """Switch to another build of the reference ("v3": -march=x86-64-v3; None: the default -O3 build).  Objects created before the
+    switch belong to the library that created them: destroy them first.  Returns False if that build is not there."""
+    global _LIB, LIB_PATH
+    path = {None: os.path.join(_HERE, "_ref", "libsmall_gicp_ref.so"), "v3": LIB_PATH_V3}[variant]
+    if not os.path.exists(path):
+        return False
+    if path != LIB_PATH:
+        LIB_PATH, _LIB = path, None
+    return True
 
 
 def build():
@@ -48,6 +63,8 @@ def lib():
         L.ref_voxelgrid_sampling.argtypes = [vp, C.c_double]
         L.ref_voxelgrid_sampling.restype = vp
         L.ref_estimate_normals_covariances.argtypes = [vp, C.c_int, C.c_int]
+        L.ref_estimate_covariances.argtypes = [vp, C.c_int, C.c_int]
+        L.ref_nearest.argtypes = [vp, dp, C.c_size_t, C.c_int, C.POINTER(C.c_int64), dp]
         L.ref_knn.argtypes = [vp, dp, C.c_size_t, C.c_int, C.POINTER(C.c_int64), dp]
         L.ref_knn.restype = C.c_size_t
         L.ref_align.argtypes = [vp, vp, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double, C.c_double, dp, C.POINTER(Result), dp]
@@ -121,6 +138,17 @@ class Cloud:
 
     def estimate_normals_covariances(self, k=20, num_threads=1):
         lib().ref_estimate_normals_covariances(self.h, int(k), int(num_threads))
+
+    def estimate_covariances(self, k=20, num_threads=1):
+        lib().ref_estimate_covariances(self.h, int(k), int(num_threads))
+
+    def nearest(self, queries, num_threads=1):
+        """KdTree::nearest_neighbor_search per query (double): (index or -1, squared distance)."""
+        q = _f64(queries, 3)
+        idx = np.empty(len(q), np.int64)
+        d2 = np.empty(len(q))
+        lib().ref_nearest(self.h, _dp(q), len(q), int(num_threads), idx.ctypes.data_as(C.POINTER(C.c_int64)), _dp(d2))
+        return idx, d2
 
     def knn(self, queries, k):
         q = _f64(queries, 3)

@@ -162,6 +162,30 @@ void ref_estimate_normals_covariances(void* h, int k, int num_threads) {
     estimate_normals_covariances(*rc->cloud, *rc->tree, k);
 }
 
+// util/normal_estimation_omp.hpp estimate_covariances_omp (the preprocessing of the odometry benchmark, odometry_benchmark_small_gicp_omp.cpp:24)
+void ref_estimate_covariances(void* h, int k, int num_threads) {
+  auto* rc = static_cast<RefCloud*>(h);
+  if (!rc->tree) rc->tree = std::make_shared<KdTree<PointCloud>>(rc->cloud, KdTreeBuilderOMP(num_threads > 1 ? num_threads : 1));
+  if (num_threads > 1)
+    estimate_covariances_omp(*rc->cloud, *rc->tree, k, num_threads);
+  else
+    estimate_covariances(*rc->cloud, *rc->tree, k);
+}
+
+// KdTree::nearest_neighbor_search (ann/kdtree.hpp:193-205) for m queries, OpenMP over the queries: idx = -1 where the tree is empty
+void ref_nearest(void* h, const double* q, size_t m, int num_threads, std::int64_t* idx, double* sqd) {
+  auto* rc = static_cast<RefCloud*>(h);
+#pragma omp parallel for num_threads(num_threads) schedule(guided, 64)
+  for (std::int64_t i = 0; i < static_cast<std::int64_t>(m); i++) {
+    const Eigen::Vector4d pt(q[3 * i], q[3 * i + 1], q[3 * i + 2], 1.0);
+    size_t ki = 0;
+    double kd = std::numeric_limits<double>::infinity();
+    const size_t n = rc->cloud->size() ? rc->tree->nearest_neighbor_search(pt, &ki, &kd) : 0;
+    idx[i] = n ? static_cast<std::int64_t>(ki) : -1;
+    sqd[i] = n ? kd : std::numeric_limits<double>::infinity();
+  }
+}
+
 size_t ref_knn(void* h, const double* q, size_t m, int k, std::int64_t* idx, double* sqd) {
   auto* rc = static_cast<RefCloud*>(h);
   size_t total = 0;

@@ -19,6 +19,7 @@ from .api import (  # noqa: F401
     estimate_covariances,
     estimate_normals,
     estimate_normals_covariances,
+    error_model_eval,
     get_warm_limit,
     set_error_model,
     set_search_mode,

@@ -55,6 +55,7 @@ class ResultC(C.Structure):
 
 
 REJECTOR_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_size_t, C.POINTER(C.c_int64), C.POINTER(C.c_float), C.POINTER(C.c_ubyte))
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_size_t)  # sga_allreduce_fn
 LINEARIZE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64))
 ERROR_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double))
 
@@ -105,6 +106,8 @@ SYMBOLS = [
     ("sga_comm_unique_id", C.c_int, [C.POINTER(C.c_ubyte)]),
     ("sga_comm_init", C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_ubyte)]),
     ("sga_comm_destroy", C.c_int, [_vp]),
+    ("sga_comm_init_callback", C.c_int, [_vp, C.c_int, C.c_int, ALLREDUCE_FN, _vp]),
+    ("sga_error_model_eval", C.c_int, [_dp, _dp, _dp, _dp]),
     ("sga_unpack_accumulator", None, [_dp, _dp, _dp, _dp, C.POINTER(C.c_uint64)]),
     ("sga_problem_set_rejector", C.c_int, [_vp, REJECTOR_FN, _vp]),
     ("sga_linearize_per_point", C.c_int, [_vp, _vp, C.POINTER(FactorParams), _dp, _dp, C.POINTER(C.c_ubyte)]),

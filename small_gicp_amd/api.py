@@ -58,6 +58,28 @@ class Context:
         buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
         check(load().sga_comm_init(self.h, int(nranks), int(rank), buf))
 
+    def comm_init_callback(self, nranks, rank, allreduce):
+        """The same protocol with the caller's transport: allreduce(values) must return the element-wise sum over all ranks of the
+        numpy array it is given (e.g. a torch.distributed / MPI all-reduce on the host)."""
+        from ._lib import ALLREDUCE_FN
+
+        def _cb(_user, ptr, count):
+            try:
+                a = np.ctypeslib.as_array(ptr, shape=(count,))
+                a[:] = np.asarray(allreduce(a.copy()), dtype=np.float64).reshape(count)
+                return 0
+            except Exception:  # noqa: BLE001
+                import traceback
+
+                traceback.print_exc()
+                return 1
+
+        self._allreduce_cb = ALLREDUCE_FN(_cb)  # keep alive as long as the context
+        check(load().sga_comm_init_callback(self.h, int(nranks), int(rank), self._allreduce_cb, None))
+
+    def comm_destroy(self):
+        check(load().sga_comm_destroy(self.h))
+
     def set_profiling(self, enabled=True):
         check(load().sga_context_set_profiling(self.h, int(enabled)))
 
@@ -544,6 +566,16 @@ def unpack_accumulator(acc30):
     e, n = C.c_double(), C.c_uint64()
     load().sga_unpack_accumulator(_dp(a), _dp(H), _dp(b), C.byref(e), C.byref(n))
     return H.reshape(6, 6), b, e.value, n.value
+
+
+def error_model_eval(acc96, T_lin, T):
+    """sga_error_model_eval (host only): the error at trial pose T from the 96-double accumulator of a linearization at T_lin."""
+    a = np.ascontiguousarray(acc96, dtype=np.float64)
+    assert a.size >= 96
+    tl, t = _T16(T_lin), _T16(T)
+    e = C.c_double()
+    check(load().sga_error_model_eval(_dp(a), _dp(tl), _dp(t), C.byref(e)))
+    return e.value
 
 
 def optimize(setting, init_T, linearize, error):

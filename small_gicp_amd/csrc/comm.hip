@@ -1,6 +1,8 @@
-// Multi-GPU: RCCL all-reduce of the 30-double linearization accumulator / the 1-double error, enqueued on the context's stream
-// between the reduction kernel and the device->host read-back, so that sga_linearize / sga_error / sga_align work unchanged on a
-// source cloud sharded over ranks.  librccl is bound at run time with dlopen — the library has no link-time
+// Multi-GPU: all-reduce of the linearization accumulator (96 doubles: the system + the error-model moments; 30 / 1 for robust
+// factors) enqueued on the context's stream between the reduction kernel and the device->host read-back, so that sga_linearize /
+// sga_error / sga_align work unchanged on a source cloud sharded over ranks (the loop being partitioned is
+// registration/reduction_omp.hpp:32-58).  Transport: RCCL (ncclAllReduce on the stream), or a caller-supplied host function
+// (sga_comm_init_callback).  librccl is bound at run time with dlopen — the library has no link-time
 // dependency on it and single-GPU users never load it.  One communicator per context; ranks exchange the 128-byte unique id out
 // of band (bench.py broadcasts it with torch.distributed).
 #include <dlfcn.h>
@@ -24,9 +26,17 @@ static RcclApi* rccl() {
   static bool tried = false;
   if (!tried) {
     tried = true;
+    // a librccl the process has already mapped (PyTorch ships its own copy) first: two RCCL instances in one process would each
+    // bring their own device state
     for (const char* name : {"librccl.so.1", "librccl.so"}) {
-      api.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      api.handle = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
       if (api.handle) break;
+    }
+    if (!api.handle) {
+      for (const char* name : {"librccl.so.1", "librccl.so"}) {
+        api.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (api.handle) break;
+      }
     }
     if (api.handle) {
       api.get_unique_id = reinterpret_cast<decltype(api.get_unique_id)>(dlsym(api.handle, "ncclGetUniqueId"));
@@ -42,6 +52,16 @@ static RcclApi* rccl() {
 
 // called by linearize.hip between the reduction and the read-back; no-op without a communicator
 int comm_allreduce_sum(sga_context* ctx, double* d_buf, size_t count) {
+  if (ctx->comm_fn) {  // the caller's transport: down, sum over ranks on the host, up — at the point of the stream order where RCCL would run
+    double h[128];
+    if (count > 128) return fail(SGA_ERR_INVALID, "accumulator of %zu doubles", count);
+    SGA_HIP(hipMemcpyAsync(h, d_buf, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SGA_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->comm_fn(ctx->comm_user, h, count) != 0) return fail(SGA_ERR_CALLBACK, "all-reduce callback failed");
+    SGA_HIP(hipMemcpyAsync(d_buf, h, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    SGA_HIP(hipStreamSynchronize(ctx->stream));  // h goes out of scope
+    return SGA_OK;
+  }
   if (!ctx->comm) return SGA_OK;
   RcclApi* api = rccl();
   if (!api) return fail(SGA_ERR_HIP, "librccl is not available");
@@ -73,7 +93,7 @@ int sga_comm_unique_id(unsigned char id[128]) {
 
 int sga_comm_init(sga_context* ctx, int nranks, int rank, const unsigned char id[128]) {
   if (!ctx || !id || nranks < 1 || rank < 0 || rank >= nranks) return fail(SGA_ERR_INVALID, "bad argument");
-  if (ctx->comm) return fail(SGA_ERR_INVALID, "context already has a communicator");
+  if (ctx->sharded()) return fail(SGA_ERR_INVALID, "context already has a communicator");
   RcclApi* api = rccl();
   if (!api) return fail(SGA_ERR_HIP, "librccl is not available");
   SGA_ENTER(ctx);
@@ -87,8 +107,23 @@ int sga_comm_init(sga_context* ctx, int nranks, int rank, const unsigned char id
   return SGA_OK;
 }
 
+int sga_comm_init_callback(sga_context* ctx, int nranks, int rank, sga_allreduce_fn fn, void* user) {
+  if (!ctx || !fn || nranks < 1 || rank < 0 || rank >= nranks) return fail(SGA_ERR_INVALID, "bad argument");
+  if (ctx->sharded()) return fail(SGA_ERR_INVALID, "context already has a communicator");
+  ctx->comm_fn = fn;
+  ctx->comm_user = user;
+  ctx->comm_ranks = nranks;
+  return SGA_OK;
+}
+
 int sga_comm_destroy(sga_context* ctx) {
   if (!ctx) return fail(SGA_ERR_INVALID, "null argument");
+  if (ctx->comm_fn) {
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->comm_fn = nullptr;
+    ctx->comm_user = nullptr;
+    ctx->comm_ranks = 1;
+  }
   if (ctx->comm) {
     RcclApi* api = rccl();
     (void)hipStreamSynchronize(ctx->stream);

@@ -133,6 +133,9 @@ struct sga_context {
   // multi-GPU (comm.hip): RCCL communicator over the ranks that share one registration, or null
   void* comm = nullptr;
   int comm_ranks = 1;
+  sga_allreduce_fn comm_fn = nullptr;  // caller-supplied sum over ranks (sga_comm_init_callback) instead of RCCL
+  void* comm_user = nullptr;
+  bool sharded() const { return comm != nullptr || comm_fn != nullptr; }
 };
 
 struct sga_cloud {

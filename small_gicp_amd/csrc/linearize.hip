@@ -1549,7 +1549,7 @@ int sga_linearize(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp
   if (!H || !b || !e) return fail(SGA_ERR_INVALID, "null output");
   SGA_ENTER(ctx);
   const unsigned long long seq = ++ctx->publish_seq;
-  const bool direct = ctx->comm == nullptr;
+  const bool direct = !ctx->sharded();
   double* host = direct ? ctx->h_accum_dev : nullptr;
   const bool model = fp->robust_kind == SGA_ROBUST_NONE && g_error_model;  // a robust kernel's error is not quadratic in the pose
   pb->model_valid = false;
@@ -1620,12 +1620,18 @@ int sga_error(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, co
   }
   SGA_ENTER(ctx);
   const unsigned long long seq = ++ctx->publish_seq;
-  const bool direct = ctx->comm == nullptr;
+  const bool direct = !ctx->sharded();
   double* host = direct ? ctx->h_accum_dev : nullptr;
   SGA_TRY(fp->math_mode == SGA_MATH_FP64 ? error_dispatch<double>(ctx, pb, fp, T, ctx->d_accum.p, host, seq) : error_dispatch<float>(ctx, pb, fp, T, ctx->d_accum.p, host, seq));
   SGA_TRY(comm_allreduce_sum(ctx, ctx->d_accum.p, 1));
   SGA_TRY(fetch_result(ctx, ctx->d_accum.p, 1, seq, direct));
   *e = ctx->h_accum[0];
+  return SGA_OK;
+}
+
+int sga_error_model_eval(const double acc96[SGA_MODEL_DOUBLES], const double T_lin[16], const double T[16], double* e) {
+  if (!acc96 || !T_lin || !T || !e) return fail(SGA_ERR_INVALID, "null argument");
+  *e = evaluate_error_model(acc96, T_lin, T);
   return SGA_OK;
 }
 

@@ -82,3 +82,76 @@ def test_two_ranks_share_one_registration_through_rccl(tmp_path, c1_gold):
         dt, dr = pose_error(np.array(r["T"]), np.array(g["T"]))
         assert dt < 1e-4 and dr < 1e-4
     assert res[0]["T"] == res[1]["T"]  # both ranks read the same reduced numbers and run the same host LM
+
+
+# ---- the same N-rank code path with a host transport: runs on ONE device, so it is always exercised ------------------------------
+WORKER_CB = r"""
+import json, os, sys
+import numpy as np
+sys.path.insert(0, os.environ["SGA_ROOT"])
+import torch, torch.distributed as dist
+import small_gicp_amd as sga
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+d = np.load(os.path.join(os.environ["SGA_ROOT"], "tests", "golden", "c1_points.npz"))
+ctx = sga.Context(0)
+tgt, tree = sga.preprocess_points(sga.PointCloud(d["target"], ctx=ctx), 0.25, 10)
+src, _ = sga.preprocess_points(sga.PointCloud(d["source"], ctx=ctx), 0.25, 10)
+n = src.size()
+lo, hi = rank * n // world, (rank + 1) * n // world
+shard = src.slice(lo, hi - lo)
+out = {"rank": rank}
+single = {}
+for math in ("fp64", "fp32"):
+    st = sga.make_setting("GICP", math_mode=math)
+    single[math] = sga.Problem(tree, src).align(st)          # the whole registration on one context, before the communicator exists
+calls = []
+def allreduce(values):                                         # sum over ranks on the host (gloo)
+    calls.append(len(values))
+    t = torch.from_numpy(values)
+    dist.all_reduce(t)
+    return t.numpy()
+ctx.comm_init_callback(world, rank, allreduce)
+for math in ("fp64", "fp32"):
+    st = sga.make_setting("GICP", math_mode=math)
+    pb = sga.Problem(tree, shard)
+    H, b, e, ninl = pb.linearize(st.factor, np.eye(4))        # local kernels -> 96-double accumulator -> all-reduce -> host
+    res = pb.align(st)                                         # error passes: the per-rank host error model, no collective
+    s = single[math]
+    out[math] = dict(T=res.T_target_source.tolist(), single=s.T_target_source.tolist(), iterations=int(res.iterations), single_iterations=int(s.iterations),
+                     num_inliers=int(res.num_inliers), single_inliers=int(s.num_inliers), lin_inliers=int(ninl), error=res.error, single_error=s.error)
+out["counts"] = sorted(set(calls))
+out["collectives"] = len(calls)
+print("RESULT " + json.dumps(out), flush=True)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_two_ranks_share_one_registration_through_the_callback_transport(tmp_path, c1_gold):
+    """sga_comm_init_callback: the real kernels, the 96-double accumulator and the per-rank error model with two ranks on device 0."""
+    script = tmp_path / "worker_cb.py"
+    script.write_text(WORKER_CB)
+    env = dict(os.environ, SGA_ROOT=ROOT, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29741", str(script)]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    res = [json.loads(ln[7:]) for ln in p.stdout.splitlines() if ln.startswith("RESULT ")]
+    assert len(res) == 2
+    g = c1_gold["cases"]["GICP"]
+    for r in res:
+        assert r["counts"] == [96], r["counts"]                 # one collective per linearization, system + error-model moments
+        for math, tol in (("fp64", 1e-9), ("fp32", 1e-5)):
+            m = r[math]
+            dt, dr = pose_error(np.array(m["T"]), np.array(m["single"]))
+            print("sharded vs unsharded (%s): dt %.2e m, dr %.2e rad, iterations %d / %d, inliers %d / %d" % (math, dt, dr, m["iterations"], m["single_iterations"], m["num_inliers"], m["single_inliers"]))
+            assert dt < tol and dr < tol, (math, dt, dr)
+            assert m["iterations"] == m["single_iterations"] == g["iterations"]
+            assert m["num_inliers"] == m["single_inliers"] == m["lin_inliers"] == g["num_inliers"] or math == "fp32"
+            assert abs(m["error"] - m["single_error"]) <= 1e-6 * abs(m["single_error"])
+            dt, dr = pose_error(np.array(m["T"]), np.array(g["T"]))
+            assert dt < 1e-4 and dr < 1e-4
+    assert res[0]["fp64"]["T"] == res[1]["fp64"]["T"] and res[0]["fp32"]["T"] == res[1]["fp32"]["T"]  # same reduced numbers, same host LM on both ranks
+    # collectives: one per linearization only (iterations + 1 per align, + the explicit linearize)
+    it = res[0]["fp64"]["iterations"] + res[0]["fp32"]["iterations"]
+    assert res[0]["collectives"] <= it + 2 + 2 + 4, res[0]["collectives"]

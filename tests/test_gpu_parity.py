@@ -566,10 +566,15 @@ def c3_cpu(c3):
     tp, sp = c3["tgt"].xyz().astype(np.float64), c3["src"].xyz().astype(np.float64)
     tcov, scov = c3["tgt"].covs()[:, :3, :3], c3["src"].covs()[:, :3, :3]
     threads = max(1, min(64, os.cpu_count() or 1))
-    out = dict(orc=_orc, threads=threads, otc=_orc.Cloud(tp, None, tcov, tree=True), osc=_orc.Cloud(sp, None, scov, tree=False), ref=None)
+    out = dict(orc=_orc, threads=threads, otc=_orc.Cloud(tp, None, tcov, tree=True), osc=_orc.Cloud(sp, None, scov, tree=False), ref=None, src_xyz64=sp)
     if _ref.available():
         out.update(ref=_ref, rtc=_ref.Cloud(tp, None, tcov, tree=True, tree_threads=min(32, threads)), rsc=_ref.Cloud(sp, None, scov, tree=False))
     return out
+
+
+# Observed on MI355X (round 3, printed by the test): differing correspondences and inlier deltas at 1M; the asserts allow twice that.
+C3_MAX_DIFFERING_PAIRS = 1000
+C3_MAX_INLIER_DELTA = 50
 
 
 def test_c3_matches_reference(c3, c3_cpu):
@@ -592,11 +597,20 @@ def test_c3_matches_reference(c3, c3_cpu):
             H, b, e, n = pb.linearize(sga.make_setting("GICP", math_mode=mode).factor, T)
             assert np.abs(H - Ho).max() <= rel * np.abs(Ho).max(), (mode, np.abs(H - Ho).max() / np.abs(Ho).max())
             assert np.abs(b - bo).max() <= rel * max(np.abs(bo).max(), 1e-3 * np.abs(Ho).max()) and abs(e - eo) <= rel * eo
-            assert abs(int(n) - int(no)) <= (50 if mode == "fp32" else 2), (mode, n, no)  # pairs within fp32 rounding of the 1 m rejector
+            print("C3 inliers %s: %d (reference %d, delta %+d)" % (mode, n, no, int(n) - int(no)))
+            assert abs(int(n) - int(no)) <= (C3_MAX_INLIER_DELTA if mode == "fp32" else 2), (mode, n, no)  # pairs within fp32 rounding of the 1 m rejector
         got = pb.factors()[0]
         want = f.get()[0]
+        if c3_cpu["ref"] is not None:  # the reference's own nearest_neighbor_search + DistanceRejector (ann/kdtree.hpp:193-205, rejector.hpp:19-28)
+            q = c3_cpu["src_xyz64"] @ T[:3, :3].T + T[:3, 3]
+            idx, d2 = c3_cpu["rtc"].nearest(q, threads)
+            want_ref = np.where(d2 > 1.0, -1, idx)
+            assert (want_ref != want).sum() <= 2, "the restatement's correspondences differ from the reference's: %d" % (want_ref != want).sum()
+            want = want_ref
         # the reference numbers target points in the caller's order, so do we
-        assert (got == want).mean() >= 0.999, (got == want).mean()
+        differing = int((got != want).sum())
+        print("C3 correspondences differing from the reference: %d of %d" % (differing, len(want)))
+        assert differing <= C3_MAX_DIFFERING_PAIRS, differing
     for mode in ("fp32", "fp64"):
         res = pb.align(sga.make_setting("GICP", math_mode=mode))
         if c3_cpu["ref"] is not None:
@@ -605,7 +619,8 @@ def test_c3_matches_reference(c3, c3_cpu):
             r = orc.align(c3_cpu["otc"], c3_cpu["osc"], orc.default_setting(factor_kind=orc.GICP, num_threads=threads))
         dt, dr = pose_error(res.T_target_source, r.T_target_source)
         assert dt < POSE_TOL_T and dr < POSE_TOL_R and res.iterations == r.iterations and res.converged == r.converged, (mode, dt, dr, res.iterations, r.iterations)
-        assert abs(int(res.num_inliers) - int(r.num_inliers)) <= 50
+        print("C3 registration %s: dt %.2e m, dr %.2e rad, iterations %d / %d, inliers %d / %d" % (mode, dt, dr, res.iterations, r.iterations, res.num_inliers, r.num_inliers))
+        assert abs(int(res.num_inliers) - int(r.num_inliers)) <= C3_MAX_INLIER_DELTA
 
 
 def test_c4_matches_reference(c3, c3_cpu):
