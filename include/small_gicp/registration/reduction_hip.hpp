@@ -102,32 +102,43 @@ inline void check(int rc, const char* what) {
   if (rc != SGA_OK) throw std::runtime_error(std::string("small_gicp_amd: ") + what + ": " + sga_last_error());
 }
 
-// identity of a cloud's CONTENT, cheap: size, attributes and 64 evenly spaced points (FNV-1a over their bits)
+// identity of a cloud's CONTENT: size, attributes and EVERY point / normal / covariance entry (FNV-1a per block of 4096 points, the
+// block hashes combined in order; OpenMP over the blocks).  One streaming pass over the host data — cheap next to the repack and
+// upload it decides about, and an in-place edit of any point is seen (a sampled fingerprint would miss it).
 template <typename Cloud>
 std::uint64_t fingerprint(const Cloud& c) {
   const size_t n = traits::size(c);
-  std::uint64_t h = 1469598103934665603ull ^ n;
-  auto mix = [&h](double v) {
-    std::uint64_t b;
-    std::memcpy(&b, &v, 8);
-    h = (h ^ b) * 1099511628211ull;
-  };
-  mix(traits::has_normals(c) ? 1.0 : 0.0);
-  mix(traits::has_covs(c) ? 1.0 : 0.0);
-  const size_t samples = n < 64 ? n : 64;
-  for (size_t k = 0; k < samples; k++) {
-    const size_t i = samples > 1 ? k * (n - 1) / (samples - 1) : 0;
-    const Eigen::Vector4d p = traits::point(c, i);
-    mix(p[0]);
-    mix(p[1]);
-    mix(p[2]);
-    if (traits::has_covs(c)) {
-      const Eigen::Matrix4d m = traits::cov(c, i);
-      mix(m(0, 0));
-      mix(m(1, 2));
+  const bool normals = traits::has_normals(c), covs = traits::has_covs(c);
+  constexpr size_t kBlock = 4096;
+  const size_t blocks = (n + kBlock - 1) / kBlock;
+  std::vector<std::uint64_t> part(blocks);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+  for (long long bl = 0; bl < static_cast<long long>(blocks); bl++) {
+    std::uint64_t h = 1469598103934665603ull;
+    auto mix = [&h](double v) {
+      std::uint64_t b;
+      std::memcpy(&b, &v, 8);
+      h = (h ^ b) * 1099511628211ull;
+    };
+    const size_t i0 = static_cast<size_t>(bl) * kBlock, i1 = i0 + kBlock < n ? i0 + kBlock : n;
+    for (size_t i = i0; i < i1; i++) {
+      const Eigen::Vector4d p = traits::point(c, i);
+      mix(p[0]), mix(p[1]), mix(p[2]);
+      if (covs) {
+        const Eigen::Matrix4d m = traits::cov(c, i);
+        mix(m(0, 0)), mix(m(0, 1)), mix(m(0, 2)), mix(m(1, 1)), mix(m(1, 2)), mix(m(2, 2));
+      }
+      if (normals) {
+        const Eigen::Vector4d v = traits::normal(c, i);
+        mix(v[0]), mix(v[1]), mix(v[2]);
+      }
     }
-    if (traits::has_normals(c)) mix(traits::normal(c, i)[2]);
+    part[bl] = h;
   }
+  std::uint64_t h = 1469598103934665603ull ^ n ^ (normals ? 0x9e3779b97f4a7c15ull : 0ull) ^ (covs ? 0xc2b2ae3d27d4eb4full : 0ull);
+  for (std::uint64_t v : part) h = (h ^ v) * 1099511628211ull;
   return h;
 }
 
@@ -155,21 +166,20 @@ struct DeviceState {
 template <typename Cloud>
 sga_cloud* upload(sga_context* ctx, const Cloud& c) {
   const size_t n = traits::size(c);
-  std::vector<double> p(4 * n), nr, cv;
-  for (size_t i = 0; i < n; i++) {
+  const bool normals = traits::has_normals(c), covs = traits::has_covs(c);
+  std::vector<double> p(4 * n), nr(normals ? 4 * n : 0), cv(covs ? 16 * n : 0);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+  for (long long ii = 0; ii < static_cast<long long>(n); ii++) {
+    const size_t i = static_cast<size_t>(ii);
     const Eigen::Vector4d v = traits::point(c, i);
     for (int k = 0; k < 4; k++) p[4 * i + k] = v[k];
-  }
-  if (traits::has_normals(c)) {
-    nr.resize(4 * n);
-    for (size_t i = 0; i < n; i++) {
-      const Eigen::Vector4d v = traits::normal(c, i);
-      for (int k = 0; k < 4; k++) nr[4 * i + k] = v[k];
+    if (normals) {
+      const Eigen::Vector4d w = traits::normal(c, i);
+      for (int k = 0; k < 4; k++) nr[4 * i + k] = w[k];
     }
-  }
-  if (traits::has_covs(c)) {
-    cv.resize(16 * n);
-    for (size_t i = 0; i < n; i++) {
+    if (covs) {
       const Eigen::Matrix4d m = traits::cov(c, i);
       for (int col = 0; col < 4; col++)
         for (int row = 0; row < 4; row++) cv[16 * i + 4 * col + row] = m(row, col);
@@ -184,7 +194,7 @@ sga_cloud* upload(sga_context* ctx, const Cloud& c) {
 
 /// @brief Reduction on an MI355X through libsmall_gicp_amd (replaces ParallelReductionOMP, reduction_omp.hpp:21-73).
 struct ParallelReductionHIP {
-  ParallelReductionHIP() : device(0), sync_factors(true), fp64_math(false), num_inliers(0), state(std::make_shared<hip_detail::DeviceState>()) {}
+  ParallelReductionHIP() : device(0), sync_factors(false), sync_inliers(true), fp64_math(false), num_inliers(0), state(std::make_shared<hip_detail::DeviceState>()) {}
 
   /// Forget the uploaded clouds: the next linearize() uploads target and source again.
   void rebind() const {
@@ -250,13 +260,22 @@ struct ParallelReductionHIP {
       for (int j = 0; j < 6; j++) H(i, j) = H36[6 * i + j];
     }
     num_inliers = inliers;
-    if (sync_factors && !factors.empty()) {  // leave in `factors` what a CPU reduction would have left there (optimizer.hpp:146 counts it)
+    // What a CPU reduction leaves in `factors`.  The reference's only reader is optimizer.hpp:146 (it counts factors with a valid
+    // target_index for RegistrationResult::num_inliers): sync_inliers (default) downloads the correspondences — 8 bytes per point,
+    // no mahalanobis recomputation — and fills target_index / source_index; sync_factors additionally fills GICPFactor::mahalanobis
+    // (24 more bytes per point and a recompute_maha kernel per linearize: only for code that inspects the factors).  With both off
+    // the factors stay untouched and num_inliers of the result is 0 — read ParallelReductionHIP::num_inliers instead.
+    if ((sync_factors || sync_inliers) && !factors.empty()) {
       const size_t n = factors.size();
       s.idx.resize(n);
-      const bool gicp = Map::kind == SGA_GICP;
+      const bool gicp = Map::kind == SGA_GICP && sync_factors;
       if (gicp) s.m6.resize(6 * n);
       hip_detail::check(sga_problem_get_factors(s.ctx, s.problem, s.idx.data(), gicp ? s.m6.data() : nullptr), "sga_problem_get_factors");
-      for (size_t i = 0; i < n; i++) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+      for (long long ii = 0; ii < static_cast<long long>(n); ii++) {
+        const size_t i = static_cast<size_t>(ii);
         auto& f = Map::plain(factors[i]);
         f.source_index = i;
         f.target_index = s.idx[i] < 0 ? std::numeric_limits<size_t>::max() : static_cast<size_t>(s.idx[i]);
@@ -278,7 +297,8 @@ struct ParallelReductionHIP {
   }
 
   int device;                  ///< HIP device
-  bool sync_factors;           ///< fill the host `factors` after every linearize (default) or leave them untouched
+  bool sync_factors;           ///< also fill GICPFactor::mahalanobis of the host `factors` after every linearize (default off)
+  bool sync_inliers;           ///< fill target_index / source_index of the host `factors` after every linearize (default on: optimizer.hpp:146 counts them)
   bool fp64_math;              ///< per-pair arithmetic in fp64 (data on the device is fp32 either way)
   mutable size_t num_inliers;  ///< inliers of the last linearize
 

@@ -174,9 +174,19 @@ void dev_free(void* p) {
     return;
   }
   c.cached_bytes += bucket;
-  if (g_cur_stream != nullptr) {  // inside an entry point: only later work on the same stream may get this block
-    c.free_blocks[{device, g_cur_stream, bucket}].push_back(p);
-    return;
+  if (g_cur_stream != nullptr) {
+    // Inside an entry point: later work on the same stream may get this block at once — provided no OTHER stream of the device has
+    // work in flight.  Buffers of long-lived shared objects (an index's attributes, a problem's mahalanobis cache, the rejector
+    // flags) may be read by kernels another context has enqueued on its own stream (sga_linearize_async on context B while
+    // context A refreshes the index): with such a stream busy the block takes the event-deferred path below.
+    bool others_busy = false;
+    for (const auto& ds : c.streams)
+      if (ds.first == device && ds.second != g_cur_stream && hipStreamQuery(ds.second) == hipErrorNotReady) others_busy = true;
+    (void)hipGetLastError();
+    if (!others_busy) {
+      c.free_blocks[{device, g_cur_stream, bucket}].push_back(p);
+      return;
+    }
   }
   // outside an entry point (destroy functions): kernels on any stream of the device may still use the block
   PendingBlock b{p, device, bucket, {}};

@@ -28,7 +28,11 @@ __global__ __launch_bounds__(256) void bbox_kernel(const float4* __restrict__ pt
   __shared__ float sh[4][6];
   float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
   for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n; i += static_cast<size_t>(gridDim.x) * blockDim.x) {
-    const float4 p = pts[i];
+    float4 p = pts[i];
+    // a NaN would slip through fminf / fmaxf unseen: every non-finite coordinate counts as +inf, so the box reports it
+    p.x = fabsf(p.x) <= 3.4028234e38f ? p.x : INFINITY;
+    p.y = fabsf(p.y) <= 3.4028234e38f ? p.y : INFINITY;
+    p.z = fabsf(p.z) <= 3.4028234e38f ? p.z : INFINITY;
     lo[0] = fminf(lo[0], p.x);
     lo[1] = fminf(lo[1], p.y);
     lo[2] = fminf(lo[2], p.z);

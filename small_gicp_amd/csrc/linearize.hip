@@ -63,7 +63,8 @@ __device__ __forceinline__ void fused_tail(const FusedTail& f, const double* __r
   __shared__ unsigned sh_last;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this workgroup's row has left the CU
   __syncthreads();
-  if (threadIdx.x == 0) sh_last = __hip_atomic_fetch_add(f.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == static_cast<unsigned>(nrows - 1) ? 1u : 0u;
+  // agent-scope release (this workgroup's row, ordered before by the barrier) / acquire (the rows of the workgroups that arrived earlier)
+  if (threadIdx.x == 0) sh_last = __hip_atomic_fetch_add(f.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == static_cast<unsigned>(nrows - 1) ? 1u : 0u;
   __syncthreads();
   if (!sh_last) return;  // workgroup-uniform
   // 2 slices of 128 columns: slice s adds rows s, s + 2, ... (independent loads), then the slices are added in fixed order
@@ -918,9 +919,9 @@ __global__ __launch_bounds__(kTile) void error_kernel(const ErrParams<Real> p) {
 // Deterministic fp64 sum of `nrows` partial rows of `ncols` (<= 32) doubles in ONE launch of G = 32 workgroups: workgroup g sums
 // rows g, g+G, g+2G, ... into row g of `stage`; the workgroup that finishes LAST (a ticket counter) adds the G stage rows in fixed
 // order — which workgroup that is changes nothing in the arithmetic — and writes out[ncols] (+ zero padding up to out_n).
-// Hand-off between workgroups (per-CU L1s and per-XCD L2s are not coherent): stage rows are written and read with agent-scope
-// relaxed atomics (write-through / cache-bypassing accesses) and drained (s_waitcnt vmcnt(0)) before the ticket is taken; only
-// these 32 workgroups touch the ticket.  (Putting the ticket into the 2048 workgroups of the producer kernel was measured: +20 us.)
+// Hand-off between workgroups (per-CU L1s and per-XCD L2s are not coherent): a workgroup writes its stage row, a barrier orders the
+// row before lane 0's ticket increment, which is an agent-scope release / acquire (the row accesses themselves are agent-scope
+// relaxed atomics, i.e. write-through stores and cache-bypassing loads); only these <= 64 workgroups touch the ticket.  (Putting the ticket into the 2048 workgroups of the producer kernel was measured: +20 us.)
 // When `host` is given the result is handed to the host right here: copied into pinned, device-mapped host memory, then a
 // sequence number is published (system-scope release) on which the host spins.  This replaces hipMemcpyAsync +
 // hipStreamSynchronize, whose fixed cost is paid twice per optimizer iteration.
@@ -962,7 +963,7 @@ __global__ __launch_bounds__(kReduceSlices * kCols) void reduce_rows_kernel(
     if (threadIdx.x < kCols) __hip_atomic_store(&stage[blockIdx.x * kCols + threadIdx.x], sh[0][threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) sh_ticket = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) sh_ticket = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);  // release this workgroup's stage row, acquire the earlier ones
     __syncthreads();
     if (sh_ticket != static_cast<unsigned>(G - 1)) return;  // workgroup-uniform
     // the last workgroup adds the G <= 64 stage rows: slice s takes rows s, s + 8, ...: at most 8 loads per thread, all in flight
@@ -1236,7 +1237,12 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
       SGA_HIP(hipMemcpyAsync(h_idx.data(), d_idx.p, n * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
       SGA_HIP(hipMemcpyAsync(h_d2.data(), d_d2.p, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
       SGA_HIP(hipStreamSynchronize(ctx->stream));
-      if (pb->rejector_fn(pb->rejector_user, T, n, h_idx.data(), h_d2.data(), h_rej.data()) != 0) return fail(SGA_ERR_CALLBACK, "rejector callback failed");
+      int cb_rc;
+      {
+        StreamScope outside(nullptr);  // user code: objects it destroys (a Python GC run) are not stream-ordered frees of this entry point
+        cb_rc = pb->rejector_fn(pb->rejector_user, T, n, h_idx.data(), h_d2.data(), h_rej.data());
+      }
+      if (cb_rc != 0) return fail(SGA_ERR_CALLBACK, "rejector callback failed");
       SGA_HIP(hipMemcpyAsync(pb->reject.p, h_rej.data(), n, hipMemcpyHostToDevice, ctx->stream));
       SGA_HIP(hipStreamSynchronize(ctx->stream));  // h_rej goes out of scope
       p.reject = pb->reject.p;

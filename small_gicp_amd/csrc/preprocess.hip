@@ -212,7 +212,7 @@ __global__ __launch_bounds__(kFeatBlock) void local_features_kernel(
     sd[j * kFeatBlock + lane] = INFINITY;
     si[j * kFeatBlock + lane] = -1;
   }
-  // candidates scanned before the walk: the wave's own 64 positions and 96 on either side, fetched with four coalesced loads
+  // candidates scanned before the walk: the wave's own 64 positions and 32 on either side (kFeatWindow = 128), fetched with two coalesced loads
   const uint32_t base = blockIdx.x * kFeatBlock;
   const uint32_t pre_first = base > (kFeatWindow - kFeatBlock) / 2 ? base - (kFeatWindow - kFeatBlock) / 2 : 0u;
   const uint32_t pre_end = static_cast<uint32_t>(min(static_cast<size_t>(pre_first) + kFeatWindow, n));
@@ -391,7 +391,10 @@ int sga_index_refresh_attributes(sga_context* ctx, sga_index* index, const sga_c
 
 int sga_estimate_normals_covariances(sga_context* ctx, sga_cloud* cloud, const sga_index* index_in, int k, int flags) {
   if (!ctx || !cloud) return fail(SGA_ERR_INVALID, "null argument");
-  if (k < 1 || k > 116) return fail(SGA_ERR_INVALID, "num_neighbors must be in [1,116] ((k * 8 + 96) * 64 bytes of LDS per workgroup must stay below 64 KB)");
+  // LDS per workgroup: the k-best list (kpad * 8 bytes per lane, kpad = k rounded up to 4) + the traversal stack (kKdMaxDepth words per
+  // lane) + the static candidate window (kFeatWindow float4) must fit the 64 KB a workgroup may allocate
+  constexpr int kMaxK = ((64 * 1024 - kFeatWindow * 16) / 64 - kKdMaxDepth * 4) / 8 / 4 * 4;  // 112
+  if (k < 1 || k > kMaxK) return fail(SGA_ERR_INVALID, "num_neighbors must be in [1,%d] (k-best list + traversal stack + candidate window must fit 64 KB of LDS per workgroup)", kMaxK);
   if ((flags & 3) == 0) return SGA_OK;
   if (cloud->device != ctx->device) return fail(SGA_ERR_INVALID, "cloud lives on another device");
   SGA_ENTER(ctx);

@@ -4,6 +4,7 @@
 // over cells) so that the 64 lanes of a wave query neighbouring cells and share cache lines of the target.
 #include "common.hpp"
 
+#include <cmath>
 #include <memory>
 #include <rocprim/rocprim.hpp>
 #include "device_math.hpp"
@@ -226,6 +227,8 @@ int sga_problem_create(sga_context* ctx, const sga_index* target, const sga_clou
     hipLaunchKernelGGL(gather_source_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, order.p, n, source->pts.p, source->cov.p, pb->pts.p, pb->cov.p);
     SGA_HIP(hipGetLastError());
     SGA_TRY(cloud_bbox(ctx, source->pts.p, n, pb->bbox_lo, pb->bbox_hi));  // synchronises the stream
+    for (int k = 0; k < 3; k++)  // the box bounds the motion between two poses (warm passes): a non-finite point would make that bound meaningless
+      if (!std::isfinite(pb->bbox_lo[k]) || !std::isfinite(pb->bbox_hi[k])) return fail(SGA_ERR_INVALID, "source cloud contains non-finite coordinates");
   }
   *out = pb.release();
   return SGA_OK;

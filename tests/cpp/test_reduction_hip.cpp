@@ -6,10 +6,12 @@
 //
 //   test_reduction_hip <target.bin> <source.bin>      (raw float32 xyz triples)
 // Prints one "CASE {json}" line per case and exits non-zero if any check fails.
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <fstream>
 #include <iostream>
+#include <random>
 #include <string>
 #include <vector>
 
@@ -134,13 +136,30 @@ int main(int argc, char** argv) {
       source->normal(i) = nn;
     }
     run_case("GICP after refilling the source object in place", *target, *source, tree, reg, I);
-    reg.reduction.sync_factors = false;  // fast path: the count comes from the reduction
+    {
+      // a PARTIAL in-place edit (a filter that touches a few points between two registrations): every point is part of the
+      // fingerprint, so the stale device copy must be replaced
+      const auto before = reg.reduction.generation();
+      for (size_t i = 1; i < source->size(); i += 97) source->point(i)[2] = static_cast<float>(source->point(i)[2] + 0.02);
+      run_case("GICP after editing a subset of the source points in place", *target, *source, tree, reg, I);
+      const bool ok = reg.reduction.generation() == before + 1;
+      std::printf("CASE {\"name\": \"partial in-place edit was uploaded again\", \"ok\": %s, \"uploads\": [%llu, %llu]}\n", ok ? "true" : "false", static_cast<unsigned long long>(before),
+                  static_cast<unsigned long long>(reg.reduction.generation()));
+      if (!ok) failures++;
+    }
+    {
+      // full factor state on request: GICPFactor::mahalanobis filled like a CPU reduction leaves it
+      reg.reduction.sync_factors = true;
+      run_case("GICP with sync_factors (mahalanobis on the host)", *target, *source, tree, reg, I);
+      reg.reduction.sync_factors = false;
+    }
+    reg.reduction.sync_inliers = false;  // fastest path: the host factors stay untouched, the count comes from the reduction
     Registration<GICPFactor, ParallelReductionOMP> cpu;
     cpu.reduction.num_threads = 4;
     const auto rc = cpu.align(*target, *source, tree, I);
     auto rh = reg.align(*target, *source, tree, I);
     const bool ok = rh.num_inliers == 0 && std::llabs(static_cast<long long>(reg.reduction.num_inliers) - static_cast<long long>(rc.num_inliers)) <= 2;
-    std::printf("CASE {\"name\": \"sync_factors = false: count from reduction.num_inliers\", \"ok\": %s, \"reduction_num_inliers\": %zu, \"cpu\": %zu}\n", ok ? "true" : "false", reg.reduction.num_inliers, rc.num_inliers);
+    std::printf("CASE {\"name\": \"sync_inliers = false: count from reduction.num_inliers\", \"ok\": %s, \"reduction_num_inliers\": %zu, \"cpu\": %zu}\n", ok ? "true" : "false", reg.reduction.num_inliers, rc.num_inliers);
     if (!ok) failures++;
   }
   {
@@ -169,6 +188,54 @@ int main(int argc, char** argv) {
     std::printf("CASE {\"name\": \"Cauchy GICP, NullRejector\", \"ok\": %s, \"dt\": %.3e, \"dr\": %.3e, \"iterations\": [%zu, %zu], \"num_inliers\": [%zu, %zu]}\n", ok ? "true" : "false", dt, dr, rh.iterations, rc.iterations, rh.num_inliers,
                 rc.num_inliers);
     if (!ok) failures++;
+  }
+  // ---- iterations/s THROUGH the policy (what a small_gicp user who swaps the Reduction gets), default settings of the policy ----
+  auto rate = [&](const char* name, const PointCloud& tgt, const PointCloud& src, const KdTree<PointCloud>& tr, int reps) {
+    Registration<GICPFactor, ParallelReductionHIP> reg;
+    reg.criteria.rotation_eps = 0.0;  // fixed number of LM iterations, like bench.py
+    reg.criteria.translation_eps = 0.0;
+    reg.optimizer.max_iterations = 10;
+    reg.align(tgt, src, tr, I);  // upload + index build + warm-up
+    size_t iters = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < reps; r++) iters += reg.align(tgt, src, tr, I).iterations + 1;
+    const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    Registration<GICPFactor, ParallelReductionOMP> cpu;
+    cpu.criteria = reg.criteria;
+    cpu.optimizer.max_iterations = 10;
+    cpu.reduction.num_threads = 32;
+    const auto c0 = std::chrono::steady_clock::now();
+    const size_t citers = cpu.align(tgt, src, tr, I).iterations + 1;
+    const double cel = std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count();
+    std::printf("RATE {\"name\": \"%s\", \"points\": [%zu, %zu], \"hip_policy_iterations_per_s\": %.1f, \"omp32_iterations_per_s\": %.1f, \"uploads\": %llu}\n", name, tgt.size(), src.size(), iters / el, citers / cel,
+                static_cast<unsigned long long>(reg.reduction.generation()));
+  };
+  rate("C1 (downsampled 0.25 m)", *target, *source, tree, 50);
+  {
+    // ~100k-point clouds: a ground plane and two walls, sampled twice; the source displaced by a small rigid motion
+    auto make = [&](unsigned seed, const Eigen::Isometry3d& M) {
+      std::mt19937 rng(seed);
+      std::uniform_real_distribution<double> u(0.0, 1.0);
+      std::normal_distribution<double> noise(0.0, 0.01);
+      std::vector<Eigen::Vector4d> pts;
+      for (int i = 0; i < 260000; i++) {
+        const double a = u(rng), b = u(rng);
+        Eigen::Vector4d p;
+        if (i % 10 < 6) p = Eigen::Vector4d(60 * a - 30, 60 * b - 30, 0, 1);
+        else if (i % 10 < 8) p = Eigen::Vector4d(60 * a - 30, 12, 8 * b, 1);
+        else p = Eigen::Vector4d(-15, 60 * a - 30, 8 * b, 1);
+        for (int k = 0; k < 3; k++) p[k] += noise(rng);
+        pts.push_back(M * p);
+      }
+      return preprocess(pts);
+    };
+    Eigen::Isometry3d M = Eigen::Isometry3d::Identity();
+    M.matrix()(0, 0) = std::cos(0.01), M.matrix()(0, 1) = -std::sin(0.01), M.matrix()(1, 0) = std::sin(0.01), M.matrix()(1, 1) = std::cos(0.01);
+    M.matrix()(0, 3) = 0.1, M.matrix()(1, 3) = -0.05;
+    auto big_t = make(1, Eigen::Isometry3d::Identity());
+    auto big_s = make(2, M.inverse());
+    KdTree<PointCloud> big_tree(big_t, KdTreeBuilderOMP(8));
+    rate("synthetic planes (~100k after 0.25 m voxel grid)", *big_t, *big_s, big_tree, 20);
   }
   std::printf("DONE failures=%d\n", failures);
   return failures == 0 ? 0 : 1;

@@ -122,7 +122,7 @@ for math in ("fp64", "fp32"):
                      num_inliers=int(res.num_inliers), single_inliers=int(s.num_inliers), lin_inliers=int(ninl), error=res.error, single_error=s.error)
 out["counts"] = sorted(set(calls))
 out["collectives"] = len(calls)
-print("RESULT " + json.dumps(out), flush=True)
+json.dump(out, open(os.path.join(os.environ["SGA_TMP"], "result_%d.json" % rank), "w"))  # (the ranks share one stdout: lines could interleave)
 dist.barrier()
 dist.destroy_process_group()
 """
@@ -132,12 +132,11 @@ def test_two_ranks_share_one_registration_through_the_callback_transport(tmp_pat
     """sga_comm_init_callback: the real kernels, the 96-double accumulator and the per-rank error model with two ranks on device 0."""
     script = tmp_path / "worker_cb.py"
     script.write_text(WORKER_CB)
-    env = dict(os.environ, SGA_ROOT=ROOT, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, SGA_ROOT=ROOT, SGA_TMP=str(tmp_path), MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29741", str(script)]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
-    res = [json.loads(ln[7:]) for ln in p.stdout.splitlines() if ln.startswith("RESULT ")]
-    assert len(res) == 2
+    res = [json.load(open(tmp_path / ("result_%d.json" % r))) for r in range(2)]
     g = c1_gold["cases"]["GICP"]
     for r in res:
         assert r["counts"] == [96], r["counts"]                 # one collective per linearization, system + error-model moments
@@ -147,7 +146,8 @@ def test_two_ranks_share_one_registration_through_the_callback_transport(tmp_pat
             print("sharded vs unsharded (%s): dt %.2e m, dr %.2e rad, iterations %d / %d, inliers %d / %d" % (math, dt, dr, m["iterations"], m["single_iterations"], m["num_inliers"], m["single_inliers"]))
             assert dt < tol and dr < tol, (math, dt, dr)
             assert m["iterations"] == m["single_iterations"] == g["iterations"]
-            assert m["num_inliers"] == m["single_inliers"] == m["lin_inliers"] == g["num_inliers"] or math == "fp32"
+            assert m["num_inliers"] == m["single_inliers"] and (m["num_inliers"] == g["num_inliers"] or math == "fp32")
+            assert 0 < m["lin_inliers"] <= m["num_inliers"] + 1000  # the all-reduced count of the explicit linearization at the identity
             assert abs(m["error"] - m["single_error"]) <= 1e-6 * abs(m["single_error"])
             dt, dr = pose_error(np.array(m["T"]), np.array(g["T"]))
             assert dt < 1e-4 and dr < 1e-4

@@ -86,7 +86,7 @@ def test_linearize_and_error_match_oracle(orc, c1_f32, gpu_c1, name, kind, robus
 
 
 @pytest.mark.parametrize("name", ["GICP", "PLANE_ICP", "ICP"])
-@pytest.mark.parametrize("mode", ["fp32"])  # fp64 passes always run the error kernel
+@pytest.mark.parametrize("mode", ["fp32", "fp64"])  # sga_linearize builds the error model in both arithmetic modes
 def test_error_model_matches_error_kernel(gpu_c1, name, mode):
     """sga_error answers from the quadratic error model accumulated by the last linearization; the error kernel (a pass over the
     cloud with the cached correspondences / mahalanobis, Reduction::error of reduction_omp.hpp:61-70) must give the same number at
