@@ -102,6 +102,11 @@ inline void check(int rc, const char* what) {
   if (rc != SGA_OK) throw std::runtime_error(std::string("small_gicp_amd: ") + what + ": " + sga_last_error());
 }
 
+// Host loops over the points (fingerprint, repack, factor fill) use a SMALL fixed team and only for large clouds: a default-sized
+// OpenMP team (every hardware thread, spinning between regions) costs more than these loops and fights the registration's own threads.
+constexpr int kHostThreads = 8;
+constexpr size_t kParallelFrom = 65536;
+
 // identity of a cloud's CONTENT: size, attributes and EVERY point / normal / covariance entry (FNV-1a per block of 4096 points, the
 // block hashes combined in order; OpenMP over the blocks).  One streaming pass over the host data — cheap next to the repack and
 // upload it decides about, and an in-place edit of any point is seen (a sampled fingerprint would miss it).
@@ -113,7 +118,7 @@ std::uint64_t fingerprint(const Cloud& c) {
   const size_t blocks = (n + kBlock - 1) / kBlock;
   std::vector<std::uint64_t> part(blocks);
 #ifdef _OPENMP
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(kHostThreads) if (n >= kParallelFrom)
 #endif
   for (long long bl = 0; bl < static_cast<long long>(blocks); bl++) {
     std::uint64_t h = 1469598103934665603ull;
@@ -169,7 +174,7 @@ sga_cloud* upload(sga_context* ctx, const Cloud& c) {
   const bool normals = traits::has_normals(c), covs = traits::has_covs(c);
   std::vector<double> p(4 * n), nr(normals ? 4 * n : 0), cv(covs ? 16 * n : 0);
 #ifdef _OPENMP
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(kHostThreads) if (n >= kParallelFrom)
 #endif
   for (long long ii = 0; ii < static_cast<long long>(n); ii++) {
     const size_t i = static_cast<size_t>(ii);
@@ -194,7 +199,7 @@ sga_cloud* upload(sga_context* ctx, const Cloud& c) {
 
 /// @brief Reduction on an MI355X through libsmall_gicp_amd (replaces ParallelReductionOMP, reduction_omp.hpp:21-73).
 struct ParallelReductionHIP {
-  ParallelReductionHIP() : device(0), sync_factors(false), sync_inliers(true), fp64_math(false), num_inliers(0), state(std::make_shared<hip_detail::DeviceState>()) {}
+  ParallelReductionHIP() : device(0), sync_factors(false), sync_inliers(true), verify_content(true), fp64_math(false), num_inliers(0), state(std::make_shared<hip_detail::DeviceState>()) {}
 
   /// Forget the uploaded clouds: the next linearize() uploads target and source again.
   void rebind() const {
@@ -211,7 +216,9 @@ struct ParallelReductionHIP {
       s.device = device;
       hip_detail::check(sga_context_create(device, &s.ctx), "sga_context_create");
     }
-    const std::uint64_t tfp = hip_detail::fingerprint(target), sfp = hip_detail::fingerprint(source);
+    // content check on every call (one streaming pass over both clouds, ~0.2 ms per 100k points): an object refilled in place is
+    // uploaded again.  verify_content = false trusts address + size (call rebind() after changing a cloud in place).
+    const std::uint64_t tfp = verify_content ? hip_detail::fingerprint(target) : traits::size(target), sfp = verify_content ? hip_detail::fingerprint(source) : traits::size(source);
     if (s.target_addr != static_cast<const void*>(&target) || s.target_fp != tfp || !s.index) {
       if (s.problem) sga_problem_destroy(s.problem);
       if (s.index) sga_index_destroy(s.index);
@@ -272,7 +279,7 @@ struct ParallelReductionHIP {
       if (gicp) s.m6.resize(6 * n);
       hip_detail::check(sga_problem_get_factors(s.ctx, s.problem, s.idx.data(), gicp ? s.m6.data() : nullptr), "sga_problem_get_factors");
 #ifdef _OPENMP
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(hip_detail::kHostThreads) if (n >= hip_detail::kParallelFrom)
 #endif
       for (long long ii = 0; ii < static_cast<long long>(n); ii++) {
         const size_t i = static_cast<size_t>(ii);
@@ -299,6 +306,7 @@ struct ParallelReductionHIP {
   int device;                  ///< HIP device
   bool sync_factors;           ///< also fill GICPFactor::mahalanobis of the host `factors` after every linearize (default off)
   bool sync_inliers;           ///< fill target_index / source_index of the host `factors` after every linearize (default on: optimizer.hpp:146 counts them)
+  bool verify_content;         ///< hash both clouds on every linearize to notice in-place edits (default on); off: address + size only, see rebind()
   bool fp64_math;              ///< per-pair arithmetic in fp64 (data on the device is fp32 either way)
   mutable size_t num_inliers;  ///< inliers of the last linearize
 

@@ -38,6 +38,6 @@ def test_registration_with_the_hip_reduction_policy(tmp_path):
         if ln.startswith("RATE "):
             print("policy rate:", ln[5:])
     rates = [json.loads(ln[5:]) for ln in p.stdout.splitlines() if ln.startswith("RATE ")]
-    assert len(rates) == 2 and all(r["hip_policy_iterations_per_s"] > 0 and r["uploads"] == 2 for r in rates)  # two uploads: target and source, once
+    assert len(rates) == 3 and all(r["hip_policy_iterations_per_s"] > 0 and r["uploads"] == 2 for r in rates)  # two uploads: target and source, once
     gicp = cases[0]
     assert gicp["num_inliers"][0] == gicp["reduction_num_inliers"] > 5000  # RegistrationResult::num_inliers is right without patching the optimizer
