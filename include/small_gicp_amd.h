@@ -138,6 +138,12 @@ void sga_factor_params_default(sga_factor_params* p);
 /* Pair a target index with a source cloud.  The problem keeps a spatially sorted copy of the source (sorted by the target kd-leaf
  * init_T * p falls into) and the per-point factor state (target index + cached mahalanobis), i.e. registration.hpp:41. */
 int sga_problem_create(sga_context* ctx, const sga_index* target, const sga_cloud* source, const double init_T[16], sga_problem** out);
+/* The same with the source given by ITS OWN kd-tree index (the odometry loop, src/benchmark/odometry_benchmark_small_gicp_omp.cpp:22-38:
+ * every scan is indexed once, for its covariances and as the next target): the problem takes the index's kd-ordered points and
+ * covariances as they are — the order is spatially coherent already, so no sort.  Factor state is reported in the ORIGINAL order of the
+ * cloud the index was built over, exactly as with sga_problem_create.  Attributes must be present in the index (build it after
+ * estimating them, or call sga_index_refresh_attributes). */
+int sga_problem_create_from_index(sga_context* ctx, const sga_index* target, const sga_index* source_index, const double init_T[16], sga_problem** out);
 int sga_problem_destroy(sga_problem* problem);
 /* Sum_i (H_i, b_i, e_i) at T over all source points with a correspondence; refreshes the factor state. */
 int sga_linearize(sga_context* ctx, sga_problem* problem, const sga_factor_params* params, const double T[16], double H[36], double b[6], double* e, uint64_t* num_inliers);

@@ -98,6 +98,7 @@ SYMBOLS = [
     ("sga_index_knn_f64", C.c_int, [_vp, _vp, _dp, C.c_size_t, C.c_int, C.c_double, C.POINTER(C.c_int64), _dp]),
     ("sga_factor_params_default", None, [C.POINTER(FactorParams)]),
     ("sga_problem_create", C.c_int, [_vp, _vp, _vp, _dp, _pvp]),
+    ("sga_problem_create_from_index", C.c_int, [_vp, _vp, _vp, _dp, _pvp]),
     ("sga_problem_destroy", C.c_int, [_vp]),
     ("sga_linearize", C.c_int, [_vp, _vp, C.POINTER(FactorParams), _dp, _dp, _dp, _dp, C.POINTER(C.c_uint64)]),
     ("sga_error", C.c_int, [_vp, _vp, C.POINTER(FactorParams), _dp, _dp]),

@@ -440,7 +440,10 @@ class Problem:
         self.ctx = ctx or source.ctx  # a problem may run on another context (stream) of the same device than the one that built its inputs
         self.h = C.c_void_p()
         t16 = _T16(init_T)
-        check(load().sga_problem_create(self.ctx.h, target.h, source.h, _dp(t16), C.byref(self.h)))
+        if isinstance(source, KdTree):  # the source by its own index: its kd order is taken as it is (no sort)
+            check(load().sga_problem_create_from_index(self.ctx.h, target.h, source.h, _dp(t16), C.byref(self.h)))
+        else:
+            check(load().sga_problem_create(self.ctx.h, target.h, source.h, _dp(t16), C.byref(self.h)))
 
     def __del__(self):
         if getattr(self, "h", None) and self.h.value:

@@ -363,6 +363,169 @@ __global__ __launch_bounds__(kFinishThreads) void kd_finish_kernel(const float4*
   for (uint32_t pos = tid; pos < m; pos += kFinishThreads) perm_out[B0 + pos] = gidx[ord[pos]];
 }
 
+// ---- top levels of SMALL clouds: one launch per level, one workgroup per segment --------------------------------------------------
+// A 15k-point scan (the odometry workload) is launch-bound: a level of the sort-based build above is a box kernel, a key kernel, a
+// rocPRIM sort (3 - 6 launches at this size) and a node kernel, ~45 us for 15k points that a single workgroup can hold in registers.
+// Here one workgroup of 1024 threads owns one segment (<= kSplitMaxPoints points, kSplitKeys per thread) and does the whole level:
+// bounding box -> longest axis -> the median by a three-round radix SELECT over the order-preserving keys (LDS histograms of 11 / 11
+// / 10 bits) -> a PARTITION around it (elements below the median, then just enough of the equal ones; positions from a block-wide
+// scan of per-thread counts, a fixed order) -> threshold.  A kd-tree needs the halves, not a sorted order inside them.  Deterministic.
+constexpr int kSplitThreads = 1024;
+constexpr int kSplitKeys = 32;                                     // keys per thread
+constexpr uint32_t kSplitMaxPoints = kSplitThreads * kSplitKeys;   // 32768
+constexpr int kSplitFinish = 256;                                  // segments of at most this many points go to kd_finish_kernel<256>
+
+// exclusive prefix sum of one value per thread over the workgroup (1024 threads = 16 waves); returns the total through `total`
+__device__ __forceinline__ uint32_t block_scan_exclusive(uint32_t v, uint32_t* __restrict__ sh_wave /* 17 words */, uint32_t& total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t inc = v;
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(inc, off);
+    if (lane >= off) inc += t;
+  }
+  __syncthreads();  // sh_wave may still be read from the previous call
+  if (lane == 63) sh_wave[wave] = inc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = 0;
+    for (int w = 0; w < kSplitThreads / 64; w++) {
+      const uint32_t t = sh_wave[w];
+      sh_wave[w] = run;
+      run += t;
+    }
+    sh_wave[kSplitThreads / 64] = run;
+  }
+  __syncthreads();
+  total = sh_wave[kSplitThreads / 64];
+  return sh_wave[wave] + inc - v;
+}
+
+__global__ __launch_bounds__(kSplitThreads) void kd_split_level_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ perm_in, uint32_t* __restrict__ perm_out, uint32_t n, int d, float2* __restrict__ nodes) {
+  __shared__ uint32_t hist[2048];
+  __shared__ uint32_t sh_wave[kSplitThreads / 64 + 1];
+  __shared__ float sh_lo[kSplitThreads / 64][3], sh_hi[kSplitThreads / 64][3];
+  __shared__ uint32_t sh_sel[3];  // bucket, keys below it, keys in it
+  __shared__ int sh_axis;
+  const uint32_t seg = blockIdx.x, tid = threadIdx.x;
+  const uint32_t first = kd_bound(n, d, seg), end = kd_bound(n, d, seg + 1), mid = kd_bound(n, d + 1, 2 * seg + 1);
+  const uint32_t len = end - first, m = mid - first;  // the left half gets m elements
+  if (len == 0) {  // cannot happen for the clouds this path is used for (segments of more than kSplitFinish points); workgroup-uniform
+    if (tid == 0) nodes[(1u << d) + seg] = make_float2(0.f, 0.f);
+    return;
+  }
+  // ---- the segment's points: element j of thread t sits at position first + j * 1024 + t
+  uint32_t src[kSplitKeys];
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+  for (int j = 0; j < kSplitKeys; j++) {
+    const uint32_t pos = j * kSplitThreads + tid;
+    src[j] = 0u;
+    if (pos < len) {
+      src[j] = perm_in[first + pos];
+      const float4 p = pts[src[j]];
+      lo[0] = fminf(lo[0], p.x), lo[1] = fminf(lo[1], p.y), lo[2] = fminf(lo[2], p.z);
+      hi[0] = fmaxf(hi[0], p.x), hi[1] = fmaxf(hi[1], p.y), hi[2] = fmaxf(hi[2], p.z);
+    }
+  }
+  for (int a = 0; a < 3; a++)
+    for (int off = 32; off > 0; off >>= 1) {
+      lo[a] = fminf(lo[a], __shfl_xor(lo[a], off));
+      hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off));
+    }
+  if ((tid & 63) == 0)
+    for (int a = 0; a < 3; a++) {
+      sh_lo[tid >> 6][a] = lo[a];
+      sh_hi[tid >> 6][a] = hi[a];
+    }
+  __syncthreads();
+  if (tid == 0) {
+    float v[3];
+    for (int a = 0; a < 3; a++) {
+      float l = INFINITY, h = -INFINITY;
+      for (int w = 0; w < kSplitThreads / 64; w++) {
+        l = fminf(l, sh_lo[w][a]);
+        h = fmaxf(h, sh_hi[w][a]);
+      }
+      v[a] = h - l;
+    }
+    sh_axis = v[0] >= v[1] ? (v[0] >= v[2] ? 0 : 2) : (v[1] >= v[2] ? 1 : 2);  // same rule as kd_longest_axis
+  }
+  __syncthreads();
+  const int axis = sh_axis;
+  uint32_t key[kSplitKeys];  // the coordinate along the split axis (read again: the lines are in the cache), order-preserving encoding
+#pragma unroll
+  for (int j = 0; j < kSplitKeys; j++) {
+    const uint32_t pos = j * kSplitThreads + tid;
+    key[j] = 0u;
+    if (pos < len) {
+      const float4 p = pts[src[j]];
+      key[j] = ordered_u32(axis == 0 ? p.x : (axis == 1 ? p.y : p.z));
+    }
+  }
+  // ---- radix select: the key of rank m (0-based) among the segment's keys, and how many keys are smaller
+  uint32_t prefix = 0u, prefix_mask = 0u, rank = min(m, len - 1u), below = 0u;
+  const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
+  for (int round = 0; round < 3; round++) {
+    hist[tid] = 0u;
+    hist[tid + kSplitThreads] = 0u;
+    __syncthreads();
+    const uint32_t bmask = (1u << bits[round]) - 1u;
+#pragma unroll
+    for (int j = 0; j < kSplitKeys; j++) {
+      const uint32_t pos = j * kSplitThreads + tid;
+      if (pos < len && (key[j] & prefix_mask) == prefix) atomicAdd(&hist[(key[j] >> shifts[round]) & bmask], 1u);
+    }
+    __syncthreads();
+    const uint32_t c0 = hist[2 * tid], c1 = hist[2 * tid + 1];
+    uint32_t total;
+    const uint32_t before = block_scan_exclusive(c0 + c1, sh_wave, total);
+    if (rank >= before && rank < before + c0 + c1) {  // exactly one thread
+      const bool second = rank >= before + c0;
+      sh_sel[0] = 2 * tid + (second ? 1u : 0u);
+      sh_sel[1] = before + (second ? c0 : 0u);
+      sh_sel[2] = second ? c1 : c0;
+    }
+    __syncthreads();
+    const uint32_t bucket = sh_sel[0], under = sh_sel[1];
+    prefix |= bucket << shifts[round];
+    prefix_mask |= bmask << shifts[round];
+    below += under;
+    rank -= under;
+    __syncthreads();
+  }
+  const uint32_t median = prefix;   // `below` keys are smaller; the first `rank` of the `eq_total` equal ones complete the left half
+  const uint32_t eq_total = sh_sel[2];
+  // ---- partition: [keys < median][`rank` of the equal keys] | [the other equal keys][keys > median].  Order inside the four parts:
+  // thread-major (thread t's elements, rows ascending, behind those of threads < t) — fixed, hence deterministic; ONE block-wide scan
+  // of the per-thread counts instead of one per row.
+  uint32_t my_less = 0u, my_eq = 0u, my_cnt = 0u;
+#pragma unroll
+  for (int j = 0; j < kSplitKeys; j++) {
+    const bool valid = j * kSplitThreads + tid < len;
+    my_less += (valid && key[j] < median) ? 1u : 0u;
+    my_eq += (valid && key[j] == median) ? 1u : 0u;
+    my_cnt += valid ? 1u : 0u;
+  }
+  uint32_t total;
+  const uint32_t packed = block_scan_exclusive(my_less | (my_eq << 16), sh_wave, total);  // <= 32 per thread, <= 32768 in all: 16 bits each
+  uint32_t n_less = packed & 0xffffu, n_eq = packed >> 16;  // elements of the two kinds owned by lower threads
+  uint32_t total2;
+  uint32_t n_all = block_scan_exclusive(my_cnt, sh_wave, total2);  // all elements owned by lower threads
+#pragma unroll  // static indices: src[] / key[] stay in registers
+  for (int j = 0; j < kSplitKeys; j++) {
+    if (j * kSplitThreads + tid < len) {
+      const bool less = key[j] < median, eq = key[j] == median;
+      const uint32_t n_greater = n_all - n_less - n_eq;
+      const uint32_t dest = less ? n_less : (eq ? (n_eq < rank ? below + n_eq : m + (n_eq - rank)) : m + (eq_total - rank) + n_greater);
+      perm_out[first + dest] = src[j];
+      n_less += less ? 1u : 0u;
+      n_eq += eq ? 1u : 0u;
+      n_all += 1u;
+    }
+  }
+  if (tid == 0) nodes[(1u << d) + seg] = make_float2(len > 0 ? float_from_ordered(static_cast<int>(median ^ 0x80000000u)) : 0.f, __int_as_float(axis));
+}
+
 // pair records for the 1-NN walk (kd_search.hpp): node of even depth + its two children in one 16-byte record; one launch covers
 // every even depth (record r of the level-by-level layout belongs to depth d = 2 * floor(log4(3 r + 1)))
 __global__ void kd_pairs_kernel(const float2* __restrict__ nodes, int D, uint32_t count, float4* __restrict__ pairs) {
@@ -531,7 +694,17 @@ static int build_kdtree(sga_context* ctx, const sga_cloud* cloud, sga_index* idx
   while (dA < D && ((n + (1ull << dA) - 1) >> dA) > static_cast<size_t>(cap)) dA++;
   const bool lds_finish = !(getenv("SGA_KD_FINISH") && atoi(getenv("SGA_KD_FINISH")) == 0);  // read per build: the tests compare both paths
   if (!lds_finish || D - dA > 8) dA = D;
-  for (int d = 0; d < dA; d++) {
+  // small clouds: one launch per level (kd_split_level_kernel) down to segments of kSplitFinish points, the rest in LDS
+  const bool split_path = lds_finish && n <= kSplitMaxPoints && !(getenv("SGA_KD_SPLIT") && atoi(getenv("SGA_KD_SPLIT")) == 0);
+  if (split_path) {
+    dA = 0;
+    while (dA < D && ((n + (1ull << dA) - 1) >> dA) > static_cast<size_t>(kSplitFinish)) dA++;
+    for (int d = 0; d < dA; d++) {
+      hipLaunchKernelGGL(kd_split_level_kernel, dim3(1u << d), dim3(kSplitThreads), 0, ctx->stream, cloud->pts.p, cur, nxt, static_cast<uint32_t>(n), d, idx->kd_nodes.p);
+      std::swap(cur, nxt);
+    }
+  }
+  for (int d = 0; d < dA && !split_path; d++) {
     const uint32_t nseg = 1u << d;
     const dim3 sgrid((nseg + 255) / 256);
     const unsigned end_bit = 32 + (d > 0 ? d : 1);
@@ -547,7 +720,10 @@ static int build_kdtree(sga_context* ctx, const sga_cloud* cloud, sga_index* idx
     std::swap(cur, nxt);
     hipLaunchKernelGGL(kd_nodes_kernel, sgrid, block, 0, ctx->stream, cloud->pts.p, cur, static_cast<uint32_t>(n), d, axis_of_seg.p, idx->kd_nodes.p, d + 1 < dA ? seg_box.p : static_cast<int*>(nullptr));
   }
-  if (dA < D) {
+  if (dA < D && split_path) {
+    hipLaunchKernelGGL(kd_finish_kernel<kSplitFinish>, dim3(1u << dA), dim3(kFinishThreads), 0, ctx->stream, cloud->pts.p, cur, nxt, static_cast<uint32_t>(n), dA, D, idx->kd_nodes.p);
+    std::swap(cur, nxt);
+  } else if (dA < D) {
     if (cap == kFinishCap)
       hipLaunchKernelGGL(kd_finish_kernel<kFinishCap>, dim3(1u << dA), dim3(kFinishThreads), 0, ctx->stream, cloud->pts.p, cur, nxt, static_cast<uint32_t>(n), dA, D, idx->kd_nodes.p);
     else

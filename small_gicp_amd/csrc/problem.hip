@@ -168,6 +168,57 @@ void sga_factor_params_default(sga_factor_params* p) {
   p->math_mode = SGA_MATH_FP32;
 }
 
+// the per-point factor state of a problem over n source points: correspondences and certificates start as "none"
+static int problem_alloc_state(sga_context* ctx, sga_problem* pb, size_t n, bool has_covs) {
+  SGA_TRY(pb->partials.alloc(problem_partials_doubles(n)));
+  SGA_TRY(pb->walked.alloc(n / 64 + 1));
+  SGA_HIP(hipMemsetAsync(pb->walked.p, 0, (n / 64 + 1) * sizeof(uint32_t), ctx->stream));
+  if (n == 0) return SGA_OK;
+  SGA_TRY(pb->pts.alloc(n));
+  if (has_covs) SGA_TRY(pb->cov.alloc(n));
+  // corr | hint | hint2 in ONE allocation-sized fill would need one buffer; three fills of -1 it is.  The mahalanobis cache is only ever
+  // read where corr >= 0, i.e. after a pass has written it: no fill.
+  SGA_TRY(pb->corr.alloc(n));
+  SGA_TRY(pb->hint.alloc(n));
+  SGA_TRY(pb->hint2.alloc(n));
+  SGA_TRY(pb->rex.alloc(n));
+  SGA_TRY(pb->maha.alloc(n * 6));
+  SGA_HIP(hipMemsetAsync(pb->corr.p, 0xff, n * sizeof(int), ctx->stream));
+  SGA_HIP(hipMemsetAsync(pb->hint.p, 0xff, n * sizeof(int), ctx->stream));
+  SGA_HIP(hipMemsetAsync(pb->hint2.p, 0xff, n * sizeof(int), ctx->stream));
+  return SGA_OK;
+}
+
+// The source given by ITS OWN kd-tree index (a scan that has just been indexed for its covariances and as the next target — the
+// odometry loop, odometry_benchmark_small_gicp_omp.cpp:22-38): the index's kd order is spatially coherent, so the problem takes the
+// kd-ordered points and covariances as they are — no sort keys, no sort, no gather, no bounding-box pass (the index knows its box).
+int sga_problem_create_from_index(sga_context* ctx, const sga_index* target, const sga_index* source, const double init_T[16], sga_problem** out) {
+  if (!ctx || !target || !source || !out) return fail(SGA_ERR_INVALID, "null argument");
+  if (target->device != ctx->device || source->device != ctx->device) return fail(SGA_ERR_INVALID, "target/source live on another device");
+  if (source->kind != SGA_INDEX_KDTREE) return fail(SGA_ERR_INVALID, "the source index must be a kd-tree");
+  (void)init_T;  // the kd order does not depend on the initial guess
+  *out = nullptr;
+  SGA_ENTER(ctx);
+  std::unique_ptr<sga_problem> pb(new sga_problem);
+  pb->device = ctx->device;
+  pb->target = target;
+  pb->n = source->n;
+  pb->has_normals = source->has_normals;
+  pb->has_covs = source->has_covs;
+  const size_t n = source->n;
+  SGA_TRY(problem_alloc_state(ctx, pb.get(), n, source->has_covs));
+  if (n > 0) {
+    SGA_HIP(hipMemcpyAsync(pb->pts.p, source->kd_pts.p, n * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
+    if (source->has_covs) SGA_HIP(hipMemcpyAsync(pb->cov.p, source->cov.p, n * sizeof(Cov8), hipMemcpyDeviceToDevice, ctx->stream));
+    for (int k = 0; k < 3; k++) {
+      pb->bbox_lo[k] = source->bbox_lo[k];
+      pb->bbox_hi[k] = source->bbox_hi[k];
+    }
+  }
+  *out = pb.release();
+  return SGA_OK;
+}
+
 int sga_problem_create(sga_context* ctx, const sga_index* target, const sga_cloud* source, const double init_T[16], sga_problem** out) {
   if (!ctx || !target || !source || !out) return fail(SGA_ERR_INVALID, "null argument");
   if (target->device != ctx->device || source->device != ctx->device) return fail(SGA_ERR_INVALID, "target/source live on another device");
@@ -182,21 +233,8 @@ int sga_problem_create(sga_context* ctx, const sga_index* target, const sga_clou
   pb->has_normals = source->has_normals;
   pb->has_covs = source->has_covs;
   const size_t n = source->n;
-  SGA_TRY(pb->partials.alloc(problem_partials_doubles(n)));
-  SGA_TRY(pb->walked.alloc(n / 64 + 1));
-  SGA_HIP(hipMemsetAsync(pb->walked.p, 0, (n / 64 + 1) * sizeof(uint32_t), ctx->stream));
+  SGA_TRY(problem_alloc_state(ctx, pb.get(), n, source->has_covs));
   if (n > 0) {
-    SGA_TRY(pb->pts.alloc(n));
-    if (source->has_covs) SGA_TRY(pb->cov.alloc(n));
-    SGA_TRY(pb->corr.alloc(n));
-    SGA_TRY(pb->hint.alloc(n));
-    SGA_TRY(pb->hint2.alloc(n));
-    SGA_TRY(pb->rex.alloc(n));
-    SGA_TRY(pb->maha.alloc(n * 6));
-    SGA_HIP(hipMemsetAsync(pb->corr.p, 0xff, n * sizeof(int), ctx->stream));
-    SGA_HIP(hipMemsetAsync(pb->hint.p, 0xff, n * sizeof(int), ctx->stream));
-    SGA_HIP(hipMemsetAsync(pb->hint2.p, 0xff, n * sizeof(int), ctx->stream));
-    SGA_HIP(hipMemsetAsync(pb->maha.p, 0, n * 6 * sizeof(float), ctx->stream));
     DevBuf<unsigned long long> keys, keys_sorted;
     DevBuf<uint32_t> vals, order;
     SGA_TRY(keys.alloc(n));

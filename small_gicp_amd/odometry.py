@@ -45,7 +45,7 @@ class OnlineOdometry:
         api.estimate_covariances(cloud, tree, self.k)
         if self.target is not None:
             tgt_cloud, tgt_tree = self.target
-            src = cloud
+            src = tree  # the scan by its own index: its kd order is spatially coherent, the problem takes it as it is (no sort)
             if self.shard is not None:
                 rank, world = self.shard
                 n = cloud.size()
@@ -195,7 +195,7 @@ class PipelinedOdometry:
             if prev is not None:
                 # the registration runs on its own context / stream; the preprocessing calls returned synchronised, so the
                 # clouds and the index are complete in device memory
-                pb = api.Problem(prev[1], cloud, np.eye(4), ctx=self.ctx_reg)
+                pb = api.Problem(prev[1], tree, np.eye(4), ctx=self.ctx_reg)
                 res = pb.align(self.setting, np.eye(4))
                 T_world = T_world @ res.T_target_source
                 iters.append(res.iterations + 1)

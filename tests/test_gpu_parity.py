@@ -1023,3 +1023,23 @@ def test_incremental_maps_edge_cases():
     assert len(coords) == 1 and counts[0] == 10 and (p[0] == dense[0]).all()
     dmin = min(np.linalg.norm(p[i] - p[j]) for i in range(10) for j in range(i))
     assert dmin >= 0.1 - 1e-6
+
+
+def test_problem_from_source_index_equals_problem_from_cloud(gpu_c1):
+    """sga_problem_create_from_index takes the source in the kd order of its own index instead of sorting it by target leaf: the
+    registration, the per-point factor state (reported in the cloud's original order) and the sums must be those of the sorted form."""
+    tgt, src, tree = gpu_c1
+    src_tree = sga.KdTree(src)  # carries the cloud's covariances / normals in kd order
+    for name in ("GICP", "PLANE_ICP"):
+        for mode, tol in (("fp64", 1e-9), ("fp32", 1e-5)):
+            st = sga.make_setting(name, math_mode=mode)
+            a, b = sga.Problem(tree, src), sga.Problem(tree, src_tree)
+            T = POSES[1]
+            Ha, ba, ea, na = a.linearize(st.factor, T)
+            Hb, bb, eb, nb = b.linearize(st.factor, T)
+            assert na == nb and (a.factors()[0] == b.factors()[0]).all()
+            rel = 1e-12 if mode == "fp64" else 2e-5
+            assert np.abs(Ha - Hb).max() <= rel * np.abs(Ha).max() and abs(ea - eb) <= rel * abs(ea)
+            ra, rb = a.align(st), b.align(st)
+            dt, dr = pose_error(ra.T_target_source, rb.T_target_source)
+            assert dt < tol and dr < tol and ra.iterations == rb.iterations and ra.num_inliers == rb.num_inliers, (name, mode, dt, dr)
