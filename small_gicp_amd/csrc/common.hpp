@@ -197,6 +197,12 @@ struct sga_problem {
   bool has_normals = false, has_covs = false;
   sga::DevBuf<float4> pts;       // spatially sorted copy of the source; w = original index bits
   sga::DevBuf<sga::Cov8> cov;
+  // a problem created from the source's own index (sga_problem_create_from_index) borrows that index's kd-ordered arrays instead
+  // of copying them: the index must outlive the problem (like the target index)
+  const float4* pts_view = nullptr;
+  const sga::Cov8* cov_view = nullptr;
+  const float4* src_pts() const { return pts_view ? pts_view : pts.p; }
+  const sga::Cov8* src_cov() const { return cov_view ? cov_view : cov.p; }
   // factor state
   sga::DevBuf<int> corr;         // kd position of the matched target point / voxel id (voxelmap); -1 = outlier
   sga::DevBuf<int> hint;         // exact nearest neighbour per source point at the last linearization pose, rejected or not (kd targets)

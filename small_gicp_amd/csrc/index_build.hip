@@ -366,46 +366,39 @@ __global__ __launch_bounds__(kFinishThreads) void kd_finish_kernel(const float4*
 // ---- top levels of SMALL clouds: one launch per level, one workgroup per segment --------------------------------------------------
 // A 15k-point scan (the odometry workload) is launch-bound: a level of the sort-based build above is a box kernel, a key kernel, a
 // rocPRIM sort (3 - 6 launches at this size) and a node kernel, ~45 us for 15k points that a single workgroup can hold in registers.
-// Here one workgroup of 1024 threads owns one segment (<= kSplitMaxPoints points, kSplitKeys per thread) and does the whole level:
+// Here one workgroup (1024 threads, or 256 for segments of at most 8192 points: cheaper barriers) owns one segment (<= kSplitKeys
+// points per thread) and does the whole level:
 // bounding box -> longest axis -> the median by a three-round radix SELECT over the order-preserving keys (LDS histograms of 11 / 11
 // / 10 bits) -> a PARTITION around it (elements below the median, then just enough of the equal ones; positions from a block-wide
 // scan of per-thread counts, a fixed order) -> threshold.  A kd-tree needs the halves, not a sorted order inside them.  Deterministic.
-constexpr int kSplitThreads = 1024;
-constexpr int kSplitKeys = 32;                                     // keys per thread
-constexpr uint32_t kSplitMaxPoints = kSplitThreads * kSplitKeys;   // 32768
+constexpr uint32_t kSplitMaxPoints = 1024 * 32;                  // 32768: the largest cloud this path builds (1024 threads x 32 keys)
 constexpr int kSplitFinish = 256;                                  // segments of at most this many points go to kd_finish_kernel<256>
+constexpr int kSplitBins = 2048;
 
-// exclusive prefix sum of one value per thread over the workgroup (1024 threads = 16 waves); returns the total through `total`
-__device__ __forceinline__ uint32_t block_scan_exclusive(uint32_t v, uint32_t* __restrict__ sh_wave /* 17 words */, uint32_t& total) {
+// exclusive prefix sum of one value per thread over the workgroup: wave scan, the wave totals through LDS (`sh_wave`: a slot of its
+// own per call site, so no barrier protects its reuse), one barrier
+template <int THREADS>
+__device__ __forceinline__ uint32_t split_scan_exclusive(uint32_t v, uint32_t* __restrict__ sh_wave) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t inc = v;
   for (int off = 1; off < 64; off <<= 1) {
     const uint32_t t = __shfl_up(inc, off);
     if (lane >= off) inc += t;
   }
-  __syncthreads();  // sh_wave may still be read from the previous call
   if (lane == 63) sh_wave[wave] = inc;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t run = 0;
-    for (int w = 0; w < kSplitThreads / 64; w++) {
-      const uint32_t t = sh_wave[w];
-      sh_wave[w] = run;
-      run += t;
-    }
-    sh_wave[kSplitThreads / 64] = run;
-  }
-  __syncthreads();
-  total = sh_wave[kSplitThreads / 64];
-  return sh_wave[wave] + inc - v;
+  uint32_t base = 0;
+  for (int w = 0; w < THREADS / 64; w++) base += w < wave ? sh_wave[w] : 0u;
+  return base + inc - v;
 }
 
-__global__ __launch_bounds__(kSplitThreads) void kd_split_level_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ perm_in, uint32_t* __restrict__ perm_out, uint32_t n, int d, float2* __restrict__ nodes) {
-  __shared__ uint32_t hist[2048];
-  __shared__ uint32_t sh_wave[kSplitThreads / 64 + 1];
-  __shared__ float sh_lo[kSplitThreads / 64][3], sh_hi[kSplitThreads / 64][3];
-  __shared__ uint32_t sh_sel[3];  // bucket, keys below it, keys in it
-  __shared__ int sh_axis;
+template <int THREADS, int kSplitKeys>  // kSplitKeys: keys per thread; the launcher picks the smallest THREADS x kSplitKeys that holds a segment
+__global__ __launch_bounds__(THREADS) void kd_split_level_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ perm_in, uint32_t* __restrict__ perm_out, uint32_t n, int d, float2* __restrict__ nodes) {
+  constexpr int kWaves = THREADS / 64, kBinsPerThread = kSplitBins / THREADS;
+  __shared__ uint32_t hist[3][kSplitBins];
+  __shared__ uint32_t sh_wave[4][kWaves];
+  __shared__ float sh_lo[kWaves][3], sh_hi[kWaves][3];
+  __shared__ uint32_t sh_sel[3][3];  // per round: bucket, keys below it, keys in it
   const uint32_t seg = blockIdx.x, tid = threadIdx.x;
   const uint32_t first = kd_bound(n, d, seg), end = kd_bound(n, d, seg + 1), mid = kd_bound(n, d + 1, 2 * seg + 1);
   const uint32_t len = end - first, m = mid - first;  // the left half gets m elements
@@ -413,18 +406,25 @@ __global__ __launch_bounds__(kSplitThreads) void kd_split_level_kernel(const flo
     if (tid == 0) nodes[(1u << d) + seg] = make_float2(0.f, 0.f);
     return;
   }
-  // ---- the segment's points: element j of thread t sits at position first + j * 1024 + t
+  for (int r = 0; r < 3; r++)
+    for (int b = 0; b < kBinsPerThread; b++) hist[r][b * THREADS + tid] = 0u;
+  // ---- the segment's points: element j of thread t sits at position first + j * THREADS + t.  The loads are UNCONDITIONAL (rows past
+  // the end re-read the last element and are ignored) so that all of a stage's loads are in flight together: a row behind a branch
+  // costs two dependent memory latencies, and there are up to 32 rows.
   uint32_t src[kSplitKeys];
-  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
-  for (int j = 0; j < kSplitKeys; j++) {
-    const uint32_t pos = j * kSplitThreads + tid;
-    src[j] = 0u;
-    if (pos < len) {
-      src[j] = perm_in[first + pos];
-      const float4 p = pts[src[j]];
-      lo[0] = fminf(lo[0], p.x), lo[1] = fminf(lo[1], p.y), lo[2] = fminf(lo[2], p.z);
-      hi[0] = fmaxf(hi[0], p.x), hi[1] = fmaxf(hi[1], p.y), hi[2] = fmaxf(hi[2], p.z);
+  for (int j = 0; j < kSplitKeys; j++) src[j] = perm_in[first + min(static_cast<uint32_t>(j * THREADS) + tid, len - 1u)];
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  constexpr int kChunk = kSplitKeys < 8 ? kSplitKeys : 8;
+#pragma unroll
+  for (int j0 = 0; j0 < kSplitKeys; j0 += kChunk) {
+    float4 p[kChunk];
+#pragma unroll
+    for (int u = 0; u < kChunk; u++) p[u] = pts[src[j0 + u]];
+#pragma unroll
+    for (int u = 0; u < kChunk; u++) {  // (a repeated last element changes nothing in a box)
+      lo[0] = fminf(lo[0], p[u].x), lo[1] = fminf(lo[1], p[u].y), lo[2] = fminf(lo[2], p[u].z);
+      hi[0] = fmaxf(hi[0], p[u].x), hi[1] = fmaxf(hi[1], p[u].y), hi[2] = fmaxf(hi[2], p[u].z);
     }
   }
   for (int a = 0; a < 3; a++)
@@ -438,82 +438,75 @@ __global__ __launch_bounds__(kSplitThreads) void kd_split_level_kernel(const flo
       sh_hi[tid >> 6][a] = hi[a];
     }
   __syncthreads();
-  if (tid == 0) {
-    float v[3];
-    for (int a = 0; a < 3; a++) {
-      float l = INFINITY, h = -INFINITY;
-      for (int w = 0; w < kSplitThreads / 64; w++) {
-        l = fminf(l, sh_lo[w][a]);
-        h = fmaxf(h, sh_hi[w][a]);
-      }
-      v[a] = h - l;
+  float ext[3];
+  for (int a = 0; a < 3; a++) {  // every thread derives the axis itself (broadcast reads): no second barrier
+    float l = INFINITY, h = -INFINITY;
+    for (int w = 0; w < kWaves; w++) {
+      l = fminf(l, sh_lo[w][a]);
+      h = fmaxf(h, sh_hi[w][a]);
     }
-    sh_axis = v[0] >= v[1] ? (v[0] >= v[2] ? 0 : 2) : (v[1] >= v[2] ? 1 : 2);  // same rule as kd_longest_axis
+    ext[a] = h - l;
   }
-  __syncthreads();
-  const int axis = sh_axis;
-  uint32_t key[kSplitKeys];  // the coordinate along the split axis (read again: the lines are in the cache), order-preserving encoding
+  const int axis = ext[0] >= ext[1] ? (ext[0] >= ext[2] ? 0 : 2) : (ext[1] >= ext[2] ? 1 : 2);  // same rule as kd_longest_axis
+  uint32_t key[kSplitKeys];  // the coordinate along the split axis (read again, one word: the lines are in the cache), order-preserving encoding
+  const float* __restrict__ coord = reinterpret_cast<const float*>(pts) + axis;
 #pragma unroll
-  for (int j = 0; j < kSplitKeys; j++) {
-    const uint32_t pos = j * kSplitThreads + tid;
-    key[j] = 0u;
-    if (pos < len) {
-      const float4 p = pts[src[j]];
-      key[j] = ordered_u32(axis == 0 ? p.x : (axis == 1 ? p.y : p.z));
-    }
-  }
+  for (int j = 0; j < kSplitKeys; j++) key[j] = ordered_u32(coord[4ull * src[j]]);
   // ---- radix select: the key of rank m (0-based) among the segment's keys, and how many keys are smaller
   uint32_t prefix = 0u, prefix_mask = 0u, rank = min(m, len - 1u), below = 0u;
   const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
+#pragma unroll
   for (int round = 0; round < 3; round++) {
-    hist[tid] = 0u;
-    hist[tid + kSplitThreads] = 0u;
-    __syncthreads();
     const uint32_t bmask = (1u << bits[round]) - 1u;
 #pragma unroll
     for (int j = 0; j < kSplitKeys; j++) {
-      const uint32_t pos = j * kSplitThreads + tid;
-      if (pos < len && (key[j] & prefix_mask) == prefix) atomicAdd(&hist[(key[j] >> shifts[round]) & bmask], 1u);
+      const uint32_t pos = j * THREADS + tid;
+      if (pos < len && (key[j] & prefix_mask) == prefix) atomicAdd(&hist[round][(key[j] >> shifts[round]) & bmask], 1u);
     }
     __syncthreads();
-    const uint32_t c0 = hist[2 * tid], c1 = hist[2 * tid + 1];
-    uint32_t total;
-    const uint32_t before = block_scan_exclusive(c0 + c1, sh_wave, total);
-    if (rank >= before && rank < before + c0 + c1) {  // exactly one thread
-      const bool second = rank >= before + c0;
-      sh_sel[0] = 2 * tid + (second ? 1u : 0u);
-      sh_sel[1] = before + (second ? c0 : 0u);
-      sh_sel[2] = second ? c1 : c0;
+    uint32_t c[kBinsPerThread], mine = 0u;  // this thread's bins: kBinsPerThread consecutive ones
+#pragma unroll
+    for (int b = 0; b < kBinsPerThread; b++) {
+      c[b] = hist[round][kBinsPerThread * tid + b];
+      mine += c[b];
+    }
+    uint32_t before = split_scan_exclusive<THREADS>(mine, sh_wave[round]);
+    if (rank >= before && rank < before + mine) {  // exactly one thread
+#pragma unroll
+      for (int b = 0; b < kBinsPerThread; b++) {
+        if (rank >= before && rank < before + c[b]) {
+          sh_sel[round][0] = kBinsPerThread * tid + b;
+          sh_sel[round][1] = before;
+          sh_sel[round][2] = c[b];
+        }
+        before += c[b];
+      }
     }
     __syncthreads();
-    const uint32_t bucket = sh_sel[0], under = sh_sel[1];
+    const uint32_t bucket = sh_sel[round][0], under = sh_sel[round][1];
     prefix |= bucket << shifts[round];
     prefix_mask |= bmask << shifts[round];
     below += under;
     rank -= under;
-    __syncthreads();
   }
   const uint32_t median = prefix;   // `below` keys are smaller; the first `rank` of the `eq_total` equal ones complete the left half
-  const uint32_t eq_total = sh_sel[2];
+  const uint32_t eq_total = sh_sel[2][2];
   // ---- partition: [keys < median][`rank` of the equal keys] | [the other equal keys][keys > median].  Order inside the four parts:
   // thread-major (thread t's elements, rows ascending, behind those of threads < t) — fixed, hence deterministic; ONE block-wide scan
   // of the per-thread counts instead of one per row.
-  uint32_t my_less = 0u, my_eq = 0u, my_cnt = 0u;
+  uint32_t my_less = 0u, my_eq = 0u;
 #pragma unroll
   for (int j = 0; j < kSplitKeys; j++) {
-    const bool valid = j * kSplitThreads + tid < len;
+    const bool valid = j * THREADS + tid < len;
     my_less += (valid && key[j] < median) ? 1u : 0u;
     my_eq += (valid && key[j] == median) ? 1u : 0u;
-    my_cnt += valid ? 1u : 0u;
   }
-  uint32_t total;
-  const uint32_t packed = block_scan_exclusive(my_less | (my_eq << 16), sh_wave, total);  // <= 32 per thread, <= 32768 in all: 16 bits each
+  const uint32_t packed = split_scan_exclusive<THREADS>(my_less | (my_eq << 16), sh_wave[3]);  // <= 32 per thread, <= 32768 in all: 16 bits each
   uint32_t n_less = packed & 0xffffu, n_eq = packed >> 16;  // elements of the two kinds owned by lower threads
-  uint32_t total2;
-  uint32_t n_all = block_scan_exclusive(my_cnt, sh_wave, total2);  // all elements owned by lower threads
+  uint32_t n_all = tid * (len / THREADS) + min(tid, len % THREADS);  // all elements owned by lower threads (thread t owns rows j with j * THREADS + t < len)
 #pragma unroll  // static indices: src[] / key[] stay in registers
   for (int j = 0; j < kSplitKeys; j++) {
-    if (j * kSplitThreads + tid < len) {
+    if (j * THREADS + tid < len) {
       const bool less = key[j] < median, eq = key[j] == median;
       const uint32_t n_greater = n_all - n_less - n_eq;
       const uint32_t dest = less ? n_less : (eq ? (n_eq < rank ? below + n_eq : m + (n_eq - rank)) : m + (eq_total - rank) + n_greater);
@@ -523,7 +516,7 @@ __global__ __launch_bounds__(kSplitThreads) void kd_split_level_kernel(const flo
       n_all += 1u;
     }
   }
-  if (tid == 0) nodes[(1u << d) + seg] = make_float2(len > 0 ? float_from_ordered(static_cast<int>(median ^ 0x80000000u)) : 0.f, __int_as_float(axis));
+  if (tid == 0) nodes[(1u << d) + seg] = make_float2(float_from_ordered(static_cast<int>(median ^ 0x80000000u)), __int_as_float(axis));
 }
 
 // pair records for the 1-NN walk (kd_search.hpp): node of even depth + its two children in one 16-byte record; one launch covers
@@ -700,7 +693,16 @@ static int build_kdtree(sga_context* ctx, const sga_cloud* cloud, sga_index* idx
     dA = 0;
     while (dA < D && ((n + (1ull << dA) - 1) >> dA) > static_cast<size_t>(kSplitFinish)) dA++;
     for (int d = 0; d < dA; d++) {
-      hipLaunchKernelGGL(kd_split_level_kernel, dim3(1u << d), dim3(kSplitThreads), 0, ctx->stream, cloud->pts.p, cur, nxt, static_cast<uint32_t>(n), d, idx->kd_nodes.p);
+      const size_t seg_max = (n + (1ull << d) - 1) >> d;
+#define SGA_SPLIT(THREADS, KEYS) hipLaunchKernelGGL((kd_split_level_kernel<THREADS, KEYS>), dim3(1u << d), dim3(THREADS), 0, ctx->stream, cloud->pts.p, cur, nxt, static_cast<uint32_t>(n), d, idx->kd_nodes.p)
+      if (seg_max <= 256 * 2) SGA_SPLIT(256, 2);
+      else if (seg_max <= 256 * 4) SGA_SPLIT(256, 4);
+      else if (seg_max <= 256 * 8) SGA_SPLIT(256, 8);
+      else if (seg_max <= 1024 * 4) SGA_SPLIT(1024, 4);
+      else if (seg_max <= 1024 * 8) SGA_SPLIT(1024, 8);
+      else if (seg_max <= 1024 * 16) SGA_SPLIT(1024, 16);
+      else SGA_SPLIT(1024, 32);
+#undef SGA_SPLIT
       std::swap(cur, nxt);
     }
   }

@@ -1093,8 +1093,8 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
   if (fp->factor_kind < 0 || fp->factor_kind > 2) return fail(SGA_ERR_INVALID, "invalid factor_kind %d", fp->factor_kind);
 
   LinParams<Real> p{};
-  p.src_pts = pb->pts.p;
-  p.src_cov = pb->cov.p;
+  p.src_pts = pb->src_pts();
+  p.src_cov = pb->src_cov();
   p.n = static_cast<int>(pb->n);
   const int pts = linearize_pts(p.n);
   p.num_tiles = (p.n + kTile * pts - 1) / (kTile * pts);  // steps of kTile * pts points
@@ -1157,7 +1157,7 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
   if (!voxel) pb->prev_valid = false;
   if (p.n > 0 && !voxel) {
     NNParams<Real> q{};
-    q.src_pts = pb->pts.p;
+    q.src_pts = pb->src_pts();
     q.n = p.n;
     q.kd = p.kd;
     q.T = p.T;
@@ -1229,7 +1229,7 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
       SGA_TRY(d_idx.alloc(n));
       SGA_TRY(d_d2.alloc(n));
       SGA_TRY(pb->reject.reserve(n));
-      hipLaunchKernelGGL((export_neighbours_kernel<Real>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, pb->pts.p, pb->hint.p, p.n, p.tgt_pts, p.T, d_idx.p, d_d2.p);
+      hipLaunchKernelGGL((export_neighbours_kernel<Real>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, pb->src_pts(), pb->hint.p, p.n, p.tgt_pts, p.T, d_idx.p, d_d2.p);
       SGA_HIP(hipGetLastError());
       std::vector<int64_t> h_idx(n);
       std::vector<float> h_d2(n);
@@ -1315,9 +1315,9 @@ int problem_ensure_maha(sga_context* ctx, sga_problem* pb) {
   const int n = static_cast<int>(pb->n);
   if (pb->last_math == SGA_MATH_FP64) {
     if (pb->maha64.n < pb->n * 6) SGA_TRY(pb->maha64.alloc(pb->n * 6));
-    hipLaunchKernelGGL((recompute_maha_kernel<double>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, pb->cov.p, idx->cov.p, pb->corr.p, n, rigid_from_colmajor<double>(pb->lin_T), pb->maha64.p);
+    hipLaunchKernelGGL((recompute_maha_kernel<double>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, pb->src_cov(), idx->cov.p, pb->corr.p, n, rigid_from_colmajor<double>(pb->lin_T), pb->maha64.p);
   } else {
-    hipLaunchKernelGGL((recompute_maha_kernel<float>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, pb->cov.p, idx->cov.p, pb->corr.p, n, rigid_from_colmajor<float>(pb->lin_T), pb->maha.p);
+    hipLaunchKernelGGL((recompute_maha_kernel<float>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, pb->src_cov(), idx->cov.p, pb->corr.p, n, rigid_from_colmajor<float>(pb->lin_T), pb->maha.p);
   }
   SGA_HIP(hipGetLastError());
   pb->maha_valid = true;
@@ -1328,7 +1328,7 @@ template <typename Real>
 static int error_dispatch(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, const double T[16], double* d_out1, double* host, unsigned long long seq) {
   const sga_index* idx = pb->target;
   ErrParams<Real> p{};
-  p.src_pts = pb->pts.p;
+  p.src_pts = pb->src_pts();
   p.n = static_cast<int>(pb->n);
   p.num_tiles = (p.n + kTile - 1) / kTile;
   p.tgt_pts = idx->kind != SGA_INDEX_KDTREE ? idx->pts.p : idx->kd_pts.p;
@@ -1492,8 +1492,8 @@ int sga_linearize_per_point(sga_context* ctx, sga_problem* pb, const sga_factor_
   if (n == 0) return SGA_OK;
   const sga_index* idx = pb->target;
   LinParams<double> p{};
-  p.src_pts = pb->pts.p;
-  p.src_cov = pb->cov.p;
+  p.src_pts = pb->src_pts();
+  p.src_cov = pb->src_cov();
   p.n = static_cast<int>(n);
   p.tgt_pts = idx->kd_pts.p;
   p.tgt_nrm = idx->nrm.p;
@@ -1657,7 +1657,7 @@ int sga_problem_get_sorted_points(sga_context* ctx, const sga_problem* pb, float
   if (!ctx || !pb || !xyzw) return fail(SGA_ERR_INVALID, "null argument");
   if (pb->n == 0) return SGA_OK;
   SGA_ENTER(ctx);
-  SGA_HIP(hipMemcpyAsync(xyzw, pb->pts.p, pb->n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+  SGA_HIP(hipMemcpyAsync(xyzw, pb->src_pts(), pb->n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
   SGA_HIP(hipStreamSynchronize(ctx->stream));
   return SGA_OK;
 }

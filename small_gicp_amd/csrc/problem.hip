@@ -169,23 +169,29 @@ void sga_factor_params_default(sga_factor_params* p) {
 }
 
 // the per-point factor state of a problem over n source points: correspondences and certificates start as "none"
-static int problem_alloc_state(sga_context* ctx, sga_problem* pb, size_t n, bool has_covs) {
+__global__ void problem_state_init_kernel(int* __restrict__ corr, int* __restrict__ hint, int* __restrict__ hint2, uint32_t* __restrict__ walked, size_t n) {
+  const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
+  if (i < n) corr[i] = hint[i] = hint2[i] = -1;
+  if (i < n / 64 + 1) walked[i] = 0u;
+}
+
+static int problem_alloc_state(sga_context* ctx, sga_problem* pb, size_t n, bool has_covs, bool own_arrays = true) {
   SGA_TRY(pb->partials.alloc(problem_partials_doubles(n)));
   SGA_TRY(pb->walked.alloc(n / 64 + 1));
-  SGA_HIP(hipMemsetAsync(pb->walked.p, 0, (n / 64 + 1) * sizeof(uint32_t), ctx->stream));
-  if (n == 0) return SGA_OK;
-  SGA_TRY(pb->pts.alloc(n));
-  if (has_covs) SGA_TRY(pb->cov.alloc(n));
-  // corr | hint | hint2 in ONE allocation-sized fill would need one buffer; three fills of -1 it is.  The mahalanobis cache is only ever
-  // read where corr >= 0, i.e. after a pass has written it: no fill.
-  SGA_TRY(pb->corr.alloc(n));
-  SGA_TRY(pb->hint.alloc(n));
-  SGA_TRY(pb->hint2.alloc(n));
-  SGA_TRY(pb->rex.alloc(n));
-  SGA_TRY(pb->maha.alloc(n * 6));
-  SGA_HIP(hipMemsetAsync(pb->corr.p, 0xff, n * sizeof(int), ctx->stream));
-  SGA_HIP(hipMemsetAsync(pb->hint.p, 0xff, n * sizeof(int), ctx->stream));
-  SGA_HIP(hipMemsetAsync(pb->hint2.p, 0xff, n * sizeof(int), ctx->stream));
+  if (n > 0 && own_arrays) {
+    SGA_TRY(pb->pts.alloc(n));
+    if (has_covs) SGA_TRY(pb->cov.alloc(n));
+  }
+  if (n > 0) {
+    SGA_TRY(pb->corr.alloc(n));
+    SGA_TRY(pb->hint.alloc(n));
+    SGA_TRY(pb->hint2.alloc(n));
+    SGA_TRY(pb->rex.alloc(n));
+    SGA_TRY(pb->maha.alloc(n * 6));  // only ever read where corr >= 0, i.e. after a pass has written it: no fill
+  }
+  // correspondences and certificates start as "none": one launch (four fills cost four launches, which is what a 15k-point scan pays for)
+  hipLaunchKernelGGL(problem_state_init_kernel, dim3((n + 255) / 256 + 1), dim3(256), 0, ctx->stream, pb->corr.p, pb->hint.p, pb->hint2.p, pb->walked.p, n);
+  SGA_HIP(hipGetLastError());
   return SGA_OK;
 }
 
@@ -206,10 +212,10 @@ int sga_problem_create_from_index(sga_context* ctx, const sga_index* target, con
   pb->has_normals = source->has_normals;
   pb->has_covs = source->has_covs;
   const size_t n = source->n;
-  SGA_TRY(problem_alloc_state(ctx, pb.get(), n, source->has_covs));
+  SGA_TRY(problem_alloc_state(ctx, pb.get(), n, source->has_covs, /*own_arrays=*/false));
   if (n > 0) {
-    SGA_HIP(hipMemcpyAsync(pb->pts.p, source->kd_pts.p, n * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
-    if (source->has_covs) SGA_HIP(hipMemcpyAsync(pb->cov.p, source->cov.p, n * sizeof(Cov8), hipMemcpyDeviceToDevice, ctx->stream));
+    pb->pts_view = source->kd_pts.p;  // borrowed: the source index outlives the problem
+    pb->cov_view = source->has_covs ? source->cov.p : nullptr;
     for (int k = 0; k < 3; k++) {
       pb->bbox_lo[k] = source->bbox_lo[k];
       pb->bbox_hi[k] = source->bbox_hi[k];
@@ -308,10 +314,11 @@ int sga_problem_get_factors(sga_context* ctx, const sga_problem* pb, int64_t* ta
   if (mahalanobis6) SGA_TRY(problem_ensure_maha(ctx, const_cast<sga_problem*>(pb)));  // written on demand (linearize.hip)
   const float4* tpts = pb->target->kind != SGA_INDEX_KDTREE ? pb->target->pts.p : pb->target->kd_pts.p;
   const int is_flat = pb->target->kind == SGA_INDEX_FLATMAP ? 1 : 0;
-  if (pb->last_math == SGA_MATH_FP64 && pb->maha64.p != nullptr)  // the last linearize cached its mahalanobis in fp64
-    hipLaunchKernelGGL((export_factors_kernel<double>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, pb->pts.p, pb->corr.p, pb->maha64.p, n, tpts, is_flat, d_idx.p, d_m.p);
+  const bool has_maha = pb->lin_factor == SGA_GICP && pb->maha_valid;  // only GICP has a mahalanobis matrix (gicp_factor.hpp:57-60); the cache is never pre-filled: zeros otherwise
+  if (has_maha && pb->last_math == SGA_MATH_FP64 && pb->maha64.p != nullptr)  // the last linearize cached its mahalanobis in fp64
+    hipLaunchKernelGGL((export_factors_kernel<double>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, pb->src_pts(), pb->corr.p, pb->maha64.p, n, tpts, is_flat, d_idx.p, d_m.p);
   else
-    hipLaunchKernelGGL((export_factors_kernel<float>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, pb->pts.p, pb->corr.p, pb->maha.p, n, tpts, is_flat, d_idx.p, d_m.p);
+    hipLaunchKernelGGL((export_factors_kernel<float>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, pb->src_pts(), pb->corr.p, has_maha ? pb->maha.p : static_cast<const float*>(nullptr), n, tpts, is_flat, d_idx.p, d_m.p);
   SGA_HIP(hipGetLastError());
   if (target_index) SGA_HIP(hipMemcpyAsync(target_index, d_idx.p, n * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
   if (mahalanobis6) SGA_HIP(hipMemcpyAsync(mahalanobis6, d_m.p, n * 6 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));

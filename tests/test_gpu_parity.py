@@ -681,25 +681,37 @@ def test_c4_vgicp_1m_properties(c3):
 # ---- the search structure itself ------------------------------------------------------------------------------------------------
 def test_kd_build_paths_give_the_same_tree(monkeypatch):
     """Bottom levels finished in LDS (kd_finish_kernel) vs every level through the global radix-sort path: identical trees, hence
-    bit-identical linearizations and identical kNN answers (index_build.hip)."""
+    bit-identical linearizations and identical kNN answers (index_build.hip).  Small clouds are built by a third path — one launch per
+    level, radix select + partition (kd_split_level_kernel): another valid tree over the same points (the order inside a half is not
+    the sorted one), so the same neighbour DISTANCES, inliers and sums to rounding."""
     rng = np.random.default_rng(11)
-    for n in (1500, 40_000, 600_000):  # one workgroup / small-cloud capacity / large-cloud capacity
+    for n in (1500, 20_000, 40_000, 600_000):  # one workgroup / the split path's range / small-cloud capacity / large-cloud capacity
         target, source, _ = sga.synthetic.registration_pair(n)
         target = target.copy()
         target[: n // 50] = target[n // 50 : 2 * (n // 50)]  # duplicates: the stable tie order must be reproduced too
         st = sga.make_setting("ICP")
         T = se3([0.2, 0.3, 0.93], np.deg2rad(1.0), [0.1, -0.1, 0.0])
         q = np.concatenate([source[rng.choice(n, 300, replace=False)], rng.uniform(-60, 60, (100, 3)).astype(np.float32)])
-        out = []
-        for finish in ("1", "0"):
-            monkeypatch.setenv("SGA_KD_FINISH", finish)
+
+        def run():
             tree = sga.KdTree(sga.PointCloud(target))
             H, b, e, inl = sga.Problem(tree, sga.PointCloud(source)).linearize(st.factor, T)
             idx, d2 = tree.batch_knn_search(q, 10)
-            out.append((H, b, e, inl, idx, d2))
+            return H, b, e, inl, idx, d2
+
+        out = []
+        monkeypatch.setenv("SGA_KD_SPLIT", "0")
+        for finish in ("1", "0"):
+            monkeypatch.setenv("SGA_KD_FINISH", finish)
+            out.append(run())
         a, c = out
         assert (a[0] == c[0]).all() and (a[1] == c[1]).all() and a[2] == c[2] and a[3] == c[3], n
         assert (a[4] == c[4]).all() and (a[5] == c[5]).all(), n
+        monkeypatch.delenv("SGA_KD_SPLIT")
+        monkeypatch.setenv("SGA_KD_FINISH", "1")
+        s = run()  # n <= 32768: the split path
+        assert s[3] == a[3] and (s[5] == a[5]).all(), n
+        assert np.abs(s[0] - a[0]).max() <= 1e-5 * np.abs(a[0]).max() and abs(s[2] - a[2]) <= 1e-5 * abs(a[2]), n
 
 
 def test_nearest_neighbour_exact_at_scale_and_seed_independent(c3):
