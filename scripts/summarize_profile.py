@@ -95,6 +95,14 @@ if totals.get("FETCH_SIZE") and totals.get("WRITE_SIZE"):
         json.dump(traffic, open(os.path.join(out, "%s_k1_traffic.json" % tag), "w"), indent=1)
         print("== K1 HBM traffic per pass: %.1f MB (algorithmic 100 MB) -> %.2fx" % (hbm / 1e6, hbm / 1e8))
 
+for f in find("c4c2/**/*kernel_stats.csv"):
+    rows = list(csv.DictReader(open(f)))
+    shutil.copyfile(f, os.path.join(out, "%s_c4_c2_kernel_stats.csv" % tag))
+    print("== kernel stats of a bench run WITH the C4 (VGICP, linearize_kernel<float, GICP, voxel map>) and C2 (PLANE_ICP) legs:", os.path.relpath(f, out))
+    for r in rows[:14]:
+        print("%-70s calls=%s avg_ns=%s total_ns=%s pct=%s" % (short(r.get("Name", "")), r.get("Calls"), r.get("AverageNs"), r.get("TotalDurationNs"), r.get("Percentage")))
+        summary.setdefault("c4_c2_kernel_stats", []).append({"name": r.get("Name"), "calls": int(r.get("Calls", 0)), "avg_ns": float(r.get("AverageNs", 0)), "pct": float(r.get("Percentage", 0))})
+
 for f in find("odom/**/*kernel_stats.csv"):
     rows = list(csv.DictReader(open(f)))
     shutil.copyfile(f, os.path.join(out, "%s_odom_kernel_stats.csv" % tag))

@@ -572,13 +572,15 @@ def c3_cpu(c3):
     return out
 
 
-# Observed on MI355X (round 3, printed by the test): differing correspondences and inlier deltas at 1M; the asserts allow twice that.
-C3_MAX_DIFFERING_PAIRS = 1000
-C3_MAX_INLIER_DELTA = 50
+# Observed on MI355X (round 3, printed by the test with -s): at the identity 0 of 1M correspondences differ from the reference's, at the
+# near-converged pose 12 (queries with two candidates within fp32 rounding of each other: the device compares fp32 distances, the
+# reference doubles); inlier deltas 0 in every case.  The asserts allow about twice the observed numbers.
+C3_MAX_DIFFERING_PAIRS = 30
+C3_MAX_INLIER_DELTA = 4
 
 
 def test_c3_matches_reference(c3, c3_cpu):
-    """Config C3 (GICP, 1M <-> 1M) at size: one linearization at two poses (H / b / e to 2e-5, correspondences >= 99.9 % identical)
+    """Config C3 (GICP, 1M <-> 1M) at size: one linearization at two poses (H / b / e to 2e-5, at most 30 of the million correspondences differ)
     and the whole registration (pose 1e-4 m / 1e-4 rad, equal iteration count) against the reference's own code —
     registration_helper.cpp:81-137 align(), Registration<GICPFactor, ParallelReductionOMP> — on the same inputs.  At this size a few
     hundred of the million queries have two candidates tied within fp32 resolution; the device compares fp32 distances in both math
