@@ -191,13 +191,26 @@ def main():
             ref_pose[m] = sga.Problem(tree, src_full, np.eye(4)).align(setting_for(ITERS_PER_ALIGN, m)).T_target_source
 
     native_comm = False
+    transport = None
     if use_dist:
         # native path: the library all-reduces its accumulators with RCCL on its own stream (no Python in the iteration loop);
         # torch.distributed only carries the 128-byte communicator id, the barriers and the max-over-ranks of the wall time
         try:
-            ids = [sga.Context.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            ctx.comm_init(world, rank, ids[0])
+            if args.oversubscribe:
+                # testing on fewer devices than ranks: the SAME protocol (one 96-double all-reduce per linearization inside the library,
+                # per-rank error model) with the sum carried by gloo through sga_comm_init_callback instead of RCCL
+                def _host_allreduce(values):
+                    t = torch.from_numpy(values)
+                    dist.all_reduce(t)
+                    return t.numpy()
+
+                ctx.comm_init_callback(world, rank, _host_allreduce)
+                transport = "host callback over gloo (sga_comm_init_callback; --oversubscribe testing mode)"
+            else:
+                ids = [sga.Context.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(ids, src=0)
+                ctx.comm_init(world, rank, ids[0])
+                transport = "native ncclAllReduce (RCCL) on the library stream"
             native_comm = True
         except Exception as ex:  # noqa: BLE001
             if not (args.allow_fallback or args.oversubscribe):
@@ -342,7 +355,7 @@ def main():
                 "step": "1 outer LM iteration = one linearize pass (search + factor kernel, which also accumulates the quadratic error model) + host 6x6 solve(s) + the trial errors evaluated on the host from that model (exact for the cached correspondences; replaces the reference's error passes); restart from identity (and a cold search state) every %d steps" % ITERS_PER_ALIGN,
                 "parallelism": ("%s scaling: source %s x%d, target index replicated, %s"
                                 % (args.scaling, "sharded (contiguous Morton ranges of one cloud)" if strong else "one independent cloud per rank", world,
-                                   "RCCL all-reduce of 96 doubles per linearize (the system + the error-model moments): native ncclAllReduce on the library stream" if native_comm
+                                   "all-reduce of 96 doubles per linearize (the system + the error-model moments): %s" % transport if native_comm
                                    else "FALLBACK (no RCCL communicator): torch.distributed all-reduce of 30 doubles per linearize + 1 per error pass through sga_linearize_async / sga_error_async callbacks")) if use_dist else "single GPU",
                 "source_points_total": n * (1 if strong else world),
                 "source_points_per_gpu": n_rank,
