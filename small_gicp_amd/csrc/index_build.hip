@@ -519,14 +519,14 @@ __global__ __launch_bounds__(THREADS) void kd_split_level_kernel(const float4* _
   if (tid == 0) nodes[(1u << d) + seg] = make_float2(float_from_ordered(static_cast<int>(median ^ 0x80000000u)), __int_as_float(axis));
 }
 
-// pair records for the 1-NN walk (kd_search.hpp): node of even depth + its two children in one 16-byte record; one launch covers
-// every even depth (record r of the level-by-level layout belongs to depth d = 2 * floor(log4(3 r + 1)))
+// pair records for the 1-NN walk (kd_search.hpp): node of even depth + its two children in one 16-byte record, stored at the node's
+// heap number; one launch covers every even depth
 __global__ void kd_pairs_kernel(const float2* __restrict__ nodes, int D, uint32_t count, float4* __restrict__ pairs) {
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= count) return;
-  int d = 0;
-  while (d + 2 < D && kd_pair_index(d + 2, 1u << (d + 2)) <= r) d += 2;  // the records of depth d + 2 start at or before r
-  const uint32_t node = (1u << d) + (r - kd_pair_index(d, 1u << d));
+  if (r >= count || r == 0) return;
+  const uint32_t node = r;  // records are indexed by heap number (kd_search.hpp); only the even depths carry one
+  const int d = 31 - __clz(static_cast<int>(node));
+  if (d & 1) return;
   const float2 a = nodes[node];
   float2 l = make_float2(0.f, 0.f), rr = make_float2(0.f, 0.f);
   if (d + 1 < D) {

@@ -70,16 +70,21 @@ __device__ __forceinline__ uint32_t kd_leaf_of(uint32_t i, uint32_t n, int d) {
   return k;
 }
 
-// Pair records are laid out level by level over the even depths: the record of node (d, k), d even, sits at
-// (4^(d/2) - 1) / 3 + k, and (4^m - 1) / 3 = 0b0101..01 (m ones) = 0x55555555 & (2^d - 1).
-__host__ __device__ __forceinline__ uint32_t kd_pair_index(int even_depth, uint32_t node) { return (0x55555555u & ((1u << even_depth) - 1u)) + (node - (1u << even_depth)); }
-__host__ __device__ __forceinline__ uint32_t kd_pair_count(int D) { return D == 0 ? 1u : (0x55555555u & ((1u << (D + (D & 1))) - 1u)); }
+// Pair records are indexed by the heap number of their (even-depth) node: the record of node v sits at nodes4[v].  The slots of the
+// odd depths stay unused (2^D records instead of two thirds of that) — the walk computes the address of a record with one shift
+// instead of the eight integer instructions a dense level-by-level layout costs in every descent step.
+__host__ __device__ __forceinline__ uint32_t kd_pair_index(int /*even_depth*/, uint32_t node) { return node; }
+__host__ __device__ __forceinline__ uint32_t kd_pair_count(int D) { return 1u << D; }
 
 // One stack entry per pending far side, 32 bits: [31:5] = cut^2 (float bits >> 4, i.e. rounded toward zero: conservative),
 // [4:0] = depth of the far node.  The far node itself is implied: it is the sibling of the depth-`dd` ancestor of the leaf
 // the walk currently stands on, so no node index has to be stored.
 __device__ __forceinline__ uint32_t kd_pack(float cut, int depth) { return ((__float_as_uint(cut) >> 4) << 5) | static_cast<uint32_t>(depth); }
 __device__ __forceinline__ float kd_cut(uint32_t e) { return __uint_as_float((e >> 5) << 4); }
+
+// min of two floats in ONE instruction: fminf() is preceded by a canonicalisation of each operand (v_max_f32 x, x) under IEEE mode; the
+// median of (a, b, -inf) is the same value for the numbers the walk deals in (distances >= 0, +inf) and needs no such step.
+__device__ __forceinline__ float kd_min(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, -INFINITY); }
 
 // THE squared distance of the search: every kernel that compares distances of target points to a query (the walk, the
 // certificate check of the warm pass) evaluates exactly this expression, so they agree bit for bit.
@@ -300,7 +305,7 @@ __device__ __forceinline__ void kd_visit_group(const KdView& t, uint32_t gnode, 
     lb2 = l == 2 ? INFINITY : lb2;
     lb3 = l == 3 ? INFINITY : lb3;
   }
-  s.dropped = fminf(s.dropped, fminf(fminf(lb0, lb1), fminf(lb2, lb3)));  // the leaves not scanned: nothing in there is closer than their box
+  s.dropped = kd_min(s.dropped, fminf(fminf(lb0, lb1), fminf(lb2, lb3)));  // the leaves not scanned: nothing in there is closer than their box
 }
 
 // The reference's recursion (descend to the near side; visit the far side iff it can hold a closer point, kdtree.hpp:207-230)
@@ -332,7 +337,7 @@ __device__ __forceinline__ void kd_walk(const KdView& t, float qx, float qy, flo
         stack[sp * STRIDE + tid] = kd_pack(cut, depth);
         const bool keep = cut <= s.open;
         sp += keep ? 1 : 0;
-        s.dropped = fminf(s.dropped, keep ? INFINITY : cut);
+        s.dropped = kd_min(s.dropped, keep ? INFINITY : cut);
         node = 2 * node + (diff < 0.f ? 0u : 1u);
       }
       if (depth < D) {
@@ -346,7 +351,7 @@ __device__ __forceinline__ void kd_walk(const KdView& t, float qx, float qy, flo
         stack[sp * STRIDE + tid] = kd_pack(cut, depth);
         const bool keep = cut <= s.open;
         sp += keep ? 1 : 0;
-        s.dropped = fminf(s.dropped, keep ? INFINITY : cut);
+        s.dropped = kd_min(s.dropped, keep ? INFINITY : cut);
         node = 2 * node + (diff < 0.f ? 0u : 1u);
       }
     }
@@ -363,7 +368,7 @@ __device__ __forceinline__ void kd_walk(const KdView& t, float qx, float qy, flo
         lb = fmaxf(lb, kd_box_dist2(t, (node >> (D - static_cast<int>(e & 31u))) ^ 1u, qx, qy, qz));
         found = lb <= s.open;
       }
-      s.dropped = fminf(s.dropped, found ? INFINITY : lb);  // discarded: nothing in there is closer than lb
+      s.dropped = kd_min(s.dropped, found ? INFINITY : lb);  // discarded: nothing in there is closer than lb
     }
     if (!found) break;
     depth = static_cast<int>(e & 31u);
@@ -440,7 +445,7 @@ __device__ __forceinline__ void kd_push_path(const KdView& t, uint32_t leaf, int
         stack[sp * STRIDE + tid] = kd_pack(cut, d + 1);
         const bool keep = cut <= s.open;
         sp += keep ? 1 : 0;
-        s.dropped = fminf(s.dropped, keep ? INFINITY : cut);
+        s.dropped = kd_min(s.dropped, keep ? INFINITY : cut);
       }
       if (d + 1 < D) {
         const uint32_t right = (leaf >> (D - d - 1)) & 1u;  // the child on the path
@@ -453,7 +458,7 @@ __device__ __forceinline__ void kd_push_path(const KdView& t, uint32_t leaf, int
         stack[sp * STRIDE + tid] = kd_pack(cut, d + 2);
         const bool keep = cut <= s.open;
         sp += keep ? 1 : 0;
-        s.dropped = fminf(s.dropped, keep ? INFINITY : cut);
+        s.dropped = kd_min(s.dropped, keep ? INFINITY : cut);
       }
     }
   }
@@ -479,7 +484,7 @@ __device__ __forceinline__ void kd_descend(const KdView& t, float qx, float qy, 
       stack[sp * STRIDE + tid] = kd_pack(cut, depth);
       const bool keep = cut <= s.open;
       sp += keep ? 1 : 0;
-      s.dropped = fminf(s.dropped, keep ? INFINITY : cut);
+      s.dropped = kd_min(s.dropped, keep ? INFINITY : cut);
       node = 2 * node + (diff < 0.f ? 0u : 1u);
     }
     if (depth < D) {
@@ -493,7 +498,7 @@ __device__ __forceinline__ void kd_descend(const KdView& t, float qx, float qy, 
       stack[sp * STRIDE + tid] = kd_pack(cut, depth);
       const bool keep = cut <= s.open;
       sp += keep ? 1 : 0;
-      s.dropped = fminf(s.dropped, keep ? INFINITY : cut);
+      s.dropped = kd_min(s.dropped, keep ? INFINITY : cut);
       node = 2 * node + (diff < 0.f ? 0u : 1u);
     }
   }
@@ -513,7 +518,7 @@ __device__ __forceinline__ bool kd_pop(const KdView& t, float qx, float qy, floa
       lb = fmaxf(lb, kd_box_dist2(t, (node >> (D - static_cast<int>(e & 31u))) ^ 1u, qx, qy, qz));
       found = lb <= s.open;
     }
-    s.dropped = fminf(s.dropped, found ? INFINITY : lb);
+    s.dropped = kd_min(s.dropped, found ? INFINITY : lb);
   }
   if (found) {
     depth = static_cast<int>(e & 31u);
@@ -567,7 +572,7 @@ __device__ __forceinline__ KdBest kd_nearest(const KdView& t, float qx, float qy
       stack[sp * STRIDE + tid] = kd_pack(cut, depth);
       const bool keep = cut <= s.open;
       sp += keep ? 1 : 0;
-      s.dropped = fminf(s.dropped, keep ? INFINITY : cut);  // discarded at once: everything beyond this plane is at >= cut
+      s.dropped = kd_min(s.dropped, keep ? INFINITY : cut);  // discarded at once: everything beyond this plane is at >= cut
       node = 2 * un + (right != 0ull ? 1u : 0u);
     }
   }
@@ -633,7 +638,7 @@ __device__ __forceinline__ KdBestFast kd_nearest_fast(const KdView& t, float qx,
       stack[sp * STRIDE + tid] = kd_pack(cut, depth);
       const bool keep = cut <= s.open;
       sp += keep ? 1 : 0;
-      s.dropped = fminf(s.dropped, keep ? INFINITY : cut);
+      s.dropped = kd_min(s.dropped, keep ? INFINITY : cut);
       node = 2 * un + (right != 0ull ? 1u : 0u);
     }
   }
