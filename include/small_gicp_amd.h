@@ -197,6 +197,11 @@ int sga_linearize_per_point(sga_context* ctx, sga_problem* problem, const sga_fa
 int sga_problem_get_factors(sga_context* ctx, const sga_problem* problem, int64_t* target_index, float* mahalanobis6);
 /* Average device time (ms) of the linearize / error kernel chains measured with HIP events on the context's stream (0 if profiling
  * off).  enabled = 0: off; 1: every pass is bracketed with events; N > 1: every N-th pass (an event record costs microseconds). */
+/* Stream-ordered mode (default off): sga_index_build_kdtree and sga_estimate_normals_covariances return as soon as their kernels are
+ * enqueued on the context's stream instead of waiting for them (a 15k-point odometry scan spends a fifth of its time in such waits).
+ * Later calls on the SAME context see their results in stream order; before their outputs are used from another context / stream,
+ * call sga_context_synchronize.  Errors of the enqueued kernels are reported by the next synchronising call. */
+int sga_context_set_stream_ordered(sga_context* ctx, int enabled);
 int sga_context_set_profiling(sga_context* ctx, int enabled);
 int sga_context_get_kernel_ms(sga_context* ctx, double* linearize_ms, uint64_t* linearize_calls, double* error_ms, uint64_t* error_calls);
 /* The part of a COLD pass's time spent in the nearest-neighbour search kernel (the rest: factor evaluation + block reduction). */

@@ -113,6 +113,7 @@ SYMBOLS = [
     ("sga_problem_set_rejector", C.c_int, [_vp, REJECTOR_FN, _vp]),
     ("sga_linearize_per_point", C.c_int, [_vp, _vp, C.POINTER(FactorParams), _dp, _dp, C.POINTER(C.c_ubyte)]),
     ("sga_problem_get_factors", C.c_int, [_vp, _vp, C.POINTER(C.c_int64), _fp]),
+    ("sga_context_set_stream_ordered", C.c_int, [_vp, C.c_int]),
     ("sga_context_set_profiling", C.c_int, [_vp, C.c_int]),
     ("sga_context_get_kernel_ms", C.c_int, [_vp, _dp, C.POINTER(C.c_uint64), _dp, C.POINTER(C.c_uint64)]),
     ("sga_context_get_search_ms", C.c_int, [_vp, _dp, C.POINTER(C.c_uint64)]),

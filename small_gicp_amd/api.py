@@ -80,6 +80,10 @@ class Context:
     def comm_destroy(self):
         check(load().sga_comm_destroy(self.h))
 
+    def set_stream_ordered(self, enabled=True):
+        """Index builds and normal / covariance estimation return once enqueued (results ordered for later calls on this context)."""
+        check(load().sga_context_set_stream_ordered(self.h, int(enabled)))
+
     def set_profiling(self, enabled=True):
         check(load().sga_context_set_profiling(self.h, int(enabled)))
 

@@ -120,6 +120,8 @@ struct sga_context {
   unsigned lin_seq = 0, err_seq = 0;
   int pending = 0;  // bit 0 = the linearize event pair (ev0, ev1) awaits collection, bit 1 = the error pair (ev2, ev3)
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr, ev_mid = nullptr;  // ev_mid: between the search and the factor kernel
+  hipEvent_t ev_aux = nullptr;   // small read-backs that must not wait for the work enqueued behind them (stream-ordered mode)
+  bool stream_ordered = false;   // sga_context_set_stream_ordered: preprocessing entry points return once their work is enqueued
   bool mid_recorded = false;
   double search_ms = 0.0;
   unsigned long long search_calls = 0;

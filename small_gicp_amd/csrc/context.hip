@@ -373,7 +373,7 @@ static int context_create_impl(int device, void* stream, bool borrow, sga_contex
     ctx->h_scratch = reinterpret_cast<int*>(ctx->h_accum + 136);  // doubles [136, 144) of the pinned block
     if (hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->h_accum_dev), ctx->h_accum, 0) != hipSuccess) rc = fail(SGA_ERR_HIP, "hipHostGetDevicePointer failed");
   }
-  if (rc == SGA_OK && (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess || hipEventCreate(&ctx->ev2) != hipSuccess || hipEventCreate(&ctx->ev3) != hipSuccess || hipEventCreate(&ctx->ev_mid) != hipSuccess)) rc = fail(SGA_ERR_HIP, "hipEventCreate failed");
+  if (rc == SGA_OK && (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess || hipEventCreate(&ctx->ev2) != hipSuccess || hipEventCreate(&ctx->ev3) != hipSuccess || hipEventCreate(&ctx->ev_mid) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_aux, hipEventDisableTiming) != hipSuccess)) rc = fail(SGA_ERR_HIP, "hipEventCreate failed");
   if (rc != SGA_OK) {
     sga_context_destroy(ctx);
     return rc;
@@ -395,6 +395,7 @@ int sga_context_destroy(sga_context* ctx) {
   if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
   if (ctx->ev3) (void)hipEventDestroy(ctx->ev3);
   if (ctx->ev_mid) (void)hipEventDestroy(ctx->ev_mid);
+  if (ctx->ev_aux) (void)hipEventDestroy(ctx->ev_aux);
   if (ctx->h_accum) (void)hipHostFree(ctx->h_accum);
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   const int device = ctx->device;
@@ -416,6 +417,13 @@ int sga_context_synchronize(sga_context* ctx) {
 }
 
 void* sga_context_stream(sga_context* ctx) { return ctx ? static_cast<void*>(ctx->stream) : nullptr; }
+
+int sga_context_set_stream_ordered(sga_context* ctx, int enabled) {
+  if (!ctx) return fail(SGA_ERR_INVALID, "null context");
+  if (!enabled && ctx->stream_ordered) (void)hipStreamSynchronize(ctx->stream);
+  ctx->stream_ordered = enabled != 0;
+  return SGA_OK;
+}
 
 int sga_context_set_profiling(sga_context* ctx, int enabled) {
   if (!ctx) return fail(SGA_ERR_INVALID, "null context");

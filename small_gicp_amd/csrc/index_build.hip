@@ -754,7 +754,7 @@ static int build_kdtree(sga_context* ctx, const sga_cloud* cloud, sga_index* idx
   SGA_TRY(idx->kd_leaf.alloc(8ull << D));
   hipLaunchKernelGGL(kd_leaf_blocks_kernel, dim3(((8u << D) + 255) / 256), block, 0, ctx->stream, idx->kd_pts.p, static_cast<uint32_t>(n), D, reinterpret_cast<float*>(idx->kd_leaf.p));
   SGA_HIP(hipGetLastError());
-  SGA_HIP(hipStreamSynchronize(ctx->stream));
+  if (!ctx->stream_ordered) SGA_HIP(hipStreamSynchronize(ctx->stream));
   return SGA_OK;
 }
 
@@ -869,7 +869,9 @@ int sga_index_build_kdtree(sga_context* ctx, const sga_cloud* target, sga_index*
     // the bounding box travels to the host behind the build: build_kdtree synchronises the stream once, at its end
     DevBuf<int> d_bbox;
     SGA_TRY(cloud_bbox_enqueue(ctx, target->pts.p, n, d_bbox, ctx->h_scratch));
+    if (ctx->stream_ordered) SGA_HIP(hipEventRecord(ctx->ev_aux, ctx->stream));  // the box is on the host once this event has completed
     SGA_TRY(build_kdtree(ctx, target, idx.get()));
+    if (ctx->stream_ordered) SGA_HIP(hipEventSynchronize(ctx->ev_aux));  // (otherwise build_kdtree has synchronised the stream)
     cloud_bbox_decode(ctx->h_scratch, n, idx->bbox_lo, idx->bbox_hi);
     for (int k = 0; k < 3; k++)
       if (!std::isfinite(idx->bbox_lo[k]) || !std::isfinite(idx->bbox_hi[k])) return fail(SGA_ERR_INVALID, "target cloud contains non-finite coordinates");

@@ -427,7 +427,7 @@ int sga_estimate_normals_covariances(sga_context* ctx, sga_cloud* cloud, const s
     else
       hipLaunchKernelGGL((local_features_kernel<0>), fgrid, fblock, shmem, ctx->stream, kv, n, k, flags, inrm, icov, cloud->nrm.p, cloud->cov.p);
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess && !ctx->stream_ordered) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) rc = fail(SGA_ERR_HIP, "local_features_kernel: %s", hipGetErrorString(e));
   }
   if (rc == SGA_OK) {

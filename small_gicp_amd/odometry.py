@@ -28,6 +28,8 @@ class OnlineOdometry:
         self.setting = api.make_setting("GICP", max_correspondence_distance=max_correspondence_distance)
         self.max_dist = max_correspondence_distance
         self.ctx = ctx or api.default_context()
+        # every step of a scan runs on this one context: no host wait between the index build, the covariances and the registration
+        self.ctx.set_stream_ordered(True)
         self.target = None  # (cloud, tree)
         self.T_world = np.eye(4)
         self.reg_ms = []
