@@ -218,11 +218,11 @@ __device__ __forceinline__ void wave_halve_swap(const float (&v)[N], float (&o)[
   }
 }
 
-// in: N <= 128 values per lane (all 64 lanes active).  out: lane l holds the totals of value `slot` (lo) and `64 + slot` (hi); slot
-// is a permutation of the lane numbers.  Totals of values >= N are meaningless.
+// in: N <= 128 values per lane (all 64 lanes active).  out: lane l holds the totals of value `slot` (lo) and, for N > 64, `64 + slot`
+// (hi); slot is a permutation of the lane numbers.  Totals of values >= N are meaningless.
 template <int N>
 __device__ __forceinline__ void wave_transpose_sum(const float (&v)[N], int lane, float& lo, float& hi, int& slot) {
-  static_assert(N > 64 && N <= 128, "sized for the 72 moment sums");
+  static_assert(N > 32 && N <= 128, "sized for the moment sums (72, or two halves of 36)");
   float a[(N + 1) / 2];
   wave_halve_dpp<0xB1>(v, a, (lane & 1) != 0);   // quad_perm [1,0,3,2]
   float b[(N + 3) / 4];
@@ -237,7 +237,10 @@ __device__ __forceinline__ void wave_transpose_sum(const float (&v)[N], int lane
   float f[(N + 63) / 64];
   wave_halve_swap<true>(e, f, m5);
   lo = f[0];
-  hi = f[1];
+  if constexpr (N > 64)
+    hi = f[1];
+  else
+    hi = 0.f;
   slot = (lane & 15) | static_cast<int>(m4 << 4) | static_cast<int>(m5 << 5);
 }
 

@@ -617,9 +617,9 @@ __device__ __forceinline__ Real moment_sum(const Real (&P)[PTS][3], const Sym3<R
   }
   return v;
 }
-template <typename Real, int PTS, int... S>
+template <typename Real, int PTS, int BASE, int... S>  // v[S] = sum number BASE + S
 __device__ __forceinline__ void moment_sums(const Real (&P)[PTS][3], const Sym3<Real> (&Mp)[PTS], const Real (&G)[PTS][3], Real (&v)[sizeof...(S)], std::integer_sequence<int, S...>) {
-  ((v[S] = moment_sum<Real, PTS, S>(P, Mp, G)), ...);
+  ((v[S] = moment_sum<Real, PTS, BASE + S>(P, Mp, G)), ...);
 }
 
 template <typename Real, int PTS>
@@ -632,8 +632,26 @@ __device__ __forceinline__ void accumulate_moments(const Real (&P)[PTS][3], cons
     acc_row[27] += et;
     acc_row[28] += static_cast<double>(inliers);
   }
+  if constexpr (sizeof(Real) == 4 && PTS == 1) {
+    // inside the one-query-per-lane search kernels (64 VGPRs): two reductions of 36 sums each — all 72 at once do not fit the register
+    // budget there, and the spills (60 bytes per lane through scratch memory) showed up as 60 MB of HBM traffic per pass
+    constexpr int kHalf = kMomentSums / 2;
+#pragma unroll
+    for (int part = 0; part < 2; part++) {
+      float v[kHalf];
+      if (part == 0)
+        moment_sums<float, PTS, 0>(P, Mp, G, v, std::make_integer_sequence<int, kHalf>{});
+      else
+        moment_sums<float, PTS, kHalf>(P, Mp, G, v, std::make_integer_sequence<int, kHalf>{});
+      float lo, hi;
+      int slot;
+      wave_transpose_sum<kHalf>(v, lane, lo, hi, slot);
+      if (slot < kHalf) acc_row[moment_column(part * kHalf + slot)] += static_cast<double>(lo);
+    }
+    return;
+  }
   Real v[kMomentSums];
-  moment_sums<Real, PTS>(P, Mp, G, v, std::make_integer_sequence<int, kMomentSums>{});
+  moment_sums<Real, PTS, 0>(P, Mp, G, v, std::make_integer_sequence<int, kMomentSums>{});
   if constexpr (sizeof(Real) == 4) {
     float lo, hi;
     int slot;
