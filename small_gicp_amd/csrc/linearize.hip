@@ -330,6 +330,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 6))) void
   int tile = chunk * p.chunk_tiles;
   const int tile_end = min(tile + p.chunk_tiles, num_tiles);
   int q_head = 0, q_count = 0;  // wave-uniform
+#ifdef SGA_KD_TRIPS
+  const unsigned long long qt0 = wall_clock64();
+  unsigned long long qt_stage = 0, qt_last = qt0;
+#endif
 
   bool busy = false, fresh = false;
   float qx = 0.f, qy = 0.f, qz = 0.f;
@@ -405,6 +409,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 6))) void
       }
       tile++;
     }
+#ifdef SGA_KD_TRIPS
+    {
+      const unsigned long long now = wall_clock64();
+      qt_stage += now - qt_last;  // (the first iteration: the staging of the whole chunk; later ones: refills)
+      qt_last = now;
+    }
+#endif
     // ---- lanes without a query take the next ones
     const unsigned long long idle = __ballot(!busy);
     if (q_count > 0 && idle != 0ull) {
@@ -452,6 +463,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 6))) void
       }
     }
   }
+#ifdef SGA_KD_TRIPS
+  const unsigned long long qt1 = wall_clock64();
+#endif
   if constexpr (FACTOR >= 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the chunk's neighbours are written
     __syncthreads();                                   // one wave: the stacks are free
@@ -463,6 +477,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 6))) void
     __syncthreads();
     for (int c = lane; c < kRow; c += 64) lp.partials[static_cast<size_t>(chunk) * kRow + c] = row[c];
   }
+#ifdef SGA_KD_TRIPS
+  if (lane == 0) {  // [12] staging, [13] walks, [14] factor stage, [15] waves; [11] latest end - earliest start is derived from the wave times
+    const unsigned long long qt2 = wall_clock64();
+    atomicAdd(&g_kd_trips[12], qt_stage);
+    atomicAdd(&g_kd_trips[13], (qt1 - qt0) - qt_stage);
+    atomicAdd(&g_kd_trips[14], qt2 - qt1);
+    atomicAdd(&g_kd_trips[15], 1ull);
+    if (blockIdx.x < 32768) {
+      g_kd_wave_times[2 * blockIdx.x] = qt0;
+      g_kd_wave_times[2 * blockIdx.x + 1] = qt2;
+    }
+  }
+#endif
 }
 
 // One correspondence (source point i at q = T p, target candidate j at t): rejector, fused mahalanobis, robust weight, the 28
