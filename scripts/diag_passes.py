@@ -19,7 +19,7 @@ sga.estimate_covariances(tgt, None, 20)
 sga.estimate_covariances(src, None, 20)
 tree = sga.KdTree(tgt)
 pb = sga.Problem(tree, src)
-st = sga.make_setting("GICP", max_correspondence_distance=1.0, max_iterations=10, rotation_eps=0.0, translation_eps=0.0)
+st = sga.make_setting(os.environ.get("DIAG_FACTOR", "GICP"), max_correspondence_distance=1.0, max_iterations=10, rotation_eps=0.0, translation_eps=0.0)
 lo, hi = source.min(0).astype(np.float64), source.max(0).astype(np.float64)
 corners = np.array([[x, y, z] for x in (lo[0], hi[0]) for y in (lo[1], hi[1]) for z in (lo[2], hi[2])])
 for rep in range(2):

@@ -181,6 +181,7 @@ struct NNParams {
   Rigid<Real> T;
   float bound2;      // the walks find neighbours with kd_dist2 < bound2 (the rejector's reach + kSearchMargin)
   float within2;     // a neighbour counts for the rejector only if kd_dist2 < within2
+  float slack_min, slack_max;  // exploration slack of a re-walk = clamp(motion, slack_min, slack_max) (SGA_SLACK_MIN / SGA_SLACK_MAX)
   int* __restrict__ nn;
   int* __restrict__ nn2;   // the runner-up of every walk: second candidate of the certificate
   float* __restrict__ rex;
@@ -237,7 +238,7 @@ __device__ __forceinline__ int search_lane(const NNParams<Real>& p, int tile, in
     seed = best;
     // this point's certificate did not survive: walk again, and explore a margin around the new neighbour proportional to the motion,
     // so that the certificate survives the following (smaller) steps
-    slack = fminf(fmaxf(moved, 3e-4f), 0.02f);
+    slack = fminf(fmaxf(moved, p.slack_min), p.slack_max);
     const unsigned long long walking = __ballot(true);
     if (threadIdx.x == __ffsll(static_cast<long long>(walking)) - 1) p.walked[tile] += static_cast<uint32_t>(__popcll(walking));  // the tile belongs to this wave: no atomic
   }
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 6))) void
             need = false;
           }
           seed = best;
-          slack = fminf(fmaxf(moved, 3e-4f), 0.02f);
+          slack = fminf(fmaxf(moved, p.slack_min), p.slack_max);
         }
       }
       // start group: the seed's; a point without a neighbour remembers the group of its cell; else locate it
@@ -1121,6 +1122,8 @@ static double g_warm_delta = getenv("SGA_WARM_DELTA") ? atof(getenv("SGA_WARM_DE
 static int g_search_queue = getenv("SGA_SEARCH_QUEUE") ? atoi(getenv("SGA_SEARCH_QUEUE")) : 2;
 // 1 (default): the search waves evaluate the factors of their own tiles (search_linearize_kernel); 0: always a separate factor kernel (linearize_kernel)
 static bool g_fuse_search = getenv("SGA_FUSE_SEARCH") ? atoi(getenv("SGA_FUSE_SEARCH")) != 0 : true;
+static const float g_slack_min = getenv("SGA_SLACK_MIN") ? static_cast<float>(atof(getenv("SGA_SLACK_MIN"))) : 3e-4f;
+static const float g_slack_max = getenv("SGA_SLACK_MAX") ? static_cast<float>(atof(getenv("SGA_SLACK_MAX"))) : 0.02f;
 static double g_queue_delta = getenv("SGA_QUEUE_DELTA") ? atof(getenv("SGA_QUEUE_DELTA")) : 0.02;
 // 1 (default): the one-query-per-lane search kernels walk with the fast leaf scan (32-bit keys, packed fp32; exact repeat of the
 // queries it cannot decide); 0: the exact 64-bit keys throughout.  Results do not depend on it.
@@ -1207,6 +1210,7 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
     q.kd = p.kd;
     q.T = p.T;
     q.within2 = p.bound2;
+    q.slack_min = g_slack_min, q.slack_max = g_slack_max;
     q.bound2 = p.bound2 * (1.f + kSearchMargin) * (1.f + kSearchMargin);
     q.nn = pb->hint.p;
     q.nn2 = pb->hint2.p;

@@ -480,6 +480,44 @@ def test_scan_to_scan_odometry_matches_oracle(orc):
         prev, prev_same = cloud, same
 
 
+def test_scan_to_scan_odometry_matches_reference():
+    """The same C5 protocol against the reference itself (oracle/_ref: the unmodified reference sources compiled in place, protocol of
+    src/benchmark/odometry_benchmark_small_gicp_omp.cpp:16-49: voxelgrid_sampling 0.25 m -> KdTree -> estimate_covariances k = 20 ->
+    Registration<GICPFactor, ParallelReductionOMP>::align against the previous scan).  (a) registration on identical inputs (the
+    reference gets the GPU's preprocessed points and covariances): 1e-4 m / 1e-4 rad and the same iteration count; (b) the whole
+    pipeline against the reference's own preprocessing of the raw scan: 2e-4 m (tied 20th neighbours, see the oracle variant above)."""
+    from oracle import ref
+    from small_gicp_amd import odometry
+
+    if not ref.available():
+        pytest.skip("oracle/_ref did not travel with the repository (make -C oracle/ref where /root/reference is mounted)")
+    odom = odometry.OnlineOdometry()
+    prev = prev_same = None
+    worst = [0.0, 0.0, 0.0, 0.0]
+    for f in range(5):
+        pts, _ = sga.synthetic.kitti_like_scan(f)
+        before = odom.T_world.copy()
+        odom.estimate(pts)
+        gcloud = odom.target[0]
+        same = ref.Cloud(gcloud.xyz().astype(np.float64), None, gcloud.covs()[:, :3, :3], tree=True, tree_threads=8)
+        down = ref.Cloud(pts.astype(np.float64), tree=False).voxelgrid_sampling(0.25).get()[0]
+        cloud = ref.Cloud(down.astype(np.float32).astype(np.float64), tree=True, tree_threads=8)
+        cloud.estimate_covariances(20, 8)
+        assert abs(len(cloud) - gcloud.size()) == 0  # the voxel grid keeps the same cells
+        if prev is not None:
+            rel = np.linalg.inv(before) @ odom.T_world
+            r_same = ref.align(prev_same, same, ref.GICP, 1.0, 1.0, 8)
+            dt, dr = pose_error(rel, r_same.T_target_source)
+            worst[0], worst[1] = max(worst[0], dt), max(worst[1], dr)
+            assert dt < POSE_TOL_T and dr < POSE_TOL_R and odom.iterations[-1] == r_same.iterations + 1, (f, dt, dr, odom.iterations[-1], r_same.iterations)
+            r = ref.align(prev, cloud, ref.GICP, 1.0, 1.0, 8)
+            dt, dr = pose_error(rel, r.T_target_source)
+            worst[2], worst[3] = max(worst[2], dt), max(worst[3], dr)
+            assert dt < 2e-4 and dr < 1e-4, (f, dt, dr)
+        prev, prev_same = cloud, same
+    print("C5 vs the compiled reference: same inputs %.2e m / %.2e rad, whole pipeline %.2e m / %.2e rad" % tuple(worst))
+
+
 def test_cpp_header_layer(tmp_path, c1_raw, c1_gold):
     """include/small_gicp_amd.hpp — Registration<Factor, ParallelReductionHIP> and the helper align() overloads, compiled with g++
     against the C-ABI library and run on config C1: same poses as the oracle goldens (1e-4 m / 1e-4 rad)."""
