@@ -474,7 +474,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 6))) void
     for (int c = lane; c < kRow; c += 64) row[c] = 0.0;
     __syncthreads();
     const int limit = min(p.n, tile_end * 64);
-    for (int t0 = chunk * p.chunk_tiles; t0 < tile_end; t0 += 4) linearize_group<Real, FACTOR, 0, 4, true>(lp, t0 * 64 + lane, 64, limit, row, lane);
+    if (p.chunk_tiles == 1)  // (small clouds) one point per lane: no arithmetic on three absent tiles
+      linearize_group<Real, FACTOR, 0, 1, true>(lp, chunk * 64 + lane, 64, limit, row, lane);
+    else
+      for (int t0 = chunk * p.chunk_tiles; t0 < tile_end; t0 += 4) linearize_group<Real, FACTOR, 0, 4, true>(lp, t0 * 64 + lane, 64, limit, row, lane);
     __syncthreads();
     for (int c = lane; c < kRow; c += 64) lp.partials[static_cast<size_t>(chunk) * kRow + c] = row[c];
   }
@@ -1129,6 +1132,7 @@ static double g_queue_delta = getenv("SGA_QUEUE_DELTA") ? atof(getenv("SGA_QUEUE
 // queries it cannot decide); 0: the exact 64-bit keys throughout.  Results do not depend on it.
 static int g_fast_scan = getenv("SGA_FAST_SCAN") ? atoi(getenv("SGA_FAST_SCAN")) : 1;
 static int g_chunk_tiles_cold = getenv("SGA_CHUNK_COLD") ? atoi(getenv("SGA_CHUNK_COLD")) : 4;
+static const bool g_chunk_adapt = getenv("SGA_CHUNK_ADAPT") ? atoi(getenv("SGA_CHUNK_ADAPT")) != 0 : true;
 static int g_chunk_tiles_warm = getenv("SGA_CHUNK_WARM") ? atoi(getenv("SGA_CHUNK_WARM")) : 4;
 
 template <typename Real>
@@ -1248,6 +1252,9 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
     } else if (queue) {
       q.inv_leaf = p.kd.n > 0 ? std::ldexp(1.0, p.kd.depth) / static_cast<double>(p.kd.n) : 0.0;
       q.chunk_tiles = std::max(1, warm ? g_chunk_tiles_warm : g_chunk_tiles_cold);
+      // a wave works through its chunk serially (two dependent round trips per tile): small clouds get shorter chunks, down to one tile,
+      // as long as that leaves no more than ~4 waves per SIMD (kWaveSlots4 = 256 CUs x 4 SIMDs x 4); C3 keeps its 4 tiles
+      if (warm && g_chunk_adapt) q.chunk_tiles = std::min(q.chunk_tiles, std::max(1, (static_cast<int>(sgrid.x) + 4095) / 4096));
       const dim3 qgrid((sgrid.x + q.chunk_tiles - 1) / q.chunk_tiles);
       const size_t lds = std::max<size_t>(words, 3) * 64 * sizeof(uint32_t);
       fused_search = g_fuse_search && !host_rejector && warm && sizeof(Real) == 4;
