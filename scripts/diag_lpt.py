@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Would starting the heavy tiles first shorten the search kernel's tail?  Per-tile work (max leaves over the 64 lanes) of every
-pass, its correlation with the previous pass, and a list-scheduling simulation (8192 wave slots, duration = a + b * work) of the
-natural order against heavy-first orders built from the previous pass.  Usage: python scripts/diag_lpt.py [points]"""
+"""Design study: would starting the expensive tiles first shorten a cold pass?  Per-tile work (max leaves scanned by any of its 64
+lanes — a wave lasts as long as its longest lane) of the passes of one C3 registration, its correlation with the PREVIOUS pass's,
+and a list-scheduling simulation on 8192 wave slots: launch order = tile order (today), = descending true cost (the bound), =
+descending cost of the previous pass (what could be built).  Usage: python scripts/diag_lpt.py [points]"""
 import heapq
 import os
 import sys
@@ -19,74 +20,40 @@ sga.estimate_covariances(src, None, 20)
 tree = sga.KdTree(tgt)
 st = sga.make_setting("GICP", max_correspondence_distance=1.0, max_iterations=10, rotation_eps=0.0, translation_eps=0.0)
 sga.set_search_mode(0)
+sga.set_warm_limit(-1.0)  # every pass walks in full: the work of a cold pass at each pose
 pb = sga.Problem(tree, src)
 pb.search_stats(True)
-works = []
-lanes = []
+costs = []
 
 
 def lin(T):
     r = pb.linearize(st.factor, T)
     lv = pb.search_stats()
     m = len(lv) // 64 * 64
-    works.append(lv[:m].reshape(-1, 64).max(axis=1).astype(np.float64))
-    lanes.append(lv[:m].reshape(-1, 64).astype(np.float64))
+    costs.append(lv[:m].reshape(-1, 64).max(axis=1).astype(np.float64))
     return r
 
 
 sga.optimize(st, np.eye(4), lin, lambda T: pb.error(st.factor, T))
 
-def makespan(dur, order, slots=8192):
+
+def makespan(cost, order, slots=8192):
+    """each wave occupies a slot for (2 + cost) units; waves start in `order` as slots free up"""
     h = [0.0] * slots
     heapq.heapify(h)
     end = 0.0
     for t in order:
         s = heapq.heappop(h)
-        e = s + dur[t]
+        e = s + 2.0 + cost[t]
         end = max(end, e)
         heapq.heappush(h, e)
     return end
 
 
-for k in range(1, min(5, len(works))):
-    w, prev = works[k], works[k - 1]
-    dur = 10.0 + 6.0 * w  # us: ~55 us for the average wave
-    nat = np.arange(len(w))
-    thr = np.percentile(prev, 70)
-    two = np.concatenate([nat[prev >= thr], nat[prev < thr]])
-    full = np.argsort(-prev, kind="stable")
-    oracle = np.argsort(-w, kind="stable")
-    print("pass %d: corr(work, prev work) = %.2f | ideal (sum/slots) %.0f us | makespan natural %.0f, heavy-first two buckets (prev) %.0f, sorted by prev %.0f, sorted by own work (oracle) %.0f"
-          % (k, np.corrcoef(w, prev)[0, 1], dur.sum() / 8192, makespan(dur, nat), makespan(dur, two), makespan(dur, full), makespan(dur, oracle)), flush=True)
-
-
-# late tiles split into narrower waves (the drain phase has idle slots and idle VALUs): last `frac` of the tiles as 64 / parts lanes
-for k in range(0, min(4, len(works))):
-    L = lanes[k]
-    base = makespan(10.0 + 6.0 * L.max(axis=1), np.arange(len(L)))
-    out = []
-    for frac in (0.25, 0.5):
-        for parts in (2, 4):
-            cut = int(len(L) * (1 - frac))
-            d = list(10.0 + 6.0 * L[:cut].max(axis=1))
-            sub = L[cut:].reshape(-1, parts, 64 // parts).max(axis=2).reshape(-1)
-            d += list(10.0 + 6.0 * sub)
-            d = np.array(d)
-            out.append("last %.0f%% in %d parts: %.0f" % (100 * frac, parts, makespan(d, np.arange(len(d)))))
-    print("pass %d: natural %.0f us | %s" % (k, base, " | ".join(out)), flush=True)
-
-# static (pose-invariant) per-tile features of the sorted source: extent of the 64 points, and the same over the kd-ordered target
-sp = pb.sorted_points()[:, :3]
-m = len(sp) // 64 * 64
-tiles = sp[:m].reshape(-1, 64, 3).astype(np.float64)
-extent = np.linalg.norm(tiles.max(axis=1) - tiles.min(axis=1), axis=1)
-print("static feature: tile extent (m) p50 %.2f p90 %.2f p99 %.2f max %.2f" % tuple(np.percentile(extent, [50, 90, 99, 100])))
-for k in range(0, min(4, len(works))):
-    w = works[k]
-    dur = 10.0 + 6.0 * w
-    order = np.argsort(-extent, kind="stable")
-    print("pass %d: corr(work, extent) = %.2f, rank corr = %.2f | makespan natural %.0f, largest extent first %.0f, own work first (oracle) %.0f"
-          % (k, np.corrcoef(w, extent)[0, 1], np.corrcoef(np.argsort(np.argsort(w)), np.argsort(np.argsort(extent)))[0, 1], makespan(dur, np.arange(len(w))), makespan(dur, order),
-             makespan(dur, np.argsort(-w, kind="stable"))), flush=True)
-
-
+for k, c in enumerate(costs[:5]):
+    tiles = np.arange(len(c))
+    line = "pass %d: tile cost mean %.1f max %d | makespan in tile order %.1f, LPT by true cost %.1f (bound: mean load %.1f)" % (k, c.mean(), c.max(), makespan(c, tiles), makespan(c, np.argsort(-c, kind="stable")), (2.0 + c).sum() / 8192)
+    if k > 0:
+        p = costs[k - 1]
+        line += " | corr with previous pass %.2f, LPT by previous pass %.1f" % (np.corrcoef(p, c)[0, 1], makespan(c, np.argsort(-p, kind="stable")))
+    print(line, flush=True)
