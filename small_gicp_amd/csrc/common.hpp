@@ -221,6 +221,10 @@ struct sga_problem {
   int last_math = 0;             // arithmetic of the last linearize of any kind (which mahalanobis cache is current)
   float bbox_lo[3] = {0, 0, 0}, bbox_hi[3] = {0, 0, 0};  // bounding box of the source (source frame): bounds the motion between two poses
   uint64_t cold_passes = 0, warm_passes = 0;  // passes against a kd-tree since the problem was created
+  // launch order of the one-query-per-lane search kernel (linearize.hip, "longest tile first"): the duration of every tile's wave
+  // in the last such pass, and the tiles of each XCD's share sorted by it; order_tiles != 0 iff tile_order belongs to that pass
+  sga::DevBuf<uint32_t> tile_cost, tile_order;
+  unsigned order_tiles = 0;
   sga::DevBuf<float> maha;       // n*6 (fp32 mode) — fused mahalanobis of the last linearize
   sga::DevBuf<double> maha64;    // n*6 (fp64 mode, allocated on first use)
   // custom CorrespondenceRejector on the host (sga_problem_set_rejector): reject flag per source point (caller's order) for the current pass

@@ -188,6 +188,8 @@ struct NNParams {
   int check;         // warm pass
   Rigid<Real> T_prev;
   uint32_t* __restrict__ walked;  // statistics, one counter per wave tile: lanes of warm passes that had to walk
+  const uint32_t* __restrict__ tile_order;  // launch slot -> tile (longest tile first), or null: slot = tile
+  uint32_t* __restrict__ tile_cost;         // out, or null: duration of the tile's wave (100 MHz ticks)
   int* __restrict__ leaves;  // diagnostics (sga_problem_set_search_stats): leaves scanned per source point in this pass, or null
   double inv_leaf;   // 2^depth / n (kd_leaf_rank)
   int chunk_tiles;   // queue-fed kernel: tiles of 64 queries per wave
@@ -824,7 +826,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   const unsigned long long wave_t0 = wall_clock64();
 #endif
   const int lane = threadIdx.x;
-  const int tile = search_tile_of_block();
+  const int slot = search_tile_of_block();
+  const int tile = p.tile_order != nullptr ? static_cast<int>(p.tile_order[slot]) : slot;  // wave-uniform
+  const unsigned long long cost_t0 = p.tile_cost != nullptr ? wall_clock64() : 0ull;
   const int i = tile * 64 + lane;
   const bool active = i < p.n;
   const float4 ps = active ? p.src_pts[i] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -863,6 +867,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   if (inliers > 0) accumulate_moments<Real, 1>(P, Mp, G, E, inliers, row, lane);
   __syncthreads();
   for (int c = lane; c < kRow; c += 64) lp.partials[static_cast<size_t>(tile) * kRow + c] = row[c];
+  if (p.tile_cost != nullptr && lane == 0) p.tile_cost[tile] = static_cast<uint32_t>(wall_clock64() - cost_t0);
 #ifdef SGA_KD_TRIPS
   if (blockIdx.x < 32768 && lane == 0) {
     g_kd_wave_times[2 * blockIdx.x] = wave_t0;
@@ -1047,6 +1052,36 @@ __global__ __launch_bounds__(kReduceSlices * kCols) void reduce_rows_kernel(
   }
 }
 
+// Longest tile first.  A pass of the one-query-per-lane kernel is 1.9 rounds of waves, and 35 - 40 % of it is the drain of the waves
+// that happened to start last and run long.  Which tiles run long is only known afterwards — but after a small
+// motion the next pass's costs resemble this one's (correlation 0.9 at <= 0.1 m, scripts/diag_lpt.py).  This kernel sorts the tiles of
+// every XCD's share (search_tile_of_block: slot s of XCD x is its (s - x * per_xcd)-th workgroup to start) by the duration their
+// wave just recorded, longest first: a counting sort over 64 duration classes of 2.56 us, one workgroup per XCD.  The order within a class is
+// whatever the LDS atomics make it: nothing but speed depends on the launch order (rows are indexed by tile).
+__global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order, int num_tiles) {
+  __shared__ uint32_t hist[64], start[64];
+  const int per_xcd = num_tiles >> 3;
+  const int x = blockIdx.x, first = x * per_xcd;
+  if (threadIdx.x < 64) hist[threadIdx.x] = 0u;
+  __syncthreads();
+  for (int k = threadIdx.x; k < per_xcd; k += blockDim.x) atomicAdd(&hist[63u - min(63u, cost[first + k] >> 8)], 1u);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t acc = 0u;
+    for (int b = 0; b < 64; b++) {
+      start[b] = acc;
+      acc += hist[b];
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < per_xcd; k += blockDim.x) {
+    const uint32_t pos = atomicAdd(&start[63u - min(63u, cost[first + k] >> 8)], 1u);
+    order[first + pos] = static_cast<uint32_t>(first + k);
+  }
+  if (x == 0)
+    for (int t = 8 * per_xcd + threadIdx.x; t < num_tiles; t += blockDim.x) order[t] = static_cast<uint32_t>(t);  // the (< 8) tiles beyond the XCD shares
+}
+
 // partial rows (one per workgroup of linearize_kernel / error_kernel, or one per 64 source points when the search kernel does the factor algebra itself);
 // the stage-1 rows of the reduction follow them
 static size_t partial_rows(size_t n) { return std::max<size_t>(kMaxBlocks, (n + 63) / 64); }
@@ -1125,6 +1160,9 @@ static double g_warm_delta = getenv("SGA_WARM_DELTA") ? atof(getenv("SGA_WARM_DE
 static int g_search_queue = getenv("SGA_SEARCH_QUEUE") ? atoi(getenv("SGA_SEARCH_QUEUE")) : 2;
 // 1 (default): the search waves evaluate the factors of their own tiles (search_linearize_kernel); 0: always a separate factor kernel (linearize_kernel)
 static bool g_fuse_search = getenv("SGA_FUSE_SEARCH") ? atoi(getenv("SGA_FUSE_SEARCH")) != 0 : true;
+// longest tile first (tile_order_kernel): 0 off, 1 = warm passes of the one-query-per-lane kernel (motion <= SGA_WARM_DELTA) when the
+// previous pass was such a pass too, 2 = every pass of that kernel that follows another (experiments)
+static const int g_lpt = getenv("SGA_LPT") ? atoi(getenv("SGA_LPT")) : 1;
 static const float g_slack_min = getenv("SGA_SLACK_MIN") ? static_cast<float>(atof(getenv("SGA_SLACK_MIN"))) : 3e-4f;
 static const float g_slack_max = getenv("SGA_SLACK_MAX") ? static_cast<float>(atof(getenv("SGA_SLACK_MAX"))) : 0.02f;
 static double g_queue_delta = getenv("SGA_QUEUE_DELTA") ? atof(getenv("SGA_QUEUE_DELTA")) : 0.02;
@@ -1202,6 +1240,7 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
     ctx->pending_warm = warm;
   }
   bool fused_search = false;  // the search kernel evaluates the factors itself ...
+  bool record_tiles = false;  // ... and records the duration of every tile's wave (longest tile first, tile_order_kernel)
   int fused_rows = 0;         // ... and leaves this many partial rows
   // The search kernels rewrite hint / hint2 / rex for THIS pose: until the pass has been launched completely the certificates belong
   // to no pose the host knows, so an early return below (allocation, rejector callback, launch error) must not leave them marked
@@ -1229,10 +1268,19 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
     const dim3 sgrid((p.n + kSearchBlock - 1) / kSearchBlock), sblock(kSearchBlock);
     const bool queue = g_search_queue == 1 || (g_search_queue == 2 && warm && displacement <= g_queue_delta);
     fused_search = g_fuse_search && !host_rejector && !queue && sizeof(Real) == 4;  // fp64 math: the fused kernel would spill
+    const unsigned order_tiles_before = pb->order_tiles;
+    pb->order_tiles = 0;  // (set again below when this pass records its tiles' durations)
     if (fused_search) {
       // every search wave evaluates the factors of its own tile: one partial row per tile of 64 points, summed by reduce_rows_kernel
       p.tail.enabled = 0;
       fused_rows = static_cast<int>(sgrid.x);
+      if (g_lpt != 0 && sgrid.x >= 8192) {  // fewer tiles than wave slots: all waves start at once, the order means nothing
+        SGA_TRY(pb->tile_cost.reserve(sgrid.x));
+        SGA_TRY(pb->tile_order.reserve(sgrid.x));
+        q.tile_cost = pb->tile_cost.p;
+        if (order_tiles_before == sgrid.x && (g_lpt == 2 || warm)) q.tile_order = pb->tile_order.p;
+        record_tiles = true;
+      }
       static const size_t lds_pad = getenv("SGA_LDS_PAD") ? static_cast<size_t>(atoi(getenv("SGA_LDS_PAD"))) : 0;  // experiments: bytes of unused LDS per wave (lowers the occupancy)
       const size_t lds = std::max<size_t>(words, 3) * 64 * sizeof(uint32_t) + lds_pad;
       switch (fp->factor_kind) {
@@ -1323,13 +1371,18 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
       }
     }
   }
-  if (fused_search)
+  if (fused_search) {
     launch_reduce(ctx, pb->partials.p, fused_rows, ncols, kRow, pb->partials.p + partial_rows(pb->n) * kRow, d_out30, out_n, host, seq, true);
+  }
   else if (!fuse)
     launch_reduce(ctx, pb->partials.p, p.n > 0 ? blocks : 0, ncols, kRow, pb->partials.p + partial_rows(pb->n) * kRow, d_out30, out_n, host, seq, true);
   if (timed) {  // the whole GPU side of the pass: search + factors + the sum of the rows
     (void)hipEventRecord(ctx->ev1, ctx->stream);
     ctx->pending |= 1;
+  }
+  if (record_tiles) {  // after the reduction has handed the result to the host: the tiles are sorted while the host solves
+    hipLaunchKernelGGL(tile_order_kernel, dim3(8), dim3(1024), 0, ctx->stream, pb->tile_cost.p, pb->tile_order.p, fused_rows);
+    pb->order_tiles = static_cast<unsigned>(fused_rows);
   }
   SGA_HIP(hipGetLastError());
   pb->last_math = math;

@@ -6,6 +6,8 @@ radius - motion) and walks the tree only for the other points.  Exactness is by 
 chains shaped like a registration (large steps first, then ever smaller ones), on tie-heavy lattices, with the rejector on and
 off, for every factor, and with the limit forced so that nearly every certificate fails.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -160,3 +162,43 @@ def test_queue_fed_search_equals_lane_search(c1_f32, chunk, maxd):
         assert pq.pass_stats()["warm_passes"] >= 4
     finally:
         sga.set_search_mode(2, 4, 4)
+
+
+_ORDER_SCRIPT = r"""
+import hashlib, sys
+import os
+
+import numpy as np
+import small_gicp_amd as sga
+target, source, T_gt = sga.synthetic.registration_pair(600_000)
+tgt, src = sga.PointCloud(target), sga.PointCloud(source)
+sga.estimate_covariances(tgt, None, 10)
+sga.estimate_covariances(src, None, 10)
+pb = sga.Problem(sga.KdTree(tgt), src)
+st = sga.make_setting("GICP", max_correspondence_distance=1.0)
+h = hashlib.sha256()
+T = np.eye(4)
+for step in (0.0, 0.3, 0.05, 0.03, 0.004):  # cold, cold, warm (one query per lane, in the recorded order), warm, warm (queue-fed)
+    T = T.copy()
+    T[0, 3] += step
+    H, b, e, n = pb.linearize(st.factor, T)
+    h.update(np.ascontiguousarray(H).tobytes() + np.ascontiguousarray(b).tobytes() + np.float64(e).tobytes() + np.int64(n).tobytes())
+print("DIGEST", h.hexdigest(), pb.pass_stats())
+"""
+
+
+@pytest.mark.gpu
+def test_launch_order_of_the_tiles_does_not_change_the_results():
+    """Longest tile first (linearize.hip: tile_order_kernel): the one-query-per-lane search kernel starts the tiles of a pass in the order
+    of the durations recorded by the previous pass.  Partial rows are indexed by tile, so H, b, e and the inlier count must be
+    BIT-identical with the feature off (SGA_LPT=0), on for warm passes (1, the default) and on for every pass (2)."""
+    import subprocess
+    import sys
+
+    digests = []
+    for mode in ("0", "1", "2"):
+        env = dict(os.environ, SGA_LPT=mode, PYTHONPATH=os.pathsep.join([os.path.dirname(os.path.dirname(os.path.abspath(__file__)))] + sys.path))
+        p = subprocess.run([sys.executable, "-c", _ORDER_SCRIPT], capture_output=True, text=True, timeout=600, env=env)
+        assert p.returncode == 0, p.stderr[-2000:]
+        digests.append([ln for ln in p.stdout.splitlines() if ln.startswith("DIGEST")][0])
+    assert digests[0] == digests[1] == digests[2], digests
