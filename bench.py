@@ -388,6 +388,15 @@ def main():
             "preprocess_s": prep_s,
             "final_pose_error": {"trans_m": pose_err_t, "rot_rad": pose_err_r},
         }
+        if MEASURED_VALU:
+            # What actually binds K1: the walks are VALU work at a third to a half of the lanes.  A wave64
+            # instruction occupies a 16-lane SIMD for 4 cycles; 256 CUs x 4 SIMDs at 2.4 GHz.
+            insts = MEASURED_VALU["insts_per_launch"]
+            floor_us = insts * 4.0 / (256 * 4) / 2400.0
+            out["roofline"]["valu_issue"] = {
+                "wave_instructions_per_launch": insts, "floor_us": floor_us, "frac_of_issue_slots": floor_us / lin_us if lin_us > 0 else None,
+                "note": "SQ_INSTS_VALU of the search + factor + reduce kernels per pass (rocprofv3 --pmc, its own pass over one more registration of %d passes) x 4 cycles / 1024 SIMDs / 2.4 GHz: "
+                        "the time the pass would take if every SIMD issued a vector instruction every cycle it can; frac = that floor / avg_launch_us" % MEASURED_VALU["passes"]}
         if shard_check is not None:
             out["sharded_vs_unsharded"] = shard_check
         if sustained is not None:
@@ -519,6 +528,9 @@ def plane_icp_leg(sga, ctx, args):
         return {"error": repr(ex)}
 
 
+MEASURED_VALU = {}  # filled by measure_traffic: wave-level VALU instructions of K1 per pass (SQ_INSTS_VALU)
+
+
 def measure_traffic(args):
     """HBM bytes of K1 per pass, measured: ONE more C3 registration (scripts/one_registration.py: the same clouds, 10 LM iterations) under
     rocprofv3 --kernel-trace --pmc FETCH_SIZE, and again with --pmc WRITE_SIZE (separate passes, kernel-trace only, as
@@ -535,11 +547,13 @@ def measure_traffic(args):
     tmp = tempfile.mkdtemp(prefix="sga_traffic_")
     totals = {}
     try:
-        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
             d = os.path.join(tmp, ctr)
             cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.join(ROOT, "scripts", "one_registration.py"), str(args.points)]
             p = subprocess.run(cmd, cwd=tmp, env=dict(os.environ, TMPDIR=tmp), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
             if p.returncode != 0:
+                if ctr == "SQ_INSTS_VALU":
+                    break  # the instruction count is extra information
                 return None, "rocprofv3 %s pass failed: %s" % (ctr, p.stderr.decode(errors="replace")[-300:])
             kb, passes = 0.0, 0
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -553,9 +567,14 @@ def measure_traffic(args):
                     elif "linearize_kernel" in kn or "reduce_rows_kernel" in kn:
                         kb += float(r.get("Counter_Value", 0))
             if passes == 0:
+                if ctr == "SQ_INSTS_VALU":
+                    break
                 return None, "no K1 dispatch in the %s pass" % ctr
             totals[ctr] = (kb / passes, passes)
         hbm = int((2.0 * totals["FETCH_SIZE"][0] + totals["WRITE_SIZE"][0]) * 1024)
+        MEASURED_VALU.clear()
+        if "SQ_INSTS_VALU" in totals:
+            MEASURED_VALU.update(insts_per_launch=totals["SQ_INSTS_VALU"][0], passes=totals["SQ_INSTS_VALU"][1])
         return hbm, ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) around one more C3 registration (%d passes); FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B), "
                      "WRITE_SIZE as reported, KB; search + factor + reduce kernels of a pass" % totals["FETCH_SIZE"][1])
     except Exception as ex:  # noqa: BLE001
