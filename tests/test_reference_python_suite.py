@@ -1,5 +1,5 @@
-"""The reference's own Python test file, UNCHANGED (tests/golden/reference_python_test/python_test.py = src/test/python_test.py of
-koide3/small_gicp v1.0.1), run against this repository's `import small_gicp` module on the GPU."""
+"""The reference's own Python test file and its Python example, UNCHANGED (tests/golden/reference_python_test/python_test.py =
+src/test/python_test.py, basic_registration.py = src/example/basic_registration.py of koide3/small_gicp v1.0.1), run against this repository's `import small_gicp` module on the GPU."""
 import os
 import subprocess
 import sys
@@ -21,7 +21,10 @@ def write_ply(path, xyz):
         f.write(v.tobytes())
 
 
-def test_reference_python_test_file_runs_unchanged(tmp_path):
+@pytest.mark.parametrize("name", ["python_test.py", "basic_registration.py"])
+def test_reference_python_test_file_runs_unchanged(tmp_path, name):
+    """python_test.py = src/test/python_test.py (the binding's test suite); basic_registration.py = src/example/basic_registration.py
+    (the four usage examples of the README, each verified against the ground truth by the file's own pytest functions)."""
     d = np.load(os.path.join(GOLDEN, "c1_points.npz"))
     data = tmp_path / "data"
     data.mkdir()
@@ -31,8 +34,8 @@ def test_reference_python_test_file_runs_unchanged(tmp_path):
     import filecmp
     import shutil
 
-    fixture = os.path.join(GOLDEN, "reference_python_test", "python_test.py")
-    suite = tmp_path / "python_test.py"  # a byte-identical copy next to its data/ directory
+    fixture = os.path.join(GOLDEN, "reference_python_test", name)
+    suite = tmp_path / name  # a byte-identical copy next to its data/ directory
     shutil.copyfile(fixture, suite)
     assert filecmp.cmp(fixture, suite, shallow=False)
     env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
