@@ -202,3 +202,15 @@ def test_launch_order_of_the_tiles_does_not_change_the_results():
         assert p.returncode == 0, p.stderr[-2000:]
         digests.append([ln for ln in p.stdout.splitlines() if ln.startswith("DIGEST")][0])
     assert digests[0] == digests[1] == digests[2], digests
+
+
+def test_exactness_soak_on_random_pose_chains():
+    """scripts/soak_exactness.py (short form): random LM-like pose chains on 70k ... 1M-point pairs, GICP and ICP, three rejector
+    distances; after every pass the product path's correspondences equal those of a problem that walks every point in every pass."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "scripts", "soak_exactness.py"), "2", "7"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "SOAK OK" in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]
+    print(p.stdout.splitlines()[-1])
