@@ -638,6 +638,12 @@ def odometry_leg(sga, args, shard):
         except Exception as ex:  # noqa: BLE001
             out["pipelined_error"] = repr(ex)
         out["protocol"] = "src/benchmark/odometry_benchmark_small_gicp_omp.cpp:16-49: registration = index build + covariances + align; total adds the 0.25 m voxel grid"
+        try:  # the same scans through the C++ driver (examples/odometry_benchmark.cpp): the reference's benchmark is a C++ program too
+            cr = odometry.run_synthetic_cpp(args.odom_frames)
+            out["cpp_driver"] = {"registration_ms_per_scan": cr["registration_ms_per_scan"], "total_ms_per_scan": cr["total_ms_per_scan"], "mean_iterations": cr["mean_iterations"],
+                                 "max_abs_pose_difference_vs_python_driver": float(max(np.abs(a - b).max() for a, b in zip(cr["estimated"], r["estimated"]))), "driver": cr["driver"]}
+        except Exception as ex:  # noqa: BLE001
+            out["cpp_driver"] = {"error": repr(ex)}
         if not args.no_cpu_baseline:
             from oracle import orc, ref
 

@@ -280,6 +280,16 @@ inline void estimate_normals_covariances(PointCloud& cloud, KdTree& tree, int nu
   check(sga_estimate_normals_covariances(cloud.ctx, cloud.h, tree.h, num_neighbors, 3), "estimate_normals_covariances");
   cloud.invalidate_host();
 }
+/// util/normal_estimation_omp.hpp estimate_covariances_omp(points, tree, k, threads): with the cloud's own tree (which then also holds
+/// the covariances in its kd order: ready to be a registration target, or a source by its index)
+inline void estimate_covariances(PointCloud& cloud, KdTree& tree, int num_neighbors = 20) {
+  check(sga_estimate_normals_covariances(cloud.ctx, cloud.h, tree.h, num_neighbors, 2), "estimate_covariances");
+  cloud.invalidate_host();
+}
+inline void estimate_normals(PointCloud& cloud, KdTree& tree, int num_neighbors = 20) {
+  check(sga_estimate_normals_covariances(cloud.ctx, cloud.h, tree.h, num_neighbors, 1), "estimate_normals");
+  cloud.invalidate_host();
+}
 
 // ---- factors (factors/*.hpp): tag types, the per-point state lives on the device ----------------------------------------------------
 struct ICPFactor {
@@ -430,6 +440,23 @@ struct Registration {
     (void)target;
     check(sga_index_refresh_attributes(source.ctx, target_tree.h, target_tree.points->h), "sga_index_refresh_attributes");
     return run(target_tree.h, source, init_T);
+  }
+  /// The same with the SOURCE given by its own KdTree (an addition to the reference's signature for the odometry loop,
+  /// odometry_benchmark_small_gicp_omp.cpp:22-38, where every scan is indexed anyway): sga_problem_create_from_index takes the index's
+  /// kd-ordered points and covariances as they are — no spatial sort, no copy.  Both trees must hold the attributes the factor needs
+  /// (estimate them with the tree, or build the tree afterwards).
+  RegistrationResult align(const PointCloud& target, const KdTree& source_tree, const KdTree& target_tree, const Isometry3d& init_T = Isometry3d::Identity()) const {
+    (void)target;
+    static_assert(std::is_same<Reduction, ParallelReductionHIP>::value, "this library provides the ParallelReductionHIP reduction only");
+    sga_context* ctx = source_tree.points->ctx;
+    const sga_registration_setting s = make_setting();
+    sga_problem* pb = nullptr;
+    check(sga_problem_create_from_index(ctx, target_tree.h, source_tree.h, init_T.data(), &pb), "sga_problem_create_from_index");
+    sga_result r;
+    const int rc = sga_align_problem(ctx, pb, init_T.data(), &s, &r);
+    sga_problem_destroy(pb);
+    check(rc, "sga_align_problem");
+    return to_result(r);
   }
   /// VGICP form (registration_helper.cpp:136: the voxel map is both target cloud and search structure)
   RegistrationResult align(const GaussianVoxelMap& target, const PointCloud& source, const GaussianVoxelMap& target_tree, const Isometry3d& init_T = Isometry3d::Identity()) const {

@@ -259,6 +259,52 @@ def run_synthetic_pipelined(num_frames=20, **kw):
     return {"frames": num_frames, "ms_per_scan": 1e3 * wall / num_frames, "estimated": poses, "mean_iterations": float(np.mean(iters)) if iters else 0.0}
 
 
+def run_synthetic_cpp(num_frames=20, workdir=None, downsampling_resolution=0.25, num_neighbors=20):
+    """The same sequence through the C++ driver examples/odometry_benchmark.cpp (the reference's benchmark protocol over
+    include/small_gicp_amd.hpp): writes the scans as KITTI .bin files, compiles the driver with g++ against the in-tree library, runs it and
+    parses its report and trajectory.  Returns registration / total ms per scan as the driver measured them and the poses."""
+    import os
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+
+    from . import _lib, synthetic
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    own = workdir is None
+    workdir = workdir or tempfile.mkdtemp(prefix="sga_odom_cpp_")
+    try:
+        data = os.path.join(workdir, "velodyne")
+        os.makedirs(data, exist_ok=True)
+        for f in range(num_frames):
+            pts, _ = synthetic.kitti_like_scan(f)
+            v = np.zeros((len(pts), 4), "<f4")
+            v[:, :3] = pts[:, :3]
+            v.tofile(os.path.join(data, "%06d.bin" % f))
+        exe = os.path.join(workdir, "odometry_benchmark")
+        libdir = os.path.dirname(_lib.LIB_PATH)
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "odometry_benchmark.cpp"), "-o", exe, "-L" + libdir, "-lsmall_gicp_amd",
+                               "-Wl,-rpath," + libdir, "-Wl,-rpath-link,/opt/rocm/lib"])
+        traj = os.path.join(workdir, "traj.txt")
+        p = subprocess.run([exe, data, traj, "--num_neighbors", str(num_neighbors), "--downsampling_resolution", str(downsampling_resolution)], capture_output=True, text=True, timeout=600)
+        if p.returncode != 0:
+            raise RuntimeError("odometry_benchmark failed: " + p.stdout[-1000:] + p.stderr[-1000:])
+        m = re.search(r"registration_time_stats=([0-9.eE+-]+) \+- ([0-9.eE+-]+) \[msec/scan\]\s+total_throughput=([0-9.eE+-]+) \+- ([0-9.eE+-]+) \[msec/scan\]\s+mean_iterations=([0-9.eE+-]+)", p.stdout)
+        if m is None:
+            raise RuntimeError("no report in the driver's output: " + p.stdout[-1000:])
+        poses = []
+        for ln in open(traj):
+            T = np.eye(4)
+            T[:3, :4] = np.array(ln.split(), dtype=np.float64).reshape(3, 4)
+            poses.append(T)
+        return {"frames": num_frames, "registration_ms_per_scan": float(m.group(1)), "registration_ms_std": float(m.group(2)), "total_ms_per_scan": float(m.group(3)), "mean_iterations": float(m.group(5)),
+                "estimated": poses, "driver": "examples/odometry_benchmark.cpp (C++ over include/small_gicp_amd.hpp), all scans read into host memory first"}
+    finally:
+        if own:
+            shutil.rmtree(workdir, ignore_errors=True)
+
+
 class Summarizer:
     """mean +- std (last=...) of a stream, formatted like benchmark.hpp:36-79."""
 

@@ -518,6 +518,23 @@ def test_scan_to_scan_odometry_matches_reference():
     print("C5 vs the compiled reference: same inputs %.2e m / %.2e rad, whole pipeline %.2e m / %.2e rad" % tuple(worst))
 
 
+def test_cpp_odometry_driver_matches_the_python_driver(tmp_path):
+    """examples/odometry_benchmark.cpp — the reference's benchmark protocol (odometry_benchmark.cpp + odometry_benchmark_small_gicp_omp.cpp:
+    16-49) over include/small_gicp_amd.hpp, with the source entering the registration by its own KdTree — compiled with g++ and run on
+    eight KITTI-shaped scans written as .bin files: the trajectory file equals the Python driver's poses (same library calls in the same
+    order; the file has six decimals) and the iteration counts agree."""
+    from small_gicp_amd import odometry
+
+    cr = odometry.run_synthetic_cpp(8, workdir=str(tmp_path))
+    pr = odometry.run_synthetic(8)
+    assert len(cr["estimated"]) == 8
+    worst = max(np.abs(a - b).max() for a, b in zip(cr["estimated"], pr["estimated"]))
+    assert worst < 2e-6, worst
+    assert abs(cr["mean_iterations"] - pr["mean_iterations"]) < 0.01, (cr["mean_iterations"], pr["mean_iterations"])  # printed with two decimals
+    assert 0 < cr["registration_ms_per_scan"] < 50
+    print("C++ odometry driver: %.3f ms/scan registration, %.3f ms/scan total (Python driver: %.3f / %.3f)" % (cr["registration_ms_per_scan"], cr["total_ms_per_scan"], pr["registration_ms_per_scan"], pr["total_ms_per_scan"]))
+
+
 def test_cpp_header_layer(tmp_path, c1_raw, c1_gold):
     """include/small_gicp_amd.hpp — Registration<Factor, ParallelReductionHIP> and the helper align() overloads, compiled with g++
     against the C-ABI library and run on config C1: same poses as the oracle goldens (1e-4 m / 1e-4 rad)."""
