@@ -171,7 +171,7 @@ constexpr float kSearchMargin = 0.05f;
 // move the points by micrometres: their passes are a stream over 40 bytes per point.
 //
 // One wave per workgroup (a finished wave frees its slot and its 4 KB of stack at once; the hardware dispatcher balances the uneven
-// walks) at 8 waves per SIMD (64 VGPRs), which the walk needs.  The factor stage either follows inside the same wave
+// walks) at 7 - 8 waves per SIMD (72 / 64 VGPRs), which the walk needs.  The factor stage either follows inside the same wave
 // (search_linearize_kernel: the moment form needs 42 VGPRs at one point per lane) or runs as linearize_kernel over nn[].
 template <typename Real>
 struct NNParams {
@@ -816,11 +816,17 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(4))) void
 
 // K1, fused: the search wave also evaluates the factors of its own 64 source points — their neighbours are in registers, no nn[]
 // round trip, no second kernel whose start waits for the slowest search wave.  The factor algebra in moment form is lean enough
-// (42 VGPRs at one point per lane) to live inside the search kernel's 64-register budget, which the walks need for 8 waves per SIMD.
+// (42 VGPRs at one point per lane) to live inside the search kernel's register budget (72 VGPRs for 7 waves per SIMD, which the walks need).
 // One partial row per wave (= per tile of 64 points, whatever workgroup took it: the row order, and with it the fp64 sum, does not
 // depend on the placement).  The row is built in the LDS the traversal stacks occupied.
+// 7 waves per SIMD (72 VGPRs): as fast as 8 (64 VGPRs; measured 179 / 190 / 200 against 182 / 185 / 198 us for the cold passes of a C3
+// registration) and without the two registers the 64-VGPR build spills around the walk (20 bytes per lane through scratch memory =
+// 2 x 20 MB of HBM traffic per cold pass).
+#ifndef SGA_SL_WAVES
+#define SGA_SL_WAVES 7
+#endif
 template <typename Real, int FACTOR, bool CHECK>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void search_linearize_kernel(const NNParams<Real> p, const LinParams<Real> lp) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGA_SL_WAVES, SGA_SL_WAVES))) void search_linearize_kernel(const NNParams<Real> p, const LinParams<Real> lp) {
   extern __shared__ uint32_t kd_stack[];  // max(tree depth, 3) x 64 words: the traversal stacks, then the wave's row of kRow doubles
 #ifdef SGA_KD_TRIPS
   const unsigned long long wave_t0 = wall_clock64();
