@@ -395,7 +395,8 @@ def main():
             floor_us = insts * 4.0 / (256 * 4) / 2400.0
             out["roofline"]["valu_issue"] = {
                 "wave_instructions_per_launch": insts, "floor_us": floor_us, "frac_of_issue_slots": floor_us / lin_us if lin_us > 0 else None,
-                "note": "SQ_INSTS_VALU of the search + factor + reduce kernels per pass (rocprofv3 --pmc, its own pass over one more registration of %d passes) x 4 cycles / 1024 SIMDs / 2.4 GHz: "
+                "floor_us_at_2_0_ghz": insts * 4.0 / (256 * 4) / 2000.0,
+                "note": "(floor_us is at the 2.4 GHz maximum clock; MI355X_MICROARCH.md, DVFS: dense vector code sustains 1.9 - 2.3 GHz, which raises the floor accordingly.)  SQ_INSTS_VALU of the search + factor + reduce kernels per pass (rocprofv3 --pmc, its own pass over one more registration of %d passes) x 4 cycles / 1024 SIMDs / 2.4 GHz: "
                         "the time the pass would take if every SIMD issued a vector instruction every cycle it can; frac = that floor / avg_launch_us" % MEASURED_VALU["passes"]}
         if shard_check is not None:
             out["sharded_vs_unsharded"] = shard_check
