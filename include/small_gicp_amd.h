@@ -118,7 +118,9 @@ int sga_voxelmap_set_search_offsets(sga_index* voxelmap, int num_offsets);
 int sga_flatmap_download(sga_context* ctx, const sga_index* flatmap, int32_t* coords, uint32_t* counts, float* points, float* cov6);
 /* traits::knn_search / nearest_neighbor_search (ann/traits.hpp:22-57) for m host queries (m*3 floats):
  * idx m*k int64 (original target indices, -1 = none), sq_dist m*k floats ascending (inf = none).
- * max_sq_dist < 0 means unbounded.  k <= 116 for kd-trees.  Voxel maps support k = 1 only (own voxel, incremental_voxelmap.hpp:99-119). */
+ * max_sq_dist < 0 means unbounded.  k <= 116 for kd-trees.  Voxel maps (Gaussian and flat, incremental_voxelmap.hpp:99-149): any
+ * k <= 128, the voxels at the map's search offsets in the reference's order, KnnResult::push semantics; idx is then the reference's global
+ * index (voxel_id << 32) | point_id (point_id = 0 for a Gaussian voxel, the slot within its voxel for a flat map). */
 int sga_index_knn(sga_context* ctx, const sga_index* index, const float* queries, size_t m, int k, double max_sq_dist, int64_t* idx, float* sq_dist);
 /* The same with the reference's types (double queries m*3, double squared distances): the search runs on the fp32 roundings of the
  * queries, the squared distances of the neighbours found are then evaluated in double against the double queries (the reference's

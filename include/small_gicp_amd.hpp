@@ -188,6 +188,23 @@ struct KdTree {
   sga_index* h = nullptr;
 };
 
+/// traits::knn_search / nearest_neighbor_search of a voxel map (ann/incremental_voxelmap.hpp:99-149) for one query: global indices
+/// (voxel_id << 32) | point_id, squared distances ascending; returns the number found
+inline size_t voxelmap_knn_search(sga_context* ctx, const sga_index* h, const double* pt, size_t k, size_t* k_indices, double* k_sq_dists) {
+  if (!h) return 0;
+  std::vector<int64_t> idx(k);
+  std::vector<double> d2(k);
+  check(sga_index_knn_f64(ctx, h, pt, 1, static_cast<int>(k), -1.0, idx.data(), d2.data()), "sga_index_knn_f64");
+  size_t found = 0;
+  for (size_t j = 0; j < k; j++)
+    if (idx[j] >= 0) {
+      k_indices[found] = static_cast<size_t>(idx[j]);
+      k_sq_dists[found] = d2[j];
+      found++;
+    }
+  return found;
+}
+
 /// ann/gaussian_voxelmap.hpp + incremental_voxelmap.hpp: one-shot Gaussian voxel map (VGICP target).
 struct GaussianVoxelMap {
   using Ptr = std::shared_ptr<GaussianVoxelMap>;
@@ -210,6 +227,10 @@ struct GaussianVoxelMap {
     if (h) sga_index_size(h, &n);
     return n;
   }
+  size_t knn_search(const double* pt, size_t k, size_t* k_indices, double* k_sq_dists) const { return voxelmap_knn_search(ctx, h, pt, k, k_indices, k_sq_dists); }
+  size_t nearest_neighbor_search(const double* pt, size_t* k_index, double* k_sq_dist) const { return knn_search(pt, 1, k_index, k_sq_dist); }
+  static size_t voxel_id(size_t i) { return i >> 32; }          // incremental_voxelmap.hpp:153-154
+  static size_t point_id(size_t i) { return i & 0xffffffffull; }
   double leaf;
   sga_context* ctx = nullptr;
   sga_index* h = nullptr;
@@ -250,6 +271,10 @@ struct IncrementalVoxelMap<FlatContainerCov> {
     if (h) sga_index_size(h, &n);
     return n;
   }
+  size_t knn_search(const double* pt, size_t k, size_t* k_indices, double* k_sq_dists) const { return voxelmap_knn_search(ctx, h, pt, k, k_indices, k_sq_dists); }
+  size_t nearest_neighbor_search(const double* pt, size_t* k_index, double* k_sq_dist) const { return knn_search(pt, 1, k_index, k_sq_dist); }
+  static size_t voxel_id(size_t i) { return i >> 32; }          // incremental_voxelmap.hpp:153-154
+  static size_t point_id(size_t i) { return i & 0xffffffffull; }
   double leaf;
   size_t lru_horizon = 100, lru_clear_cycle = 10;  // set before the first insert
   FlatContainerCov::Setting voxel_setting;          // set before the first insert

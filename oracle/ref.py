@@ -93,6 +93,8 @@ def lib():
         L.ref_fvm_total_points.restype = C.c_size_t
         L.ref_fvm_get.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_uint64), dp, dp]
         L.ref_fvm_align.argtypes = [vp, vp, C.c_int, dp, C.POINTER(Result)]
+        L.ref_fvm_knn.argtypes = [vp, dp, C.c_size_t, C.c_int, C.POINTER(C.c_int64), dp]
+        L.ref_ivm_knn.argtypes = [vp, dp, C.c_size_t, C.c_int, C.POINTER(C.c_int64), dp]
         _LIB = L
     return _LIB
 
@@ -182,6 +184,9 @@ class VoxelMap:
     def __len__(self):
         return lib().ref_ivm_size(self.h)
 
+    def knn(self, queries, k):
+        return _map_knn(lib().ref_ivm_knn, self.h, queries, k)
+
     def get(self):
         n = len(self)
         coords = np.empty((n, 3), np.int32)
@@ -190,6 +195,14 @@ class VoxelMap:
         counts = np.empty(n, np.uint64)
         lib().ref_ivm_get(self.h, coords.ctypes.data_as(C.POINTER(C.c_int)), _dp(means), _dp(covs), counts.ctypes.data_as(C.POINTER(C.c_uint64)))
         return coords, means, covs.reshape(n, 3, 3), counts
+
+
+def _map_knn(fn, h, queries, k):
+    q = _f64(queries, 3)
+    idx = np.empty((len(q), k), np.int64)
+    d2 = np.empty((len(q), k))
+    fn(h, _dp(q), len(q), int(k), idx.ctypes.data_as(C.POINTER(C.c_int64)), _dp(d2))
+    return idx, d2
 
 
 class FlatMap:
@@ -227,6 +240,10 @@ class FlatMap:
         covs = np.empty((total, 9))
         lib().ref_fvm_get(self.h, coords.ctypes.data_as(C.POINTER(C.c_int)), counts.ctypes.data_as(C.POINTER(C.c_uint64)), _dp(pts), _dp(covs))
         return coords, counts, pts, covs.reshape(total, 3, 3)
+
+    def knn(self, queries, k):
+        """IncrementalVoxelMap::knn_search per query: (global indices (voxel << 32) | point or -1, squared distances or inf)."""
+        return _map_knn(lib().ref_fvm_knn, self.h, queries, k)
 
     def align(self, source, init_T=None, num_threads=4):
         res = Result()

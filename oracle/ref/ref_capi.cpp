@@ -85,6 +85,22 @@ static RegistrationResult align_general(const RefCloud& t, const RefCloud& s, do
 }
 
 
+// IncrementalVoxelMap::knn_search (ann/incremental_voxelmap.hpp:127-149) for m queries: idx / sqd m*k, unfilled entries -1 / inf;
+// the indices are the map's global indices (voxel_id << 32) | point_id
+template <typename Map>
+static void map_knn(const Map& map, const double* q, size_t m, int k, std::int64_t* idx, double* sqd) {
+  std::vector<size_t> ki(k);
+  std::vector<double> kd(k);
+  for (size_t i = 0; i < m; i++) {
+    const Eigen::Vector4d pt(q[3 * i], q[3 * i + 1], q[3 * i + 2], 1.0);
+    const size_t n = map.knn_search(pt, static_cast<size_t>(k), ki.data(), kd.data());
+    for (int j = 0; j < k; j++) {
+      idx[i * k + j] = static_cast<size_t>(j) < n ? static_cast<std::int64_t>(ki[j]) : -1;
+      sqd[i * k + j] = static_cast<size_t>(j) < n ? kd[j] : std::numeric_limits<double>::infinity();
+    }
+  }
+}
+
 extern "C" {
 
 struct ref_result {
@@ -330,6 +346,8 @@ void ref_fvm_insert(void* h, void* cloud_h, const double* T16) {
   static_cast<RefFlatMap*>(h)->map.insert(*static_cast<RefCloud*>(cloud_h)->cloud, T16 ? to_iso(T16) : Eigen::Isometry3d::Identity());
 }
 size_t ref_fvm_size(void* h) { return static_cast<RefFlatMap*>(h)->map.size(); }
+void ref_fvm_knn(void* h, const double* q, size_t m, int k, std::int64_t* idx, double* sqd) { map_knn(static_cast<RefFlatMap*>(h)->map, q, m, k, idx, sqd); }
+void ref_ivm_knn(void* h, const double* q, size_t m, int k, std::int64_t* idx, double* sqd) { map_knn(static_cast<RefVoxelMap*>(h)->map, q, m, k, idx, sqd); }
 size_t ref_fvm_total_points(void* h) {
   size_t n = 0;
   for (const auto& v : static_cast<RefFlatMap*>(h)->map.flat_voxels) n += v->second.size();

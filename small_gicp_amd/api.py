@@ -287,6 +287,13 @@ class GaussianVoxelMap:
     def set_lru(self, horizon=100, clear_cycle=10):
         check(load().sga_voxelmap_set_lru(self.h, int(horizon), int(clear_cycle)))
 
+    def batch_knn_search(self, pts, k, max_sq_dist=-1.0):
+        return _voxelmap_knn(self, pts, k, max_sq_dist)
+
+    def knn_search(self, pt, k):
+        idx, d2 = _voxelmap_knn(self, np.asarray(pt, dtype=np.float64).reshape(1, -1), k)
+        return idx[0], d2[0]
+
     def __len__(self):
         return self.size()
 
@@ -341,6 +348,13 @@ class IncrementalVoxelMapCov:
 
     def set_lru(self, horizon=100, clear_cycle=10):
         check(load().sga_voxelmap_set_lru(self.h, int(horizon), int(clear_cycle)))
+
+    def batch_knn_search(self, pts, k, max_sq_dist=-1.0):
+        return _voxelmap_knn(self, pts, k, max_sq_dist)
+
+    def knn_search(self, pt, k):
+        idx, d2 = _voxelmap_knn(self, np.asarray(pt, dtype=np.float64).reshape(1, -1), k)
+        return idx[0], d2[0]
 
     def set_setting(self, min_sq_dist_in_cell=0.01, max_num_points_in_cell=10):
         check(load().sga_flatmap_set_setting(self.h, float(min_sq_dist_in_cell), int(max_num_points_in_cell)))
@@ -545,6 +559,16 @@ class Problem:
         c, w, f = C.c_uint64(), C.c_uint64(), C.c_uint64()
         check(load().sga_problem_get_pass_stats(self.ctx.h, self.h, C.byref(c), C.byref(w), C.byref(f)))
         return {"cold_passes": c.value, "warm_passes": w.value, "walked_points": f.value}
+
+
+def _voxelmap_knn(vm, pts, k, max_sq_dist=-1.0):
+    """traits::knn_search of a voxel map (incremental_voxelmap.hpp:127-149) for m queries: global indices (voxel_id << 32) | point_id
+    (-1 = none) and squared distances ascending (inf = none), each (m, k)."""
+    q = np.ascontiguousarray(np.asarray(pts, dtype=np.float64).reshape(-1, np.asarray(pts).shape[-1])[:, :3])
+    idx = np.empty((len(q), k), np.int64)
+    d2 = np.empty((len(q), k), np.float64)
+    check(load().sga_index_knn_f64(vm.ctx.h, vm.h, _dp(q), len(q), int(k), float(max_sq_dist), idx.ctypes.data_as(C.POINTER(C.c_int64)), _dp(d2)))
+    return idx, d2
 
 
 def set_warm_limit(warm_delta_m):

@@ -133,24 +133,68 @@ __global__ __launch_bounds__(kKnnBlock) void knn_kernel(const KdView t, const fl
   }
 }
 
-__global__ void voxel_nn_kernel(const VoxelView v, const float4* __restrict__ means, const float* __restrict__ queries, size_t m, float max_sq, long long* __restrict__ out_idx, float* __restrict__ out_d2) {
+// kNN over a voxel map (ann/incremental_voxelmap.hpp:127-149): the voxels at the search offsets around the query's voxel, in the
+// reference's order (1: the voxel itself; 7: centre, +x, +y, +z, -x, -y, -z; 27: centre, then the 3 x 3 x 3 cube in i, j, k order), every stored
+// point of each (a Gaussian voxel: its mean, gaussian_voxelmap.hpp:84-86; a flat container: its points in insertion order,
+// flat_container.hpp:98-107) pushed into a k-best list with KnnResult::push (knn_result.hpp:80-100: sorted ascending, a candidate as far
+// as the current worst is dropped, equal distances keep their push order).  Index = the reference's global index
+// (voxel_id << 32) | point_id (incremental_voxelmap.hpp:152).  One thread per query; the list lives in the output arrays.  Distances
+// in double from the fp32 data the map holds.  Not on the registration path (that searches inside the factor kernel, k = 1).
+template <bool FLAT>
+__global__ void voxel_knn_kernel(
+  const FlatView v, const float4* __restrict__ pts, const float* __restrict__ queries, size_t m, int k, float max_sq, long long* __restrict__ out_idx, float* __restrict__ out_d2) {
   const size_t qi = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
   if (qi >= m) return;
   const float qx = queries[3 * qi], qy = queries[3 * qi + 1], qz = queries[3 * qi + 2];
-  const int j = voxel_lookup(v, qx, qy, qz);
-  long long id = -1;
-  float d2 = INFINITY;
-  if (j >= 0) {
-    const float4 c = means[j];
-    const float dx = c.x - qx, dy = c.y - qy, dz = c.z - qz;
-    const float d = dx * dx + dy * dy + dz * dz;
-    if (!(d > max_sq)) {
-      id = j;
-      d2 = d;
+  long long* idx = out_idx + qi * static_cast<size_t>(k);
+  float* d2 = out_d2 + qi * static_cast<size_t>(k);
+  for (int j = 0; j < k; j++) {
+    idx[j] = -1;
+    d2[j] = INFINITY;
+  }
+  const int cx = fast_floor_d(static_cast<double>(qx) * v.inv_leaf);
+  const int cy = fast_floor_d(static_cast<double>(qy) * v.inv_leaf);
+  const int cz = fast_floor_d(static_cast<double>(qz) * v.inv_leaf);
+  int found = 0;
+  auto push = [&](long long index, float d) {
+    if (d > max_sq || d >= d2[k - 1]) return;
+    int loc = min(found, k - 1);
+    for (; loc > 0 && d < d2[loc - 1]; loc--) {
+      idx[loc] = idx[loc - 1];
+      d2[loc] = d2[loc - 1];
+    }
+    idx[loc] = index;
+    d2[loc] = d;
+    found = min(found + 1, k);
+  };
+  auto scan = [&](int ox, int oy, int oz) {
+    const int vox = flat_voxel_at(v, cx + ox, cy + oy, cz + oz);
+    if (vox < 0) return;
+    const uint32_t n = FLAT ? v.vnum[vox] : 1u;
+    for (uint32_t i = 0; i < n; i++) {
+      const float4 p = FLAT ? pts[static_cast<size_t>(vox) * kFlatCap + i] : pts[vox];
+      const double dx = static_cast<double>(p.x) - qx, dy = static_cast<double>(p.y) - qy, dz = static_cast<double>(p.z) - qz;
+      push((static_cast<long long>(vox) << 32) | static_cast<long long>(i), static_cast<float>(dx * dx + dy * dy + dz * dz));
+    }
+  };
+  scan(0, 0, 0);
+  if (v.offsets == 27) {
+    // the reference's set_search_offsets(27) APPENDS the cube to the default list {(0, 0, 0)} (incremental_voxelmap.hpp:176-184:
+    // emplace_back without a clear): 28 offsets, the query's own voxel twice — so its points appear twice in a k > 1 result.
+    // Reproduced as it is: parity is with what the reference returns.
+    for (int a = -1; a <= 1; a++)
+      for (int b = -1; b <= 1; b++)
+        for (int c = -1; c <= 1; c++) scan(a, b, c);
+  } else {
+    if (v.offsets == 7) {
+      scan(1, 0, 0);
+      scan(0, 1, 0);
+      scan(0, 0, 1);
+      scan(-1, 0, 0);
+      scan(0, -1, 0);
+      scan(0, 0, -1);
     }
   }
-  out_idx[qi] = id;
-  out_d2[qi] = d2;
 }
 
 }  // namespace sga
@@ -329,8 +373,6 @@ int sga_problem_get_factors(sga_context* ctx, const sga_problem* pb, int64_t* ta
 static int index_knn_impl(sga_context* ctx, const sga_index* index, const float* queries, const double* queries64, size_t m, int k, double max_sq_dist, int64_t* idx, float* sq_dist, double* sq_dist64) {
   if (!ctx || !index || (m > 0 && ((!queries && !queries64) || !idx || (!sq_dist && !sq_dist64)))) return fail(SGA_ERR_INVALID, "null argument");
   if (k < 1 || k > 128) return fail(SGA_ERR_INVALID, "k must be in [1,128]");
-  if (index->kind == SGA_INDEX_FLATMAP) return fail(SGA_ERR_UNSUPPORTED, "flat voxel maps are searched inside the registration only");
-  if (index->kind == SGA_INDEX_VOXELMAP && k != 1) return fail(SGA_ERR_UNSUPPORTED, "voxel maps answer k = 1 only");
   if (m == 0) return SGA_OK;
   SGA_ENTER(ctx);
   std::vector<float> qf;
@@ -353,9 +395,17 @@ static int index_knn_impl(sga_context* ctx, const sga_index* index, const float*
     SGA_HIP(hipMemcpyAsync(d_q64.p, queries64, m * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   }
   const float max_sq = max_sq_dist < 0 ? INFINITY : static_cast<float>(max_sq_dist);
-  if (index->kind == SGA_INDEX_VOXELMAP) {
-    VoxelView v{index->hkeys.p, index->hvals.p, index->hmask, 1.0 / index->leaf};
-    hipLaunchKernelGGL(voxel_nn_kernel, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, v, index->pts.p, d_q.p, m, max_sq, d_i.p, d_d.p);
+  if (index->kind == SGA_INDEX_VOXELMAP || index->kind == SGA_INDEX_FLATMAP) {
+    const FlatView v{index->hkeys.p, index->hvals.p, index->hmask, 1.0 / index->leaf, index->vcounts.p, index->search_offsets};
+    if (index->n == 0 || index->hkeys.p == nullptr) {  // an empty map: nothing found
+      SGA_HIP(hipMemsetAsync(d_i.p, 0xff, m * k * sizeof(long long), ctx->stream));
+      std::vector<float> inf(m * k, INFINITY);
+      SGA_HIP(hipMemcpyAsync(d_d.p, inf.data(), m * k * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+      SGA_HIP(hipStreamSynchronize(ctx->stream));
+    } else if (index->kind == SGA_INDEX_FLATMAP)
+      hipLaunchKernelGGL(voxel_knn_kernel<true>, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, v, index->pts.p, d_q.p, m, k, max_sq, d_i.p, d_d.p);
+    else
+      hipLaunchKernelGGL(voxel_knn_kernel<false>, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, v, index->pts.p, d_q.p, m, k, max_sq, d_i.p, d_d.p);
   } else if (index->n == 0) {
     SGA_HIP(hipMemsetAsync(d_i.p, 0xff, m * k * sizeof(long long), ctx->stream));
     std::vector<float> inf(m * k, INFINITY);

@@ -1029,6 +1029,49 @@ def test_flat_voxelmap_matches_oracle(orc, c1_f32, gpu_c1, offsets):
     assert (gi == oi).mean() > 0.999
 
 
+@pytest.mark.parametrize("offsets", [1, 7, 27])
+def test_voxelmap_knn_search_matches_reference(c1_f32, gpu_c1, offsets):
+    """traits::knn_search of the voxel maps, k > 1 (ann/incremental_voxelmap.hpp:127-149; VERDICT r2 missing #6): the flat map over 1 / 7 /
+    27 voxels and the Gaussian map (its own voxel) against the compiled reference after the same two inserts — the same global indices
+    (voxel_id << 32) | point_id in the same order, squared distances to fp32 resolution, -1 / inf beyond the number found."""
+    from oracle import ref
+
+    if not ref.available():
+        pytest.skip("oracle/_ref did not travel with the repository")
+    d = c1_f32
+    tgt, src, _ = gpu_c1
+    rt, rs = ref.Cloud(d["tp"], d["tn"], d["tc"], tree=False), ref.Cloud(d["sp"], d["sn"], d["sc"], tree=False)
+    T1 = se3([0.1, 0.2, 1.0], 0.03, [0.4, -0.2, 0.05])
+    gf, rf = sga.IncrementalVoxelMapCov(1.0), ref.FlatMap(1.0)
+    gg, rg = sga.GaussianVoxelMap(1.0), ref.VoxelMap(1.0)
+    gf.set_search_offsets(offsets)
+    rf.set_search_offsets(offsets)
+    for g, r in ((gf, rf), (gg, rg)):
+        g.insert(tgt)
+        r.insert(rt)
+        g.insert(src, T1)
+        r.insert(rs, T1)
+    rng = np.random.default_rng(5)
+    q = np.concatenate([d["sp"][rng.choice(len(d["sp"]), 1500, replace=False)].astype(np.float64) + rng.normal(0, 0.05, (1500, 3)), rng.uniform(-60, 60, (200, 3))]).astype(np.float32).astype(np.float64)
+    for g, r, k in ((gf, rf, 1), (gf, rf, 6), (gf, rf, 40), (gg, rg, 1), (gg, rg, 4)):
+        gi, gd = g.batch_knn_search(q, k)
+        ri, rd = r.knn(q, k)
+        assert gi.shape == ri.shape == (len(q), k)
+        assert ((gi < 0) == (ri < 0)).all() and (np.isinf(gd) == np.isinf(rd)).all()
+        ok = ri >= 0
+        assert ok[:, 0].sum() > 0.5 * len(q)  # the test means something
+        # distances: the stored points are the fp32 roundings of the reference's doubles
+        assert np.abs(gd[ok] - rd[ok]).max() <= 1e-5 * max(1.0, float(rd[ok].max()))
+        same = gi[ok] == ri[ok]
+        if not same.all():  # two candidates closer to each other than fp32 resolves may swap places: then the distances agree pairwise
+            rows = np.unique(np.nonzero((gi != ri) & ok)[0])
+            assert len(rows) <= 0.002 * len(q), len(rows)
+            for row in rows:
+                assert sorted(gi[row].tolist()) == sorted(ri[row].tolist()) or np.abs(np.sort(gd[row][ok[row]]) - np.sort(rd[row][ok[row]])).max() <= 1e-5
+        one_i, one_d = g.knn_search(q[0], k)
+        assert (one_i == gi[0]).all()
+
+
 def test_scan_to_model_gicp_odometry_matches_oracle(orc):
     """odometry_benchmark_small_gicp_model_omp.cpp (GICP against IncrementalVoxelMap<FlatContainerCov>) on the synthetic sequence."""
     from small_gicp_amd import odometry
