@@ -510,25 +510,15 @@ __device__ __forceinline__ bool kd_pop(const KdView& t, float qx, float qy, floa
   const int D = t.gdepth;
   uint32_t e = 0;
   bool found = false;
-  // Two loops instead of one: (a) discard entries whose plane distance is out of reach by now — LDS reads and compares only, no
-  // wait — until every lane of the wave holds one that is not (or an empty stack); (b) ONE box fetch for all of them together.  (One
-  // loop that does both makes the whole wave wait for a box in nearly every trip: some lane always passes the plane test.  Measured:
-  // cold passes -1 ... -3 %.)
-  for (;;) {
-    bool cand = false;
-    float lb = 0.f;
-    while (sp > 0 && !cand) {
-      sp--;
-      e = stack[sp * STRIDE + tid];
-      lb = kd_cut(e);
-      cand = lb <= s.open;
-      s.dropped = kd_min(s.dropped, cand ? INFINITY : lb);
+  while (sp > 0 && !found) {
+    sp--;
+    e = stack[sp * STRIDE + tid];
+    float lb = kd_cut(e);
+    if (lb <= s.open) {
+      lb = fmaxf(lb, kd_box_dist2(t, (node >> (D - static_cast<int>(e & 31u))) ^ 1u, qx, qy, qz));
+      found = lb <= s.open;
     }
-    if (!cand) break;
-    lb = fmaxf(lb, kd_box_dist2(t, (node >> (D - static_cast<int>(e & 31u))) ^ 1u, qx, qy, qz));
-    found = lb <= s.open;
-    if (found) break;
-    s.dropped = kd_min(s.dropped, lb);
+    s.dropped = kd_min(s.dropped, found ? INFINITY : lb);
   }
   if (found) {
     depth = static_cast<int>(e & 31u);
