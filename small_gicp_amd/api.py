@@ -433,7 +433,8 @@ def make_setting(
     s = RegistrationSettingC()
     load().sga_registration_setting_default(C.byref(s))
     s.factor.factor_kind = _FACTOR_BY_NAME[registration_type] if isinstance(registration_type, str) else int(registration_type)
-    s.factor.max_dist_sq = -1.0 if max_correspondence_distance is None else float(max_correspondence_distance) ** 2
+    # None or a negative distance: no rejector (NullRejector, rejector.hpp:11-16); else DistanceRejector with the squared distance
+    s.factor.max_dist_sq = -1.0 if (max_correspondence_distance is None or float(max_correspondence_distance) < 0) else float(max_correspondence_distance) ** 2
     s.factor.robust_kind = {None: 0, "NONE": 0, "HUBER": 1, "CAUCHY": 2}[robust_kernel if robust_kernel is None else robust_kernel.upper()]
     s.factor.robust_c = float(robust_c)
     s.factor.math_mode = {"fp32": 0, "fp64": 1}[math_mode]

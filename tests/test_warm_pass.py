@@ -214,3 +214,19 @@ def test_exactness_soak_on_random_pose_chains():
     p = subprocess.run([sys.executable, os.path.join(root, "scripts", "soak_exactness.py"), "2", "7"], capture_output=True, text=True, timeout=900)
     assert p.returncode == 0 and "SOAK OK" in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]
     print(p.stdout.splitlines()[-1])
+
+
+def test_fast_leaf_scan_equals_exact_scan_on_adversarial_inputs(tmp_path):
+    """scripts/stress_fast_scan.py: uniform volume, two planes 0.1 mm apart, an integer lattice with duplicates, a cloud 12 km from the
+    origin, millimetre scale, dense blobs with far outliers and no rejector, 63 points, one point — the correspondences with the fast leaf
+    scan (32-bit truncated keys + exact repeat of undecided queries, the default) equal those with 64-bit keys throughout (SGA_FAST_SCAN=0)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "scripts", "stress_fast_scan.py")
+    for mode in ("1", "0"):
+        p = subprocess.run([sys.executable, script, str(tmp_path / ("f%s.npz" % mode))], capture_output=True, text=True, timeout=600, env=dict(os.environ, SGA_FAST_SCAN=mode))
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    p = subprocess.run([sys.executable, script, "--compare", str(tmp_path / "f1.npz"), str(tmp_path / "f0.npz")], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout[-3000:]
