@@ -771,6 +771,38 @@ def test_kd_build_paths_give_the_same_tree(monkeypatch):
         assert np.abs(s[0] - a[0]).max() <= 1e-5 * np.abs(a[0]).max() and abs(s[2] - a[2]) <= 1e-5 * abs(a[2]), n
 
 
+def test_kd_split_path_on_degenerate_clouds(monkeypatch):
+    """kd_split_level_kernel (radix select + partition, clouds <= 32768 points) on inputs that stress the select: all points identical, a
+    line, two distinct points, a lattice with triplicates, coordinates up to 1e6 with ties, and sizes around the kernel's segment classes
+    (256 / 1024 threads x 2 ... 32 keys).  The kNN DISTANCES must equal those of the sort-based build (another valid tree over the same
+    points) and brute force."""
+    rng = np.random.default_rng(21)
+    g = np.arange(16, dtype=np.float32)
+    lattice = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    clouds = {
+        "identical": np.tile(np.array([[1.5, -2.0, 0.25]], np.float32), (5000, 1)),
+        "line": np.c_[rng.uniform(-100, 100, 9000), np.zeros(9000), np.zeros(9000)].astype(np.float32),
+        "two points": np.array([[0, 0, 0], [1, 1, 1]], np.float32)[rng.integers(0, 2, 3000)],
+        "lattice x3": np.concatenate([lattice, lattice, lattice]),
+        "large range with ties": (rng.integers(-1000, 1000, (20000, 3)) * 1000.0).astype(np.float32),
+    }
+    for n in (255, 257, 1023, 1025, 4097, 8193, 16385, 32767, 32768):
+        clouds["uniform %d" % n] = rng.uniform(-10, 10, (n, 3)).astype(np.float32)
+    for name, pts in clouds.items():
+        q = np.concatenate([pts[rng.choice(len(pts), min(200, len(pts)), replace=False)] + rng.normal(0, 0.3, (min(200, len(pts)), 3)).astype(np.float32), rng.uniform(-20, 20, (50, 3)).astype(np.float32)])
+        k = min(5, len(pts))
+        res = []
+        for split in ("1", "0"):
+            monkeypatch.setenv("SGA_KD_SPLIT", split)
+            tree = sga.KdTree(sga.PointCloud(pts))
+            res.append(tree.batch_knn_search(q, k)[1])
+        monkeypatch.delenv("SGA_KD_SPLIT")
+        assert np.array_equal(res[0], res[1]), name
+        d = ((q[:, None, :].astype(np.float64) - pts[None, : min(len(pts), 40000), :].astype(np.float64)) ** 2).sum(-1)
+        brute = np.sort(d, axis=1)[:, :k]
+        assert np.abs(res[0] - brute).max() <= 1e-5 * max(1.0, float(brute.max())), name
+
+
 def test_nearest_neighbour_exact_at_scale_and_seed_independent(c3):
     """The registration search (pair records + plane and box pruning + seeds from the previous pose) returns the exact nearest
     neighbour at the C3 size: checked against brute force on a sample, and seeded == unseeded on all 1M correspondences."""
