@@ -626,7 +626,7 @@ def odometry_leg(sga, args, shard):
             r = odometry.run_synthetic(args.odom_frames, ctx=ctx, shard=(rank, world))
             out = {k: v for k, v in r.items() if k not in ("estimated", "ground_truth")}
             out["unit"] = "ms/scan"
-            out["sharding"] = "source points of every scan split into %d contiguous shards, target index and preprocessing replicated, 30-double all-reduce per linearization" % world
+            out["sharding"] = "source points of every scan split into %d contiguous shards, target index and preprocessing replicated, one all-reduce of 96 doubles per linearization (the system + the error-model moments)" % world
             return out
         r = odometry.run_synthetic(args.odom_frames)
         out = {k: v for k, v in r.items() if k not in ("estimated", "ground_truth")}
