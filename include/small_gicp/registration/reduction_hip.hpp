@@ -1,37 +1,70 @@
-// ParallelReductionHIP — the Reduction policy that runs Registration<>::align's data-parallel loop on an MI355X.
+// ParallelReductionHIP — the Reduction policy that runs Registration<>::align's data-parallel loop on an MI355X, and
+// HipAligned<Optimizer> — the Optimizer-slot adaptor that makes one align() pay the host-side bookkeeping ONCE.
 //
 // This header belongs on the REFERENCE's side of the boundary: it is written against koide3/small_gicp's own headers (Eigen types,
-// points/traits.hpp accessors, its factor structs) and against the plain C ABI of small_gicp_amd.h, and it fills the `Reduction`
-// slot of Registration<PointFactor, Reduction, ...> (registration/registration.hpp:17-54) exactly like ParallelReductionOMP
-// (registration/reduction_omp.hpp:21-73) does:
+// points/traits.hpp accessors, its factor structs, its optimizers) and against the plain C ABI of small_gicp_amd.h, and it fills the
+// `Reduction` (and optionally the `Optimizer`) slot of Registration<PointFactor, Reduction, GeneralFactor, Rejector, Optimizer>
+// (registration/registration.hpp:17-54) exactly like ParallelReductionOMP (registration/reduction_omp.hpp:21-73) does:
 //
 //   #include <small_gicp/registration/reduction_hip.hpp>        // -I<small_gicp>/include -I<small_gicp_amd>/include -lsmall_gicp_amd
-//   Registration<GICPFactor, ParallelReductionHIP> registration;
+//   Registration<GICPFactor, ParallelReductionHIP, NullFactor, DistanceRejector, HipAligned<LevenbergMarquardtOptimizer>> registration;
 //   auto result = registration.align(target, source, target_tree, init_T);   // same call, same RegistrationResult
 //
 // linearize() / error() have the reference's signatures (reduction.hpp:20-62).  The clouds are uploaded once and stay on the
 // device together with the search index and the per-point factor state (registration.hpp:41); every call costs a few kernel
-// launches and one 240-byte result.  After each linearize the host `factors` are filled from the device (target_index,
-// source_index, GICP mahalanobis), so everything the reference reads from them afterwards — `result.num_inliers`
-// (optimizer.hpp:146), user code inspecting correspondences — sees what a CPU reduction would have left there.  Set
-// `sync_factors = false` to skip that download (8-32 bytes per point per iteration) and read `reduction.num_inliers` instead.
+// launches and one 768-byte result.
 //
-// Caching.  The policy recognises the clouds it has already uploaded by (address, size, fingerprint of 64 sampled points); a caller
-// that refills a cloud object in place (every odometry loop does) is therefore noticed and the cloud uploaded again.  rebind()
+// Two ways to use it.
+//  * Reduction slot only (`Registration<GICPFactor, ParallelReductionHIP>`): nothing else of the reference changes.  The policy cannot
+//    see where an align() begins or ends, so EVERY linearize checks that the clouds it uploaded are still the caller's (a hash over
+//    both clouds, `verify_content`) and fills target_index / source_index of the host `factors` (`sync_inliers`), because the
+//    reference counts them after its loop (optimizer.hpp:146).  Correct and convenient; at 1M points those two per-call passes over
+//    host memory cost several times what the device pass costs.
+//  * Reduction + Optimizer slot (`HipAligned<LevenbergMarquardtOptimizer>` or `HipAligned<GaussNewtonOptimizer>`): the adaptor IS the
+//    reference's optimizer (it derives from it and calls its optimize() unchanged, optimizer.hpp:24-149) bracketed by
+//    reduction.begin_align() — hash / upload / index build once — and reduction.end_align() — the host `factors` filled once, after the
+//    loop, which is when the reference reads them; RegistrationResult::num_inliers is then counted exactly as optimizer.hpp:146 does.
+//    Inside the bracket a linearize is the device pass and nothing else: the rate of the C ABI (bench.py `policy_c3`).
+//
+// Host factors.  `sync_inliers` (default on) fills target_index / source_index; `sync_factors` (default off) additionally fills
+// GICPFactor::mahalanobis (24 more bytes per point and a recompute kernel).  NOTE for code that inspects the factors itself: with
+// sync_factors off the 3x3 block of GICPFactor::mahalanobis is set to NaN whenever the indices are filled — GICPFactor::error() on
+// the host would otherwise silently use matrices that no longer belong to the correspondences (ParallelReductionOMP leaves them
+// filled, gicp_factor.hpp:60,94).
+//
+// Threads.  Registration<>::align is const and the reference runs it from many threads at once
+// (src/benchmark/odometry_benchmark_small_gicp_tbb_flow.cpp:81-96).  Every calling thread gets its own device context, stream and
+// uploaded clouds (looked up by thread id in a pool shared by the copies of one policy object), so concurrent align() calls on one
+// Registration — or on copies of it — are independent, on the host and on the GPU.
+//
+// Several GPUs in one process: `num_gpus` > 1 (the analogue of ParallelReductionOMP::num_threads, reduction_omp.hpp:22,72) shards the
+// source over devices `device` .. `device + num_gpus - 1` with the target replicated (sga_multi_*, small_gicp_amd.h); the sums of the
+// shards are added on the host in a fixed order.
+//
+// Caching.  The policy recognises the clouds it has already uploaded by (address, size, hash of every point / normal / covariance); a
+// caller that refills a cloud object in place (every odometry loop does) is therefore noticed and the cloud uploaded again.  rebind()
 // forces it.  The target_tree argument is not used: the device builds its own exact nearest-neighbour index over `target`.
 // Supported factors: ICPFactor, PointToPlaneICPFactor, GICPFactor and RobustFactor<Huber|Cauchy, F> over them; rejectors:
-// DistanceRejector, NullRejector.  (A GaussianVoxelMap target — VGICP — goes through the helper-level entry points of
-// small_gicp_amd.h; custom rejectors / factors with host callbacks stay on the CPU reductions.)
+// DistanceRejector, NullRejector; targets: point clouds (traits::point / normal / cov).  A voxel-map target — VGICP,
+// registration_helper.cpp:125-137 — is REJECTED AT COMPILE TIME here (its traits::point(i) takes packed voxel indices, not 0..size-1):
+// it goes through sga_index_build_gaussian_voxelmap / sga_align of small_gicp_amd.h, see INTEGRATION.md section 2.  Custom rejectors /
+// factors with host callbacks stay on the CPU reductions (or use sga_problem_set_rejector).
 #pragma once
 
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <algorithm>
+#include <chrono>
 #include <limits>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <tuple>
+#include <type_traits>
 #include <vector>
 
 #include <Eigen/Core>
@@ -43,6 +76,8 @@
 #include <small_gicp/factors/plane_icp_factor.hpp>
 #include <small_gicp/factors/robust_kernel.hpp>
 #include <small_gicp/points/traits.hpp>
+#include <small_gicp/registration/optimizer.hpp>
+#include <small_gicp/registration/registration_result.hpp>
 #include <small_gicp/registration/rejector.hpp>
 
 namespace small_gicp {

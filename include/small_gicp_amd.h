@@ -10,8 +10,11 @@
  *   - 6x6 H is row-major double[36] (symmetric), b is double[6]; twist order is [rx ry rz tx ty tz] (util/lie.hpp:73-77).
  *   - Symmetric 3x3 matrices ("cov6", "mahalanobis6") are packed xx,xy,xz,yy,yz,zz.
  *   - All device work of a context is serialised on ONE HIP stream; blocking calls synchronise that stream only.
- *   - A context is bound to one GPU; multi-GPU = one process (or context) per GPU with the source cloud sharded and
- *     the 30-double accumulator all-reduced between sga_linearize_async() and the host read-back.
+ *   - A context is bound to one GPU; multi-GPU = one process (or context) per GPU with the source cloud sharded: after
+ *     sga_comm_init() every sga_linearize all-reduces its 96-double accumulator (system + error-model moments) over the ranks on the
+ *     context's stream before the host reads it (the 30-double sga_linearize_async() form is the building block for other transports).
+ *   - Diagnostics (search statistics, debug counters) are declared in small_gicp_amd_debug.h; environment switches (SGA_*) read when the
+ *     library loads select between equivalent kernels for experiments and are NOT part of this ABI.
  */
 #ifndef SMALL_GICP_AMD_H
 #define SMALL_GICP_AMD_H
@@ -197,13 +200,13 @@ int sga_problem_set_rejector(sga_problem* problem, sga_rejector_fn fn, void* use
 int sga_linearize_per_point(sga_context* ctx, sga_problem* problem, const sga_factor_params* params, const double T[16], double* values28, unsigned char* inlier);
 /* Factor state in the caller's source order: target_index n int64 (-1 = outlier; voxel id for voxel maps), mahalanobis6 n*6 floats (GICP only). */
 int sga_problem_get_factors(sga_context* ctx, const sga_problem* problem, int64_t* target_index, float* mahalanobis6);
-/* Average device time (ms) of the linearize / error kernel chains measured with HIP events on the context's stream (0 if profiling
- * off).  enabled = 0: off; 1: every pass is bracketed with events; N > 1: every N-th pass (an event record costs microseconds). */
 /* Stream-ordered mode (default off): sga_index_build_kdtree and sga_estimate_normals_covariances return as soon as their kernels are
  * enqueued on the context's stream instead of waiting for them (a 15k-point odometry scan spends a fifth of its time in such waits).
  * Later calls on the SAME context see their results in stream order; before their outputs are used from another context / stream,
  * call sga_context_synchronize.  Errors of the enqueued kernels are reported by the next synchronising call. */
 int sga_context_set_stream_ordered(sga_context* ctx, int enabled);
+/* Average device time (ms) of the linearize / error kernel chains measured with HIP events on the context's stream (0 if profiling
+ * off).  enabled = 0: off; 1: every pass is bracketed with events; N > 1: every N-th pass (an event record costs microseconds). */
 int sga_context_set_profiling(sga_context* ctx, int enabled);
 int sga_context_get_kernel_ms(sga_context* ctx, double* linearize_ms, uint64_t* linearize_calls, double* error_ms, uint64_t* error_calls);
 /* The part of a COLD pass's time spent in the nearest-neighbour search kernel (the rest: factor evaluation + block reduction). */
@@ -218,12 +221,6 @@ int sga_context_get_pass_ms(sga_context* ctx, double* cold_ms, uint64_t* cold_ca
 void sga_set_warm_limit(double warm_delta_m);
 /* 0: sga_error always runs the error kernel (the reference's literal procedure; tests compare the two). Default 1. */
 void sga_set_error_model(int enabled);
-/* Diagnostics: record, for the following linearization passes of this problem, the number of kd-tree leaves each source point's
- * search scanned (source order of the engine, i.e. sorted); get returns the last pass's counts (n ints). */
-int sga_problem_set_search_stats(sga_context* ctx, sga_problem* pb, int enabled);
-int sga_problem_get_search_stats(sga_context* ctx, const sga_problem* pb, int* leaves_per_point);
-/* Diagnostics: the source points in the engine's order (n x 4 floats: x, y, z, original index as bits). */
-int sga_problem_get_sorted_points(sga_context* ctx, const sga_problem* pb, float* xyzw);
 /* Which nearest-neighbour kernel the linearization runs (results do not depend on it; tests compare the two): 1 = the queue-fed
  * kernel (a wave owns chunk_tiles x 64 source points and refills its lanes from a queue), 0 = one query per lane, 2 (default) =
  * queue-fed for warm passes after a small motion, one query per lane otherwise.  chunk_tiles_* <= 0 keep the current value (4 / 4). */
@@ -265,6 +262,29 @@ typedef struct sga_result {
 int sga_align(sga_context* ctx, const sga_index* target, const sga_cloud* source, const double init_T[16], const sga_registration_setting* setting, sga_result* out);
 /* Same, on an existing problem (re-uses the sorted source and the factor buffers). */
 int sga_align_problem(sga_context* ctx, sga_problem* problem, const double init_T[16], const sga_registration_setting* setting, sga_result* out);
+
+/* ---- one registration over several GPUs of THIS process ------------------------------------------------------------------------
+ * The single-process form of the sharded path and the analogue of ParallelReductionOMP::num_threads (registration/reduction_omp.hpp:22,72:
+ * the loop over the source points, :32-58, is what gets partitioned).  Shard g owns the source points [g n / G, (g + 1) n / G) of the
+ * caller's order and their factor state on device devices[g]; the target and its search index are replicated on every device.  A
+ * linearization enqueues the pass on every device from the calling thread, collects the G accumulators and adds them in shard order on
+ * the host (bit-reproducible; no collective, no communicator, no launcher).  The same device may be listed more than once (logical
+ * shards on one GPU: how the path is tested on single-GPU machines).  Inputs use the reference's PointCloud layout like
+ * sga_cloud_create_f64.  The process-per-GPU form with an RCCL all-reduce on the stream is sga_comm_init. */
+typedef struct sga_multi sga_multi;
+int sga_multi_create(const int* devices, int num_devices, sga_multi** out);
+int sga_multi_destroy(sga_multi* m);
+int sga_multi_num_devices(const sga_multi* m);
+int sga_multi_set_target_f64(sga_multi* m, const double* xyzw, const double* normals4, const double* cov4x4, size_t n);
+int sga_multi_set_source_f64(sga_multi* m, const double* xyzw, const double* normals4, const double* cov4x4, size_t n, const double init_T[16]);
+/* Reduction::linearize / ::error over all shards (reduction_omp.hpp:24-70), Registration<>::align (registration.hpp:33-43) on the host */
+int sga_multi_linearize(sga_multi* m, const sga_factor_params* params, const double T[16], double H[36], double b[6], double* e, uint64_t* num_inliers);
+int sga_multi_error(sga_multi* m, const sga_factor_params* params, const double T[16], double* e);
+int sga_multi_align(sga_multi* m, const double init_T[16], const sga_registration_setting* setting, sga_result* out);
+/* every registration starts without search hints (sga_multi_align calls it; callers that drive linearize / error themselves call it per align) */
+int sga_multi_reset_search_state(sga_multi* m);
+/* factor state of the whole source in the caller's order (see sga_problem_get_factors) */
+int sga_multi_get_factors(sga_multi* m, int64_t* target_index, float* mahalanobis6);
 
 /* The optimizer alone, over user reductions (the reference's Optimizer::optimize with a pluggable Reduction, optimizer.hpp:27-36):
  * used for sharded multi-GPU runs where linearize = local kernels + all-reduce.  Callbacks return 0 on success. */

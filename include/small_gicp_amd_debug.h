@@ -1,0 +1,35 @@
+/*
+ * small_gicp_amd — diagnostics of the MI355X registration hot path.  NOT part of the drop-in boundary (small_gicp_amd.h): these entry
+ * points expose how the searches went (for the scripts under scripts/ and for DESIGN.md's measurements), never what they returned.
+ */
+#ifndef SMALL_GICP_AMD_DEBUG_H
+#define SMALL_GICP_AMD_DEBUG_H
+
+#include "small_gicp_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Record, for the following linearization passes of this problem, the number of kd-tree leaves each source point's search scanned
+ * (source order of the engine, i.e. sorted); get returns the last pass's counts (n ints).  While enabled every pass walks the kd-tree. */
+int sga_problem_set_search_stats(sga_context* ctx, sga_problem* pb, int enabled);
+int sga_problem_get_search_stats(sga_context* ctx, const sga_problem* pb, int* leaves_per_point);
+/* The source points in the engine's order (n x 4 floats: x, y, z, original index as bits). */
+int sga_problem_get_sorted_points(sga_context* ctx, const sga_problem* pb, float* xyzw);
+/* Cell-grid passes (cell_grid.hip) since the problem was created: out[0] = passes searched through the grid, out[1] = queries their
+ * first ring left open (finished by the second kernel), out[2] = sum of the rings those queries then scanned, out[3] = cell edge in
+ * micrometres (0: the target has no grid). */
+int sga_problem_get_grid_stats(const sga_problem* pb, uint64_t out[4]);
+/* When the cell grid searches (results do not depend on it; tests compare the searches): mode 0 (default) never (and no grid is built), 1
+ * every cold pass of a registration but its first, 2 the first pass too, 3 every pass; min_points: targets with fewer points get no grid
+ * (default 65536; applies to indices built afterwards).  Negative arguments keep the current value.  Environment: SGA_GRID, SGA_GRID_MIN_POINTS. */
+void sga_set_grid_mode(int mode, long long min_points);
+/* Diagnostics build only (make trips): loop-trip counters of the kd walk and the start / end clock of every search wave. */
+int sga_debug_kd_trips(unsigned long long* out16);
+int sga_debug_kd_wave_times(unsigned long long* out, int waves);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMALL_GICP_AMD_DEBUG_H */

@@ -20,6 +20,8 @@ import csv, glob, sys, os
 from collections import defaultdict
 out = sys.argv[1]
 def name_of(kn):
+    if "grid_ring1" in kn: return "G_ring1"      # cell grid: ring 1 of every query
+    if "grid_finish" in kn: return "G_finish"    # cell grid: the queries ring 1 left open
     if "search_linearize" in kn: return "K1_lane_warm" if "true" in kn else "K1_lane_cold"   # search + factors, one query per lane
     if "nn_search_queue" in kn: return "K1_queue_warm"                                        # check + queue-fed walks (+ factors)
     if "nn_search" in kn: return "K1a_warm" if "true" in kn else "K1a_cold"                   # search only (non-fused paths)
@@ -28,14 +30,14 @@ agg = defaultdict(lambda: [0.0, 0])
 for f in glob.glob(os.path.join(out, "p*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         kn = r.get("Kernel_Name", "")
-        if "linearize_kernel" not in kn and "error_kernel" not in kn and "nn_search" not in kn: continue  # (search_linearize_kernel matches too)
+        if "linearize_kernel" not in kn and "error_kernel" not in kn and "nn_search" not in kn and "grid_" not in kn: continue  # (search_linearize_kernel matches too)
         k = (name_of(kn), r.get("Counter_Name"))
         agg[k][0] += float(r.get("Counter_Value", 0)); agg[k][1] += 1
 dur = defaultdict(lambda: [0.0, 0])
 for f in glob.glob(os.path.join(out, "p1", "**", "*kernel_trace.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         kn = r.get("Kernel_Name", "")
-        if "linearize_kernel" in kn or "error_kernel" in kn or "nn_search" in kn:
+        if "linearize_kernel" in kn or "error_kernel" in kn or "nn_search" in kn or "grid_" in kn:
             key = name_of(kn)
             dur[key][0] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3; dur[key][1] += 1
 for k, (v, c) in sorted(dur.items()):

@@ -22,6 +22,7 @@ from .api import (  # noqa: F401
     error_model_eval,
     get_warm_limit,
     set_error_model,
+    set_grid_mode,
     set_search_mode,
     set_warm_limit,
     make_setting,

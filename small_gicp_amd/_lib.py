@@ -59,7 +59,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_size_
 LINEARIZE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64))
 ERROR_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double))
 
-# every symbol include/small_gicp_amd.h declares: (name, restype, argtypes)
+# every symbol include/small_gicp_amd.h and include/small_gicp_amd_debug.h declare: (name, restype, argtypes)
 _vp, _dp, _fp = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_float)
 _pvp = C.POINTER(C.c_void_p)
 SYMBOLS = [
@@ -123,12 +123,26 @@ SYMBOLS = [
     ("sga_problem_set_search_stats", C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     ("sga_problem_get_search_stats", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("sga_problem_get_sorted_points", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("sga_problem_get_grid_stats", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    ("sga_set_grid_mode", None, [C.c_int, C.c_longlong]),
+    ("sga_debug_kd_trips", C.c_int, [C.c_void_p]),
+    ("sga_debug_kd_wave_times", C.c_int, [C.c_void_p, C.c_int]),
     ("sga_set_search_mode", None, [C.c_int, C.c_int, C.c_int]),
     ("sga_get_warm_limit", C.c_double, []),
     ("sga_problem_get_pass_stats", C.c_int, [_vp, _vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("sga_registration_setting_default", None, [C.POINTER(RegistrationSettingC)]),
     ("sga_align", C.c_int, [_vp, _vp, _vp, _dp, C.POINTER(RegistrationSettingC), C.POINTER(ResultC)]),
     ("sga_align_problem", C.c_int, [_vp, _vp, _dp, C.POINTER(RegistrationSettingC), C.POINTER(ResultC)]),
+    ("sga_multi_create", C.c_int, [C.POINTER(C.c_int), C.c_int, _pvp]),
+    ("sga_multi_destroy", C.c_int, [_vp]),
+    ("sga_multi_num_devices", C.c_int, [_vp]),
+    ("sga_multi_set_target_f64", C.c_int, [_vp, _dp, _dp, _dp, C.c_size_t]),
+    ("sga_multi_set_source_f64", C.c_int, [_vp, _dp, _dp, _dp, C.c_size_t, _dp]),
+    ("sga_multi_linearize", C.c_int, [_vp, C.POINTER(FactorParams), _dp, _dp, _dp, _dp, C.POINTER(C.c_uint64)]),
+    ("sga_multi_error", C.c_int, [_vp, C.POINTER(FactorParams), _dp, _dp]),
+    ("sga_multi_align", C.c_int, [_vp, _dp, C.POINTER(RegistrationSettingC), C.POINTER(ResultC)]),
+    ("sga_multi_reset_search_state", C.c_int, [_vp]),
+    ("sga_multi_get_factors", C.c_int, [_vp, C.c_void_p, C.c_void_p]),
     ("sga_optimize", C.c_int, [C.POINTER(RegistrationSettingC), _dp, LINEARIZE_FN, ERROR_FN, _vp, C.POINTER(ResultC)]),
     ("sga_se3_exp", None, [_dp, _dp]),
 ]

@@ -238,6 +238,8 @@ class KdTree:
         check(load().sga_index_size(self.h, C.byref(n)))
         return n.value
 
+    __len__ = size
+
     def refresh_attributes(self):
         """Pull the cloud's current normals / covariances into the index (needed when they were set after the index was built)."""
         check(load().sga_index_refresh_attributes(self.ctx.h, self.h, self.cloud.h))
@@ -433,8 +435,9 @@ def make_setting(
     s = RegistrationSettingC()
     load().sga_registration_setting_default(C.byref(s))
     s.factor.factor_kind = _FACTOR_BY_NAME[registration_type] if isinstance(registration_type, str) else int(registration_type)
-    # None or a negative distance: no rejector (NullRejector, rejector.hpp:11-16); else DistanceRejector with the squared distance
-    s.factor.max_dist_sq = -1.0 if (max_correspondence_distance is None or float(max_correspondence_distance) < 0) else float(max_correspondence_distance) ** 2
+    # None: no rejector (NullRejector, rejector.hpp:11-16).  Any number, negative ones included, is squared like the reference does
+    # (registration_helper.cpp:90,100,110; src/python/align.cpp:246): DistanceRejector with max_dist_sq = d * d
+    s.factor.max_dist_sq = -1.0 if max_correspondence_distance is None else float(max_correspondence_distance) ** 2
     s.factor.robust_kind = {None: 0, "NONE": 0, "HUBER": 1, "CAUCHY": 2}[robust_kernel if robust_kernel is None else robust_kernel.upper()]
     s.factor.robust_c = float(robust_c)
     s.factor.math_mode = {"fp32": 0, "fp64": 1}[math_mode]
@@ -559,7 +562,9 @@ class Problem:
         the warm passes had to search again."""
         c, w, f = C.c_uint64(), C.c_uint64(), C.c_uint64()
         check(load().sga_problem_get_pass_stats(self.ctx.h, self.h, C.byref(c), C.byref(w), C.byref(f)))
-        return {"cold_passes": c.value, "warm_passes": w.value, "walked_points": f.value}
+        g = (C.c_uint64 * 4)()
+        check(load().sga_problem_get_grid_stats(self.h, g))
+        return {"cold_passes": c.value, "warm_passes": w.value, "walked_points": f.value, "grid_passes": g[0], "grid_open": g[1], "grid_rings": g[2], "grid_cell_m": g[3] * 1e-6}
 
 
 def _voxelmap_knn(vm, pts, k, max_sq_dist=-1.0):
@@ -586,6 +591,12 @@ def set_search_mode(queue=2, chunk_tiles_cold=0, chunk_tiles_warm=0):
     """sga_set_search_mode: 1 / True = queue-fed search kernel, 0 / False = one query per lane, 2 = automatic (default); tiles of 64
     source points per wave of the queue-fed kernel."""
     load().sga_set_search_mode(int(queue), int(chunk_tiles_cold), int(chunk_tiles_warm))
+
+
+def set_grid_mode(mode=-1, min_points=-1):
+    """sga_set_grid_mode (small_gicp_amd_debug.h): when the cell grid searches (0 never, 1 default: cold passes but the first, 2 the first
+    too, 3 every pass) and from how many target points on an index gets one.  Results do not depend on it."""
+    load().sga_set_grid_mode(int(mode), int(min_points))
 
 
 def get_warm_limit():

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/small_gicp_amd.h"
+#include "../../include/small_gicp_amd_debug.h"
 
 namespace sga {
 
@@ -168,6 +169,12 @@ struct sga_index {
   sga::DevBuf<float4> kd_leaf;      // leaf blocks of the 1-NN walk: per leaf x[8], y[8], z[8], original index[8] (kd_search.hpp: the fast leaf scan)
   int kd_depth = 0;
   float bbox_lo[3] = {0, 0, 0}, bbox_hi[3] = {0, 0, 0};
+  // uniform cell grid over the same points (cell_grid.hpp / cell_grid.hip): the exact search of cold passes near the optimum; grid_h == 0: none
+  sga::DevBuf<float4> grid_pts;       // cell order, w = kd position bits
+  sga::DevBuf<uint32_t> grid_start;   // cells + 1
+  float grid_h = 0.f, grid_eps = 0.f;
+  float grid_org[3] = {0, 0, 0};
+  int grid_dim[3] = {0, 0, 0};
   // voxel map
   sga::DevBuf<float4> pts;                // voxel means in voxel-id order, w = voxel id bits
   double leaf = 0.0;
@@ -221,6 +228,11 @@ struct sga_problem {
   int last_math = 0;             // arithmetic of the last linearize of any kind (which mahalanobis cache is current)
   float bbox_lo[3] = {0, 0, 0}, bbox_hi[3] = {0, 0, 0};  // bounding box of the source (source frame): bounds the motion between two poses
   uint64_t cold_passes = 0, warm_passes = 0;  // passes against a kd-tree since the problem was created
+  uint64_t grid_passes = 0;                   // cold passes searched through the cell grid (cell_grid.hip)
+  sga::DevBuf<uint32_t> grid_stats;           // [0] queries ring 1 left open in the current pass, [1] sum of the rings they then scanned
+  bool grid_stats_pending = false;            // the result being fetched carries the statistics of a grid pass in its spare columns
+  uint64_t grid_open_total = 0, grid_ring_total = 0;  // totals of those statistics since the problem was created
+  double grid_open_frac = 0.0;                // share of the queries the last grid pass's ring 1 left open (policy: too many -> kd walk)
   // launch order of the one-query-per-lane search kernel (linearize.hip, "longest tile first"): the duration of every tile's wave
   // in the last such pass, and the tiles of each XCD's share sorted by it; order_tiles != 0 iff tile_order belongs to that pass
   sga::DevBuf<uint32_t> tile_cost, tile_order;

@@ -15,6 +15,7 @@
 namespace sga {
 
 int ensure_temp(sga_context* ctx, size_t bytes);
+int build_cell_grid(sga_context* ctx, sga_index* idx);  // cell_grid.hip
 
 // ---- bounding box --------------------------------------------------------------------------------------------------------
 // <= 256 workgroups stream the cloud; wave shuffles + one LDS stage reduce a workgroup to six values, so only six atomics per
@@ -875,6 +876,7 @@ int sga_index_build_kdtree(sga_context* ctx, const sga_cloud* target, sga_index*
     cloud_bbox_decode(ctx->h_scratch, n, idx->bbox_lo, idx->bbox_hi);
     for (int k = 0; k < 3; k++)
       if (!std::isfinite(idx->bbox_lo[k]) || !std::isfinite(idx->bbox_hi[k])) return fail(SGA_ERR_INVALID, "target cloud contains non-finite coordinates");
+    SGA_TRY(build_cell_grid(ctx, idx.get()));  // large targets: the second search structure (cell_grid.hpp)
   }
   *out = idx.release();
   return SGA_OK;

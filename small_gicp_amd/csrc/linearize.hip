@@ -31,12 +31,17 @@ void sga_profile_collect_pending(sga_context* ctx);
 namespace sga {
 
 int comm_allreduce_sum(sga_context* ctx, double* d_buf, size_t count);
+// cell_grid.hip: one exact search pass over the target's cell grid (nn / nn2 / rex of every source point), and the rings a reach needs
+template <typename Real>
+int grid_search_pass(sga_context* ctx, const sga_index* idx, const float4* src_pts, int n, const Rigid<Real>& T, float reach2, int* nn, int* nn2, float* rex, uint32_t* stats);
+int grid_rings_for(const sga_index* idx, double reach);
 
 constexpr int kTile = 256;           // threads per workgroup = source points per tile
 constexpr int kRow = 96;             // doubles per partial row: [0, 29) the system (21 H, 6 b, e, inliers), [32, 95) the quadratic error model
 constexpr int kCols = 128;           // columns the reduction kernels handle (>= kRow)
 constexpr int kModelOff = 32;        // error model: [32, 41) sum p_a g_j, [41, 59) sum p_a M'_c, [59, 95) sum p_a p_b M'_c
 constexpr int kModelCols = 95;
+constexpr int kStatsCol = 30;        // spare columns 30, 31: search statistics of a grid pass (cell_grid.hip), not sums over points
 constexpr int kSearchBlock = 64;      // search kernels: one wave per workgroup
 constexpr int kMaxBlocks = 2048;     // linearize_kernel / error_kernel: 8 workgroups per CU, the whole grid is resident
 
@@ -990,7 +995,7 @@ constexpr int kReduceGroups = 64;
 constexpr int kReduceSlices = 8;  // 1024 threads = 8 slices of 128 columns
 __global__ __launch_bounds__(kReduceSlices * kCols) void reduce_rows_kernel(
   const double* __restrict__ partials, int nrows, int ncols, int row_stride, double* __restrict__ stage, unsigned* __restrict__ ticket, double* __restrict__ out, int out_n, double* __restrict__ host,
-  unsigned long long seq, int derive) {
+  unsigned long long seq, int derive, const uint32_t* __restrict__ stats) {
   __shared__ double sh[kReduceSlices][kCols];
   __shared__ unsigned sh_ticket;
   const int c = threadIdx.x & (kCols - 1), s = threadIdx.x / kCols;
@@ -1045,7 +1050,8 @@ __global__ __launch_bounds__(kReduceSlices * kCols) void reduce_rows_kernel(
     const int cc = threadIdx.x;
     const double t = (derive && is_derived_col(cc)) ? derived_entry(cc, sh[0]) : sh[0][cc];  // moment form: H_rr, H_rt, b_r from the totals
     if (cc < out_n) {
-      const double r = cc < ncols ? t : 0.0;
+      double r = cc < ncols ? t : 0.0;
+      if (stats != nullptr && (cc == kStatsCol || cc == kStatsCol + 1)) r = static_cast<double>(stats[cc - kStatsCol]);  // a grid pass's search statistics ride along in two spare columns
       out[cc] = r;
       if (host != nullptr) host[cc] = r;
     }
@@ -1092,9 +1098,9 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __rest
 // the stage-1 rows of the reduction follow them
 static size_t partial_rows(size_t n) { return std::max<size_t>(kMaxBlocks, (n + 63) / 64); }
 
-static void launch_reduce(sga_context* ctx, const double* partials, int nrows, int ncols, int row_stride, double* stage, double* out, int out_n, double* host, unsigned long long seq, bool derive = false) {
+static void launch_reduce(sga_context* ctx, const double* partials, int nrows, int ncols, int row_stride, double* stage, double* out, int out_n, double* host, unsigned long long seq, bool derive = false, const uint32_t* stats = nullptr) {
   const int groups = nrows > 256 ? std::min(kReduceGroups, std::max(8, nrows / 128)) : 1;  // <= 256 rows: one workgroup, no hand-off between workgroups
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3(groups), dim3(kReduceSlices * kCols), 0, ctx->stream, partials, nrows, ncols, row_stride, stage, ctx->d_ticket.p, out, out_n, host, seq, derive ? 1 : 0);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(groups), dim3(kReduceSlices * kCols), 0, ctx->stream, partials, nrows, ncols, row_stride, stage, ctx->d_ticket.p, out, out_n, host, seq, derive ? 1 : 0, stats);
 }
 
 static bool g_lazy_maha = getenv("SGA_LAZY_MAHA") ? atoi(getenv("SGA_LAZY_MAHA")) != 0 : true;
@@ -1179,6 +1185,9 @@ static int g_chunk_tiles_cold = getenv("SGA_CHUNK_COLD") ? atoi(getenv("SGA_CHUN
 static const bool g_chunk_adapt = getenv("SGA_CHUNK_ADAPT") ? atoi(getenv("SGA_CHUNK_ADAPT")) != 0 : true;
 static int g_chunk_tiles_warm = getenv("SGA_CHUNK_WARM") ? atoi(getenv("SGA_CHUNK_WARM")) : 4;
 
+int g_grid_mode = getenv("SGA_GRID") ? atoi(getenv("SGA_GRID")) : 0;  // cell-grid passes (see linearize_dispatch; off by default: DESIGN.md section 3.9); sga_set_grid_mode
+long long g_grid_min_points = getenv("SGA_GRID_MIN_POINTS") ? atoll(getenv("SGA_GRID_MIN_POINTS")) : 65536;  // targets below this get no grid (cell_grid.hip)
+
 template <typename Real>
 static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, const double T[16], double* d_out30, double* host, unsigned long long seq, bool with_model = false) {
   const sga_index* idx = pb->target;
@@ -1237,7 +1246,16 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
   // while no source point can have moved farther than the certificates can possibly cover.
   const int math = sizeof(Real) == 4 ? SGA_MATH_FP32 : SGA_MATH_FP64;
   const double displacement = (!voxel && p.n > 0 && pb->prev_valid && pb->prev_math == math) ? max_displacement(T, pb->T_prev, pb->bbox_lo, pb->bbox_hi) : INFINITY;
-  const bool warm = displacement <= g_warm_delta;
+  bool warm = displacement <= g_warm_delta;
+  // Cell-grid pass (cell_grid.hip): the exact search of a cold pass NEAR the optimum — every pass of a registration but its first
+  // (whose queries lie as far from the target as the initial guess is off: there the kd walk's pruning pays) and but the warm passes after
+  // a small motion (hardly anything to search).  SGA_GRID: 0 (default) never — measured on C3 the grid does not beat the kd walk, DESIGN.md section 3.9 —, 1 by this rule, 2 the first pass too, 3 every pass.
+  // If ring 1 of the last grid pass left more than SGA_GRID_MAX_OPEN of the queries open, the next cold pass walks the kd-tree instead.
+  const int grid_mode = g_grid_mode;
+  static const int grid_max_rings = getenv("SGA_GRID_MAX_RINGS") ? atoi(getenv("SGA_GRID_MAX_RINGS")) : 16;
+  static const double grid_max_open = getenv("SGA_GRID_MAX_OPEN") ? atof(getenv("SGA_GRID_MAX_OPEN")) : 0.5;
+  const bool first_pass = !pb->prev_valid;
+  bool use_grid = false;
 
   const bool timed = ctx->profiling && (ctx->lin_seq++ % ctx->profile_period) == 0;  // sampled: event records cost ~7 us each
   if (timed) {
@@ -1272,11 +1290,28 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
     if (q.leaves != nullptr) SGA_HIP(hipMemsetAsync(q.leaves, 0, pb->n * sizeof(int), ctx->stream));
     const size_t words = static_cast<size_t>(std::max(p.kd.depth, 1));
     const dim3 sgrid((p.n + kSearchBlock - 1) / kSearchBlock), sblock(kSearchBlock);
-    const bool queue = g_search_queue == 1 || (g_search_queue == 2 && warm && displacement <= g_queue_delta);
-    fused_search = g_fuse_search && !host_rejector && !queue && sizeof(Real) == 4;  // fp64 math: the fused kernel would spill
+    if (grid_mode != 0 && idx->grid_h > 0.f && q.bound2 < 3.0e38f && !host_rejector && q.leaves == nullptr) {
+      const int rings = grid_rings_for(idx, std::sqrt(static_cast<double>(q.bound2)));
+      const bool small_warm = warm && displacement <= g_queue_delta;
+      use_grid = rings > 0 && rings <= grid_max_rings &&
+                 (grid_mode >= 3 || (!small_warm && (grid_mode == 2 || (!first_pass && pb->grid_open_frac <= grid_max_open))));
+      if (first_pass || (!use_grid && !warm)) pb->grid_open_frac = 0.0;  // a kd pass in between: the grid gets another chance afterwards
+    }
+    if (use_grid) {
+      warm = false;  // a full search of every point: the pass counts as cold
+      if (timed) ctx->pending_warm = false;
+      if (pb->grid_stats.n < 2) SGA_TRY(pb->grid_stats.alloc(2));
+      SGA_TRY(grid_search_pass<Real>(ctx, idx, pb->src_pts(), p.n, p.T, q.bound2, pb->hint.p, pb->hint2.p, pb->rex.p, pb->grid_stats.p));
+      pb->order_tiles = 0;
+      pb->grid_passes++;
+    }
+    const bool queue = !use_grid && (g_search_queue == 1 || (g_search_queue == 2 && warm && displacement <= g_queue_delta));
+    fused_search = !use_grid && g_fuse_search && !host_rejector && !queue && sizeof(Real) == 4;  // fp64 math: the fused kernel would spill
     const unsigned order_tiles_before = pb->order_tiles;
     pb->order_tiles = 0;  // (set again below when this pass records its tiles' durations)
-    if (fused_search) {
+    if (use_grid) {
+      // searched above; the factors follow as linearize_kernel over nn[]
+    } else if (fused_search) {
       // every search wave evaluates the factors of its own tile: one partial row per tile of 64 points, summed by reduce_rows_kernel
       p.tail.enabled = 0;
       fused_rows = static_cast<int>(sgrid.x);
@@ -1381,7 +1416,8 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
     launch_reduce(ctx, pb->partials.p, fused_rows, ncols, kRow, pb->partials.p + partial_rows(pb->n) * kRow, d_out30, out_n, host, seq, true);
   }
   else if (!fuse)
-    launch_reduce(ctx, pb->partials.p, p.n > 0 ? blocks : 0, ncols, kRow, pb->partials.p + partial_rows(pb->n) * kRow, d_out30, out_n, host, seq, true);
+    launch_reduce(ctx, pb->partials.p, p.n > 0 ? blocks : 0, ncols, kRow, pb->partials.p + partial_rows(pb->n) * kRow, d_out30, out_n, host, seq, true, use_grid ? pb->grid_stats.p : nullptr);
+  pb->grid_stats_pending = use_grid && !fuse && out_n > kStatsCol + 1;
   if (timed) {  // the whole GPU side of the pass: search + factors + the sum of the rows
     (void)hipEventRecord(ctx->ev1, ctx->stream);
     ctx->pending |= 1;
@@ -1665,10 +1701,13 @@ int sga_error_async(sga_context* ctx, sga_problem* pb, const sga_factor_params* 
   return fp->math_mode == SGA_MATH_FP64 ? error_dispatch<double>(ctx, pb, fp, T, d_out1, nullptr, 0) : error_dispatch<float>(ctx, pb, fp, T, d_out1, nullptr, 0);
 }
 
-int sga_linearize(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, const double T[16], double H[36], double b[6], double* e, uint64_t* num_inliers) {
-  SGA_TRY(check_args(ctx, pb, fp, T));
-  if (!H || !b || !e) return fail(SGA_ERR_INVALID, "null output");
-  SGA_ENTER(ctx);
+}  // extern "C"
+
+namespace sga {
+// sga_linearize in two halves, so that one host thread can keep several devices busy (multi.hip): enqueue = the kernels of the pass, the
+// sum over ranks if the context has a communicator, and the hand-off of the result to the host; collect = wait for it (ctx->h_accum
+// then holds `count` doubles: the system, or the system and the error model).
+int linearize_enqueue(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, const double T[16], unsigned long long* seq_out, int* count_out) {
   const unsigned long long seq = ++ctx->publish_seq;
   const bool direct = !ctx->sharded();
   double* host = direct ? ctx->h_accum_dev : nullptr;
@@ -1676,20 +1715,53 @@ int sga_linearize(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp
   pb->model_valid = false;
   const int count = model ? kRow : SGA_ACCUM_DOUBLES;
   SGA_TRY(fp->math_mode == SGA_MATH_FP64 ? linearize_dispatch<double>(ctx, pb, fp, T, ctx->d_accum.p, host, seq, model) : linearize_dispatch<float>(ctx, pb, fp, T, ctx->d_accum.p, host, seq, model));
-  {
-    int rc = comm_allreduce_sum(ctx, ctx->d_accum.p, count);  // source sharded over ranks: sum the shards' systems (and error models)
-    if (rc == SGA_OK) rc = fetch_result(ctx, ctx->d_accum.p, count, seq, direct);
-    if (rc != SGA_OK) {
-      pb->prev_valid = false;  // the pass did not complete: its certificates are not to be trusted
-      return rc;
+  int rc = comm_allreduce_sum(ctx, ctx->d_accum.p, count);  // source sharded over ranks: sum the shards' systems (and error models)
+  if (rc == SGA_OK && !direct) {
+    hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(kCols), 0, ctx->stream, ctx->d_accum.p, count, ctx->h_accum_dev, seq);
+    if (hipGetLastError() != hipSuccess) rc = fail(SGA_ERR_HIP, "publish_kernel launch failed");
+  }
+  if (rc != SGA_OK) {
+    pb->prev_valid = false;  // the pass did not complete: its certificates are not to be trusted
+    return rc;
+  }
+  *seq_out = seq;
+  *count_out = count;
+  return SGA_OK;
+}
+int linearize_collect(sga_context* ctx, sga_problem* pb, const double T[16], unsigned long long seq, int count) {
+  const int rc = wait_result(ctx, seq);
+  if (rc != SGA_OK) {
+    pb->prev_valid = false;
+    return rc;
+  }
+  if (pb->grid_stats_pending) {  // search statistics of a grid pass: the share of the queries its first ring left open steers the next cold pass
+    pb->grid_stats_pending = false;
+    if (!ctx->sharded() && pb->n > 0) {
+      pb->grid_open_frac = ctx->h_accum[kStatsCol] / static_cast<double>(pb->n);
+      pb->grid_open_total += static_cast<uint64_t>(ctx->h_accum[kStatsCol]);
+      pb->grid_ring_total += static_cast<uint64_t>(ctx->h_accum[kStatsCol + 1]);
     }
   }
-  sga_unpack_accumulator(ctx->h_accum, H, b, e, num_inliers);
-  if (model) {
+  if (count == kRow) {
     memcpy(pb->model, ctx->h_accum, sizeof(pb->model));
     memcpy(pb->model_T, T, sizeof(pb->model_T));
     pb->model_valid = true;
   }
+  return SGA_OK;
+}
+}  // namespace sga
+
+extern "C" {
+
+int sga_linearize(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, const double T[16], double H[36], double b[6], double* e, uint64_t* num_inliers) {
+  SGA_TRY(check_args(ctx, pb, fp, T));
+  if (!H || !b || !e) return fail(SGA_ERR_INVALID, "null output");
+  SGA_ENTER(ctx);
+  unsigned long long seq = 0;
+  int count = 0;
+  SGA_TRY(linearize_enqueue(ctx, pb, fp, T, &seq, &count));
+  SGA_TRY(linearize_collect(ctx, pb, T, seq, count));
+  sga_unpack_accumulator(ctx->h_accum, H, b, e, num_inliers);
   return SGA_OK;
 }
 
@@ -1732,6 +1804,34 @@ static double evaluate_error_model(const double* acc, const double T[16], const 
   return acc[27] - lin + 0.5 * quad;
 }
 
+}  // extern "C"
+
+namespace sga {
+double error_model_value(const double* acc96, const double T_lin[16], const double T[16]) { return evaluate_error_model(acc96, T_lin, T); }
+bool error_model_enabled() { return g_error_model; }
+// sga_error's device pass in two halves (see linearize_enqueue)
+int error_enqueue(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, const double T[16], unsigned long long* seq_out) {
+  const unsigned long long seq = ++ctx->publish_seq;
+  const bool direct = !ctx->sharded();
+  double* host = direct ? ctx->h_accum_dev : nullptr;
+  SGA_TRY(fp->math_mode == SGA_MATH_FP64 ? error_dispatch<double>(ctx, pb, fp, T, ctx->d_accum.p, host, seq) : error_dispatch<float>(ctx, pb, fp, T, ctx->d_accum.p, host, seq));
+  SGA_TRY(comm_allreduce_sum(ctx, ctx->d_accum.p, 1));
+  if (!direct) {
+    hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(kCols), 0, ctx->stream, ctx->d_accum.p, 1, ctx->h_accum_dev, seq);
+    SGA_HIP(hipGetLastError());
+  }
+  *seq_out = seq;
+  return SGA_OK;
+}
+int error_collect(sga_context* ctx, unsigned long long seq, double* e) {
+  SGA_TRY(wait_result(ctx, seq));
+  *e = ctx->h_accum[0];
+  return SGA_OK;
+}
+}  // namespace sga
+
+extern "C" {
+
 int sga_error(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, const double T[16], double* e) {
   SGA_TRY(check_args(ctx, pb, fp, T));
   if (!e) return fail(SGA_ERR_INVALID, "null output");
@@ -1740,14 +1840,9 @@ int sga_error(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, co
     return SGA_OK;
   }
   SGA_ENTER(ctx);
-  const unsigned long long seq = ++ctx->publish_seq;
-  const bool direct = !ctx->sharded();
-  double* host = direct ? ctx->h_accum_dev : nullptr;
-  SGA_TRY(fp->math_mode == SGA_MATH_FP64 ? error_dispatch<double>(ctx, pb, fp, T, ctx->d_accum.p, host, seq) : error_dispatch<float>(ctx, pb, fp, T, ctx->d_accum.p, host, seq));
-  SGA_TRY(comm_allreduce_sum(ctx, ctx->d_accum.p, 1));
-  SGA_TRY(fetch_result(ctx, ctx->d_accum.p, 1, seq, direct));
-  *e = ctx->h_accum[0];
-  return SGA_OK;
+  unsigned long long seq = 0;
+  SGA_TRY(error_enqueue(ctx, pb, fp, T, &seq));
+  return error_collect(ctx, seq, e);
 }
 
 int sga_error_model_eval(const double acc96[SGA_MODEL_DOUBLES], const double T_lin[16], const double T[16], double* e) {
@@ -1799,7 +1894,17 @@ int sga_debug_kd_wave_times(unsigned long long* out, int waves) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_kd_wave_times), sizeof(unsigned long long) * 2 * static_cast<size_t>(waves)) != hipSuccess) return SGA_ERR_HIP;
   return SGA_OK;
 }
+#else
+int sga_debug_kd_trips(unsigned long long*) { return fail(SGA_ERR_UNSUPPORTED, "loop-trip counters exist in the diagnostics build only (make trips)"); }
+int sga_debug_kd_wave_times(unsigned long long*, int) { return fail(SGA_ERR_UNSUPPORTED, "wave timers exist in the diagnostics build only (make trips)"); }
 #endif
+
+// experiments / tests: when the cell grid searches (SGA_GRID) and from how many target points on an index gets one (SGA_GRID_MIN_POINTS;
+// affects indices built afterwards); negative values keep the current setting
+void sga_set_grid_mode(int mode, long long min_points) {
+  if (mode >= 0) sga::g_grid_mode = mode;
+  if (min_points >= 0) sga::g_grid_min_points = min_points;
+}
 
 // experiments / tests: which search kernel runs (queue != 0: nn_search_queue_kernel with the given tiles per wave; <= 0 keeps a value)
 void sga_set_search_mode(int queue, int chunk_tiles_cold, int chunk_tiles_warm) {

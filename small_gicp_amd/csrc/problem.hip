@@ -346,6 +346,15 @@ int sga_problem_get_pass_stats(sga_context* ctx, const sga_problem* pb, uint64_t
   return SGA_OK;
 }
 
+int sga_problem_get_grid_stats(const sga_problem* pb, uint64_t out[4]) {
+  if (!pb || !out) return fail(SGA_ERR_INVALID, "null argument");
+  out[0] = pb->grid_passes;
+  out[1] = pb->grid_open_total;
+  out[2] = pb->grid_ring_total;
+  out[3] = pb->target ? static_cast<uint64_t>(static_cast<double>(pb->target->grid_h) * 1e6) : 0;
+  return SGA_OK;
+}
+
 int sga_problem_get_factors(sga_context* ctx, const sga_problem* pb, int64_t* target_index, float* mahalanobis6) {
   if (!ctx || !pb) return fail(SGA_ERR_INVALID, "null argument");
   const size_t n = pb->n;

@@ -15,7 +15,7 @@ from small_gicp_amd import _lib
 
 def test_library_exports_every_declared_symbol():
     assert os.path.exists(sga.LIB_PATH), "run `make lib` / __graft_entry__.build() first"
-    header = open(os.path.join(ROOT, "include", "small_gicp_amd.h")).read()
+    header = open(os.path.join(ROOT, "include", "small_gicp_amd.h")).read() + open(os.path.join(ROOT, "include", "small_gicp_amd_debug.h")).read()
     declared = set(re.findall(r"\b(sga_[a-z0-9_]+)\s*\(", header))
     typedefs = {"sga_linearize_fn", "sga_error_fn"}
     declared -= typedefs

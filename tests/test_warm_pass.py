@@ -91,7 +91,7 @@ def test_warm_with_every_certificate_failing(c1_f32):
     src = sga.PointCloud(d["sp"], d["sn"], d["sc"])
     tree = sga.KdTree(tgt)
     goal = se3([0.3, -0.2, 1.0], np.deg2rad(3.0), [0.6, -0.3, 0.1])
-    for st in (sga.make_setting("GICP"), sga.make_setting("GICP", max_correspondence_distance=-1.0), sga.make_setting("ICP", max_correspondence_distance=0.3)):
+    for st in (sga.make_setting("GICP"), sga.make_setting("GICP", max_correspondence_distance=None), sga.make_setting("ICP", max_correspondence_distance=0.3)):
         stats = run_chain(tree, src, st, pose_chain(goal, (0.0, 0.3, 0.6, 0.8, 0.9, 1.0)), 100.0, 1e-6)
         assert stats["warm_passes"] == 5 and stats["walked_points"] > 0.5 * len(d["sp"]), stats
 
