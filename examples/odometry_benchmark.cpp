@@ -78,6 +78,12 @@ public:
     small_gicp_amd::check(sga_context_set_stream_ordered(small_gicp_amd::default_context(), 1), "sga_context_set_stream_ordered");
     registration.rejector.max_dist_sq = params.max_correspondence_distance * params.max_correspondence_distance;
   }
+  // the mode changes what "returned" means for every user of the default context: restored when the estimator goes away
+  ~OnlineOdometryEstimationHIP() {
+    target_points.reset();
+    target_tree.reset();
+    (void)sga_context_set_stream_ordered(small_gicp_amd::default_context(), 0);
+  }
 
   // `points` is already downsampled (odometry_benchmark_small_gicp_omp.cpp:20-21)
   small_gicp_amd::Isometry3d estimate(const small_gicp_amd::PointCloud::Ptr& points) {

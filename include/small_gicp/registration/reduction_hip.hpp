@@ -71,6 +71,7 @@
 #include <Eigen/Geometry>
 
 #include <small_gicp_amd.h>
+#include <small_gicp/ann/incremental_voxelmap.hpp>
 #include <small_gicp/factors/gicp_factor.hpp>
 #include <small_gicp/factors/icp_factor.hpp>
 #include <small_gicp/factors/plane_icp_factor.hpp>
@@ -182,102 +183,185 @@ std::uint64_t fingerprint(const Cloud& c) {
   return h;
 }
 
-struct DeviceState {
-  int device = 0;
-  sga_context* ctx = nullptr;
-  sga_cloud *target = nullptr, *source = nullptr;
-  sga_index* index = nullptr;
-  sga_problem* problem = nullptr;
-  const void *target_addr = nullptr, *source_addr = nullptr;
-  std::uint64_t target_fp = 0, source_fp = 0;
-  std::uint64_t generation = 0;  // bumped whenever something is uploaded again
-  std::vector<std::int64_t> idx;
-  std::vector<float> m6;
-  ~DeviceState() {
-    if (problem) sga_problem_destroy(problem);
-    if (index) sga_index_destroy(index);
-    if (source) sga_cloud_destroy(source);
-    if (target) sga_cloud_destroy(target);
-    if (ctx) sga_context_destroy(ctx);
-  }
+// traits::point / normal / cov (points/traits.hpp:15-78) -> the reference PointCloud layout the C ABI takes (point_cloud.hpp:69-71)
+struct PackedCloud {
+  std::vector<double> p, nr, cv;
+  size_t n = 0;
 };
-
-// points/traits.hpp:15-78 accessor protocol -> the reference PointCloud layout the C ABI takes (point_cloud.hpp:69-71)
 template <typename Cloud>
-sga_cloud* upload(sga_context* ctx, const Cloud& c) {
-  const size_t n = traits::size(c);
+PackedCloud pack(const Cloud& c) {
+  PackedCloud out;
+  const size_t n = out.n = traits::size(c);
   const bool normals = traits::has_normals(c), covs = traits::has_covs(c);
-  std::vector<double> p(4 * n), nr(normals ? 4 * n : 0), cv(covs ? 16 * n : 0);
+  out.p.resize(4 * n);
+  out.nr.resize(normals ? 4 * n : 0);
+  out.cv.resize(covs ? 16 * n : 0);
 #ifdef _OPENMP
 #pragma omp parallel for schedule(static) num_threads(kHostThreads) if (n >= kParallelFrom)
 #endif
   for (long long ii = 0; ii < static_cast<long long>(n); ii++) {
     const size_t i = static_cast<size_t>(ii);
     const Eigen::Vector4d v = traits::point(c, i);
-    for (int k = 0; k < 4; k++) p[4 * i + k] = v[k];
+    for (int k = 0; k < 4; k++) out.p[4 * i + k] = v[k];
     if (normals) {
       const Eigen::Vector4d w = traits::normal(c, i);
-      for (int k = 0; k < 4; k++) nr[4 * i + k] = w[k];
+      for (int k = 0; k < 4; k++) out.nr[4 * i + k] = w[k];
     }
     if (covs) {
       const Eigen::Matrix4d m = traits::cov(c, i);
       for (int col = 0; col < 4; col++)
-        for (int row = 0; row < 4; row++) cv[16 * i + 4 * col + row] = m(row, col);
+        for (int row = 0; row < 4; row++) out.cv[16 * i + 4 * col + row] = m(row, col);
     }
   }
-  sga_cloud* out = nullptr;
-  check(sga_cloud_create_f64(ctx, p.data(), nr.empty() ? nullptr : nr.data(), cv.empty() ? nullptr : cv.data(), n, &out), "sga_cloud_create_f64");
   return out;
 }
+
+// What one calling thread keeps on the device(s): contexts + streams, the uploaded clouds, the search index, the factor state.
+struct DeviceState {
+  int device = 0, num_gpus = 1;
+  sga_multi* multi = nullptr;  // one registration over num_gpus devices (sga_multi_*; num_gpus = 1: one context, one stream)
+  const void *target_addr = nullptr, *source_addr = nullptr;
+  std::uint64_t target_fp = 0, source_fp = 0;
+  bool has_target = false, has_source = false;
+  std::uint64_t generation = 0;  // bumped whenever something is uploaded again
+  bool in_align = false;         // between begin_align() and end_align(): linearize() is the device pass and nothing else
+  std::vector<std::int64_t> idx;
+  std::vector<float> m6;
+  // timings of the last begin_align / end_align bracket (seconds)
+  double bind_s = 0.0, fill_s = 0.0, loop_s = 0.0, calls_s = 0.0;  // calls_s: inside linearize() / error() during the bracket
+  ~DeviceState() {
+    if (multi) sga_multi_destroy(multi);
+  }
+};
+
+// The states of all threads that use (copies of) one policy object.  A thread's state is created on its first call and lives as long
+// as the pool (TBB / OpenMP worker threads are persistent; a thread that is gone leaves its state behind until the last copy of the
+// policy dies).
+struct StatePool {
+  std::mutex mutex;
+  std::map<std::thread::id, std::unique_ptr<DeviceState>> per_thread;
+  std::uint64_t generation_total = 0;  // uploads of all threads (under the mutex)
+  DeviceState& mine() {
+    std::lock_guard<std::mutex> lock(mutex);
+    auto& slot = per_thread[std::this_thread::get_id()];
+    if (!slot) slot.reset(new DeviceState);
+    return *slot;
+  }
+  void uploaded() {
+    std::lock_guard<std::mutex> lock(mutex);
+    generation_total++;
+  }
+};
+
+// a voxel map in the target slot (VGICP) is not a point cloud: see the header comment
+template <typename T>
+struct is_voxelmap : std::false_type {};
+template <typename Contents>
+struct is_voxelmap<IncrementalVoxelMap<Contents>> : std::true_type {};
+
+inline double seconds_since(const std::chrono::steady_clock::time_point& t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
 
 }  // namespace hip_detail
 
 /// @brief Reduction on an MI355X through libsmall_gicp_amd (replaces ParallelReductionOMP, reduction_omp.hpp:21-73).
 struct ParallelReductionHIP {
-  ParallelReductionHIP() : device(0), sync_factors(false), sync_inliers(true), verify_content(true), fp64_math(false), num_inliers(0), state(std::make_shared<hip_detail::DeviceState>()) {}
+  ParallelReductionHIP()
+  : device(0),
+    num_gpus(1),
+    sync_factors(false),
+    sync_inliers(true),
+    verify_content(true),
+    fp64_math(false),
+    num_inliers(0),
+    pool(std::make_shared<hip_detail::StatePool>()) {}
 
-  /// Forget the uploaded clouds: the next linearize() uploads target and source again.
+  /// Forget the clouds this thread uploaded: its next linearize() / begin_align() uploads target and source again.
   void rebind() const {
-    state->target_addr = state->source_addr = nullptr;
+    auto& s = pool->mine();
+    s.target_addr = s.source_addr = nullptr;
   }
 
-  /// Uploads so far (diagnostic: a loop that re-registers unchanged objects must not re-upload them).
-  std::uint64_t generation() const { return state->generation; }
+  /// Uploads so far, over all threads (diagnostic: a loop that re-registers unchanged objects must not re-upload them).
+  std::uint64_t generation() const {
+    std::lock_guard<std::mutex> lock(pool->mutex);
+    return pool->generation_total;
+  }
 
+  /// Hash / upload / index what is not on the device(s) yet.  Called by every linearize() outside an align bracket.
   template <typename TargetPointCloud, typename SourcePointCloud>
   void bind(const TargetPointCloud& target, const SourcePointCloud& source, const Eigen::Isometry3d& T) const {
-    auto& s = *state;
-    if (!s.ctx) {
-      s.device = device;
-      hip_detail::check(sga_context_create(device, &s.ctx), "sga_context_create");
+    static_assert(
+      !hip_detail::is_voxelmap<TargetPointCloud>::value,
+      "ParallelReductionHIP: a voxel map as the target (VGICP, registration_helper.cpp:125-137) is not a point cloud — its traits::point(i) takes "
+      "packed (voxel, point) indices.  Use sga_index_build_gaussian_voxelmap + sga_align (small_gicp_amd.h, INTEGRATION.md section 2) for VGICP.");
+    auto& s = pool->mine();
+    if (s.multi && (s.device != device || s.num_gpus != num_gpus)) {
+      sga_multi_destroy(s.multi);
+      s.multi = nullptr;
+      s.has_target = s.has_source = false;
     }
-    // content check on every call (one streaming pass over both clouds, ~0.2 ms per 100k points): an object refilled in place is
-    // uploaded again.  verify_content = false trusts address + size (call rebind() after changing a cloud in place).
+    if (!s.multi) {
+      s.device = device;
+      s.num_gpus = num_gpus < 1 ? 1 : num_gpus;
+      std::vector<int> devices(static_cast<size_t>(s.num_gpus));
+      int visible = sga_device_count();
+      for (int g = 0; g < s.num_gpus; g++) devices[g] = visible > 0 ? (device + g) % visible : device + g;  // more shards than devices: logical shards share a device
+      hip_detail::check(sga_multi_create(devices.data(), s.num_gpus, &s.multi), "sga_multi_create");
+    }
+    // content check (one streaming pass over both clouds, ~0.2 ms per 100k points): an object refilled in place is uploaded again.
+    // verify_content = false trusts address + size (call rebind() after changing a cloud in place).
     const std::uint64_t tfp = verify_content ? hip_detail::fingerprint(target) : traits::size(target), sfp = verify_content ? hip_detail::fingerprint(source) : traits::size(source);
-    if (s.target_addr != static_cast<const void*>(&target) || s.target_fp != tfp || !s.index) {
-      if (s.problem) sga_problem_destroy(s.problem);
-      if (s.index) sga_index_destroy(s.index);
-      if (s.target) sga_cloud_destroy(s.target);
-      s.problem = nullptr;
-      s.index = nullptr;
-      s.target = hip_detail::upload(s.ctx, target);
-      hip_detail::check(sga_index_build_kdtree(s.ctx, s.target, &s.index), "sga_index_build_kdtree");  // replaces KdTree<PointCloud>(target), ann/kdtree.hpp:250-252
+    if (s.target_addr != static_cast<const void*>(&target) || s.target_fp != tfp || !s.has_target) {
+      const hip_detail::PackedCloud c = hip_detail::pack(target);
+      // replaces KdTree<PointCloud>(target), ann/kdtree.hpp:250-252: every device builds its own exact index over its copy
+      hip_detail::check(sga_multi_set_target_f64(s.multi, c.p.data(), c.nr.empty() ? nullptr : c.nr.data(), c.cv.empty() ? nullptr : c.cv.data(), c.n), "sga_multi_set_target_f64");
       s.target_addr = &target;
       s.target_fp = tfp;
-      s.source_addr = nullptr;
+      s.has_target = true;
+      s.has_source = false;
       s.generation++;
+      pool->uploaded();
     }
-    if (s.source_addr != static_cast<const void*>(&source) || s.source_fp != sfp || !s.problem) {
-      if (s.problem) sga_problem_destroy(s.problem);
-      if (s.source) sga_cloud_destroy(s.source);
-      s.problem = nullptr;
-      s.source = hip_detail::upload(s.ctx, source);
-      hip_detail::check(sga_problem_create(s.ctx, s.index, s.source, T.matrix().data(), &s.problem), "sga_problem_create");  // registration.hpp:41
+    if (s.source_addr != static_cast<const void*>(&source) || s.source_fp != sfp || !s.has_source) {
+      const hip_detail::PackedCloud c = hip_detail::pack(source);
+      hip_detail::check(sga_multi_set_source_f64(s.multi, c.p.data(), c.nr.empty() ? nullptr : c.nr.data(), c.cv.empty() ? nullptr : c.cv.data(), c.n, T.matrix().data()), "sga_multi_set_source_f64");  // registration.hpp:41
       s.source_addr = &source;
       s.source_fp = sfp;
+      s.has_source = true;
       s.generation++;
+      pool->uploaded();
     }
   }
+
+  /// The bracket HipAligned<> puts around the reference's optimizer: everything that has to happen once per align() happens here.
+  template <typename TargetPointCloud, typename SourcePointCloud>
+  void begin_align(const TargetPointCloud& target, const SourcePointCloud& source, const Eigen::Isometry3d& init_T) const {
+    const auto t0 = std::chrono::steady_clock::now();
+    bind(target, source, init_T);
+    auto& s = pool->mine();
+    hip_detail::check(sga_multi_reset_search_state(s.multi), "sga_multi_reset_search_state");  // a registration's result must not depend on earlier ones
+    s.in_align = true;
+    s.calls_s = 0.0;
+    s.bind_s = hip_detail::seconds_since(t0);
+  }
+  /// End of the bracket: the host `factors` as a CPU reduction would have left them after the last linearize (what optimizer.hpp:146 counts).
+  template <typename Factor>
+  void end_align(std::vector<Factor>& factors) const {
+    auto& s = pool->mine();
+    s.in_align = false;
+    const auto t0 = std::chrono::steady_clock::now();
+    fill_factors(s, factors);
+    s.fill_s = hip_detail::seconds_since(t0);
+  }
+  /// Seconds the last bracket of this thread took: begin_align (hash + upload + index build, if any), the optimizer between the
+  /// two (the policy's linearize / error calls AND the reference's own host code: 6x6 solves, and its count over the host factors,
+  /// optimizer.hpp:146, a pass over 144 bytes per source point), end_align (factor fill); last: the share of the optimizer's time spent
+  /// inside this policy's linearize() / error().
+  std::tuple<double, double, double, double> last_bracket_seconds() const {
+    auto& s = pool->mine();
+    return {s.bind_s, s.loop_s, s.fill_s, s.calls_s};
+  }
+  void note_loop_seconds(double v) const { pool->mine().loop_s = v; }
 
   /// reduction.hpp:20-47 / reduction_omp.hpp:24-59
   template <typename TargetPointCloud, typename SourcePointCloud, typename TargetTree, typename CorrespondenceRejector, typename Factor>
@@ -288,64 +372,72 @@ struct ParallelReductionHIP {
     const CorrespondenceRejector& rejector,
     const Eigen::Isometry3d& T,
     std::vector<Factor>& factors) const {
-    using Map = hip_detail::factor_map<Factor>;
-    bind(target, source, T);
-    auto& s = *state;
+    auto& s = pool->mine();
+    const auto call_t0 = std::chrono::steady_clock::now();
+    if (!s.in_align) bind(target, source, T);
     sga_factor_params fp = params<Factor>(factors, hip_detail::max_dist_sq_of(rejector));
     Eigen::Matrix<double, 6, 6> H;
     Eigen::Matrix<double, 6, 1> b;
     double H36[36], b6[6], e = 0.0;
     std::uint64_t inliers = 0;
-    hip_detail::check(sga_linearize(s.ctx, s.problem, &fp, T.matrix().data(), H36, b6, &e, &inliers), "sga_linearize");
+    hip_detail::check(sga_multi_linearize(s.multi, &fp, T.matrix().data(), H36, b6, &e, &inliers), "sga_multi_linearize");
     for (int i = 0; i < 6; i++) {
       b(i) = b6[i];
       for (int j = 0; j < 6; j++) H(i, j) = H36[6 * i + j];
     }
     num_inliers = inliers;
-    // What a CPU reduction leaves in `factors`.  The reference's only reader is optimizer.hpp:146 (it counts factors with a valid
-    // target_index for RegistrationResult::num_inliers): sync_inliers (default) downloads the correspondences — 8 bytes per point,
-    // no mahalanobis recomputation — and fills target_index / source_index; sync_factors additionally fills GICPFactor::mahalanobis
-    // (24 more bytes per point and a recompute_maha kernel per linearize: only for code that inspects the factors).  With both off
-    // the factors stay untouched and num_inliers of the result is 0 — read ParallelReductionHIP::num_inliers instead.
-    if ((sync_factors || sync_inliers) && !factors.empty()) {
-      const size_t n = factors.size();
-      s.idx.resize(n);
-      const bool gicp = Map::kind == SGA_GICP && sync_factors;
-      if (gicp) s.m6.resize(6 * n);
-      hip_detail::check(sga_problem_get_factors(s.ctx, s.problem, s.idx.data(), gicp ? s.m6.data() : nullptr), "sga_problem_get_factors");
-#ifdef _OPENMP
-#pragma omp parallel for schedule(static) num_threads(hip_detail::kHostThreads) if (n >= hip_detail::kParallelFrom)
-#endif
-      for (long long ii = 0; ii < static_cast<long long>(n); ii++) {
-        const size_t i = static_cast<size_t>(ii);
-        auto& f = Map::plain(factors[i]);
-        f.source_index = i;
-        f.target_index = s.idx[i] < 0 ? std::numeric_limits<size_t>::max() : static_cast<size_t>(s.idx[i]);
-        if (gicp) hip_detail::set_mahalanobis(f, &s.m6[6 * i]);
-      }
-    }
+    // Outside an align bracket the policy cannot know which linearize is the last one: the host factors are filled after each
+    // (sync_inliers: indices, 8 bytes per point; sync_factors: the GICP mahalanobis too).  Inside a bracket end_align() does it once.
+    if (!s.in_align) fill_factors(s, factors);
+    s.calls_s += hip_detail::seconds_since(call_t0);
     return {H, b, e};
   }
 
   /// reduction.hpp:55-62 / reduction_omp.hpp:61-70 — with the correspondences and mahalanobis cached by the last linearize (gicp_factor.hpp:80-89)
   template <typename TargetPointCloud, typename SourcePointCloud, typename Factor>
   double error(const TargetPointCloud&, const SourcePointCloud&, const Eigen::Isometry3d& T, std::vector<Factor>& factors) const {
-    auto& s = *state;
-    if (!s.problem) throw std::runtime_error("ParallelReductionHIP::error before linearize");
+    auto& s = pool->mine();
+    if (!s.multi || !s.has_source) throw std::runtime_error("ParallelReductionHIP::error before linearize");
+    const auto call_t0 = std::chrono::steady_clock::now();
     sga_factor_params fp = params<Factor>(factors, last_max_dist_sq);
     double e = 0.0;
-    hip_detail::check(sga_error(s.ctx, s.problem, &fp, T.matrix().data(), &e), "sga_error");
+    hip_detail::check(sga_multi_error(s.multi, &fp, T.matrix().data(), &e), "sga_multi_error");
+    s.calls_s += hip_detail::seconds_since(call_t0);
     return e;
   }
 
-  int device;                  ///< HIP device
-  bool sync_factors;           ///< also fill GICPFactor::mahalanobis of the host `factors` after every linearize (default off)
-  bool sync_inliers;           ///< fill target_index / source_index of the host `factors` after every linearize (default on: optimizer.hpp:146 counts them)
-  bool verify_content;         ///< hash both clouds on every linearize to notice in-place edits (default on); off: address + size only, see rebind()
+  int device;                  ///< first HIP device
+  int num_gpus;                ///< devices device .. device + num_gpus - 1 share every registration: source sharded, target replicated (the num_threads of reduction_omp.hpp:22)
+  bool sync_factors;           ///< also fill GICPFactor::mahalanobis of the host `factors` (default off: then its 3x3 block is set to NaN, see the header comment)
+  bool sync_inliers;           ///< fill target_index / source_index of the host `factors` (default on: optimizer.hpp:146 counts them)
+  bool verify_content;         ///< hash both clouds on every bind to notice in-place edits (default on); off: address + size only, see rebind()
   bool fp64_math;              ///< per-pair arithmetic in fp64 (data on the device is fp32 either way)
-  mutable size_t num_inliers;  ///< inliers of the last linearize
+  mutable size_t num_inliers;  ///< inliers of the last linearize (of the thread that wrote last)
 
 private:
+  template <typename Factor>
+  void fill_factors(hip_detail::DeviceState& s, std::vector<Factor>& factors) const {
+    using Map = hip_detail::factor_map<Factor>;
+    if (!(sync_factors || sync_inliers) || factors.empty()) return;
+    const size_t n = factors.size();
+    s.idx.resize(n);
+    constexpr bool is_gicp = Map::kind == SGA_GICP;
+    const bool maha = is_gicp && sync_factors;
+    if (maha) s.m6.resize(6 * n);
+    hip_detail::check(sga_multi_get_factors(s.multi, s.idx.data(), maha ? s.m6.data() : nullptr), "sga_multi_get_factors");
+    const float nan6[6] = {std::nanf(""), std::nanf(""), std::nanf(""), std::nanf(""), std::nanf(""), std::nanf("")};
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(hip_detail::kHostThreads) if (n >= hip_detail::kParallelFrom)
+#endif
+    for (long long ii = 0; ii < static_cast<long long>(n); ii++) {
+      const size_t i = static_cast<size_t>(ii);
+      auto& f = Map::plain(factors[i]);
+      f.source_index = i;
+      f.target_index = s.idx[i] < 0 ? std::numeric_limits<size_t>::max() : static_cast<size_t>(s.idx[i]);
+      if (is_gicp) hip_detail::set_mahalanobis(f, maha ? &s.m6[6 * i] : nan6);  // not synced: poisoned rather than stale
+    }
+  }
+
   template <typename Factor>
   sga_factor_params params(const std::vector<Factor>& factors, double max_dist_sq) const {
     using Map = hip_detail::factor_map<Factor>;
@@ -361,7 +453,55 @@ private:
   }
 
   mutable double last_max_dist_sq = 1.0;
-  std::shared_ptr<hip_detail::DeviceState> state;  // shared by copies of the policy (Registration<> objects are copied freely)
+  std::shared_ptr<hip_detail::StatePool> pool;  // shared by copies of the policy (Registration<> objects are copied freely); one state per calling thread
+};
+
+/// @brief Optimizer-slot adaptor: the reference's optimizer, unchanged, between ParallelReductionHIP::begin_align and ::end_align.
+/// `HipAligned<LevenbergMarquardtOptimizer>` / `HipAligned<GaussNewtonOptimizer>` (optimizer.hpp:13-58, :62-149) keep every setting of the
+/// optimizer they derive from (max_iterations, init_lambda, ...).  With any other Reduction the adaptor is the plain optimizer.
+template <typename Optimizer = LevenbergMarquardtOptimizer>
+struct HipAligned : public Optimizer {
+  template <
+    typename TargetPointCloud,
+    typename SourcePointCloud,
+    typename TargetTree,
+    typename CorrespondenceRejector,
+    typename TerminationCriteria,
+    typename Reduction,
+    typename Factor,
+    typename GeneralFactor>
+  RegistrationResult optimize(
+    const TargetPointCloud& target,
+    const SourcePointCloud& source,
+    const TargetTree& target_tree,
+    const CorrespondenceRejector& rejector,
+    const TerminationCriteria& criteria,
+    Reduction& reduction,
+    const Eigen::Isometry3d& init_T,
+    std::vector<Factor>& factors,
+    GeneralFactor& general_factor) const {
+    if constexpr (std::is_same<typename std::remove_cv<Reduction>::type, ParallelReductionHIP>::value) {
+      reduction.begin_align(target, source, init_T);  // hash / upload / index: once
+      RegistrationResult result(init_T);
+      const auto t0 = std::chrono::steady_clock::now();
+      try {
+        result = Optimizer::optimize(target, source, target_tree, rejector, criteria, reduction, init_T, factors, general_factor);  // registration/optimizer.hpp, as it is
+        reduction.note_loop_seconds(hip_detail::seconds_since(t0));
+      } catch (...) {
+        std::vector<Factor> none;
+        reduction.end_align(none);
+        throw;
+      }
+      reduction.end_align(factors);  // the host factors: once, when the reference reads them
+      if (reduction.sync_inliers || reduction.sync_factors)
+        result.num_inliers = std::count_if(factors.begin(), factors.end(), [](const auto& factor) { return factor.inlier(); });  // optimizer.hpp:146, after the fill
+      else
+        result.num_inliers = reduction.num_inliers;  // host factors untouched on request: the count of the last linearization, from the device
+      return result;
+    } else {
+      return Optimizer::optimize(target, source, target_tree, rejector, criteria, reduction, init_T, factors, general_factor);
+    }
+  }
 };
 
 }  // namespace small_gicp

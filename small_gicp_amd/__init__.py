@@ -11,6 +11,7 @@ from .api import (  # noqa: F401
     GaussianVoxelMap,
     IncrementalVoxelMapCov,
     KdTree,
+    MultiProblem,
     PointCloud,
     Problem,
     RegistrationResult,

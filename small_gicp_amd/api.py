@@ -81,8 +81,12 @@ class Context:
         check(load().sga_comm_destroy(self.h))
 
     def set_stream_ordered(self, enabled=True):
-        """Index builds and normal / covariance estimation return once enqueued (results ordered for later calls on this context)."""
+        """Index builds and normal / covariance estimation return once enqueued (results ordered for later calls on this context; a
+        consumer on another context waits for the producer's event).  Returns the previous mode."""
+        prev = getattr(self, "stream_ordered", False)
         check(load().sga_context_set_stream_ordered(self.h, int(enabled)))
+        self.stream_ordered = bool(enabled)
+        return prev
 
     def set_profiling(self, enabled=True):
         check(load().sga_context_set_profiling(self.h, int(enabled)))
@@ -565,6 +569,61 @@ class Problem:
         g = (C.c_uint64 * 4)()
         check(load().sga_problem_get_grid_stats(self.h, g))
         return {"cold_passes": c.value, "warm_passes": w.value, "walked_points": f.value, "grid_passes": g[0], "grid_open": g[1], "grid_rings": g[2], "grid_cell_m": g[3] * 1e-6}
+
+
+class MultiProblem:
+    """sga_multi: one registration over several GPUs of this process (source sharded, target replicated; small_gicp_amd.h).  `devices`
+    may name a device more than once (logical shards on one GPU).  Clouds are given as host arrays: points (n, 3), normals (n, 3) or
+    None, covariances (n, 3, 3) or None."""
+
+    def __init__(self, devices, target, source, init_T=None):
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        self.h = C.c_void_p()
+        check(load().sga_multi_create(devs, len(devices), C.byref(self.h)))
+        tp, tn, tc = self._pack(*target)
+        check(load().sga_multi_set_target_f64(self.h, _dp(tp), _dp(tn) if tn is not None else None, _dp(tc) if tc is not None else None, len(tp)))
+        sp, sn, sc = self._pack(*source)
+        self.n_source = len(sp)
+        check(load().sga_multi_set_source_f64(self.h, _dp(sp), _dp(sn) if sn is not None else None, _dp(sc) if sc is not None else None, len(sp), _dp(_T16(np.eye(4) if init_T is None else init_T))))
+
+    @staticmethod
+    def _pack(points, normals=None, covs=None):
+        p = np.ones((len(points), 4))
+        p[:, :3] = np.asarray(points, dtype=np.float64)[:, :3]
+        nr = cv = None
+        if normals is not None:
+            nr = np.zeros((len(points), 4))
+            nr[:, :3] = np.asarray(normals, dtype=np.float64)[:, :3]
+        if covs is not None:
+            cv = np.zeros((len(points), 4, 4))
+            cv[:, :3, :3] = np.asarray(covs, dtype=np.float64)[:, :3, :3]
+            cv = np.ascontiguousarray(cv.transpose(0, 2, 1))  # column-major 4x4 (symmetric: the same numbers)
+        return np.ascontiguousarray(p), nr, cv
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            load().sga_multi_destroy(self.h)
+            self.h = None
+
+    def linearize(self, factor_params, T):
+        H, b, e, n = np.zeros(36), np.zeros(6), C.c_double(), C.c_uint64()
+        check(load().sga_multi_linearize(self.h, C.byref(factor_params), _dp(_T16(T)), _dp(H), _dp(b), C.byref(e), C.byref(n)))
+        return H.reshape(6, 6), b, e.value, n.value
+
+    def error(self, factor_params, T):
+        e = C.c_double()
+        check(load().sga_multi_error(self.h, C.byref(factor_params), _dp(_T16(T)), C.byref(e)))
+        return e.value
+
+    def align(self, setting, init_T=None):
+        res = ResultC()
+        check(load().sga_multi_align(self.h, _dp(_T16(np.eye(4) if init_T is None else init_T)), C.byref(setting), C.byref(res)))
+        return RegistrationResult(res)
+
+    def factors(self):
+        idx = np.empty(self.n_source, np.int64)
+        check(load().sga_multi_get_factors(self.h, idx.ctypes.data_as(C.c_void_p), None))
+        return idx
 
 
 def _voxelmap_knn(vm, pts, k, max_sq_dist=-1.0):

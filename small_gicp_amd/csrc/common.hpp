@@ -141,8 +141,29 @@ struct sga_context {
   bool sharded() const { return comm != nullptr || comm_fn != nullptr; }
 };
 
+// Producer / consumer ordering across streams.  In stream-ordered mode (sga_context_set_stream_ordered) an index build or an attribute
+// estimation returns while its kernels are still in flight on the producing context's stream.  The object remembers that stream and an
+// event recorded behind the work; an entry point that consumes the object on ANOTHER stream first makes its stream wait for the event
+// (sga::wait_ready), so outputs never race with a half-built input whichever context consumes them.  (Same stream: stream order suffices.)
+namespace sga {
+struct Ready {
+  hipEvent_t event = nullptr;
+  hipStream_t stream = nullptr;
+  bool pending = false;
+  ~Ready() {
+    if (event) (void)hipEventDestroy(event);
+  }
+  Ready() = default;
+  Ready(const Ready&) = delete;
+  Ready& operator=(const Ready&) = delete;
+};
+int mark_ready(sga_context* ctx, Ready& r);            // behind the producing work; no-op unless the context is stream-ordered
+int wait_ready(sga_context* ctx, const Ready& r);      // before consuming on ctx's stream
+}  // namespace sga
+
 struct sga_cloud {
   int device = 0;
+  mutable sga::Ready ready;
   size_t n = 0;
   bool has_normals = false, has_covs = false;
   sga::DevBuf<float4> pts;   // w = bitcast(original index)
@@ -156,6 +177,7 @@ constexpr int kFlatCap = 16;  // point slots per voxel of a flat map (max_num_po
 struct sga_index {
   int kind = SGA_INDEX_KDTREE;
   int device = 0;
+  mutable sga::Ready ready;
   size_t n = 0;  // points (kd-tree) or voxels (voxel map)
   bool has_normals = false, has_covs = false;
   // implicit balanced kd-tree over the target (kd_search.hpp): points in kd order + {threshold, axis} heap
@@ -237,6 +259,7 @@ struct sga_problem {
   // in the last such pass, and the tiles of each XCD's share sorted by it; order_tiles != 0 iff tile_order belongs to that pass
   sga::DevBuf<uint32_t> tile_cost, tile_order;
   unsigned order_tiles = 0;
+  hipStream_t order_stream = nullptr;  // the stream tile_order was (or is being) written on: a pass on another stream ignores it
   sga::DevBuf<float> maha;       // n*6 (fp32 mode) — fused mahalanobis of the last linearize
   sga::DevBuf<double> maha64;    // n*6 (fp64 mode, allocated on first use)
   // custom CorrespondenceRejector on the host (sga_problem_set_rejector): reject flag per source point (caller's order) for the current pass

@@ -418,6 +418,26 @@ int sga_context_synchronize(sga_context* ctx) {
 
 void* sga_context_stream(sga_context* ctx) { return ctx ? static_cast<void*>(ctx->stream) : nullptr; }
 
+}  // extern "C"
+namespace sga {
+int mark_ready(sga_context* ctx, Ready& r) {
+  if (!ctx->stream_ordered) {  // the entry point synchronised its stream before returning: nothing in flight
+    r.pending = false;
+    return SGA_OK;
+  }
+  if (!r.event) SGA_HIP(hipEventCreateWithFlags(&r.event, hipEventDisableTiming));
+  SGA_HIP(hipEventRecord(r.event, ctx->stream));
+  r.stream = ctx->stream;
+  r.pending = true;
+  return SGA_OK;
+}
+int wait_ready(sga_context* ctx, const Ready& r) {
+  if (r.pending && r.event && r.stream != ctx->stream) SGA_HIP(hipStreamWaitEvent(ctx->stream, r.event, 0));
+  return SGA_OK;
+}
+}  // namespace sga
+extern "C" {
+
 int sga_context_set_stream_ordered(sga_context* ctx, int enabled) {
   if (!ctx) return fail(SGA_ERR_INVALID, "null context");
   if (!enabled && ctx->stream_ordered) (void)hipStreamSynchronize(ctx->stream);

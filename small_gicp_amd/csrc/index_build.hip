@@ -866,6 +866,7 @@ int sga_index_build_kdtree(sga_context* ctx, const sga_cloud* target, sga_index*
   idx->n = n;
   idx->has_normals = target->has_normals;
   idx->has_covs = target->has_covs;
+  SGA_TRY(wait_ready(ctx, target->ready));  // attributes estimated on another context in stream-ordered mode
   if (n > 0) {
     // the bounding box travels to the host behind the build: build_kdtree synchronises the stream once, at its end
     DevBuf<int> d_bbox;
@@ -877,6 +878,7 @@ int sga_index_build_kdtree(sga_context* ctx, const sga_cloud* target, sga_index*
     for (int k = 0; k < 3; k++)
       if (!std::isfinite(idx->bbox_lo[k]) || !std::isfinite(idx->bbox_hi[k])) return fail(SGA_ERR_INVALID, "target cloud contains non-finite coordinates");
     SGA_TRY(build_cell_grid(ctx, idx.get()));  // large targets: the second search structure (cell_grid.hpp)
+    SGA_TRY(mark_ready(ctx, idx->ready));
   }
   *out = idx.release();
   return SGA_OK;

@@ -1319,7 +1319,8 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
         SGA_TRY(pb->tile_cost.reserve(sgrid.x));
         SGA_TRY(pb->tile_order.reserve(sgrid.x));
         q.tile_cost = pb->tile_cost.p;
-        if (order_tiles_before == sgrid.x && (g_lpt == 2 || warm)) q.tile_order = pb->tile_order.p;
+        // (the order was written behind the previous pass's hand-off on that pass's stream: a pass issued on another stream could read it half-written)
+        if (order_tiles_before == sgrid.x && pb->order_stream == ctx->stream && (g_lpt == 2 || warm)) q.tile_order = pb->tile_order.p;
         record_tiles = true;
       }
       static const size_t lds_pad = getenv("SGA_LDS_PAD") ? static_cast<size_t>(atoi(getenv("SGA_LDS_PAD"))) : 0;  // experiments: bytes of unused LDS per wave (lowers the occupancy)
@@ -1425,6 +1426,7 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
   if (record_tiles) {  // after the reduction has handed the result to the host: the tiles are sorted while the host solves
     hipLaunchKernelGGL(tile_order_kernel, dim3(8), dim3(1024), 0, ctx->stream, pb->tile_cost.p, pb->tile_order.p, fused_rows);
     pb->order_tiles = static_cast<unsigned>(fused_rows);
+    pb->order_stream = ctx->stream;
   }
   SGA_HIP(hipGetLastError());
   pb->last_math = math;

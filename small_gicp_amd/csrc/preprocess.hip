@@ -407,7 +407,9 @@ int sga_estimate_normals_covariances(sga_context* ctx, sga_cloud* cloud, const s
   } else {
     if (index->kind != SGA_INDEX_KDTREE) return fail(SGA_ERR_INVALID, "a kd-tree index is required");
     if (index->n != n) return fail(SGA_ERR_INVALID, "index was built over a cloud of %zu points, got %zu", index->n, n);
+    SGA_TRY(wait_ready(ctx, index->ready));  // built on another context that returned before its kernels had run
   }
+  SGA_TRY(wait_ready(ctx, cloud->ready));
   int rc = SGA_OK;
   if ((flags & 1) && cloud->nrm.n < n) rc = cloud->nrm.alloc(n);
   if (rc == SGA_OK && (flags & 2) && cloud->cov.n < n) rc = cloud->cov.alloc(n);
@@ -437,7 +439,9 @@ int sga_estimate_normals_covariances(sga_context* ctx, sga_cloud* cloud, const s
   if (rc == SGA_OK && !temp) {  // the kernel wrote the index's kd-ordered copies as well
     if (flags & 1) index->has_normals = true;
     if (flags & 2) index->has_covs = true;
+    rc = mark_ready(ctx, index->ready);
   }
+  if (rc == SGA_OK) rc = mark_ready(ctx, cloud->ready);
   if (temp) sga_index_destroy(temp);
   return rc;
 }

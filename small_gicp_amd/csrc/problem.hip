@@ -249,6 +249,8 @@ int sga_problem_create_from_index(sga_context* ctx, const sga_index* target, con
   (void)init_T;  // the kd order does not depend on the initial guess
   *out = nullptr;
   SGA_ENTER(ctx);
+  SGA_TRY(wait_ready(ctx, target->ready));  // inputs produced on another context in stream-ordered mode (common.hpp: Ready)
+  SGA_TRY(wait_ready(ctx, source->ready));
   std::unique_ptr<sga_problem> pb(new sga_problem);
   pb->device = ctx->device;
   pb->target = target;
@@ -274,6 +276,8 @@ int sga_problem_create(sga_context* ctx, const sga_index* target, const sga_clou
   if (target->device != ctx->device || source->device != ctx->device) return fail(SGA_ERR_INVALID, "target/source live on another device");
   *out = nullptr;
   SGA_ENTER(ctx);
+  SGA_TRY(wait_ready(ctx, target->ready));  // inputs produced on another context in stream-ordered mode (common.hpp: Ready)
+  SGA_TRY(wait_ready(ctx, source->ready));
   static const double I16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   const double* T = init_T ? init_T : I16;
   std::unique_ptr<sga_problem> pb(new sga_problem);

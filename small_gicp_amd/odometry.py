@@ -27,14 +27,29 @@ class OnlineOdometry:
         self.k = num_neighbors
         self.setting = api.make_setting("GICP", max_correspondence_distance=max_correspondence_distance)
         self.max_dist = max_correspondence_distance
-        self.ctx = ctx or api.default_context()
-        # every step of a scan runs on this one context: no host wait between the index build, the covariances and the registration
-        self.ctx.set_stream_ordered(True)
+        # every step of a scan runs on ONE context in stream-ordered mode: no host wait between the index build, the covariances and the
+        # registration.  The mode changes what "returned" means for every user of that context, so the estimator takes a context of its own
+        # unless it is handed one (the sharded bench leg: the context that carries the communicator), whose mode it restores in close().
+        self._own_ctx = ctx is None
+        self.ctx = ctx or api.Context(0)
+        self._prev_mode = self.ctx.set_stream_ordered(True)
         self.target = None  # (cloud, tree)
         self.T_world = np.eye(4)
         self.reg_ms = []
         self.total_ms = []
         self.iterations = []
+
+    def close(self):
+        """Give a borrowed context its previous mode back (synchronises it)."""
+        if self.ctx is not None and not self._own_ctx:
+            self.ctx.set_stream_ordered(self._prev_mode)
+        self.target = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
 
     def estimate(self, points):
         """points: (N,3|4) float32 in the sensor frame. Returns T_world_sensor of this scan."""

@@ -13,6 +13,8 @@
 #include <iostream>
 #include <random>
 #include <string>
+#include <thread>
+#include <type_traits>
 #include <vector>
 
 #include <small_gicp/ann/kdtree.hpp>
@@ -70,9 +72,12 @@ static void pose_error(const Eigen::Isometry3d& A, const Eigen::Isometry3d& B, d
 
 static int failures = 0;
 
-template <typename Factor>
-static void run_case(const char* name, const PointCloud& target, const PointCloud& source, const KdTree<PointCloud>& tree, Registration<Factor, ParallelReductionHIP>& hip, const Eigen::Isometry3d& init) {
-  Registration<Factor, ParallelReductionOMP> cpu;
+template <typename Factor, typename HipOptimizer>
+static void run_case(const char* name, const PointCloud& target, const PointCloud& source, const KdTree<PointCloud>& tree, Registration<Factor, ParallelReductionHIP, NullFactor, DistanceRejector, HipOptimizer>& hip,
+                     const Eigen::Isometry3d& init) {
+  // the CPU side runs the optimizer the adaptor derives from (HipAligned<X> -> X)
+  using CpuOptimizer = typename std::conditional<std::is_base_of<GaussNewtonOptimizer, HipOptimizer>::value, GaussNewtonOptimizer, LevenbergMarquardtOptimizer>::type;
+  Registration<Factor, ParallelReductionOMP, NullFactor, DistanceRejector, CpuOptimizer> cpu;
   cpu.reduction.num_threads = 4;
   cpu.rejector.max_dist_sq = hip.rejector.max_dist_sq;
   cpu.point_factor = hip.point_factor;
@@ -93,6 +98,36 @@ static void run_case(const char* name, const PointCloud& target, const PointClou
     "CASE {\"name\": \"%s\", \"ok\": %s, \"dt\": %.3e, \"dr\": %.3e, \"iterations\": [%zu, %zu], \"num_inliers\": [%zu, %zu], \"reduction_num_inliers\": %zu, \"rel_err_H\": %.3e, \"uploads\": %llu}\n", name, ok ? "true" : "false", dt, dr,
     rh.iterations, rc.iterations, rh.num_inliers, rc.num_inliers, hip.reduction.num_inliers, relH, static_cast<unsigned long long>(hip.reduction.generation()));
   if (!ok) failures++;
+}
+
+// iterations/s THROUGH the policy (what a small_gicp user who swaps the Reduction — and, for HipAligned, the Optimizer — gets): whole
+// align() calls with a fixed number of LM iterations like bench.py, the reference's OpenMP reduction on 32 threads beside it
+template <typename Reg>
+static void rate(const char* name, const PointCloud& tgt, const PointCloud& src, const KdTree<PointCloud>& tr, int reps, bool lean = false) {
+  const Eigen::Isometry3d I = Eigen::Isometry3d::Identity();
+  Reg reg;
+  if (lean) reg.reduction.verify_content = reg.reduction.sync_inliers = false;  // nothing per call but the device passes
+  reg.criteria.rotation_eps = 0.0;
+  reg.criteria.translation_eps = 0.0;
+  reg.optimizer.max_iterations = 10;
+  reg.align(tgt, src, tr, I);  // upload + index build + warm-up
+  size_t iters = 0;
+  double loop_s = 0.0;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int r = 0; r < reps; r++) {
+    iters += reg.align(tgt, src, tr, I).iterations + 1;
+    loop_s += std::get<1>(reg.reduction.last_bracket_seconds());
+  }
+  const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  Registration<GICPFactor, ParallelReductionOMP> cpu;
+  cpu.criteria = reg.criteria;
+  cpu.optimizer.max_iterations = 10;
+  cpu.reduction.num_threads = 32;
+  const auto c0 = std::chrono::steady_clock::now();
+  const size_t citers = cpu.align(tgt, src, tr, I).iterations + 1;
+  const double cel = std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count();
+  std::printf("RATE {\"name\": \"%s\", \"points\": [%zu, %zu], \"hip_policy_iterations_per_s\": %.1f, \"inside_the_optimizer_iterations_per_s\": %.1f, \"omp32_iterations_per_s\": %.1f, \"uploads\": %llu}\n", name, tgt.size(),
+              src.size(), iters / el, loop_s > 0 ? iters / loop_s : 0.0, citers / cel, static_cast<unsigned long long>(reg.reduction.generation()));
 }
 
 int main(int argc, char** argv) {
@@ -189,29 +224,106 @@ int main(int argc, char** argv) {
                 rc.num_inliers);
     if (!ok) failures++;
   }
-  // ---- iterations/s THROUGH the policy (what a small_gicp user who swaps the Reduction gets), default settings of the policy ----
-  auto rate = [&](const char* name, const PointCloud& tgt, const PointCloud& src, const KdTree<PointCloud>& tr, int reps, bool lean = false) {
-    Registration<GICPFactor, ParallelReductionHIP> reg;
-    if (lean) reg.reduction.verify_content = reg.reduction.sync_inliers = false;  // nothing per call but the device passes
-    reg.criteria.rotation_eps = 0.0;  // fixed number of LM iterations, like bench.py
-    reg.criteria.translation_eps = 0.0;
-    reg.optimizer.max_iterations = 10;
-    reg.align(tgt, src, tr, I);  // upload + index build + warm-up
-    size_t iters = 0;
-    const auto t0 = std::chrono::steady_clock::now();
-    for (int r = 0; r < reps; r++) iters += reg.align(tgt, src, tr, I).iterations + 1;
-    const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  // ---- the Optimizer-slot adaptor: the reference's optimizer between begin_align() and end_align()
+  {
+    Registration<GICPFactor, ParallelReductionHIP, NullFactor, DistanceRejector, HipAligned<LevenbergMarquardtOptimizer>> reg;
+    run_case("HipAligned<LM> GICP", *target, *source, tree, reg, I);
+    const auto uploads = reg.reduction.generation();
+    run_case("HipAligned<LM> GICP again (cached uploads)", *target, *source, tree, reg, I);
+    if (reg.reduction.generation() != uploads) {
+      std::printf("CASE {\"name\": \"HipAligned: unchanged clouds were uploaded again\", \"ok\": false}\n");
+      failures++;
+    }
+    // sync_factors: the mahalanobis of the host factors after the bracket; without it the block is NaN (never stale)
+    {
+      std::vector<GICPFactor> factors(source->size());
+      TerminationCriteria crit;
+      NullFactor gf;
+      reg.reduction.sync_factors = true;
+      reg.optimizer.optimize(*target, *source, tree, reg.rejector, crit, reg.reduction, I, factors, gf);
+      size_t filled = 0, inl = 0;
+      for (const auto& f : factors)
+        if (f.inlier()) {
+          inl++;
+          filled += std::isfinite(f.mahalanobis(0, 0)) && f.mahalanobis(0, 0) > 0.0;
+        }
+      reg.reduction.sync_factors = false;
+      std::vector<GICPFactor> factors2(source->size());
+      reg.optimizer.optimize(*target, *source, tree, reg.rejector, crit, reg.reduction, I, factors2, gf);
+      size_t poisoned = 0;
+      for (const auto& f : factors2) poisoned += std::isnan(f.mahalanobis(0, 0));
+      const bool ok = inl > 5000 && filled == inl && poisoned == factors2.size();
+      std::printf("CASE {\"name\": \"HipAligned: mahalanobis filled with sync_factors, NaN without\", \"ok\": %s, \"inliers\": %zu, \"filled\": %zu, \"poisoned\": %zu}\n", ok ? "true" : "false", inl, filled, poisoned);
+      if (!ok) failures++;
+    }
+  }
+  {
+    Registration<GICPFactor, ParallelReductionHIP, NullFactor, DistanceRejector, HipAligned<GaussNewtonOptimizer>> reg;
+    run_case("HipAligned<GN> GICP", *target, *source, tree, reg, I);
+  }
+  {
+    Registration<PointToPlaneICPFactor, ParallelReductionHIP, NullFactor, DistanceRejector, HipAligned<LevenbergMarquardtOptimizer>> reg;
+    run_case("HipAligned<LM> PLANE_ICP", *target, *source, tree, reg, I);
+  }
+  {
+    // source sharded over two (logical) devices inside this process: the same registration
+    Registration<GICPFactor, ParallelReductionHIP, NullFactor, DistanceRejector, HipAligned<LevenbergMarquardtOptimizer>> reg;
+    reg.reduction.num_gpus = 2;
+    run_case("HipAligned<LM> GICP, num_gpus = 2 (two shards)", *target, *source, tree, reg, I);
+    Registration<GICPFactor, ParallelReductionHIP> plain;
+    plain.reduction.num_gpus = 3;
+    run_case("GICP, num_gpus = 3, Reduction slot only", *target, *source, tree, plain, I);
+  }
+  {
+    // Registration<>::align is const and the reference runs it from many threads at once (odometry_benchmark_small_gicp_tbb_flow.cpp:
+    // 81-96): four threads, ONE registration object, every thread its own target / source pair (the source displaced differently)
+    Registration<GICPFactor, ParallelReductionHIP, NullFactor, DistanceRejector, HipAligned<LevenbergMarquardtOptimizer>> reg;
     Registration<GICPFactor, ParallelReductionOMP> cpu;
-    cpu.criteria = reg.criteria;
-    cpu.optimizer.max_iterations = 10;
-    cpu.reduction.num_threads = 32;
-    const auto c0 = std::chrono::steady_clock::now();
-    const size_t citers = cpu.align(tgt, src, tr, I).iterations + 1;
-    const double cel = std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count();
-    std::printf("RATE {\"name\": \"%s\", \"points\": [%zu, %zu], \"hip_policy_iterations_per_s\": %.1f, \"omp32_iterations_per_s\": %.1f, \"uploads\": %llu}\n", name, tgt.size(), src.size(), iters / el, citers / cel,
+    cpu.reduction.num_threads = 4;
+    constexpr int kThreads = 4;
+    std::vector<std::shared_ptr<PointCloud>> sources(kThreads);
+    std::vector<RegistrationResult> want(kThreads, RegistrationResult(I)), got(kThreads, RegistrationResult(I));
+    for (int t = 0; t < kThreads; t++) {
+      Eigen::Isometry3d M = Eigen::Isometry3d::Identity();
+      M.matrix()(0, 3) = 0.02 * t;
+      M.matrix()(1, 3) = -0.01 * t;
+      sources[t] = std::make_shared<PointCloud>(*source);
+      for (size_t i = 0; i < sources[t]->size(); i++) {
+        Eigen::Vector4d q = M * sources[t]->point(i);
+        for (int k = 0; k < 3; k++) q[k] = static_cast<float>(q[k]);
+        sources[t]->point(i) = q;
+      }
+      want[t] = cpu.align(*target, *sources[t], tree, I);
+    }
+    std::vector<std::thread> pool;
+    std::vector<std::string> errors(kThreads);
+    for (int t = 0; t < kThreads; t++)
+      pool.emplace_back([&, t] {
+        try {
+          for (int rep = 0; rep < 3; rep++) got[t] = reg.align(*target, *sources[t], tree, I);
+        } catch (const std::exception& ex) {
+          errors[t] = ex.what();
+        }
+      });
+    for (auto& th : pool) th.join();
+    bool ok = true;
+    double worst = 0.0;
+    for (int t = 0; t < kThreads; t++) {
+      double dt, dr;
+      pose_error(want[t].T_target_source, got[t].T_target_source, &dt, &dr);
+      worst = std::max(worst, std::max(dt, dr));
+      ok = ok && errors[t].empty() && dt < 1e-4 && dr < 1e-4 && want[t].iterations == got[t].iterations && std::llabs(static_cast<long long>(want[t].num_inliers) - static_cast<long long>(got[t].num_inliers)) <= 2;
+      if (!errors[t].empty()) std::fprintf(stderr, "thread %d: %s\n", t, errors[t].c_str());
+    }
+    std::printf("CASE {\"name\": \"4 threads align concurrently through one Registration object\", \"ok\": %s, \"worst_pose_error\": %.3e, \"uploads\": %llu}\n", ok ? "true" : "false", worst,
                 static_cast<unsigned long long>(reg.reduction.generation()));
-  };
-  rate("C1 (downsampled 0.25 m)", *target, *source, tree, 50);
+    if (!ok) failures++;
+  }
+  // ---- iterations/s THROUGH the policy (what a small_gicp user who swaps the Reduction gets), default settings of the policy ----
+  using Plain = Registration<GICPFactor, ParallelReductionHIP>;
+  using Aligned = Registration<GICPFactor, ParallelReductionHIP, NullFactor, DistanceRejector, HipAligned<LevenbergMarquardtOptimizer>>;
+  rate<Plain>("C1 (downsampled 0.25 m)", *target, *source, tree, 50);
+  rate<Aligned>("C1, HipAligned<LM>", *target, *source, tree, 50);
   {
     // ~100k-point clouds: a ground plane and two walls, sampled twice; the source displaced by a small rigid motion
     auto make = [&](unsigned seed, const Eigen::Isometry3d& M) {
@@ -236,8 +348,9 @@ int main(int argc, char** argv) {
     auto big_t = make(1, Eigen::Isometry3d::Identity());
     auto big_s = make(2, M.inverse());
     KdTree<PointCloud> big_tree(big_t, KdTreeBuilderOMP(8));
-    rate("synthetic planes (~100k after 0.25 m voxel grid)", *big_t, *big_s, big_tree, 20);
-    rate("synthetic planes, verify_content = sync_inliers = false", *big_t, *big_s, big_tree, 20, true);
+    rate<Plain>("synthetic planes (~100k after 0.25 m voxel grid)", *big_t, *big_s, big_tree, 20);
+    rate<Plain>("synthetic planes, verify_content = sync_inliers = false", *big_t, *big_s, big_tree, 20, true);
+    rate<Aligned>("synthetic planes, HipAligned<LM>", *big_t, *big_s, big_tree, 20);
   }
   std::printf("DONE failures=%d\n", failures);
   return failures == 0 ? 0 : 1;

@@ -155,3 +155,36 @@ def test_two_ranks_share_one_registration_through_the_callback_transport(tmp_pat
     # collectives: one per linearization only (iterations + 1 per align, + the explicit linearize)
     it = res[0]["fp64"]["iterations"] + res[0]["fp32"]["iterations"]
     assert res[0]["collectives"] <= it + 2 + 2 + 4, res[0]["collectives"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shards", [2, 3])
+def test_single_process_shards_equal_one_problem(shards):
+    """sga_multi (small_gicp_amd.h): the source sharded over G contexts inside ONE process — here G logical shards on device 0 —
+    gives the system of the unsharded problem (the loop being partitioned: reduction_omp.hpp:32-58), to summation order in fp32
+    arithmetic and to 1e-12 in fp64 arithmetic, and the same registration."""
+    import small_gicp_amd as sga
+
+    target, source, T_gt = sga.synthetic.registration_pair(120_000)
+    tgt, src = sga.PointCloud(target), sga.PointCloud(source)
+    sga.estimate_covariances(tgt, None, 10)
+    sga.estimate_covariances(src, None, 10)
+    tc, sc = tgt.covs()[:, :3, :3], src.covs()[:, :3, :3]
+    one = sga.Problem(sga.KdTree(tgt), src)
+    multi = sga.MultiProblem([0] * shards, (target, None, tc), (source, None, sc))
+    for mode, rel in (("fp64", 1e-12), ("fp32", 2e-6)):
+        st = sga.make_setting("GICP", math_mode=mode)
+        for T in (np.eye(4), T_gt):
+            H1, b1, e1, n1 = one.linearize(st.factor, T)
+            Hm, bm, em, nm = multi.linearize(st.factor, T)
+            assert n1 == nm
+            assert np.abs(H1 - Hm).max() <= rel * np.abs(H1).max() and np.abs(b1 - bm).max() <= rel * max(np.abs(b1).max(), 1e-3 * np.abs(H1).max())
+            assert abs(e1 - em) <= rel * abs(e1)
+            Tn = T.copy()
+            Tn[:3, 3] += [0.01, -0.02, 0.005]
+            assert abs(one.error(st.factor, Tn) - multi.error(st.factor, Tn)) <= max(rel, 1e-9) * abs(e1)
+            c1, _ = one.factors()
+            assert (c1 == multi.factors()).all()
+        r1, rm = one.align(st, np.eye(4)), multi.align(st, np.eye(4))
+        assert r1.iterations == rm.iterations and r1.num_inliers == rm.num_inliers and r1.converged == rm.converged
+        assert np.abs(r1.T_target_source - rm.T_target_source).max() < (1e-10 if mode == "fp64" else 1e-6)

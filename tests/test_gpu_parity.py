@@ -350,8 +350,20 @@ def test_voxelgrid_matches_oracle(orc, c1_raw, leaf):
     assert np.abs(out - ref).max() < 1e-5
 
 
+def _neighbourhood_differences(gn, gcov, on, ocov):
+    """Per-point comparison of normals / covariances: the points whose neighbourhood (or whose near-degenerate spectrum) came out
+    different on the two sides — an entry off by more than 1e-3; everything else must agree to 1e-5."""
+    dn = np.abs(gn - on).max(axis=1)
+    dc = np.abs(gcov - ocov).reshape(len(on), -1).max(axis=1)
+    bad = (dn > 1e-3) | (dc > 1e-3)
+    return bad, float(dn[~bad].max(initial=0.0)), float(dc[~bad].max(initial=0.0))
+
+
 @pytest.mark.parametrize("k", [10, 20])
 def test_normals_covariances_match_oracle(orc, c1_raw, k):
+    """util/normal_estimation.hpp:65-92 on C1 (6k points): every point but a counted handful — neighbourhoods whose k-th and (k+1)-th
+    neighbours tie within fp32 resolution (the device searches fp32 distances, the CPU doubles), or whose two smallest eigenvalues
+    nearly coincide — equals the oracle to 1e-5."""
     down = orc.voxelgrid_sampling(c1_raw[0], 0.25).astype(np.float32)
     cloud = sga.PointCloud(down)
     sga.estimate_normals_covariances(cloud, None, k)
@@ -360,10 +372,9 @@ def test_normals_covariances_match_oracle(orc, c1_raw, k):
     _, on, ocov = oc.get()
     gn, gcov = cloud.normals()[:, :3], cloud.covs()[:, :3, :3]
     assert np.abs(np.linalg.norm(gn, axis=1) - 1).max() < 1e-5  # normal_estimation_test.cpp: unit normals
-    # neighbourhoods whose k-th and (k+1)-th neighbours tie in fp32, or with near-degenerate spectra, may differ: allow 0.5 %
-    bad_n = (np.abs(gn - on).max(axis=1) > 1e-3).mean()
-    bad_c = (np.abs(gcov - ocov).reshape(len(on), -1).max(axis=1) > 1e-3).mean()
-    assert bad_n < 0.005 and bad_c < 0.005, (bad_n, bad_c)
+    bad, worst_n, worst_c = _neighbourhood_differences(gn, gcov, on, ocov)
+    print("C1 k=%d: %d of %d neighbourhoods differ; the others agree to %.1e (normals) / %.1e (covariances)" % (k, int(bad.sum()), len(on), worst_n, worst_c))
+    assert int(bad.sum()) <= P2_MAX_DIFFERING_C1 and worst_n < 1e-5 and worst_c < 1e-5, (int(bad.sum()), worst_n, worst_c)
     assert np.abs(gcov - np.transpose(gcov, (0, 2, 1))).max() == 0
     # flows through an explicit index too, and updates the index's own attribute copies
     cloud2 = sga.PointCloud(down)
@@ -579,6 +590,82 @@ def test_cpp_header_layer(tmp_path, c1_raw, c1_gold):
     assert np.abs(rm.T_target_source - cases["MODEL_GICP"]["T"]).max() < 1e-9 and rm.iterations == cases["MODEL_GICP"]["iterations"]
     Tr = cases["RESTRICT_GICP"]["T"]
     assert abs(Tr[2, 3]) < 2e-3 and abs(Tr[2, 0]) < 1e-3 and abs(Tr[2, 1]) < 1e-3  # soft constraints (general_factor.hpp:42)
+
+
+# Observed on MI355X (round 4, printed with -s): C1 0 of 6147 (k = 10 and 20); the C3 target 1 of 1 000 000 against the compiled reference;
+# a C5 scan 0 of 11 441; every other point agrees to 3e-8 (the fp32 rounding of the stored result).  The bounds leave room for a handful.
+P2_MAX_DIFFERING_C1 = 2
+P2_MAX_DIFFERING_PER_MILLION = 10
+
+
+def _cpu_features(points32, k, threads):
+    """estimate_normals_covariances of the compiled reference (oracle/_ref: util/normal_estimation_omp.hpp over KdTreeBuilderOMP) when it
+    travelled with the repository, the oracle's restatement otherwise, on the fp32 points the device holds."""
+    from oracle import orc as _orc, ref as _ref
+
+    if _ref.available():
+        c = _ref.Cloud(points32.astype(np.float64), tree=True, tree_threads=min(32, threads))
+        c.estimate_normals_covariances(k, threads)
+        kind = "reference"
+    else:
+        _orc.build()
+        c = _orc.Cloud(points32.astype(np.float64))
+        c.estimate_normals_covariances(k, threads)
+        kind = "port"
+    _, on, ocov = c.get()
+    return on, ocov, kind
+
+
+def test_covariances_at_scale_match_reference():
+    """p2 at the size of C3 and on a C5 scan: local_features_kernel (k = 20; the LDS-window path of large clouds) against
+    the reference's own estimate_normals_covariances_omp on the same fp32 points.  The number of differing neighbourhoods is printed and
+    bounded; every other point agrees to 1e-5."""
+    threads = max(1, min(64, os.cpu_count() or 1))
+    target = sga.synthetic.scene(1_000_000, 1)
+    scan, _ = sga.synthetic.kitti_like_scan(3)
+    down = sga.voxelgrid_sampling(scan, 0.25).xyz().astype(np.float32)
+    for name, pts in (("C3 target (1M)", target), ("C5 scan after the 0.25 m grid", down)):
+        cloud = sga.PointCloud(pts)
+        sga.estimate_normals_covariances(cloud, None, 20)
+        gn, gcov = cloud.normals()[:, :3], cloud.covs()[:, :3, :3]
+        on, ocov, kind = _cpu_features(pts, 20, threads)
+        bad, worst_n, worst_c = _neighbourhood_differences(gn, gcov, on, ocov)
+        per_million = 1e6 * bad.sum() / len(pts)
+        print("%s vs %s: %d of %d neighbourhoods differ (%.0f per million); the others agree to %.1e (normals) / %.1e (covariances)" % (name, kind, int(bad.sum()), len(pts), per_million, worst_n, worst_c))
+        assert (per_million <= P2_MAX_DIFFERING_PER_MILLION or bad.sum() <= P2_MAX_DIFFERING_C1) and worst_n < 1e-5 and worst_c < 1e-5, (name, int(bad.sum()), worst_n, worst_c)
+
+
+def test_c3_with_cpu_estimated_covariances():
+    """The two stages pinned independently: the covariances of a C3-shaped pair (300k points) estimated by the CPU
+    reference, handed to BOTH sides; linearization at two poses and the registration against the CPU."""
+    from oracle import orc as _orc, ref as _ref
+
+    _orc.build()
+    threads = max(1, min(64, os.cpu_count() or 1))
+    target, source, T_gt = sga.synthetic.registration_pair(300_000)
+    _, tcov, _ = _cpu_features(target, 20, threads)
+    _, scov, _ = _cpu_features(source, 20, threads)
+    tgt = sga.PointCloud(target, None, tcov)
+    src = sga.PointCloud(source, None, scov)
+    pb = sga.Problem(sga.KdTree(tgt), src)
+    # the device rounds the covariances to fp32: the CPU gets those very numbers
+    tc32, sc32 = tgt.covs()[:, :3, :3], src.covs()[:, :3, :3]
+    otc = _orc.Cloud(target.astype(np.float64), None, tc32, tree=True)
+    osc = _orc.Cloud(source.astype(np.float64), None, sc32, tree=False)
+    st = sga.make_setting("GICP")
+    for T in (np.eye(4), T_gt @ se3([0.3, -0.5, 0.8], np.deg2rad(0.05), [0.004, -0.003, 0.002])):
+        f = _orc.Factors(len(osc))
+        Ho, bo, eo, no = _orc.linearize(otc, osc, _orc.default_setting(factor_kind=_orc.GICP, num_threads=threads, max_dist_sq=1.0), T, f)
+        H, b, e, n = pb.linearize(st.factor, T)
+        assert abs(int(n) - int(no)) <= 3 and np.abs(H - Ho).max() <= FP32_REL * np.abs(Ho).max() and abs(e - eo) <= FP32_REL * eo
+    res = pb.align(st)
+    if _ref.available():
+        r = _ref.align(_ref.Cloud(target.astype(np.float64), None, tc32, tree=True, tree_threads=min(32, threads)), _ref.Cloud(source.astype(np.float64), None, sc32, tree=False), _ref.GICP, 1.0, 1.0, threads)
+    else:
+        r = _orc.align(otc, osc, _orc.default_setting(factor_kind=_orc.GICP, num_threads=threads))
+    dt, dr = pose_error(res.T_target_source, r.T_target_source)
+    print("C3-shaped registration on CPU-estimated covariances: dt %.2e m, dr %.2e rad, iterations %d / %d" % (dt, dr, res.iterations, r.iterations))
+    assert dt < POSE_TOL_T and dr < POSE_TOL_R and res.iterations == r.iterations
 
 
 def test_c2_plane_icp_100k_matches_oracle(orc):
