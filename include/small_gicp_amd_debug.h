@@ -21,9 +21,11 @@ int sga_problem_get_sorted_points(sga_context* ctx, const sga_problem* pb, float
  * first ring left open (finished by the second kernel), out[2] = sum of the rings those queries then scanned, out[3] = cell edge in
  * micrometres (0: the target has no grid). */
 int sga_problem_get_grid_stats(const sga_problem* pb, uint64_t out[4]);
-/* When the cell grid searches (results do not depend on it; tests compare the searches): mode 0 (default) never (and no grid is built), 1
- * every cold pass of a registration but its first, 2 the first pass too, 3 every pass; min_points: targets with fewer points get no grid
- * (default 65536; applies to indices built afterwards).  Negative arguments keep the current value.  Environment: SGA_GRID, SGA_GRID_MIN_POINTS. */
+/* What the cell grid (a second, flat search structure of large kd-tree indices) is used for; results do not depend on it (tests compare
+ * the searches): mode 0 nothing (no grid is built); 1 (default) the walkers of warm passes try its first ring before they walk the tree;
+ * 2 also the cold passes of a registration but its first; 3 the first pass too; 4 every pass.  min_points: targets with fewer points get
+ * no grid (default 65536; applies to indices built afterwards).  Negative arguments keep the current value.
+ * Environment: SGA_GRID, SGA_GRID_MIN_POINTS. */
 void sga_set_grid_mode(int mode, long long min_points);
 /* Diagnostics build only (make trips): loop-trip counters of the kd walk and the start / end clock of every search wave. */
 int sga_debug_kd_trips(unsigned long long* out16);

@@ -653,8 +653,9 @@ def set_search_mode(queue=2, chunk_tiles_cold=0, chunk_tiles_warm=0):
 
 
 def set_grid_mode(mode=-1, min_points=-1):
-    """sga_set_grid_mode (small_gicp_amd_debug.h): when the cell grid searches (0 never, 1 default: cold passes but the first, 2 the first
-    too, 3 every pass) and from how many target points on an index gets one.  Results do not depend on it."""
+    """sga_set_grid_mode (small_gicp_amd_debug.h): what the cell grid is used for (0 nothing, 1 default: the walkers of warm passes, 2 also
+    cold passes but a registration's first, 3 the first too, 4 every pass) and from how many target points on an index gets one.  Results
+    do not depend on it."""
     load().sga_set_grid_mode(int(mode), int(min_points))
 
 

@@ -162,19 +162,6 @@ struct GridParams {
   uint32_t* __restrict__ stats;
 };
 
-__device__ __forceinline__ float grid_rex_from_r2(float r2) { return sqrtf(r2) * 0.9999995f; }  // as linearize.hip: sqrt of the bound, rounded down
-
-// nn / nn2 / rex of a query whose block has been scanned.  Returns false if the block does not settle it.
-__device__ __forceinline__ bool grid_settle(const GridTop3& t, float rho2, float bound2, int& nn, int& nn2, float& rex) {
-  const float d1 = grid_key_dist(t.k1);
-  const bool hit = d1 < bound2;
-  const bool settled = d1 < rho2 || rho2 >= bound2;  // the nearest point lies inside the certified ball, or the ball covers the whole reach
-  nn = hit ? grid_key_pos(t.k1) : -1;
-  nn2 = (hit && t.k2 != kGridNoKey) ? grid_key_pos(t.k2) : -1;
-  rex = grid_rex_from_r2(fminf(hit ? t.d3 : d1, rho2));
-  return settled;
-}
-
 __device__ __forceinline__ int grid_tile_of_block() {  // XCD-aware tile order (linearize.hip: search_tile_of_block)
   const int nblk = gridDim.x, per_xcd = nblk >> 3, b = blockIdx.x;
   return b < 8 * per_xcd ? (b & 7) * per_xcd + (b >> 3) : b;
@@ -195,35 +182,14 @@ __global__ __launch_bounds__(64 * kRing1Waves) void grid_ring1_kernel(const Grid
   Real x, y, z;
   transform_point<Real>(p.T, ps.x, ps.y, ps.z, x, y, z);
   const float qx = static_cast<float>(x), qy = static_cast<float>(y), qz = static_cast<float>(z);
-  const int cx = grid_cell(qx, g.ox, g.inv_h, g.nx), cy = grid_cell(qy, g.oy, g.inv_h, g.ny), cz = grid_cell(qz, g.oz, g.inv_h, g.nz);
-  uint32_t s[9], e[9];
-#pragma unroll
-  for (int r = 0; r < 9; r++) {
-    // the query's own row first, then its neighbours in y, then the rows above and below
-    constexpr int order[9] = {4, 3, 5, 1, 7, 0, 2, 6, 8};
-    const int k = order[r];
-    const int row = ((cz + k / 3 - 1) * g.ny + (cy + k % 3 - 1)) * g.nx + cx;
-    s[r] = g.start[row - 1];
-    e[r] = g.start[row + 2];
-  }
-  GridTop3 t = grid_top3();
-  GridBatch nxt = grid_load4(g, s[0], e[0]);
-#pragma unroll
-  for (int r = 0; r < 9; r++) {
-    const GridBatch cur = nxt;
-    if (r + 1 < 9) nxt = grid_load4(g, s[r + 1], e[r + 1]);
-    grid_offer4(cur, s[r], e[r], qx, qy, qz, t);
-    grid_scan_run(g, s[r] + 4u, e[r], qx, qy, qz, t);  // the rest of a run longer than four (wave-uniform loop; skipped when no lane has one)
-  }
   int nn, nn2;
-  float rex;
-  const bool settled = grid_settle(t, grid_rho2(g, qx, qy, qz, cx, cy, cz, 1), p.bound2, nn, nn2, rex);
-  if (settled) {
+  float rex, seen;
+  if (grid_ring1_lane(g, qx, qy, qz, p.bound2, nn, nn2, rex, seen)) {
     p.nn[i] = nn;
     p.nn2[i] = nn2;
     p.rex[i] = rex;
   } else {
-    p.rex[i] = t.k1 != kGridNoKey ? -fmaxf(sqrtf(grid_key_dist(t.k1)), 1e-30f) : -INFINITY;
+    p.rex[i] = seen < 3.0e38f ? -fmaxf(seen, 1e-30f) : -INFINITY;
   }
 }
 

@@ -114,4 +114,47 @@ __device__ __forceinline__ float grid_rho2(const GridView& g, float qx, float qy
   return safe > 0.f ? safe * safe : 0.f;
 }
 
+__device__ __forceinline__ float grid_rex_from_r2(float r2) { return sqrtf(r2) * 0.9999995f; }  // as linearize.hip: sqrt of the bound, rounded down
+
+// nn / nn2 / rex of a query whose block has been scanned.  Returns false if the block does not settle it.
+__device__ __forceinline__ bool grid_settle(const GridTop3& t, float rho2, float bound2, int& nn, int& nn2, float& rex) {
+  const float d1 = grid_key_dist(t.k1);
+  const bool hit = d1 < bound2;
+  const bool settled = d1 < rho2 || rho2 >= bound2;  // the nearest point lies inside the certified ball, or the ball covers the whole reach
+  nn = hit ? grid_key_pos(t.k1) : -1;
+  nn2 = (hit && t.k2 != kGridNoKey) ? grid_key_pos(t.k2) : -1;
+  rex = grid_rex_from_r2(fminf(hit ? t.d3 : d1, rho2));
+  return settled;
+}
+
+// Ring 1 for the query of one lane (callable by any subset of a wave's lanes): 9 independent header loads, then the candidates of the
+// 9 runs, four at a time, the first four of the NEXT run already in flight while a run's candidates are compared.  Returns whether the
+// 27 cells settle the query (then nn / nn2 / rex are its exact neighbour, runner-up and exclusion radius); otherwise `seen` = the distance
+// of the nearest point the ring saw (+inf: none).  A chain of two dependent loads where the seeded kd walk has a dozen: this is what the
+// walkers of warm passes use (linearize.hip: certify_linearize_kernel).
+__device__ __forceinline__ bool grid_ring1_lane(const GridView& g, float qx, float qy, float qz, float bound2, int& nn, int& nn2, float& rex, float& seen) {
+  const int cx = grid_cell(qx, g.ox, g.inv_h, g.nx), cy = grid_cell(qy, g.oy, g.inv_h, g.ny), cz = grid_cell(qz, g.oz, g.inv_h, g.nz);
+  uint32_t s[9], e[9];
+#pragma unroll
+  for (int r = 0; r < 9; r++) {
+    // the query's own row first, then its neighbours in y, then the rows above and below
+    constexpr int order[9] = {4, 3, 5, 1, 7, 0, 2, 6, 8};
+    const int k = order[r];
+    const int row = ((cz + k / 3 - 1) * g.ny + (cy + k % 3 - 1)) * g.nx + cx;
+    s[r] = g.start[row - 1];
+    e[r] = g.start[row + 2];
+  }
+  GridTop3 t = grid_top3();
+  GridBatch nxt = grid_load4(g, s[0], e[0]);
+#pragma unroll
+  for (int r = 0; r < 9; r++) {
+    const GridBatch cur = nxt;
+    if (r + 1 < 9) nxt = grid_load4(g, s[r + 1], e[r + 1]);
+    grid_offer4(cur, s[r], e[r], qx, qy, qz, t);
+    grid_scan_run(g, s[r] + 4u, e[r], qx, qy, qz, t);  // the rest of a run longer than four (wave-uniform loop; skipped when no lane has one)
+  }
+  seen = t.k1 != kGridNoKey ? sqrtf(grid_key_dist(t.k1)) : INFINITY;
+  return grid_settle(t, grid_rho2(g, qx, qy, qz, cx, cy, cz, 1), bound2, nn, nn2, rex);
+}
+
 }  // namespace sga

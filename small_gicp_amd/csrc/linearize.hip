@@ -23,6 +23,7 @@
 
 #include "common.hpp"
 #include "device_math.hpp"
+#include "cell_grid.hpp"
 #include "kd_search.hpp"
 #include "voxel_hash.hpp"
 
@@ -129,6 +130,15 @@ struct LinParams {
   Real robust_c;
   double* __restrict__ partials;
   FusedTail tail;
+  // warm pass with the certificate check inside the factor kernel (certify_linearize_kernel): the certificate of the previous
+  // linearization pose T_prev is checked per point on the way through; a point whose certificate fails contributes nothing to the
+  // streaming part, is flagged (rex[i] = -(exploration slack) < 0) and walks at the end of its workgroup's step
+  int* __restrict__ cert_nn;
+  int* __restrict__ cert_nn2;
+  float* __restrict__ cert_rex;
+  uint32_t* __restrict__ cert_walked;
+  Rigid<Real> T_prev;
+  float cert_within2, cert_slack_min, cert_slack_max;
 };
 
 // XCD-aware tile schedule: workgroup b runs on XCD b % 8 (observed placement; used for L2 affinity only).  Each XCD
@@ -199,6 +209,8 @@ struct NNParams {
   double inv_leaf;   // 2^depth / n (kd_leaf_rank)
   int chunk_tiles;   // queue-fed kernel: tiles of 64 queries per wave
   int fast;          // one-query-per-lane kernels: walk with the fast leaf scan (exact repeat where it cannot decide)
+  GridView grid;     // the target's cell grid (cell_grid.hpp), if grid_walk
+  int grid_walk;     // the walkers of certify_linearize_kernel try ring 1 of the grid before they walk the tree
 };
 
 // Returns the shrunken radius (relative to the new pose) or a negative value if the certificate fails.
@@ -207,6 +219,25 @@ __device__ __forceinline__ float certify(float rex, float moved, bool has_neighb
   const float lim2 = lim > 0.f ? lim * lim * 0.999995f : -1.f;
   const bool ok = has_neighbour ? d2_new < lim2 : lim2 > within2;  // no neighbour within reach before: still none
   return ok ? lim * 0.9999995f : -1.f;
+}
+
+// The walk of ONE source point, top-down and seeded, with the fast leaf scan (kd_search.hpp); the rare query it cannot decide (two
+// candidates within 1e-6 of each other, or of the search bound) is searched again with the exact keys.  Stores nn / nn2 / rex.
+template <typename Real, int BLOCK>
+__device__ __forceinline__ int walk_lane(const NNParams<Real>& p, int i, float fx, float fy, float fz, int seed, float slack, uint32_t* __restrict__ kd_stack) {
+  KdBest nb{};
+  bool exact = p.fast == 0;
+  if (!exact) {
+    const KdBestFast f = kd_nearest_fast<BLOCK>(p.kd, fx, fy, fz, p.bound2, seed, kd_stack, threadIdx.x, slack);
+    nb = f.best;
+    exact = f.ambiguous;
+  }
+  if (exact) nb = kd_nearest<BLOCK>(p.kd, fx, fy, fz, p.bound2, seed, kd_stack, threadIdx.x, slack);
+  p.nn[i] = nb.idx;
+  p.nn2[i] = nb.idx2;
+  p.rex[i] = rex_from_r2(nb.r2);
+  if (p.leaves != nullptr) p.leaves[i] = nb.leaves;
+  return nb.idx;
 }
 
 // The search of ONE source point (a lane of a one-query-per-lane kernel): certificate check (warm) or walk, results stored to nn[] /
@@ -249,21 +280,7 @@ __device__ __forceinline__ int search_lane(const NNParams<Real>& p, int tile, in
     const unsigned long long walking = __ballot(true);
     if (threadIdx.x == __ffsll(static_cast<long long>(walking)) - 1) p.walked[tile] += static_cast<uint32_t>(__popcll(walking));  // the tile belongs to this wave: no atomic
   }
-  // the walk with the fast leaf scan (kd_search.hpp); the rare query it cannot decide (two candidates within 1e-6 of each other, or
-  // of the search bound) is searched again with the exact keys
-  KdBest nb{};
-  bool exact = p.fast == 0;
-  if (!exact) {
-    const KdBestFast f = kd_nearest_fast<BLOCK>(p.kd, fx, fy, fz, p.bound2, seed, kd_stack, threadIdx.x, CHECK ? slack : 0.f);
-    nb = f.best;
-    exact = f.ambiguous;
-  }
-  if (exact) nb = kd_nearest<BLOCK>(p.kd, fx, fy, fz, p.bound2, seed, kd_stack, threadIdx.x, CHECK ? slack : 0.f);
-  p.nn[i] = nb.idx;
-  p.nn2[i] = nb.idx2;
-  p.rex[i] = rex_from_r2(nb.r2);
-  if (p.leaves != nullptr) p.leaves[i] = nb.leaves;
-  return nb.idx;
+  return walk_lane<Real, BLOCK>(p, i, fx, fy, fz, seed, CHECK ? slack : 0.f, kd_stack);
 }
 
 // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed placement; only speed depends on it), and the source is sorted by
@@ -317,8 +334,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
 constexpr int kQueueCap = 128;        // entries; a tile is staged while at most kQueueCap - 64 are waiting
 constexpr int kPathRecords = 10;      // pair records fetched at once by kd_push_path: covers depth 20 (8 M points); deeper trees take a second batch
 
-template <typename Real, int FACTOR, int TARGET, int PTS, bool FRESH_NN = false>
-__device__ __forceinline__ void linearize_group(const LinParams<Real>& p, int first, int stride, int limit, double* __restrict__ acc_row, int lane);
+template <typename Real, int FACTOR, int TARGET, int PTS, bool FRESH_NN = false, bool CERT = false>
+__device__ __forceinline__ void linearize_group(const LinParams<Real>& p, int first, int stride, int limit, double* __restrict__ acc_row, int lane, unsigned long long* __restrict__ failed_masks = nullptr);
+template <typename Real, int FACTOR>
+__device__ __forceinline__ bool pair_moments(const LinParams<Real>& p, int i, int j, bool within_bound, Real qx, Real qy, Real qz, Real tx, Real ty, Real tz, Sym3<Real>& Mp, Real* g, Real& e, Sym3<Real>& M_out);
+template <typename Real, int PTS>
+__device__ __forceinline__ void accumulate_moments(const Real (&P)[PTS][3], const Sym3<Real> (&Mp)[PTS], const Real (&G)[PTS][3], const Real (&E)[PTS], int inliers, double* __restrict__ acc_row, int lane);
 
 // FACTOR >= 0: when the chunk's searches are done the wave also evaluates the factors of its chunk (four tiles at a time, like
 // linearize_kernel) and writes ONE partial row per chunk — in the warm passes this kernel runs, the memory system and the VALUs are
@@ -710,8 +731,8 @@ __device__ __forceinline__ void accumulate_moments(const Real (&P)[PTS][3], cons
 // workgroup step), their products are added up in registers, reduced with DPP inside the wave, in fp64 across waves.
 // The factors of PTS points per lane — points first, first + stride, ... below `limit` — added to the wave's row.
 // FRESH_NN: hint[] was written earlier in this very kernel (by any lane of this wave): read it past the vector L1.
-template <typename Real, int FACTOR, int TARGET, int PTS, bool FRESH_NN>
-__device__ __forceinline__ void linearize_group(const LinParams<Real>& p, int first, int stride, int limit, double* __restrict__ acc_row, int lane) {
+template <typename Real, int FACTOR, int TARGET, int PTS, bool FRESH_NN, bool CERT>
+__device__ __forceinline__ void linearize_group(const LinParams<Real>& p, int first, int stride, int limit, double* __restrict__ acc_row, int lane, unsigned long long* __restrict__ failed_masks) {
   Real P[PTS][3], G[PTS][3], E[PTS];
   Sym3<Real> Mp[PTS];
   int inliers = 0;
@@ -727,7 +748,10 @@ __device__ __forceinline__ void linearize_group(const LinParams<Real>& p, int fi
     act[u] = i < limit;
     ps4[u] = act[u] ? p.src_pts[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     jn[u] = -1;
-    if constexpr (TARGET == 0) jn[u] = act[u] ? (FRESH_NN ? __hip_atomic_load(&p.hint[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : p.hint[i]) : -1;
+    if constexpr (TARGET == 0 && CERT)
+      jn[u] = act[u] ? p.cert_nn[i] : -1;  // (the same array as hint[]: read through the pointer it is written through)
+    else if constexpr (TARGET == 0)
+      jn[u] = act[u] ? (FRESH_NN ? __hip_atomic_load(&p.hint[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : p.hint[i]) : -1;
   }
   Real Q[PTS][3], Tg[PTS][3];
   bool within[PTS];
@@ -750,8 +774,59 @@ __device__ __forceinline__ void linearize_group(const LinParams<Real>& p, int fi
   }
   if constexpr (TARGET != 2) {
     float4 m4[PTS];
+    if constexpr (CERT && TARGET == 0) {
+      // The certificate check of the warm pass (search_lane / nn_search_queue_kernel: the same arithmetic, bit for bit) on the way through:
+      // both candidates of the previous pass are fetched, the nearer one (canonical rule) is the neighbour if its new distance is
+      // below the exclusion radius minus the point's motion; otherwise the point is flagged for the walkers' kernel and skipped here.
+      int c2[PTS];
+      float rx[PTS];
 #pragma unroll
-    for (int u = 0; u < PTS; u++) m4[u] = jn[u] >= 0 ? p.tgt_pts[jn[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int u = 0; u < PTS; u++) {
+        const int i = first + u * stride;
+        c2[u] = act[u] ? p.cert_nn2[i] : -1;
+        rx[u] = act[u] ? p.cert_rex[i] : 0.f;
+      }
+      float4 m4b[PTS];
+#pragma unroll
+      for (int u = 0; u < PTS; u++) {
+        m4[u] = jn[u] >= 0 ? p.tgt_pts[jn[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
+        m4b[u] = c2[u] >= 0 ? p.tgt_pts[c2[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < PTS; u++) {
+        const int i = first + u * stride;
+        bool failed = false;
+        if (act[u]) {
+          const float fx = static_cast<float>(Q[u][0]), fy = static_cast<float>(Q[u][1]), fz = static_cast<float>(Q[u][2]);
+          Real ox, oy, oz;
+          transform_point<Real>(p.T_prev, P[u][0], P[u][1], P[u][2], ox, oy, oz);
+          const float moved = sqrtf(kd_dist2(static_cast<float>(ox), static_cast<float>(oy), static_cast<float>(oz), fx, fy, fz));
+          const float d1 = jn[u] >= 0 ? kd_dist2(m4[u].x, m4[u].y, m4[u].z, fx, fy, fz) : INFINITY;
+          const float d2 = c2[u] >= 0 ? kd_dist2(m4b[u].x, m4b[u].y, m4b[u].z, fx, fy, fz) : INFINITY;
+          const bool swap = c2[u] >= 0 && (d2 < d1 || (d2 == d1 && c2[u] < jn[u]));  // the canonical rule: equidistant -> lower position
+          const int best = swap ? c2[u] : jn[u];
+          const float r = certify(rx[u], moved, best >= 0, swap ? d2 : d1, p.cert_within2);
+          failed = !(r >= 0.f);
+          // settled: the shrunken radius; failed: the flag of the walkers' kernel, which is also the exploration slack of the re-walk
+          p.cert_rex[i] = failed ? -fminf(fmaxf(moved, p.cert_slack_min), p.cert_slack_max) : r;
+          if (swap) {  // (for a walker: its seed is the nearer candidate)
+            p.cert_nn[i] = c2[u];
+            p.cert_nn2[i] = jn[u];
+            m4[u] = m4b[u];
+          }
+          jn[u] = failed ? -1 : best;
+        }
+        const unsigned long long fm = __ballot(failed);
+        if (lane == 0) {
+          failed_masks[u] = fm;  // (LDS) which of this wave's 64 points of sub-step u walk
+          if (fm != 0ull) p.cert_walked[i >> 6] += static_cast<uint32_t>(__popcll(fm));  // the 64 points belong to this wave: no atomic
+        }
+        if (failed) act[u] = false;  // the walk phase writes its correspondence
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < PTS; u++) m4[u] = jn[u] >= 0 ? p.tgt_pts[jn[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 #pragma unroll
     for (int u = 0; u < PTS; u++) {
       Tg[u][0] = m4[u].x, Tg[u][1] = m4[u].y, Tg[u][2] = m4[u].z;
@@ -817,6 +892,105 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(4))) void
       p.partials[static_cast<size_t>(blockIdx.x) * kRow + threadIdx.x] = t;
   }
   if (p.tail.enabled) fused_tail(p.tail, p.partials, gridDim.x, kModelCols, kRow, true);
+}
+
+// K1 of a warm pass after a small motion (large clouds): linearize_kernel with the certificate check on the way through.
+// The streaming part is the factor kernel as it is (4 points per lane, everything of a stage in flight together: the kernel that reaches
+// half of the HBM peak) plus, per point, the second candidate and the 12 bytes of certificate; the few points whose certificate fails are
+// left out, flagged, and collected per step of 1024 points (one ballot per wave and sub-step into LDS: a fixed order).  Wave 0 of the
+// workgroup then walks them, 64 at a time (seeded top-down walk with exploration slack, walk_lane), and adds their factors to its row —
+// while the other workgroups stream on.  One launch, one partial row per workgroup; the old form (nn_search_queue_kernel: certificate
+// check, queue-fed walks and factors per chunk of 4 tiles in one wave) streams at half this rate and stays for small clouds.
+template <typename Real, int FACTOR>
+__global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(4))) void certify_linearize_kernel(const LinParams<Real> p, const NNParams<Real> q) {
+  constexpr int PTS = 4;
+  extern __shared__ uint32_t kd_stack[];  // 4 x tree depth x 64 words: the traversal stacks of the waves' walks
+  __shared__ double sh_acc[kTile / 64][kRow];
+  __shared__ unsigned long long sh_failed[kTile / 64][PTS];
+  __shared__ int sh_list[PTS * kTile];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int c = lane; c < kRow; c += 64) sh_acc[wave][c] = 0.0;
+  double* acc_row = sh_acc[wave];
+
+  int tile, stride, tile_end;
+  tile_schedule(p.num_tiles, tile, stride, tile_end);
+  for (; tile < tile_end; tile += stride) {
+    const int base = tile * PTS * kTile;
+    linearize_group<Real, FACTOR, 0, PTS, false, true>(p, base + static_cast<int>(threadIdx.x), kTile, p.n, acc_row, lane, sh_failed[wave]);
+    __syncthreads();
+    {  // the walkers of this step: point of (sub-step u, wave w, lane l) = base + u * kTile + w * 64 + l; every wave counts them, wave 0 lists them
+      int total = 0;
+#pragma unroll
+      for (int u = 0; u < PTS; u++)
+#pragma unroll
+        for (int w = 0; w < kTile / 64; w++) {
+          const unsigned long long m = sh_failed[w][u];
+          if (wave == 0 && ((m >> lane) & 1ull)) sh_list[total + __popcll(m & ((1ull << lane) - 1ull))] = base + u * kTile + w * 64 + lane;
+          total += __popcll(m);
+        }
+      __syncthreads();
+      // spread over the four waves (entry 4 l + w of every 256 goes to lane l of wave w: a fixed assignment): four times the walks in flight
+      uint32_t* my_stack = kd_stack + static_cast<size_t>(wave) * static_cast<size_t>(max(q.kd.depth, 1)) * 64;
+      for (int k0 = 0; k0 < total; k0 += kTile) {
+        const int k = k0 + 4 * lane + wave;
+        const bool mine = k < total;
+        const int i = mine ? sh_list[k] : 0;
+        Real P[1][3] = {{Real(0), Real(0), Real(0)}}, G[1][3] = {{Real(0), Real(0), Real(0)}}, E[1] = {Real(0)};
+        Sym3<Real> Mp[1] = {Sym3<Real>{}};
+        Sym3<Real> Mh{};
+        bool inl = false;
+        if (mine) {
+          const float4 ps = p.src_pts[i];
+          P[0][0] = ps.x, P[0][1] = ps.y, P[0][2] = ps.z;
+          Real t[3];
+          transform_point<Real>(p.T, P[0][0], P[0][1], P[0][2], t[0], t[1], t[2]);
+          const float fx = static_cast<float>(t[0]), fy = static_cast<float>(t[1]), fz = static_cast<float>(t[2]);
+          // seed: the nearer candidate (the check put it first); slack: what the check left in rex[] — both written by this workgroup
+          const int seed = __hip_atomic_load(&q.nn[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const float slack = -__hip_atomic_load(&q.rex[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          // A walker of a warm pass sits next to a surface (its certificate failed by millimetres): ring 1 of the cell grid settles it
+          // with a chain of two dependent loads where the seeded kd walk has a dozen, and its 27 cells give the new certificate a radius
+          // of at least a cell.  The rare walker ring 1 does not settle walks the tree.
+          int j = -1;
+          bool settled = false;
+          if (q.grid_walk) {  // wave-uniform
+            int g_nn, g_nn2;
+            float g_rex, g_seen;
+            settled = grid_ring1_lane(q.grid, fx, fy, fz, q.bound2, g_nn, g_nn2, g_rex, g_seen);
+            if (settled) {
+              q.nn[i] = g_nn;
+              q.nn2[i] = g_nn2;
+              q.rex[i] = g_rex;
+              j = g_nn;
+            }
+          }
+          if (!settled) j = walk_lane<Real, 64>(q, i, fx, fy, fz, seed, slack, my_stack);
+          if (j >= 0) {
+            const float4 m = p.tgt_pts[j];
+            const bool within = kd_dist2(m.x, m.y, m.z, fx, fy, fz) < p.bound2;
+            inl = pair_moments<Real, FACTOR>(p, i, j, within, t[0], t[1], t[2], Real(m.x), Real(m.y), Real(m.z), Mp[0], G[0], E[0], Mh);
+          }
+          p.corr[i] = inl ? j : -1;
+          if constexpr (FACTOR == SGA_GICP) {
+            if (inl && p.store_maha) {
+              Real* mm = p.maha + static_cast<size_t>(i) * 6;
+              mm[0] = Mh.xx, mm[1] = Mh.xy, mm[2] = Mh.xz, mm[3] = Mh.yy, mm[4] = Mh.yz, mm[5] = Mh.zz;
+            }
+          }
+        }
+        const int inliers = __popcll(__ballot(inl));
+        if (inliers > 0) accumulate_moments<Real, 1>(P, Mp, G, E, inliers, acc_row, lane);
+      }
+    }
+    __syncthreads();  // (sh_failed / sh_list are reused by the next step)
+  }
+  __syncthreads();
+  if (threadIdx.x < kRow) {
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < kTile / 64; w++) t += sh_acc[w][threadIdx.x];
+    p.partials[static_cast<size_t>(blockIdx.x) * kRow + threadIdx.x] = t;
+  }
 }
 
 // K1, fused: the search wave also evaluates the factors of its own 64 source points — their neighbours are in registers, no nn[]
@@ -1185,7 +1359,7 @@ static int g_chunk_tiles_cold = getenv("SGA_CHUNK_COLD") ? atoi(getenv("SGA_CHUN
 static const bool g_chunk_adapt = getenv("SGA_CHUNK_ADAPT") ? atoi(getenv("SGA_CHUNK_ADAPT")) != 0 : true;
 static int g_chunk_tiles_warm = getenv("SGA_CHUNK_WARM") ? atoi(getenv("SGA_CHUNK_WARM")) : 4;
 
-int g_grid_mode = getenv("SGA_GRID") ? atoi(getenv("SGA_GRID")) : 0;  // cell-grid passes (see linearize_dispatch; off by default: DESIGN.md section 3.9); sga_set_grid_mode
+int g_grid_mode = getenv("SGA_GRID") ? atoi(getenv("SGA_GRID")) : 1;  // what the cell grid is used for (see linearize_dispatch); sga_set_grid_mode
 long long g_grid_min_points = getenv("SGA_GRID_MIN_POINTS") ? atoll(getenv("SGA_GRID_MIN_POINTS")) : 65536;  // targets below this get no grid (cell_grid.hip)
 
 template <typename Real>
@@ -1247,9 +1421,10 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
   const int math = sizeof(Real) == 4 ? SGA_MATH_FP32 : SGA_MATH_FP64;
   const double displacement = (!voxel && p.n > 0 && pb->prev_valid && pb->prev_math == math) ? max_displacement(T, pb->T_prev, pb->bbox_lo, pb->bbox_hi) : INFINITY;
   bool warm = displacement <= g_warm_delta;
-  // Cell-grid pass (cell_grid.hip): the exact search of a cold pass NEAR the optimum — every pass of a registration but its first
-  // (whose queries lie as far from the target as the initial guess is off: there the kd walk's pruning pays) and but the warm passes after
-  // a small motion (hardly anything to search).  SGA_GRID: 0 (default) never — measured on C3 the grid does not beat the kd walk, DESIGN.md section 3.9 —, 1 by this rule, 2 the first pass too, 3 every pass.
+  // The cell grid (cell_grid.hpp).  SGA_GRID: 0 no grid at all; 1 (default) the WALKERS of warm passes try ring 1 of the grid before they
+  // walk the tree (certify_linearize_kernel) and every full search stays with the kd walk — measured on C3 whole grid passes do not beat
+  // it; 2 = also the cold passes of a registration but its first (whose queries lie as far from the target as the
+  // initial guess is off: there the kd walk's pruning pays) and the warm passes after a larger motion; 3 the first pass too; 4 every pass.
   // If ring 1 of the last grid pass left more than SGA_GRID_MAX_OPEN of the queries open, the next cold pass walks the kd-tree instead.
   const int grid_mode = g_grid_mode;
   static const int grid_max_rings = getenv("SGA_GRID_MAX_RINGS") ? atoi(getenv("SGA_GRID_MAX_RINGS")) : 16;
@@ -1293,8 +1468,10 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
     if (grid_mode != 0 && idx->grid_h > 0.f && q.bound2 < 3.0e38f && !host_rejector && q.leaves == nullptr) {
       const int rings = grid_rings_for(idx, std::sqrt(static_cast<double>(q.bound2)));
       const bool small_warm = warm && displacement <= g_queue_delta;
-      use_grid = rings > 0 && rings <= grid_max_rings &&
-                 (grid_mode >= 3 || (!small_warm && (grid_mode == 2 || (!first_pass && pb->grid_open_frac <= grid_max_open))));
+      use_grid = grid_mode >= 2 && rings > 0 && rings <= grid_max_rings &&
+                 (grid_mode >= 4 || (!small_warm && (grid_mode == 3 || (!first_pass && pb->grid_open_frac <= grid_max_open))));
+      q.grid_walk = 1;  // (used by certify_linearize_kernel only)
+      q.grid = make_grid_view(idx);
       if (first_pass || (!use_grid && !warm)) pb->grid_open_frac = 0.0;  // a kd pass in between: the grid gets another chance afterwards
     }
     if (use_grid) {
@@ -1306,11 +1483,37 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
       pb->grid_passes++;
     }
     const bool queue = !use_grid && (g_search_queue == 1 || (g_search_queue == 2 && warm && displacement <= g_queue_delta));
+    // Warm pass of a large cloud after a small motion: the certificates are checked inside the streaming factor kernel
+    // (certify_linearize_kernel), whose workgroups walk their few failed points themselves.  SGA_WARM_SPLIT=0: the older form
+    // (certificate check, queue-fed walks and factors per chunk in nn_search_queue_kernel).
+    static const bool warm_split = getenv("SGA_WARM_SPLIT") ? atoi(getenv("SGA_WARM_SPLIT")) != 0 : true;
+    // Measured on C3 (profiles/r04_warm_split.txt): it wins where few points walk (after motions of a millimetre or two: 38 - 54 us
+    // against 44 - 66) and loses where many do (the walkers of a pass sit where the points moved most, i.e. in a few workgroups, which
+    // then walk alone: 121 against 99 us after a 1 cm motion), hence the second, smaller limit SGA_SPLIT_DELTA.
+    static const double split_delta = getenv("SGA_SPLIT_DELTA") ? atof(getenv("SGA_SPLIT_DELTA")) : 0.002;
+    const bool split = warm_split && queue && warm && displacement <= split_delta && g_search_queue == 2 && g_fuse_search && !host_rejector && sizeof(Real) == 4 && pts == kLinPts && q.leaves == nullptr && !fuse;
     fused_search = !use_grid && g_fuse_search && !host_rejector && !queue && sizeof(Real) == 4;  // fp64 math: the fused kernel would spill
     const unsigned order_tiles_before = pb->order_tiles;
     pb->order_tiles = 0;  // (set again below when this pass records its tiles' durations)
     if (use_grid) {
       // searched above; the factors follow as linearize_kernel over nn[]
+    } else if (split) {
+      p.tail.enabled = 0;
+      p.cert_nn = pb->hint.p;
+      p.cert_nn2 = pb->hint2.p;
+      p.cert_rex = pb->rex.p;
+      p.cert_walked = pb->walked.p;
+      p.T_prev = q.T_prev;
+      p.cert_within2 = q.within2;
+      p.cert_slack_min = q.slack_min, p.cert_slack_max = q.slack_max;
+      const size_t lds = std::max<size_t>(words, 1) * 64 * sizeof(uint32_t) * (kTile / 64);
+      switch (fp->factor_kind) {
+        case SGA_GICP: hipLaunchKernelGGL((certify_linearize_kernel<Real, SGA_GICP>), dim3(blocks), dim3(kTile), lds, ctx->stream, p, q); break;
+        case SGA_PLANE_ICP: hipLaunchKernelGGL((certify_linearize_kernel<Real, SGA_PLANE_ICP>), dim3(blocks), dim3(kTile), lds, ctx->stream, p, q); break;
+        default: hipLaunchKernelGGL((certify_linearize_kernel<Real, SGA_ICP>), dim3(blocks), dim3(kTile), lds, ctx->stream, p, q); break;
+      }
+      fused_search = true;
+      fused_rows = blocks;
     } else if (fused_search) {
       // every search wave evaluates the factors of its own tile: one partial row per tile of 64 points, summed by reduce_rows_kernel
       p.tail.enabled = 0;

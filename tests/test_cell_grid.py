@@ -19,10 +19,10 @@ def restore_modes():
     lim = sga.get_warm_limit()
     yield
     sga.set_warm_limit(lim)
-    sga.set_grid_mode(0, 65536)
+    sga.set_grid_mode(1, 65536)
 
 
-def both(tree, src, setting, poses, rel=2e-6, grid_mode=3):
+def both(tree, src, setting, poses, rel=2e-6, grid_mode=4):
     """linearize along `poses` on two problems — one searched by the grid, one by the kd walk only — and compare everything."""
     pg, pk = sga.Problem(tree, src), sga.Problem(tree, src)
     for k, T in enumerate(poses):
@@ -48,7 +48,7 @@ def both(tree, src, setting, poses, rel=2e-6, grid_mode=3):
 def test_grid_equals_kd_on_c1(c1_f32, kind, mode):
     """C1 (real scans, 6k points after the voxel grid) with a grid forced onto the small target: every pass of an LM-shaped pose chain."""
     d = c1_f32
-    sga.set_grid_mode(3, 16)
+    sga.set_grid_mode(4, 16)
     tgt = sga.PointCloud(d["tp"], d["tn"], d["tc"])
     src = sga.PointCloud(d["sp"], d["sn"], d["sc"])
     tree = sga.KdTree(tgt)
@@ -64,7 +64,7 @@ def test_grid_equals_kd_on_the_synthetic_scene(max_dist):
     """200k <-> 200k points of the benchmark scene (walls six times denser than the ground, 10 % clutter far from everything): far pose,
     near pose, optimum; rejector reach from a fifth of a cell to ten cells."""
     target, source, T_gt = sga.synthetic.registration_pair(200_000)
-    sga.set_grid_mode(3, 16)
+    sga.set_grid_mode(4, 16)
     tgt, src = sga.PointCloud(target), sga.PointCloud(source)
     tree = sga.KdTree(tgt)
     st = sga.make_setting("ICP", max_correspondence_distance=max_dist)
@@ -74,10 +74,10 @@ def test_grid_equals_kd_on_the_synthetic_scene(max_dist):
 
 
 def test_grid_certificates_serve_the_warm_passes():
-    """mode 2: the first pass and the cold passes go through the grid, the passes after small motions are warm and consume the
+    """mode 3: the first pass and the cold passes go through the grid, the passes after small motions are warm and consume the
     certificates the grid wrote — compared with cold kd walks at every pose."""
     target, source, T_gt = sga.synthetic.registration_pair(150_000)
-    sga.set_grid_mode(2, 16)
+    sga.set_grid_mode(3, 16)
     tgt, src = sga.PointCloud(target), sga.PointCloud(source)
     sga.estimate_covariances(tgt, None, 10)
     sga.estimate_covariances(src, None, 10)
@@ -86,7 +86,7 @@ def test_grid_certificates_serve_the_warm_passes():
     poses = pose_chain(T_gt, fractions=(0.0, 0.9, 0.99, 0.998, 0.9995, 0.9999, 1.0, 1.0))
     pg, pk = sga.Problem(tree, src), sga.Problem(tree, src)
     for k, T in enumerate(poses):
-        sga.set_grid_mode(2)
+        sga.set_grid_mode(3)
         sga.set_warm_limit(0.1)
         Hg, bg, eg, ng = pg.linearize(st.factor, T)
         cg, _ = pg.factors()
@@ -111,7 +111,7 @@ def test_grid_ties_follow_the_canonical_rule():
     base = target[rng.integers(0, len(target), 60_000)]
     off = rng.choice([0.0, 0.125], size=base.shape).astype(np.float32)  # exactly between lattice points along a random subset of the axes
     source = (base + off).astype(np.float32)
-    sga.set_grid_mode(3, 16)
+    sga.set_grid_mode(4, 16)
     tgt, src = sga.PointCloud(target), sga.PointCloud(source)
     tree = sga.KdTree(tgt)
     st = sga.make_setting("ICP", max_correspondence_distance=1.0)
@@ -123,7 +123,7 @@ def test_grid_queries_outside_the_target_box_and_without_neighbours():
     rng = np.random.default_rng(11)
     target = (rng.uniform(-5, 5, size=(120_000, 3)) * np.array([1.0, 1.0, 0.02])).astype(np.float32)  # a 10 m x 10 m slab
     source = (rng.uniform(-15, 15, size=(80_000, 3)) * np.array([1.0, 1.0, 0.1])).astype(np.float32)
-    sga.set_grid_mode(3, 16)
+    sga.set_grid_mode(4, 16)
     tgt, src = sga.PointCloud(target), sga.PointCloud(source)
     tree = sga.KdTree(tgt)
     for md in (0.2, 1.5):
@@ -132,9 +132,9 @@ def test_grid_queries_outside_the_target_box_and_without_neighbours():
 
 
 def test_registration_result_does_not_depend_on_the_search():
-    """A whole C3-shaped registration (300k points, GICP, default policy: the grid from the second pass on) against kd walks only."""
+    """A whole C3-shaped registration (300k points, GICP, mode 2: the grid from the second pass on) against kd walks only."""
     target, source, T_gt = sga.synthetic.registration_pair(300_000)
-    sga.set_grid_mode(1)  # (the index gets its grid when it is built)
+    sga.set_grid_mode(2)  # (the index gets its grid when it is built)
     tgt, src = sga.PointCloud(target), sga.PointCloud(source)
     sga.estimate_covariances(tgt, None, 20)
     sga.estimate_covariances(src, None, 20)

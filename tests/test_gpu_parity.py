@@ -407,8 +407,16 @@ def test_c3_properties(c3):
     H3, b3, e3, n3 = pb.linearize(st.factor, T)
     ps = pb.pass_stats()
     assert ps["cold_passes"] == 1 and ps["warm_passes"] == 2 and ps["walked_points"] < 2000, ps  # only near-ties (runner-up within 1e-5) walk again
-    # determinism: same launch, bit-identical sums; warm vs cold: the same pairs, sums equal to fp64 rounding
-    assert (H2 == H3).all() and (b2 == b3).all() and e2 == e3 and n2 == n3
+    # two warm passes at the same pose: the same pairs; the few points that walked in the first (near-ties) are certified in the second,
+    # so their terms move from the walk phase's fp32 wave sums (one point per lane) to the streaming phase's (four): equal to fp32 rounding of
+    # a few hundred terms among a million, not bit for bit
+    assert np.abs(H2 - H3).max() <= 1e-8 * np.abs(H2).max() and np.abs(b2 - b3).max() <= 1e-8 * np.abs(H2).max() and abs(e2 - e3) <= 1e-8 * e2 and n2 == n3
+    # determinism: the same sequence of calls on a fresh problem gives bit-identical sums (no floating-point atomics anywhere)
+    pb_again = sga.Problem(c3["tree"], c3["src"])
+    Ha, ba, ea, na = pb_again.linearize(st.factor, T)
+    Ha2, ba2, ea2, na2 = pb_again.linearize(st.factor, T)
+    assert (Ha == H).all() and (ba == b).all() and ea == e and na == n
+    assert (Ha2 == H2).all() and (ba2 == b2).all() and ea2 == e2 and na2 == n2
     # cold vs warm: the same neighbours; the two passes run different kernels (one point per lane and row per tile / four points per
     # lane and row per chunk), so the fp32 partial sums group differently
     assert np.abs(H - H2).max() <= 1e-6 * np.abs(H).max() and np.abs(b - b2).max() <= 1e-6 * np.abs(H).max() and abs(e - e2) <= 1e-7 * e and n == n2
