@@ -211,6 +211,9 @@ int sga_context_set_profiling(sga_context* ctx, int enabled);
 int sga_context_get_kernel_ms(sga_context* ctx, double* linearize_ms, uint64_t* linearize_calls, double* error_ms, uint64_t* error_calls);
 /* The part of a COLD pass's time spent in the nearest-neighbour search kernel (the rest: factor evaluation + block reduction). */
 int sga_context_get_search_ms(sga_context* ctx, double* search_ms, uint64_t* search_calls);
+/* Sharded contexts (sga_comm_init*): average time (ms) of the timed passes between the end of the row reduction and the end of the all-reduce
+ * of the accumulator on the context's stream — the time inside the collective, incl. waiting for the slowest rank. */
+int sga_context_get_comm_ms(sga_context* ctx, double* comm_ms, uint64_t* comm_calls);
 /* linearize_ms split by kind of pass against a kd-tree.  cold = the exact nearest-neighbour walk (kdtree.hpp:193-233) for every source
  * point; warm = the neighbour of the previous linearization is kept wherever it is certified still exact (its exclusion radius minus
  * the point's motion since, triangle inequality) and only the other points walk.  Same results either way, bit for bit in the

@@ -34,7 +34,7 @@ for f in find("trace/**/*kernel_trace.csv"):
     durs = defaultdict(list)
     for r in csv.DictReader(open(f)):
         kn = r.get("Kernel_Name", "")
-        for key in ("search_linearize_kernel", "nn_search_queue_kernel", "nn_search_kernel", "linearize_kernel", "error_kernel", "reduce_rows_kernel"):
+        for key in ("search_linearize_kernel", "certify_linearize_kernel", "nn_search_queue_kernel", "nn_search_kernel", "linearize_kernel", "error_kernel", "reduce_rows_kernel"):
             if key in kn:
                 durs[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
                 break
@@ -44,7 +44,7 @@ for f in find("trace/**/*kernel_trace.csv"):
         print("%-22s n=%d  %.1f / %.1f / %.1f / %.1f" % (k, len(v), v[0], v[len(v) // 2], sum(v) / len(v), v[-1]))
         summary.setdefault("durations_us", {})[k] = {"n": len(v), "min": v[0], "median": v[len(v) // 2], "mean": sum(v) / len(v), "max": v[-1]}
 
-K1_SEARCH = ("search_linearize_kernel", "nn_search_queue_kernel", "nn_search_kernel")  # one launch of these per linearization pass
+K1_SEARCH = ("search_linearize_kernel", "certify_linearize_kernel", "nn_search_queue_kernel", "nn_search_kernel")  # one launch of these per linearization pass
 
 
 def k1_kind(name):
@@ -81,8 +81,8 @@ if totals.get("FETCH_SIZE") and totals.get("WRITE_SIZE"):
         hbm = int((2.0 * fetch_kb / passes + write_kb / passes_w) * 1024)
         traffic = {
             "kernel": "K1 = the launch(es) of one linearization pass, config C3 1M<->1M: sga::search_linearize_kernel<float, GICP> (cold passes and the first warm ones: search + factors in one launch), "
-                      "sga::nn_search_queue_kernel<float, warm, GICP> (warm passes after small motions: certificate check, queue-fed walks, factors), and on the non-fused paths "
-                      "sga::nn_search_kernel + sga::linearize_kernel; averaged over the passes of whole registrations",
+                      "sga::nn_search_queue_kernel<float, warm, GICP> (warm passes after motions of 2 - 20 mm: certificate check, queue-fed walks, factors), sga::certify_linearize_kernel<float, GICP> (warm passes "
+                      "after smaller motions: certificate check inside the streaming factor kernel), and on the non-fused paths sga::nn_search_kernel + sga::linearize_kernel; averaged over the passes of whole registrations",
             "source": "scripts/profile_gpu.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py",
             "commit": commit,
             "passes": passes,

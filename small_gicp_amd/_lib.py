@@ -116,6 +116,7 @@ SYMBOLS = [
     ("sga_context_set_stream_ordered", C.c_int, [_vp, C.c_int]),
     ("sga_context_set_profiling", C.c_int, [_vp, C.c_int]),
     ("sga_context_get_kernel_ms", C.c_int, [_vp, _dp, C.POINTER(C.c_uint64), _dp, C.POINTER(C.c_uint64)]),
+    ("sga_context_get_comm_ms", C.c_int, [_vp, _dp, C.POINTER(C.c_uint64)]),
     ("sga_context_get_search_ms", C.c_int, [_vp, _dp, C.POINTER(C.c_uint64)]),
     ("sga_context_get_pass_ms", C.c_int, [_vp, _dp, C.POINTER(C.c_uint64), _dp, C.POINTER(C.c_uint64), _dp]),
     ("sga_set_warm_limit", None, [C.c_double]),

@@ -101,8 +101,11 @@ class Context:
         cc, wc = C.c_uint64(), C.c_uint64()
         wf = C.c_double()
         check(load().sga_context_get_pass_ms(self.h, C.byref(cm), C.byref(cc), C.byref(wm), C.byref(wc), C.byref(wf)))
+        km, kc = C.c_double(), C.c_uint64()
+        check(load().sga_context_get_comm_ms(self.h, C.byref(km), C.byref(kc)))
         return {"linearize_ms": lm.value, "linearize_calls": lc.value, "error_ms": em.value, "error_calls": ec.value, "search_ms": sm.value, "search_calls": sc.value,
-                "cold_ms": cm.value, "cold_calls": cc.value, "warm_ms": wm.value, "warm_calls": wc.value, "warm_search_ms": wf.value}
+                "cold_ms": cm.value, "cold_calls": cc.value, "warm_ms": wm.value, "warm_calls": wc.value, "warm_search_ms": wf.value,
+                "comm_ms": km.value, "comm_calls": kc.value}
 
 
 _DEFAULT_CTX = None

@@ -121,6 +121,10 @@ struct sga_context {
   unsigned lin_seq = 0, err_seq = 0;
   int pending = 0;  // bit 0 = the linearize event pair (ev0, ev1) awaits collection, bit 1 = the error pair (ev2, ev3)
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr, ev_mid = nullptr;  // ev_mid: between the search and the factor kernel
+  hipEvent_t ev_comm = nullptr;  // behind the all-reduce of a timed pass (sharded contexts): ev1 -> ev_comm = the time inside the collective
+  bool comm_recorded = false;
+  double comm_ms = 0.0;
+  uint64_t comm_calls = 0;
   hipEvent_t ev_aux = nullptr;   // small read-backs that must not wait for the work enqueued behind them (stream-ordered mode)
   bool stream_ordered = false;   // sga_context_set_stream_ordered: preprocessing entry points return once their work is enqueued
   bool mid_recorded = false;

@@ -373,7 +373,7 @@ static int context_create_impl(int device, void* stream, bool borrow, sga_contex
     ctx->h_scratch = reinterpret_cast<int*>(ctx->h_accum + 136);  // doubles [136, 144) of the pinned block
     if (hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->h_accum_dev), ctx->h_accum, 0) != hipSuccess) rc = fail(SGA_ERR_HIP, "hipHostGetDevicePointer failed");
   }
-  if (rc == SGA_OK && (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess || hipEventCreate(&ctx->ev2) != hipSuccess || hipEventCreate(&ctx->ev3) != hipSuccess || hipEventCreate(&ctx->ev_mid) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_aux, hipEventDisableTiming) != hipSuccess)) rc = fail(SGA_ERR_HIP, "hipEventCreate failed");
+  if (rc == SGA_OK && (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess || hipEventCreate(&ctx->ev2) != hipSuccess || hipEventCreate(&ctx->ev3) != hipSuccess || hipEventCreate(&ctx->ev_mid) != hipSuccess || hipEventCreate(&ctx->ev_comm) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_aux, hipEventDisableTiming) != hipSuccess)) rc = fail(SGA_ERR_HIP, "hipEventCreate failed");
   if (rc != SGA_OK) {
     sga_context_destroy(ctx);
     return rc;
@@ -395,6 +395,7 @@ int sga_context_destroy(sga_context* ctx) {
   if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
   if (ctx->ev3) (void)hipEventDestroy(ctx->ev3);
   if (ctx->ev_mid) (void)hipEventDestroy(ctx->ev_mid);
+  if (ctx->ev_comm) (void)hipEventDestroy(ctx->ev_comm);
   if (ctx->ev_aux) (void)hipEventDestroy(ctx->ev_aux);
   if (ctx->h_accum) (void)hipHostFree(ctx->h_accum);
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
@@ -456,6 +457,9 @@ int sga_context_set_profiling(sga_context* ctx, int enabled) {
   ctx->search_calls = 0;
   ctx->warm_ms = ctx->cold_ms = ctx->warm_first_ms = 0.0;
   ctx->warm_calls = ctx->cold_calls = 0;
+  ctx->comm_ms = 0.0;
+  ctx->comm_calls = 0;
+  ctx->comm_recorded = false;
   ctx->pending = 0;
   return SGA_OK;
 }
@@ -478,6 +482,14 @@ int sga_context_get_pass_ms(sga_context* ctx, double* cold_ms, uint64_t* cold_ca
   if (warm_ms) *warm_ms = ctx->warm_calls ? ctx->warm_ms / ctx->warm_calls : 0.0;
   if (warm_calls) *warm_calls = ctx->warm_calls;
   if (warm_search_ms) *warm_search_ms = ctx->warm_calls ? ctx->warm_first_ms / ctx->warm_calls : 0.0;
+  return SGA_OK;
+}
+
+int sga_context_get_comm_ms(sga_context* ctx, double* comm_ms, uint64_t* comm_calls) {
+  if (!ctx) return fail(SGA_ERR_INVALID, "null context");
+  sga_profile_collect_pending(ctx);
+  if (comm_ms) *comm_ms = ctx->comm_calls ? ctx->comm_ms / ctx->comm_calls : 0.0;
+  if (comm_calls) *comm_calls = ctx->comm_calls;
   return SGA_OK;
 }
 

@@ -1802,6 +1802,11 @@ void sga_profile_collect_pending(sga_context* ctx) {
       }
     }
     ctx->mid_recorded = false;
+    if (ctx->comm_recorded && hipEventSynchronize(ctx->ev_comm) == hipSuccess && hipEventElapsedTime(&ms, ctx->ev1, ctx->ev_comm) == hipSuccess) {
+      ctx->comm_ms += ms;
+      ctx->comm_calls++;
+    }
+    ctx->comm_recorded = false;
   }
   if (ctx->pending & 2) {
     if (hipEventSynchronize(ctx->ev3) == hipSuccess && hipEventElapsedTime(&ms, ctx->ev2, ctx->ev3) == hipSuccess) {
@@ -1921,6 +1926,10 @@ int linearize_enqueue(sga_context* ctx, sga_problem* pb, const sga_factor_params
   const int count = model ? kRow : SGA_ACCUM_DOUBLES;
   SGA_TRY(fp->math_mode == SGA_MATH_FP64 ? linearize_dispatch<double>(ctx, pb, fp, T, ctx->d_accum.p, host, seq, model) : linearize_dispatch<float>(ctx, pb, fp, T, ctx->d_accum.p, host, seq, model));
   int rc = comm_allreduce_sum(ctx, ctx->d_accum.p, count);  // source sharded over ranks: sum the shards' systems (and error models)
+  if (rc == SGA_OK && !direct && (ctx->pending & 1)) {  // a timed pass: ev1 (behind the row reduction) -> ev_comm = the time inside the collective
+    (void)hipEventRecord(ctx->ev_comm, ctx->stream);
+    ctx->comm_recorded = true;
+  }
   if (rc == SGA_OK && !direct) {
     hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(kCols), 0, ctx->stream, ctx->d_accum.p, count, ctx->h_accum_dev, seq);
     if (hipGetLastError() != hipSuccess) rc = fail(SGA_ERR_HIP, "publish_kernel launch failed");

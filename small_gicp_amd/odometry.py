@@ -263,6 +263,35 @@ def run_synthetic(num_frames=20, **kw):
     }
 
 
+def run_synthetic_pairs(num_frames, rank, world, device=0, **kw):
+    """Frame-pair parallelism over ranks (the other way to spread C5 over GPUs): under the reference's protocol every pair (scan f-1, scan f)
+    is registered from the identity (odometry_benchmark_small_gicp_omp.cpp:16-49), so the pairs are independent — rank r takes the
+    contiguous block of frames [r F / W, (r + 1) F / W), preprocesses those scans plus the one before the block, and registers its pairs
+    on a context of its own with no collective at all.  Returns this rank's wall time, its relative poses {f: T_(f-1) f} and frame count;
+    the job's ms/scan is max over ranks of the wall time / F."""
+    import time as _time
+
+    from . import synthetic
+
+    lo, hi = rank * num_frames // world, (rank + 1) * num_frames // world
+    odom = OnlineOdometry(ctx=api.Context(device), **kw)
+    rel = {}
+    # generate the scans first: the generator is host work that a real stream would not pay
+    scans = {f: synthetic.kitti_like_scan(f)[0] for f in range(max(lo - 1, 0), hi)}
+    odom.ctx.synchronize()
+    t0 = _time.perf_counter()
+    prev_T = None
+    for f in sorted(scans):
+        T = odom.estimate(scans[f])
+        if prev_T is not None and f >= max(lo, 1):
+            rel[f] = np.linalg.inv(prev_T) @ T
+        prev_T = T
+    odom.ctx.synchronize()
+    el = _time.perf_counter() - t0
+    odom.close()
+    return {"seconds": el, "frames": hi - lo, "relative_poses": rel}
+
+
 def run_synthetic_pipelined(num_frames=20, **kw):
     """Throughput of the two-stream pipeline on the synthetic sequence: wall time / frame with all frames in flight."""
     from . import synthetic
