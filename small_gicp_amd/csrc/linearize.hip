@@ -901,9 +901,8 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(4))) void
 // workgroup then walks them, 64 at a time (seeded top-down walk with exploration slack, walk_lane), and adds their factors to its row —
 // while the other workgroups stream on.  One launch, one partial row per workgroup; the old form (nn_search_queue_kernel: certificate
 // check, queue-fed walks and factors per chunk of 4 tiles in one wave) streams at half this rate and stays for small clouds.
-template <typename Real, int FACTOR>
+template <typename Real, int FACTOR, int PTS>
 __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(4))) void certify_linearize_kernel(const LinParams<Real> p, const NNParams<Real> q) {
-  constexpr int PTS = 4;
   extern __shared__ uint32_t kd_stack[];  // 4 x tree depth x 64 words: the traversal stacks of the waves' walks
   __shared__ double sh_acc[kTile / 64][kRow];
   __shared__ unsigned long long sh_failed[kTile / 64][PTS];
@@ -989,8 +988,12 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(4))) void
     double t = 0.0;
 #pragma unroll
     for (int w = 0; w < kTile / 64; w++) t += sh_acc[w][threadIdx.x];
-    p.partials[static_cast<size_t>(blockIdx.x) * kRow + threadIdx.x] = t;
+    if (p.tail.enabled)
+      __hip_atomic_store(&p.partials[static_cast<size_t>(blockIdx.x) * kRow + threadIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+      p.partials[static_cast<size_t>(blockIdx.x) * kRow + threadIdx.x] = t;
   }
+  if (p.tail.enabled) fused_tail(p.tail, p.partials, gridDim.x, kModelCols, kRow, true);  // small grids: the last workgroup adds the rows and hands the result over
 }
 
 // K1, fused: the search wave also evaluates the factors of its own 64 source points — their neighbours are in registers, no nn[]
@@ -1438,6 +1441,7 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
     (void)hipEventRecord(ctx->ev0, ctx->stream);
     ctx->pending_warm = warm;
   }
+  bool split_fused_tail = false;  // certify_linearize_kernel of a small grid: the row reduction and the hand-off happen inside it
   bool fused_search = false;  // the search kernel evaluates the factors itself ...
   bool record_tiles = false;  // ... and records the duration of every tile's wave (longest tile first, tile_order_kernel)
   int fused_rows = 0;         // ... and leaves this many partial rows
@@ -1491,14 +1495,26 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
     // against 44 - 66) and loses where many do (the walkers of a pass sit where the points moved most, i.e. in a few workgroups, which
     // then walk alone: 121 against 99 us after a 1 cm motion), hence the second, smaller limit SGA_SPLIT_DELTA.
     static const double split_delta = getenv("SGA_SPLIT_DELTA") ? atof(getenv("SGA_SPLIT_DELTA")) : 0.002;
-    const bool split = warm_split && queue && warm && displacement <= split_delta && g_search_queue == 2 && g_fuse_search && !host_rejector && sizeof(Real) == 4 && pts == kLinPts && q.leaves == nullptr && !fuse;
+    // Only from SGA_SPLIT_MIN_POINTS source points on (default 131072 = SGA_LIN_PTS_MIN): measured on C2 (100k points) and C5 (12k-point
+    // scans) the kernel — one point per lane there, the row reduction folded into it (fused_tail) when the grid is small — is no faster
+    // than the queue-fed one (C2 warm pass 39.9 against 40.3 us, C5 registration 0.51 against 0.48 ms/scan; with 4 points per lane 53.9 us):
+    // at those sizes a pass is a chain of launch, a few dependent loads and the hand-off, whichever kernel runs it.
+    static const size_t split_min_points = getenv("SGA_SPLIT_MIN_POINTS") ? static_cast<size_t>(atoll(getenv("SGA_SPLIT_MIN_POINTS"))) : 131072;
+    static const int split_pts_env = getenv("SGA_SPLIT_PTS") ? atoi(getenv("SGA_SPLIT_PTS")) : 0;
+    const bool split = warm_split && queue && warm && displacement <= split_delta && g_search_queue == 2 && g_fuse_search && !host_rejector && sizeof(Real) == 4 && pb->n >= split_min_points && q.leaves == nullptr;
     fused_search = !use_grid && g_fuse_search && !host_rejector && !queue && sizeof(Real) == 4;  // fp64 math: the fused kernel would spill
     const unsigned order_tiles_before = pb->order_tiles;
     pb->order_tiles = 0;  // (set again below when this pass records its tiles' durations)
     if (use_grid) {
       // searched above; the factors follow as linearize_kernel over nn[]
     } else if (split) {
-      p.tail.enabled = 0;
+      const int spts = split_pts_env == 1 || split_pts_env == 4 ? split_pts_env : pts;
+      LinParams<Real>& pc = p;
+      pc.num_tiles = (p.n + kTile * spts - 1) / (kTile * spts);
+      const int cblocks = grid_blocks(pc.num_tiles);
+      const bool cfuse = cblocks <= g_fuse_max;
+      pc.tail = FusedTail{cfuse ? 1 : 0, ctx->d_ticket.p, d_out30, out_n, host, seq};
+      split_fused_tail = cfuse;
       p.cert_nn = pb->hint.p;
       p.cert_nn2 = pb->hint2.p;
       p.cert_rex = pb->rex.p;
@@ -1507,13 +1523,21 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
       p.cert_within2 = q.within2;
       p.cert_slack_min = q.slack_min, p.cert_slack_max = q.slack_max;
       const size_t lds = std::max<size_t>(words, 1) * 64 * sizeof(uint32_t) * (kTile / 64);
+#define SGA_CERTIFY(F)                                                                                                                      \
+  do {                                                                                                                                      \
+    if (spts == kLinPts)                                                                                                                    \
+      hipLaunchKernelGGL((certify_linearize_kernel<Real, F, kLinPts>), dim3(cblocks), dim3(kTile), lds, ctx->stream, p, q);                 \
+    else                                                                                                                                    \
+      hipLaunchKernelGGL((certify_linearize_kernel<Real, F, 1>), dim3(cblocks), dim3(kTile), lds, ctx->stream, p, q);                       \
+  } while (0)
       switch (fp->factor_kind) {
-        case SGA_GICP: hipLaunchKernelGGL((certify_linearize_kernel<Real, SGA_GICP>), dim3(blocks), dim3(kTile), lds, ctx->stream, p, q); break;
-        case SGA_PLANE_ICP: hipLaunchKernelGGL((certify_linearize_kernel<Real, SGA_PLANE_ICP>), dim3(blocks), dim3(kTile), lds, ctx->stream, p, q); break;
-        default: hipLaunchKernelGGL((certify_linearize_kernel<Real, SGA_ICP>), dim3(blocks), dim3(kTile), lds, ctx->stream, p, q); break;
+        case SGA_GICP: SGA_CERTIFY(SGA_GICP); break;
+        case SGA_PLANE_ICP: SGA_CERTIFY(SGA_PLANE_ICP); break;
+        default: SGA_CERTIFY(SGA_ICP); break;
       }
+#undef SGA_CERTIFY
       fused_search = true;
-      fused_rows = blocks;
+      fused_rows = cblocks;
     } else if (fused_search) {
       // every search wave evaluates the factors of its own tile: one partial row per tile of 64 points, summed by reduce_rows_kernel
       p.tail.enabled = 0;
@@ -1616,7 +1640,9 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
       }
     }
   }
-  if (fused_search) {
+  if (fused_search && split_fused_tail) {
+    // (done inside the kernel)
+  } else if (fused_search) {
     launch_reduce(ctx, pb->partials.p, fused_rows, ncols, kRow, pb->partials.p + partial_rows(pb->n) * kRow, d_out30, out_n, host, seq, true);
   }
   else if (!fuse)
