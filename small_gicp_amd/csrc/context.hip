@@ -3,6 +3,22 @@
 
 #include <map>
 #include <mutex>
+
+namespace sga {
+void preload_hot_kernels();  // linearize.hip
+
+// The first kernel of a queue that needs scratch memory (a few spilled registers are enough: certify_linearize_kernel has 20 bytes per
+// lane) makes the runtime allocate the queue's scratch arena: ~0.2 ms, paid in the middle of somebody's first registration.  A context
+// pays it when it is created instead: one tiny launch with 256 bytes of private memory per lane on its stream.
+__global__ void scratch_prime_kernel(int* out, int n) {
+  volatile int buf[64];
+  for (int i = 0; i < 64; i++) buf[i] = i * n;
+  int t = 0;
+  for (int i = 0; i < 64; i++) t += buf[(i * 7 + n) & 63];
+  if (n < 0) *out = t;  // never taken: the array must not be optimised away
+}
+}  // namespace sga
+
 #include <unordered_map>
 
 namespace sga {
@@ -377,6 +393,12 @@ static int context_create_impl(int device, void* stream, bool borrow, sga_contex
   if (rc != SGA_OK) {
     sga_context_destroy(ctx);
     return rc;
+  }
+  hipLaunchKernelGGL(scratch_prime_kernel, dim3(1), dim3(64), 0, ctx->stream, static_cast<int*>(nullptr), 1);
+  (void)hipGetLastError();
+  {  // once per process: resolve the hot kernels now instead of in the middle of the first registration (linearize.hip)
+    static std::once_flag preload_once;
+    std::call_once(preload_once, [] { preload_hot_kernels(); });
   }
   *out = ctx;
   return SGA_OK;

@@ -2139,6 +2139,39 @@ int sga_debug_kd_trips(unsigned long long*) { return fail(SGA_ERR_UNSUPPORTED, "
 int sga_debug_kd_wave_times(unsigned long long*, int) { return fail(SGA_ERR_UNSUPPORTED, "wave timers exist in the diagnostics build only (make trips)"); }
 #endif
 
+}  // extern "C"
+
+namespace sga {
+// The HIP runtime resolves a kernel (code object lookup, kernel descriptor, launch metadata) the first time it is used: 100 - 200 us each,
+// paid in the middle of somebody's first registration — the kernels of the late LM iterations are first launched several passes in.
+// Called once per process when the first context is created: asking for a kernel's attributes resolves it without launching anything.
+void preload_hot_kernels() {
+  hipFuncAttributes a;
+#define SGA_PRELOAD(...) (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&__VA_ARGS__))
+#define SGA_PRELOAD_FACTOR(F)                                        \
+  SGA_PRELOAD(search_linearize_kernel<float, F, false>);            \
+  SGA_PRELOAD(search_linearize_kernel<float, F, true>);             \
+  SGA_PRELOAD(nn_search_queue_kernel<float, true, F>);              \
+  SGA_PRELOAD(certify_linearize_kernel<float, F, kLinPts>);         \
+  SGA_PRELOAD(linearize_kernel<float, F, 0, kLinPts>);              \
+  SGA_PRELOAD(linearize_kernel<float, F, 0, 1>)
+  SGA_PRELOAD_FACTOR(SGA_GICP);
+  SGA_PRELOAD_FACTOR(SGA_PLANE_ICP);
+  SGA_PRELOAD_FACTOR(SGA_ICP);
+  SGA_PRELOAD(linearize_kernel<float, SGA_GICP, 1, kLinPts>);
+  SGA_PRELOAD(linearize_kernel<float, SGA_GICP, 1, 1>);
+  SGA_PRELOAD(reduce_rows_kernel);
+  SGA_PRELOAD(tile_order_kernel);
+  SGA_PRELOAD(publish_kernel);
+  SGA_PRELOAD(error_kernel<float, SGA_GICP>);
+#undef SGA_PRELOAD_FACTOR
+#undef SGA_PRELOAD
+  (void)hipGetLastError();
+}
+}  // namespace sga
+
+extern "C" {
+
 // experiments / tests: when the cell grid searches (SGA_GRID) and from how many target points on an index gets one (SGA_GRID_MIN_POINTS;
 // affects indices built afterwards); negative values keep the current setting
 void sga_set_grid_mode(int mode, long long min_points) {
