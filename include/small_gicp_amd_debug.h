@@ -19,8 +19,9 @@ int sga_problem_get_search_stats(sga_context* ctx, const sga_problem* pb, int* l
 int sga_problem_get_sorted_points(sga_context* ctx, const sga_problem* pb, float* xyzw);
 /* Cell-grid passes (cell_grid.hip) since the problem was created: out[0] = passes searched through the grid, out[1] = queries their
  * first ring left open (finished by the second kernel), out[2] = sum of the rings those queries then scanned, out[3] = cell edge in
- * micrometres (0: the target has no grid). */
-int sga_problem_get_grid_stats(const sga_problem* pb, uint64_t out[4]);
+ * micrometres (0: the target has no grid); with SGA_ADJ_STATS set: out[4] = queries that went through the leaf adjacency lists, out[5] =
+ * those the lists did not settle (they walked the tree), cumulative. */
+int sga_problem_get_grid_stats(const sga_problem* pb, uint64_t out[6]);
 /* What the cell grid (a second, flat search structure of large kd-tree indices) is used for; results do not depend on it (tests compare
  * the searches): mode 0 nothing (no grid is built); 1 (default) the walkers of warm passes try its first ring before they walk the tree;
  * 2 also the cold passes of a registration but its first; 3 the first pass too; 4 every pass.  min_points: targets with fewer points get

@@ -33,7 +33,7 @@ for rep in range(2):
         s = pb.pass_stats()
         moved = None if prev["T"] is None else float(np.linalg.norm(corners @ (T[:3, :3] - prev["T"][:3, :3]).T + (T[:3, 3] - prev["T"][:3, 3]), axis=1).max())
         kind = "warm" if s["warm_passes"] > prev["stats"]["warm_passes"] else ("grid" if s["grid_passes"] > prev["stats"]["grid_passes"] else "cold")
-        rows.append((moved, kind, k["linearize_ms"] * 1e3, k["search_ms"] * 1e3, s["walked_points"] - prev["stats"]["walked_points"], s["grid_open"] - prev["stats"]["grid_open"], s["grid_rings"] - prev["stats"]["grid_rings"]))
+        rows.append((moved, kind, k["linearize_ms"] * 1e3, k["search_ms"] * 1e3, s["walked_points"] - prev["stats"]["walked_points"], s["grid_open"] - prev["stats"]["grid_open"], s["grid_rings"] - prev["stats"]["grid_rings"], s["adj_queries"] - prev["stats"]["adj_queries"], s["adj_unsettled"] - prev["stats"]["adj_unsettled"]))
         prev["T"], prev["stats"] = T.copy(), s
         ctx.set_profiling(0)
         return r
@@ -46,7 +46,7 @@ for rep in range(2):
         lin(res.T_target_source)  # same pose again: (nearly) every certificate holds
     if rep == 1:
         for i, r in enumerate(rows):
-            print("pass %d moved=%s %s K1=%.1fus search=%.1fus walked=%d grid_open=%d rings=%d" % (i, "-" if r[0] is None else "%.5f" % r[0], r[1], r[2], r[3], r[4], r[5], r[6]))
+            print("pass %d moved=%s %s K1=%.1fus search=%.1fus walked=%d grid_open=%d rings=%d adj=%d unsettled=%d" % (i, "-" if r[0] is None else "%.5f" % r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8]))
         print("grid cell %.4f m" % pb.pass_stats()["grid_cell_m"])
         print("total K1 %.1f us over %d passes -> avg %.1f us; limits %s" % (sum(r[2] for r in rows), len(rows), sum(r[2] for r in rows) / len(rows), sga.get_warm_limit()))
     pb2 = sga.Problem(tree, src)  # fresh state for the second repetition (warm-up effects only)

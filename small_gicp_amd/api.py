@@ -569,9 +569,10 @@ class Problem:
         the warm passes had to search again."""
         c, w, f = C.c_uint64(), C.c_uint64(), C.c_uint64()
         check(load().sga_problem_get_pass_stats(self.ctx.h, self.h, C.byref(c), C.byref(w), C.byref(f)))
-        g = (C.c_uint64 * 4)()
+        g = (C.c_uint64 * 6)()
         check(load().sga_problem_get_grid_stats(self.h, g))
-        return {"cold_passes": c.value, "warm_passes": w.value, "walked_points": f.value, "grid_passes": g[0], "grid_open": g[1], "grid_rings": g[2], "grid_cell_m": g[3] * 1e-6}
+        return {"cold_passes": c.value, "warm_passes": w.value, "walked_points": f.value, "grid_passes": g[0], "grid_open": g[1], "grid_rings": g[2], "grid_cell_m": g[3] * 1e-6,
+                "adj_queries": g[4], "adj_unsettled": g[5]}
 
 
 class MultiProblem:

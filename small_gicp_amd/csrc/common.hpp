@@ -193,6 +193,8 @@ struct sga_index {
   sga::DevBuf<float4> kd_boxes;     // tight bounding box of every node: [2 * node] = min corner, [2 * node + 1] = max corner
   sga::DevBuf<float4> kd_groups;    // group headers of the 1-NN walk: the boxes of the (up to) 4 leaves under every node of depth kd_depth - 2
   sga::DevBuf<float4> kd_leaf;      // leaf blocks of the 1-NN walk: per leaf x[8], y[8], z[8], original index[8] (kd_search.hpp: the fast leaf scan)
+  sga::DevBuf<float4> kd_adj;       // leaf adjacency (kd_search.hpp: kd_adj_nearest_fast): per leaf its 32 nearest leaves, two float4 each {box lo, rank | box hi, squared distance to this leaf's cell}
+  sga::DevBuf<float> kd_adj_delta;  // per leaf: squared distance from its cell to the nearest leaf NOT in its list
   int kd_depth = 0;
   float bbox_lo[3] = {0, 0, 0}, bbox_hi[3] = {0, 0, 0};
   // uniform cell grid over the same points (cell_grid.hpp / cell_grid.hip): the exact search of cold passes near the optimum; grid_h == 0: none

@@ -655,6 +655,139 @@ __global__ void kd_leaf_blocks_kernel(const float4* __restrict__ pts, uint32_t n
   b[24 + slot] = p.w;
 }
 
+// Leaf adjacency (kd_search.hpp: kd_adj_nearest_fast).  One lane per leaf L: its CELL C_L — the box the split planes of its root path cut
+// out, unbounded where no plane limits it; every query that descends to L lies inside — then a best-first descent over the tree with the
+// tight boxes, keeping the kKdAdj + 1 leaves whose boxes are nearest to the cell (box-to-box distance, rounded down): the first kKdAdj,
+// ascending, are the list, the distance of the next one is delta_L.  For a query q in C_L and a point p of a leaf X outside the list:
+// |p - q| >= dist(box(X), C_L) >= delta_L.  The candidate list lives in LDS as [slot][lane], unsorted while the search runs (a better
+// candidate replaces the worst, found by a sweep), sorted once at the end.
+constexpr int kAdjKeep = kKdAdj + 1;
+__device__ __forceinline__ float box_cell_dist2(const float4 blo, const float4 bhi, const float (&clo)[3], const float (&chi)[3]) {
+  const float dx = fmaxf(fmaxf(blo.x - chi[0], clo[0] - bhi.x), 0.f);
+  const float dy = fmaxf(fmaxf(blo.y - chi[1], clo[1] - bhi.y), 0.f);
+  const float dz = fmaxf(fmaxf(blo.z - chi[2], clo[2] - bhi.z), 0.f);
+  return fmaf(dx, dx, fmaf(dy, dy, dz * dz)) * 0.999999f;  // never above the true distance
+}
+__global__ __launch_bounds__(64) void kd_adjacency_kernel(const KdView t, float4* __restrict__ adj, float* __restrict__ delta) {
+  __shared__ float sd[kAdjKeep][64];
+  __shared__ uint32_t si[kAdjKeep][64];
+  __shared__ uint32_t stack[2 * kKdMaxDepth][64];
+  const int lane = threadIdx.x, D = t.depth;
+  const uint32_t k = blockIdx.x * 64u + lane, leaf0 = 1u << D;
+  if (k >= leaf0) return;
+  const uint32_t self = leaf0 + k;
+  float clo[3] = {-INFINITY, -INFINITY, -INFINITY}, chi[3] = {INFINITY, INFINITY, INFINITY};
+  for (int d = 0; d < D; d++) {
+    const uint32_t a = self >> (D - d);
+    const bool right = ((self >> (D - d - 1)) & 1u) != 0u;
+    const float2 nd = t.nodes[a];
+    const int axis = __float_as_int(nd.y);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      if (axis == c) {
+        if (right) clo[c] = fmaxf(clo[c], nd.x);  // the descent sends q >= threshold to the right
+        else chi[c] = fminf(chi[c], nd.x);
+      }
+    }
+  }
+  int count = 0, worst_slot = 0;
+  float worst = INFINITY;  // admission bound: the largest kept distance once kAdjKeep are kept
+  auto offer = [&](float d2, uint32_t rank) {
+    if (!(d2 < worst)) return;
+    if (count < kAdjKeep) {
+      sd[count][lane] = d2;
+      si[count][lane] = rank;
+      count++;
+      if (count < kAdjKeep) return;
+    } else {
+      sd[worst_slot][lane] = d2;
+      si[worst_slot][lane] = rank;
+    }
+    float wd = -1.f;
+    int ws = 0;
+    for (int j = 0; j < kAdjKeep; j++) {
+      const float v = sd[j][lane];
+      if (v > wd) wd = v, ws = j;
+    }
+    worst = wd;
+    worst_slot = ws;
+  };
+  int sp = 0;
+  uint32_t node = 1;
+  for (;;) {
+    int depth = 31 - __clz(static_cast<int>(node));
+    bool alive = true;
+    while (depth < D) {
+      const uint32_t c0 = 2 * node, c1 = c0 + 1;
+      const float d0 = box_cell_dist2(t.boxes[2 * c0], t.boxes[2 * c0 + 1], clo, chi), d1 = box_cell_dist2(t.boxes[2 * c1], t.boxes[2 * c1 + 1], clo, chi);
+      const bool first0 = d0 <= d1;
+      const float dn = first0 ? d0 : d1, df = first0 ? d1 : d0;
+      if (df < worst) stack[sp++][lane] = first0 ? c1 : c0;
+      if (!(dn < worst)) {
+        alive = false;
+        break;
+      }
+      node = first0 ? c0 : c1;
+      depth++;
+    }
+    if (alive && node != self) offer(box_cell_dist2(t.boxes[2 * node], t.boxes[2 * node + 1], clo, chi), node - leaf0);
+    bool found = false;
+    while (sp > 0) {
+      node = stack[--sp][lane];
+      if (box_cell_dist2(t.boxes[2 * node], t.boxes[2 * node + 1], clo, chi) < worst) {
+        found = true;
+        break;
+      }
+    }
+    if (!found) break;
+  }
+  // ascending by (distance, rank): selection sort of the `count` entries
+  for (int a = 0; a + 1 < count; a++) {
+    float bd = sd[a][lane];
+    uint32_t bi = si[a][lane];
+    int bs = a;
+    for (int j = a + 1; j < count; j++) {
+      const float v = sd[j][lane];
+      const uint32_t vi = si[j][lane];
+      if (v < bd || (v == bd && vi < bi)) bd = v, bi = vi, bs = j;
+    }
+    if (bs != a) {
+      sd[bs][lane] = sd[a][lane];
+      si[bs][lane] = si[a][lane];
+      sd[a][lane] = bd;
+      si[a][lane] = bi;
+    }
+  }
+  float4* out = adj + 2ull * kKdAdj * k;  // every entry carries its leaf's tight box: the query tests it without another dependent load
+  for (int j = 0; j < kKdAdj; j++) {
+    if (j < count) {
+      const uint32_t r = si[j][lane];
+      const float4 blo = t.boxes[2 * (leaf0 + r)], bhi = t.boxes[2 * (leaf0 + r) + 1];
+      out[2 * j] = make_float4(blo.x, blo.y, blo.z, __uint_as_float(r));
+      out[2 * j + 1] = make_float4(bhi.x, bhi.y, bhi.z, sd[j][lane]);
+    } else {
+      out[2 * j] = make_float4(INFINITY, INFINITY, INFINITY, __uint_as_float(kKdAdjNone));
+      out[2 * j + 1] = make_float4(-INFINITY, -INFINITY, -INFINITY, INFINITY);
+    }
+  }
+  delta[k] = count > kKdAdj ? sd[kKdAdj][lane] : INFINITY;
+}
+
+int build_leaf_adjacency(sga_context* ctx, sga_index* idx) {
+  static const long long min_points = getenv("SGA_ADJ_MIN_POINTS") ? atoll(getenv("SGA_ADJ_MIN_POINTS")) : 65536;
+  static const int enabled = getenv("SGA_ADJ") ? atoi(getenv("SGA_ADJ")) : 0;  // off: measured on C3 the lists lose to the walk
+  idx->kd_adj.release();
+  idx->kd_adj_delta.release();
+  if (!enabled || static_cast<long long>(idx->n) < min_points || idx->kd_depth < 1) return SGA_OK;
+  const size_t leaves = 1ull << idx->kd_depth;
+  SGA_TRY(idx->kd_adj.alloc(leaves * kKdAdj * 2));
+  SGA_TRY(idx->kd_adj_delta.alloc(leaves));
+  const KdView kv = make_kd_view(idx);
+  hipLaunchKernelGGL(kd_adjacency_kernel, dim3((leaves + 63) / 64), dim3(64), 0, ctx->stream, kv, idx->kd_adj.p, idx->kd_adj_delta.p);
+  SGA_HIP(hipGetLastError());
+  return SGA_OK;
+}
+
 static int build_kdtree(sga_context* ctx, const sga_cloud* cloud, sga_index* idx) {
   const size_t n = cloud->n;
   idx->kd_depth = 0;
@@ -755,6 +888,7 @@ static int build_kdtree(sga_context* ctx, const sga_cloud* cloud, sga_index* idx
   SGA_TRY(idx->kd_leaf.alloc(8ull << D));
   hipLaunchKernelGGL(kd_leaf_blocks_kernel, dim3(((8u << D) + 255) / 256), block, 0, ctx->stream, idx->kd_pts.p, static_cast<uint32_t>(n), D, reinterpret_cast<float*>(idx->kd_leaf.p));
   SGA_HIP(hipGetLastError());
+  SGA_TRY(build_leaf_adjacency(ctx, idx));
   if (!ctx->stream_ordered) SGA_HIP(hipStreamSynchronize(ctx->stream));
   return SGA_OK;
 }

@@ -209,6 +209,8 @@ struct NNParams {
   double inv_leaf;   // 2^depth / n (kd_leaf_rank)
   int chunk_tiles;   // queue-fed kernel: tiles of 64 queries per wave
   int fast;          // one-query-per-lane kernels: walk with the fast leaf scan (exact repeat where it cannot decide)
+  int adj;           // one-query-per-lane searches go through the leaf adjacency lists first (kd_search.hpp: kd_adj_nearest_fast)
+  uint32_t* __restrict__ adj_stats;  // [0] queries that went through the lists, [1] those the lists did not settle (they walk); or null
   GridView grid;     // the target's cell grid (cell_grid.hpp), if grid_walk
   int grid_walk;     // the walkers of certify_linearize_kernel try ring 1 of the grid before they walk the tree
 };
@@ -279,6 +281,27 @@ __device__ __forceinline__ int search_lane(const NNParams<Real>& p, int tile, in
     slack = fminf(fmaxf(moved, p.slack_min), p.slack_max);
     const unsigned long long walking = __ballot(true);
     if (threadIdx.x == __ffsll(static_cast<long long>(walking)) - 1) p.walked[tile] += static_cast<uint32_t>(__popcll(walking));  // the tile belongs to this wave: no atomic
+  }
+  if (p.adj) {  // wave-uniform: the query's leaf and its precomputed neighbourhood first; the walk only for what that cannot settle
+    KdBestFast f;
+    if (kd_adj_nearest_fast<BLOCK>(p.kd, fx, fy, fz, p.bound2, seed, kd_stack, threadIdx.x, f) && !f.ambiguous) {
+      p.nn[i] = f.best.idx;
+      p.nn2[i] = f.best.idx2;
+      p.rex[i] = rex_from_r2(f.best.r2);
+      if (p.leaves != nullptr) p.leaves[i] = f.best.leaves;
+      if (p.adj_stats != nullptr) {
+        const unsigned long long m = __ballot(true);
+        if (threadIdx.x == __ffsll(static_cast<long long>(m)) - 1) atomicAdd(&p.adj_stats[0], static_cast<uint32_t>(__popcll(m)));
+      }
+      return f.best.idx;
+    }
+    if (p.adj_stats != nullptr) {
+      const unsigned long long m = __ballot(true);
+      if (threadIdx.x == __ffsll(static_cast<long long>(m)) - 1) {
+        atomicAdd(&p.adj_stats[0], static_cast<uint32_t>(__popcll(m)));
+        atomicAdd(&p.adj_stats[1], static_cast<uint32_t>(__popcll(m)));
+      }
+    }
   }
   return walk_lane<Real, BLOCK>(p, i, fx, fy, fz, seed, CHECK ? slack : 0.f, kd_stack);
 }
@@ -1463,11 +1486,23 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
     q.rex = pb->rex.p;
     q.check = warm ? 1 : 0;
     q.fast = g_fast_scan;
+    // leaf adjacency lists (experiment, needs SGA_ADJ=1 at index build; SGA_ADJ_PASS: 0 never, 1 every one-query-per-lane pass but a
+    // registration's first, 2 every such pass)
+    static const int adj_pass = getenv("SGA_ADJ_PASS") ? atoi(getenv("SGA_ADJ_PASS")) : 1;
+    q.adj = (p.kd.adj != nullptr && g_fast_scan && (adj_pass >= 2 || (adj_pass == 1 && !first_pass))) ? 1 : 0;
+    static const bool adj_count = getenv("SGA_ADJ_STATS") != nullptr;  // diagnostics: two atomics per wave
+    if (q.adj && adj_count) {
+      if (pb->grid_stats.n < 4) {
+        SGA_TRY(pb->grid_stats.alloc(4));
+        SGA_HIP(hipMemsetAsync(pb->grid_stats.p, 0, 4 * sizeof(uint32_t), ctx->stream));
+      }
+      q.adj_stats = pb->grid_stats.p + 2;
+    }
     if (warm) q.T_prev = rigid_from_colmajor<Real>(pb->T_prev);
     q.walked = pb->walked.p;
     q.leaves = pb->dbg_leaves.n >= pb->n ? pb->dbg_leaves.p : nullptr;
     if (q.leaves != nullptr) SGA_HIP(hipMemsetAsync(q.leaves, 0, pb->n * sizeof(int), ctx->stream));
-    const size_t words = static_cast<size_t>(std::max(p.kd.depth, 1));
+    const size_t words = static_cast<size_t>(std::max(p.kd.depth, 2 * kKdAdjPick));  // traversal stack rows; the adjacency search notes its leaves in 16 of them
     const dim3 sgrid((p.n + kSearchBlock - 1) / kSearchBlock), sblock(kSearchBlock);
     if (grid_mode != 0 && idx->grid_h > 0.f && q.bound2 < 3.0e38f && !host_rejector && q.leaves == nullptr) {
       const int rings = grid_rings_for(idx, std::sqrt(static_cast<double>(q.bound2)));
@@ -1481,7 +1516,10 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
     if (use_grid) {
       warm = false;  // a full search of every point: the pass counts as cold
       if (timed) ctx->pending_warm = false;
-      if (pb->grid_stats.n < 2) SGA_TRY(pb->grid_stats.alloc(2));
+      if (pb->grid_stats.n < 4) {
+        SGA_TRY(pb->grid_stats.alloc(4));
+        SGA_HIP(hipMemsetAsync(pb->grid_stats.p, 0, 4 * sizeof(uint32_t), ctx->stream));
+      }
       SGA_TRY(grid_search_pass<Real>(ctx, idx, pb->src_pts(), p.n, p.T, q.bound2, pb->hint.p, pb->hint2.p, pb->rex.p, pb->grid_stats.p));
       pb->order_tiles = 0;
       pb->grid_passes++;
