@@ -281,6 +281,19 @@ __device__ __forceinline__ int search_lane(const NNParams<Real>& p, int tile, in
     slack = fminf(fmaxf(moved, p.slack_min), p.slack_max);
     const unsigned long long walking = __ballot(true);
     if (threadIdx.x == __ffsll(static_cast<long long>(walking)) - 1) p.walked[tile] += static_cast<uint32_t>(__popcll(walking));  // the tile belongs to this wave: no atomic
+    // A point whose certificate failed sits next to a surface (isolated points carry wide certificates and rarely fail): ring 1 of the
+    // cell grid (cell_grid.hpp) settles it exactly with two dependent loads and gives the new certificate the tightest radius there is
+    // (the third-nearest distance); the walk — with its exploration margin — only for what the ring does not settle.
+    if (p.grid_walk & 2) {
+      int g_nn, g_nn2;
+      float g_rex, g_seen;
+      if (grid_ring1_lane(p.grid, fx, fy, fz, p.bound2, g_nn, g_nn2, g_rex, g_seen)) {
+        p.nn[i] = g_nn;
+        p.nn2[i] = g_nn2;
+        p.rex[i] = g_rex;
+        return g_nn;
+      }
+    }
   }
   if (p.adj) {  // wave-uniform: the query's leaf and its precomputed neighbourhood first; the walk only for what that cannot settle
     KdBestFast f;
@@ -487,9 +500,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 6))) void
       const int taken = min(__popcll(idle), q_count);
       q_head = (q_head + taken) & (kQueueCap - 1);
       q_count -= taken;
+      if constexpr (CHECK) {
+        // the walkers of a warm pass sit next to a surface: ring 1 of the cell grid settles nearly all of them with two dependent loads
+        // (see search_lane); a lane whose query the ring settles is free again for the next one
+        if (p.grid_walk & 4) {  // wave-uniform
+          const bool trying = busy && fresh;
+          if (__ballot(trying) != 0ull) {
+            if (trying) {
+              int g_nn, g_nn2;
+              float g_rex, g_seen;
+              if (grid_ring1_lane(p.grid, qx, qy, qz, p.bound2, g_nn, g_nn2, g_rex, g_seen)) {
+                p.nn[qi] = g_nn;
+                p.nn2[qi] = g_nn2;
+                p.rex[qi] = g_rex;
+                busy = false;
+                fresh = false;
+              }
+            }
+          }
+        }
+      }
     }
     if (__ballot(busy) == 0ull) {
-      if (tile >= tile_end) break;
+      if (tile >= tile_end && q_count == 0) break;  // (the ring may have settled every query just taken while more are queued)
       continue;
     }
     // ---- one round of the walk
@@ -975,7 +1008,7 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(4))) void
           // of at least a cell.  The rare walker ring 1 does not settle walks the tree.
           int j = -1;
           bool settled = false;
-          if (q.grid_walk) {  // wave-uniform
+          if (q.grid_walk & 1) {  // wave-uniform
             int g_nn, g_nn2;
             float g_rex, g_seen;
             settled = grid_ring1_lane(q.grid, fx, fy, fz, q.bound2, g_nn, g_nn2, g_rex, g_seen);
@@ -1509,7 +1542,10 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
       const bool small_warm = warm && displacement <= g_queue_delta;
       use_grid = grid_mode >= 2 && rings > 0 && rings <= grid_max_rings &&
                  (grid_mode >= 4 || (!small_warm && (grid_mode == 3 || (!first_pass && pb->grid_open_frac <= grid_max_open))));
-      q.grid_walk = 1;  // (used by certify_linearize_kernel only)
+      // which walkers try ring 1 of the grid first (SGA_GRID_WALK, bits): 1 those of certify_linearize_kernel, 2 those of the
+      // one-query-per-lane warm pass (search_linearize_kernel<CHECK>), 4 those of the queue-fed kernel
+      static const int grid_walk_bits = getenv("SGA_GRID_WALK") ? atoi(getenv("SGA_GRID_WALK")) : 7;
+      q.grid_walk = grid_walk_bits;
       q.grid = make_grid_view(idx);
       if (first_pass || (!use_grid && !warm)) pb->grid_open_frac = 0.0;  // a kd pass in between: the grid gets another chance afterwards
     }
