@@ -45,10 +45,11 @@
 // caller that refills a cloud object in place (every odometry loop does) is therefore noticed and the cloud uploaded again.  rebind()
 // forces it.  The target_tree argument is not used: the device builds its own exact nearest-neighbour index over `target`.
 // Supported factors: ICPFactor, PointToPlaneICPFactor, GICPFactor and RobustFactor<Huber|Cauchy, F> over them; rejectors:
-// DistanceRejector, NullRejector; targets: point clouds (traits::point / normal / cov).  A voxel-map target — VGICP,
-// registration_helper.cpp:125-137 — is REJECTED AT COMPILE TIME here (its traits::point(i) takes packed voxel indices, not 0..size-1):
-// it goes through sga_index_build_gaussian_voxelmap / sga_align of small_gicp_amd.h, see INTEGRATION.md section 2.  Custom rejectors /
-// factors with host callbacks stay on the CPU reductions (or use sga_problem_set_rejector).
+// DistanceRejector, NullRejector; targets: point clouds (traits::point / normal / cov) and GaussianVoxelMap — VGICP,
+// registration_helper.cpp:125-137: `registration.align(voxelmap, source, voxelmap, init_T)` with GICPFactor.  The map's voxels go to
+// the device in flat order (sga_multi_set_target_voxels), so the voxel ids of target_index (voxel << 32, incremental_voxelmap.hpp:153)
+// are the caller's; search_offsets must be the default 1.  Other voxel contents (FlatContainer) are rejected at compile time.
+// Custom rejectors / factors with host callbacks stay on the CPU reductions (or use sga_problem_set_rejector).
 #pragma once
 
 #include <cmath>
@@ -71,6 +72,7 @@
 #include <Eigen/Geometry>
 
 #include <small_gicp_amd.h>
+#include <small_gicp/ann/gaussian_voxelmap.hpp>
 #include <small_gicp/ann/incremental_voxelmap.hpp>
 #include <small_gicp/factors/gicp_factor.hpp>
 #include <small_gicp/factors/icp_factor.hpp>
@@ -223,6 +225,7 @@ struct DeviceState {
   const void *target_addr = nullptr, *source_addr = nullptr;
   std::uint64_t target_fp = 0, source_fp = 0;
   bool has_target = false, has_source = false;
+  bool voxel_target = false;  // target_index of the host factors = voxel id << 32 (incremental_voxelmap.hpp:153)
   std::uint64_t generation = 0;  // bumped whenever something is uploaded again
   bool in_align = false;         // between begin_align() and end_align(): linearize() is the device pass and nothing else
   std::vector<std::int64_t> idx;
@@ -253,11 +256,65 @@ struct StatePool {
   }
 };
 
-// a voxel map in the target slot (VGICP) is not a point cloud: see the header comment
+// A voxel map in the target slot (VGICP, registration_helper.cpp:125-137) is not a point cloud: traits::point(i) takes packed
+// (voxel, point) indices (incremental_voxelmap.hpp:153-155).  A GaussianVoxelMap goes to the device as it is — its voxels in flat
+// order, so that voxel ids mean the same on both sides; other contents (FlatContainer: several points per voxel) are refused.
 template <typename T>
 struct is_voxelmap : std::false_type {};
 template <typename Contents>
 struct is_voxelmap<IncrementalVoxelMap<Contents>> : std::true_type {};
+template <typename T>
+struct is_gaussian_voxelmap : std::false_type {};
+template <>
+struct is_gaussian_voxelmap<IncrementalVoxelMap<GaussianVoxel>> : std::true_type {};
+
+struct PackedVoxels {
+  std::vector<std::int32_t> coord;
+  std::vector<double> mean, cov6;
+  size_t n = 0;
+};
+inline PackedVoxels pack_voxels(const IncrementalVoxelMap<GaussianVoxel>& vm) {
+  PackedVoxels out;
+  const size_t n = out.n = vm.flat_voxels.size();
+  out.coord.resize(3 * n);
+  out.mean.resize(3 * n);
+  out.cov6.resize(6 * n);
+  for (size_t i = 0; i < n; i++) {
+    const auto& v = *vm.flat_voxels[i];
+    for (int k = 0; k < 3; k++) out.coord[3 * i + k] = v.first.coord[k], out.mean[3 * i + k] = v.second.mean[k];
+    const Eigen::Matrix4d& m = v.second.cov;
+    double* c = &out.cov6[6 * i];
+    c[0] = m(0, 0), c[1] = m(0, 1), c[2] = m(0, 2), c[3] = m(1, 1), c[4] = m(1, 2), c[5] = m(2, 2);
+  }
+  return out;
+}
+inline std::uint64_t fingerprint(const IncrementalVoxelMap<GaussianVoxel>& vm) {
+  std::uint64_t h = 1469598103934665603ull ^ vm.flat_voxels.size();
+  auto mix = [&h](double v) {
+    std::uint64_t b;
+    std::memcpy(&b, &v, 8);
+    h = (h ^ b) * 1099511628211ull;
+  };
+  mix(vm.inv_leaf_size);
+  for (const auto& pv : vm.flat_voxels) {
+    const auto& v = *pv;
+    h = (h ^ static_cast<std::uint32_t>(v.first.coord[0])) * 1099511628211ull;
+    h = (h ^ static_cast<std::uint32_t>(v.first.coord[1])) * 1099511628211ull;
+    h = (h ^ static_cast<std::uint32_t>(v.first.coord[2])) * 1099511628211ull;
+    mix(v.second.mean[0]), mix(v.second.mean[1]), mix(v.second.mean[2]);
+    const Eigen::Matrix4d& m = v.second.cov;
+    mix(m(0, 0)), mix(m(0, 1)), mix(m(0, 2)), mix(m(1, 1)), mix(m(1, 2)), mix(m(2, 2));
+  }
+  return h;
+}
+template <typename Target>
+size_t target_size(const Target& t) {
+  if constexpr (is_voxelmap<Target>::value) {
+    return t.flat_voxels.size();
+  } else {
+    return traits::size(t);
+  }
+}
 
 inline double seconds_since(const std::chrono::steady_clock::time_point& t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
 
@@ -290,10 +347,15 @@ struct ParallelReductionHIP {
   /// Hash / upload / index what is not on the device(s) yet.  Called by every linearize() outside an align bracket.
   template <typename TargetPointCloud, typename SourcePointCloud>
   void bind(const TargetPointCloud& target, const SourcePointCloud& source, const Eigen::Isometry3d& T) const {
+    constexpr bool voxel_target = hip_detail::is_voxelmap<TargetPointCloud>::value;
     static_assert(
-      !hip_detail::is_voxelmap<TargetPointCloud>::value,
-      "ParallelReductionHIP: a voxel map as the target (VGICP, registration_helper.cpp:125-137) is not a point cloud — its traits::point(i) takes "
-      "packed (voxel, point) indices.  Use sga_index_build_gaussian_voxelmap + sga_align (small_gicp_amd.h, INTEGRATION.md section 2) for VGICP.");
+      !voxel_target || hip_detail::is_gaussian_voxelmap<TargetPointCloud>::value,
+      "ParallelReductionHIP: of the voxel maps only GaussianVoxelMap (one Gaussian per voxel: VGICP, registration_helper.cpp:125-137) is a target the device knows; "
+      "an IncrementalVoxelMap<FlatContainer*> holds several points per voxel — use it as the tree of a CPU reduction, or sga_flatmap_* (small_gicp_amd.h).");
+    if constexpr (voxel_target) {
+      // incremental_voxelmap.hpp:99-119 visits the voxels of search_offsets around the query's own; the device looks into the query's own only (the default)
+      if (target.search_offsets.size() != 1) throw std::runtime_error("ParallelReductionHIP: a GaussianVoxelMap target with search_offsets != 1 is not supported");
+    }
     auto& s = pool->mine();
     if (s.multi && (s.device != device || s.num_gpus != num_gpus)) {
       sga_multi_destroy(s.multi);
@@ -310,11 +372,18 @@ struct ParallelReductionHIP {
     }
     // content check (one streaming pass over both clouds, ~0.2 ms per 100k points): an object refilled in place is uploaded again.
     // verify_content = false trusts address + size (call rebind() after changing a cloud in place).
-    const std::uint64_t tfp = verify_content ? hip_detail::fingerprint(target) : traits::size(target), sfp = verify_content ? hip_detail::fingerprint(source) : traits::size(source);
+    const std::uint64_t tfp = verify_content ? hip_detail::fingerprint(target) : hip_detail::target_size(target), sfp = verify_content ? hip_detail::fingerprint(source) : traits::size(source);
     if (s.target_addr != static_cast<const void*>(&target) || s.target_fp != tfp || !s.has_target) {
-      const hip_detail::PackedCloud c = hip_detail::pack(target);
-      // replaces KdTree<PointCloud>(target), ann/kdtree.hpp:250-252: every device builds its own exact index over its copy
-      hip_detail::check(sga_multi_set_target_f64(s.multi, c.p.data(), c.nr.empty() ? nullptr : c.nr.data(), c.cv.empty() ? nullptr : c.cv.data(), c.n), "sga_multi_set_target_f64");
+      if constexpr (voxel_target) {
+        // the voxel map IS the search structure (incremental_voxelmap.hpp:99-119): its voxels in flat order + a hash of their coordinates per device
+        const hip_detail::PackedVoxels v = hip_detail::pack_voxels(target);
+        hip_detail::check(sga_multi_set_target_voxels(s.multi, 1.0 / target.inv_leaf_size, v.coord.data(), v.mean.data(), v.cov6.data(), v.n), "sga_multi_set_target_voxels");
+      } else {
+        const hip_detail::PackedCloud c = hip_detail::pack(target);
+        // replaces KdTree<PointCloud>(target), ann/kdtree.hpp:250-252: every device builds its own exact index over its copy
+        hip_detail::check(sga_multi_set_target_f64(s.multi, c.p.data(), c.nr.empty() ? nullptr : c.nr.data(), c.cv.empty() ? nullptr : c.cv.data(), c.n), "sga_multi_set_target_f64");
+      }
+      s.voxel_target = voxel_target;
       s.target_addr = &target;
       s.target_fp = tfp;
       s.has_target = true;
@@ -433,7 +502,7 @@ private:
       const size_t i = static_cast<size_t>(ii);
       auto& f = Map::plain(factors[i]);
       f.source_index = i;
-      f.target_index = s.idx[i] < 0 ? std::numeric_limits<size_t>::max() : static_cast<size_t>(s.idx[i]);
+      f.target_index = s.idx[i] < 0 ? std::numeric_limits<size_t>::max() : (s.voxel_target ? static_cast<size_t>(s.idx[i]) << 32 : static_cast<size_t>(s.idx[i]));
       if (is_gicp) hip_detail::set_mahalanobis(f, maha ? &s.m6[6 * i] : nan6);  // not synced: poisoned rather than stale
     }
   }

@@ -289,6 +289,22 @@ class GaussianVoxelMap:
             load().sga_index_destroy(self.h)
             self.h = C.c_void_p()
 
+    @classmethod
+    def from_voxels(cls, leaf_size, coords, means, cov6, ctx=None):
+        """A map from voxels that exist on the host in the reference's flat order (sga_index_create_voxelmap_from_voxels: what
+        ParallelReductionHIP uploads for a GaussianVoxelMap target).  A search target only: insert() needs the running sums."""
+        self = cls.__new__(cls)
+        self.leaf = float(leaf_size)
+        self.ctx = ctx or default_context()
+        self.h = C.c_void_p()
+        coords = np.ascontiguousarray(coords, dtype=np.int32).reshape(-1, 3)
+        means = np.ascontiguousarray(means, dtype=np.float64).reshape(-1, 3)
+        cov6 = np.ascontiguousarray(cov6, dtype=np.float64).reshape(-1, 6)
+        if not (len(coords) == len(means) == len(cov6)):
+            raise ValueError("coords, means and cov6 must have one row per voxel")
+        check(load().sga_index_create_voxelmap_from_voxels(self.ctx.h, self.leaf, coords.ctypes.data_as(C.c_void_p), _dp(means), _dp(cov6), len(coords), C.byref(self.h)))
+        return self
+
     def insert(self, cloud, T=None):
         t16 = None if T is None else _T16(T)
         check(load().sga_voxelmap_insert(self.ctx.h, self.h, cloud.h, None if t16 is None else _dp(t16)))

@@ -322,6 +322,45 @@ int sga_voxelmap_create(sga_context* ctx, double leaf, sga_index** out) {
   return SGA_OK;
 }
 
+// A Gaussian voxel map from voxels that already exist on the host: the reference's GaussianVoxelMap object itself (its flat_voxels in
+// flat order: coord, mean, cov; ann/incremental_voxelmap.hpp:39-92, gaussian_voxelmap.hpp:15-60) handed over as it is, so that
+// Registration<GICPFactor, ParallelReductionHIP>::align(voxelmap, source, voxelmap) (registration_helper.cpp:125-137) searches exactly the
+// voxels the caller built, with the caller's voxel ids.
+int sga_index_create_voxelmap_from_voxels(sga_context* ctx, double leaf, const int32_t* coords, const double* means3, const double* cov6, size_t n, sga_index** out) {
+  if (!ctx || !out || (n > 0 && (!coords || !means3 || !cov6))) return fail(SGA_ERR_INVALID, "null argument");
+  if (!(leaf > 0)) return fail(SGA_ERR_INVALID, "leaf size must be positive");
+  if (n >= (1ull << 31)) return fail(SGA_ERR_INVALID, "too many voxels");
+  *out = nullptr;
+  SGA_ENTER(ctx);
+  std::unique_ptr<sga_index> idx(new sga_index);
+  idx->kind = SGA_INDEX_VOXELMAP;
+  idx->device = ctx->device;
+  idx->leaf = leaf;
+  idx->has_covs = true;
+  idx->n = n;
+  if (n > 0) {
+    DevBuf<double> d_mean, d_cov;
+    SGA_TRY(d_mean.alloc(3 * n));
+    SGA_TRY(d_cov.alloc(6 * n));
+    SGA_TRY(idx->vcoords.alloc(3 * n));
+    SGA_TRY(idx->vcounts.alloc(n));
+    SGA_TRY(idx->pts.alloc(n));
+    SGA_TRY(idx->cov.alloc(n));
+    SGA_HIP(hipMemcpyAsync(d_mean.p, means3, 3 * n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    SGA_HIP(hipMemcpyAsync(d_cov.p, cov6, 6 * n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    SGA_HIP(hipMemcpyAsync(idx->vcoords.p, coords, 3 * n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    SGA_HIP(hipMemsetAsync(idx->vcounts.p, 0, n * sizeof(uint32_t), ctx->stream));  // (the number of points behind a voxel is not part of what the registration reads)
+    hipLaunchKernelGGL(ivm_export_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, static_cast<uint32_t>(n), d_mean.p, d_cov.p, idx->pts.p, idx->cov.p);
+    SGA_HIP(hipGetLastError());
+    SGA_TRY(rebuild_hash(ctx, idx.get(), n));
+    SGA_HIP(hipStreamSynchronize(ctx->stream));  // the host buffers are the caller's
+  } else {
+    SGA_TRY(rebuild_hash(ctx, idx.get(), 0));
+  }
+  *out = idx.release();
+  return SGA_OK;
+}
+
 int sga_flatmap_create(sga_context* ctx, double leaf, sga_index** out) {
   SGA_TRY(sga_voxelmap_create(ctx, leaf, out));
   (*out)->kind = SGA_INDEX_FLATMAP;

@@ -17,6 +17,7 @@
 #include <type_traits>
 #include <vector>
 
+#include <small_gicp/ann/gaussian_voxelmap.hpp>
 #include <small_gicp/ann/kdtree.hpp>
 #include <small_gicp/ann/kdtree_omp.hpp>
 #include <small_gicp/factors/gicp_factor.hpp>
@@ -318,6 +319,75 @@ int main(int argc, char** argv) {
     std::printf("CASE {\"name\": \"4 threads align concurrently through one Registration object\", \"ok\": %s, \"worst_pose_error\": %.3e, \"uploads\": %llu}\n", ok ? "true" : "false", worst,
                 static_cast<unsigned long long>(reg.reduction.generation()));
     if (!ok) failures++;
+  }
+  // ---- VGICP (registration_helper.cpp:125-137): a GaussianVoxelMap as target AND as tree, through the policy ----
+  {
+    auto voxelmap = std::make_shared<GaussianVoxelMap>(1.0);
+    voxelmap->insert(*target);
+    auto run_vgicp = [&](const char* name, auto& hip, const Eigen::Isometry3d& init) {
+      Registration<GICPFactor, ParallelReductionOMP> cpu;
+      cpu.reduction.num_threads = 4;
+      cpu.rejector.max_dist_sq = hip.rejector.max_dist_sq;
+      const RegistrationResult rc = cpu.align(*voxelmap, *source, *voxelmap, init);
+      const RegistrationResult rh = hip.align(*voxelmap, *source, *voxelmap, init);
+      double dt, dr;
+      pose_error(rc.T_target_source, rh.T_target_source, &dt, &dr);
+      double dH = 0.0, mH = 0.0;
+      for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++) dH = std::max(dH, std::abs(rc.H(i, j) - rh.H(i, j))), mH = std::max(mH, std::abs(rc.H(i, j)));
+      // a query within float rounding of a voxel face may fall into the other voxel (the device floors in fp32): a handful of correspondences
+      const long long dinl = std::llabs(static_cast<long long>(rc.num_inliers) - static_cast<long long>(rh.num_inliers));
+      const bool ok = dt < 2e-4 && dr < 2e-4 && rc.converged == rh.converged && std::llabs(static_cast<long long>(rc.iterations) - static_cast<long long>(rh.iterations)) <= 1 && dinl <= 4 && dH / mH < 1e-3;
+      std::printf("CASE {\"name\": \"%s\", \"ok\": %s, \"voxels\": %zu, \"dt\": %.3e, \"dr\": %.3e, \"iterations\": [%zu, %zu], \"num_inliers\": [%zu, %zu], \"rel_err_H\": %.3e}\n", name, ok ? "true" : "false", voxelmap->size(), dt,
+                  dr, rh.iterations, rc.iterations, rh.num_inliers, rc.num_inliers, dH / mH);
+      if (!ok) failures++;
+    };
+    Eigen::Isometry3d near = Eigen::Isometry3d::Identity();
+    near.matrix()(0, 3) = 0.1, near.matrix()(1, 3) = -0.05;
+    {
+      Registration<GICPFactor, ParallelReductionHIP> hip;
+      run_vgicp("VGICP: GaussianVoxelMap target, Reduction slot only", hip, I);
+      // the host factors carry the reference's packed indices: voxel id << 32 (incremental_voxelmap.hpp:153), a voxel of the caller's map
+      std::vector<GICPFactor> factors(source->size());
+      hip.reduction.linearize(*voxelmap, *source, *voxelmap, hip.rejector, I, factors);
+      std::vector<GICPFactor> want(source->size());
+      ParallelReductionOMP omp;
+      omp.linearize(*voxelmap, *source, *voxelmap, hip.rejector, I, want);
+      size_t differ = 0, inl = 0;
+      for (size_t i = 0; i < factors.size(); i++) {
+        differ += factors[i].target_index != want[i].target_index;
+        inl += want[i].target_index != std::numeric_limits<size_t>::max();
+      }
+      const bool ok = differ <= 2 && inl > source->size() / 2;
+      std::printf("CASE {\"name\": \"VGICP: packed voxel indices of the host factors\", \"ok\": %s, \"differ\": %zu, \"inliers\": %zu}\n", ok ? "true" : "false", differ, inl);
+      if (!ok) failures++;
+    }
+    {
+      Registration<GICPFactor, ParallelReductionHIP, NullFactor, DistanceRejector, HipAligned<LevenbergMarquardtOptimizer>> hip;
+      run_vgicp("VGICP: HipAligned<LM>, displaced start", hip, near);
+      // a map that grows (the odometry use, odometry_benchmark_small_vgicp.cpp:41-43): the policy sees the new voxels and uploads the map again
+      const auto before = hip.reduction.generation();
+      voxelmap->insert(*source, Eigen::Isometry3d::Identity());
+      run_vgicp("VGICP: after inserting the source into the map", hip, near);
+      const bool ok = hip.reduction.generation() > before;
+      std::printf("CASE {\"name\": \"VGICP: a grown map was uploaded again\", \"ok\": %s}\n", ok ? "true" : "false");
+      if (!ok) failures++;
+    }
+    {
+      Registration<GICPFactor, ParallelReductionHIP> hip;
+      hip.reduction.num_gpus = 2;
+      run_vgicp("VGICP: num_gpus = 2", hip, I);
+      bool threw = false;
+      voxelmap->set_search_offsets(7);
+      try {
+        hip.align(*voxelmap, *source, *voxelmap, I);
+      } catch (const std::exception&) {
+        threw = true;
+      }
+      voxelmap->set_search_offsets(1);
+      std::printf("CASE {\"name\": \"VGICP: search_offsets = 7 is refused\", \"ok\": %s}\n", threw ? "true" : "false");
+      if (!threw) failures++;
+    }
   }
   // ---- iterations/s THROUGH the policy (what a small_gicp user who swaps the Reduction gets), default settings of the policy ----
   using Plain = Registration<GICPFactor, ParallelReductionHIP>;

@@ -1063,6 +1063,39 @@ def test_incremental_voxelmap_matches_oracle(orc, c1_f32, gpu_c1):
     assert dt < POSE_TOL_T and dr < POSE_TOL_R and res.iterations == ores.iterations and res.num_inliers == ores.num_inliers, (dt, dr)
 
 
+def test_voxelmap_from_host_voxels_equals_the_map_they_came_from(gpu_c1):
+    """sga_index_create_voxelmap_from_voxels (the upload of a reference GaussianVoxelMap object, reduction_hip.hpp): the voxels of a device
+    map, downloaded and handed back in the same order, give the same correspondences (voxel ids) and the same sums; handed back in a
+    shuffled order, the same sums with permuted ids.  Inserting into such a map is refused (it has no running sums)."""
+    tgt, src, _ = gpu_c1
+    a = sga.GaussianVoxelMap(1.0)
+    a.insert(tgt)
+    coords, means, c6, _ = a.download()
+    st = sga.make_setting("GICP")
+    T = se3([0.1, 0.2, 1.0], 0.01, [0.2, -0.1, 0.0])
+    pa = sga.Problem(a, src)
+    Ha, ba, ea, na = pa.linearize(st.factor, T)
+    ia, _ = pa.factors()
+    b = sga.GaussianVoxelMap.from_voxels(1.0, coords, means, c6)
+    assert b.size() == a.size()
+    pb = sga.Problem(b, src)
+    Hb, bb, eb, nb = pb.linearize(st.factor, T)
+    ib, _ = pb.factors()
+    assert (ia == ib).all() and na == nb and (Ha == Hb).all() and (ba == bb).all() and ea == eb  # the exported fp32 state is the state
+    perm = np.random.default_rng(3).permutation(len(coords))
+    c = sga.GaussianVoxelMap.from_voxels(1.0, coords[perm], means[perm], c6[perm])
+    pc = sga.Problem(c, src)
+    Hc, bc, ec, nc = pc.linearize(st.factor, T)
+    ic, _ = pc.factors()
+    assert nc == na and ((ic >= 0) == (ia >= 0)).all() and (perm[ic[ic >= 0]] == ia[ia >= 0]).all()
+    assert (Hc == Ha).all() and ec == ea  # same pairs in the same source order
+    with pytest.raises(sga.SgaError):
+        b.insert(tgt)
+    empty = sga.GaussianVoxelMap.from_voxels(1.0, np.zeros((0, 3), np.int32), np.zeros((0, 3)), np.zeros((0, 6)))
+    He, be, ee, ne = sga.Problem(empty, src).linearize(st.factor, T)
+    assert ne == 0 and ee == 0.0 and not He.any()
+
+
 def test_incremental_single_insert_equals_one_shot_build(gpu_c1):
     """One insert into an empty incremental map == sga_index_build_gaussian_voxelmap (the helper's one-shot path)."""
     import ctypes as C

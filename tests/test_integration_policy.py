@@ -24,20 +24,25 @@ def test_policy_builds_from_the_unmodified_reference_headers():
     assert os.path.exists(BIN)
 
 
-def test_policy_rejects_a_voxelmap_target_at_compile_time(tmp_path):
-    """registration_helper.cpp:125-137 runs VGICP as Registration<GICPFactor, Reduction> with a GaussianVoxelMap in the target slot; the HIP
-    policy would upload garbage for it (traits::point takes packed voxel indices), so it must refuse to compile — with a message that says
-    where VGICP lives instead."""
+def _syntax_only(tmp_path, body):
+    src = tmp_path / "vm.cpp"
+    src.write_text(
+        "#include <small_gicp/ann/flat_container.hpp>\n#include <small_gicp/ann/gaussian_voxelmap.hpp>\n#include <small_gicp/points/point_cloud.hpp>\n#include <small_gicp/registration/registration.hpp>\n"
+        "#include <small_gicp/registration/reduction_hip.hpp>\nusing namespace small_gicp;\n" + body)
+    ref = os.path.join(ROOT, "oracle", "ref")
+    return subprocess.run(["g++", "-std=c++17", "-fopenmp", "-w", "-fsyntax-only", "-I" + os.path.join(ref, "eigen_shim"), "-I/root/reference/include", "-I" + os.path.join(ROOT, "include"), str(src)], capture_output=True, text=True)
+
+
+def test_policy_takes_gaussian_voxelmaps_and_rejects_other_voxel_contents_at_compile_time(tmp_path):
+    """registration_helper.cpp:125-137 runs VGICP as Registration<GICPFactor, Reduction> with a GaussianVoxelMap as target and tree: the HIP
+    policy takes that (tests/cpp/test_reduction_hip.cpp runs it on the GPU).  A voxel map of FlatContainers (several points per voxel,
+    traits::point takes packed indices) would be uploaded as garbage, so it must refuse to compile — with a message that says why."""
     if not os.path.isdir("/root/reference/include/small_gicp"):
         pytest.skip("no reference tree here (GPU box)")
-    src = tmp_path / "vgicp.cpp"
-    src.write_text(
-        "#include <small_gicp/ann/gaussian_voxelmap.hpp>\n#include <small_gicp/points/point_cloud.hpp>\n#include <small_gicp/registration/registration.hpp>\n"
-        "#include <small_gicp/registration/reduction_hip.hpp>\nusing namespace small_gicp;\n"
-        "int main() { GaussianVoxelMap vm(0.5); PointCloud src; Registration<GICPFactor, ParallelReductionHIP> reg; auto r = reg.align(vm, src, vm); return (int)r.iterations; }\n")
-    ref = os.path.join(ROOT, "oracle", "ref")
-    p = subprocess.run(["g++", "-std=c++17", "-fopenmp", "-w", "-fsyntax-only", "-I" + os.path.join(ref, "eigen_shim"), "-I/root/reference/include", "-I" + os.path.join(ROOT, "include"), str(src)], capture_output=True, text=True)
-    assert p.returncode != 0 and "voxel map as the target" in p.stderr, p.stderr[-2000:]
+    ok = _syntax_only(tmp_path, "int main() { GaussianVoxelMap vm(0.5); PointCloud src; Registration<GICPFactor, ParallelReductionHIP> reg; auto r = reg.align(vm, src, vm); return (int)r.iterations; }\n")
+    assert ok.returncode == 0, ok.stderr[-2000:]
+    bad = _syntax_only(tmp_path, "int main() { IncrementalVoxelMap<FlatContainerCov> vm(0.5); PointCloud src; Registration<GICPFactor, ParallelReductionHIP> reg; auto r = reg.align(vm, src, vm); return (int)r.iterations; }\n")
+    assert bad.returncode != 0 and "only GaussianVoxelMap" in bad.stderr, bad.stderr[-2000:]
 
 
 @pytest.mark.gpu
@@ -49,7 +54,7 @@ def test_registration_with_the_hip_reduction_policy(tmp_path):
         np.ascontiguousarray(d[name][:, :3], dtype="<f4").tofile(tmp_path / (name + ".bin"))
     p = subprocess.run([BIN, str(tmp_path / "target.bin"), str(tmp_path / "source.bin")], capture_output=True, text=True, timeout=600)
     cases = [json.loads(ln[5:]) for ln in p.stdout.splitlines() if ln.startswith("CASE ")]
-    assert p.returncode == 0 and len(cases) >= 19 and all(c["ok"] for c in cases), p.stdout[-3000:] + p.stderr[-2000:]
+    assert p.returncode == 0 and len(cases) >= 26 and all(c["ok"] for c in cases), p.stdout[-3000:] + p.stderr[-2000:]
     for ln in p.stdout.splitlines():
         if ln.startswith("RATE "):
             print("policy rate:", ln[5:])
