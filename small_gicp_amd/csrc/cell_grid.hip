@@ -205,29 +205,6 @@ __global__ __launch_bounds__(64 * kRing1Waves) void grid_ring1_kernel(const Grid
 constexpr int kGridQueue = 1024;  // chunk_tiles <= 16
 constexpr int kGridLaneRings = 3;  // stage A scans rings up to this one
 
-__device__ __forceinline__ unsigned long long grid_wave_min_u64(unsigned long long v) {
-#pragma unroll
-  for (int sft = 32; sft >= 1; sft >>= 1) {
-    const uint32_t lo = __shfl_xor(static_cast<uint32_t>(v), sft, 64), hi = __shfl_xor(static_cast<uint32_t>(v >> 32), sft, 64);
-    const unsigned long long o = (static_cast<unsigned long long>(hi) << 32) | lo;
-    v = o < v ? o : v;
-  }
-  return v;
-}
-__device__ __forceinline__ float grid_wave_min_f32(float v) {
-#pragma unroll
-  for (int sft = 32; sft >= 1; sft >>= 1) v = fminf(v, __shfl_xor(v, sft, 64));
-  return v;
-}
-
-// ring whose block certifies a ball of radius `need` around the query: (r + the distance to the nearest face of its own cell) * h >= need
-__device__ __forceinline__ int grid_ring_for(const GridView& g, float need, float qx, float qy, float qz, int cx, int cy, int cz) {
-  const float fx = qx - fmaf(static_cast<float>(cx), g.h, g.ox), fy = qy - fmaf(static_cast<float>(cy), g.h, g.oy), fz = qz - fmaf(static_cast<float>(cz), g.h, g.oz);
-  const float inside = fminf(fminf(fminf(fx, g.h - fx), fminf(fy, g.h - fy)), fminf(fz, g.h - fz));  // negative for a query outside the grid
-  const float rr = ceilf((need - inside + 2.f * g.eps) * g.inv_h * 1.0001f);
-  return static_cast<int>(fminf(fmaxf(rr, 2.f), 1.0e6f));
-}
-
 template <typename Real>
 __global__ __launch_bounds__(64) void grid_finish_kernel(const GridParams<Real> p) {
   __shared__ int q_idx[kGridQueue];
@@ -249,7 +226,6 @@ __global__ __launch_bounds__(64) void grid_finish_kernel(const GridParams<Real> 
   if (total == 0) return;
   __syncthreads();
   const float reach = sqrtf(p.bound2) * 1.00001f;
-  const int rcap = max(max(g.nx, g.ny), g.nz);  // a block never needs to reach beyond the grid
   unsigned ring_sum = 0;
   for (int k0 = 0; k0 < total; k0 += 64) {
     const bool active = k0 + lane < total;
@@ -316,51 +292,14 @@ __global__ __launch_bounds__(64) void grid_finish_kernel(const GridParams<Real> 
       const int l = __ffsll(static_cast<long long>(open)) - 1;
       open &= open - 1ull;
       const float ux = __shfl(qx, l, 64), uy = __shfl(qy, l, 64), uz = __shfl(qz, l, 64), useen = __shfl(seen, l, 64);
-      const int ucx = __shfl(cx, l, 64), ucy = __shfl(cy, l, 64), ucz = __shfl(cz, l, 64), ui = __shfl(i, l, 64);
-      // the ring that settles it for certain: as far as the nearest point seen, or as the whole reach
-      int ur = min(grid_ring_for(g, fminf(useen * 1.00001f, reach), ux, uy, uz, ucx, ucy, ucz), rcap);
-      for (;;) {
-        ring_sum += lane == 0 ? static_cast<unsigned>(ur) : 0u;
-        const int W = 2 * ur + 1, rows = W * W;
-        const float inv_w = 1.0f / static_cast<float>(W);
-        const int xlo = max(ucx - ur, 0), xhi = min(ucx + ur, g.nx - 1);
-        GridTop3 t = grid_top3();
-        for (int base = 0; base < rows; base += 64) {
-          const int k = base + lane;
-          int a = static_cast<int>((static_cast<float>(k) + 0.5f) * inv_w);  // k / W for k < 2^20
-          a -= a * W > k ? 1 : 0;
-          a += (a + 1) * W <= k ? 1 : 0;
-          const int zz = ucz + a - ur, yy = ucy + (k - a * W) - ur;
-          uint32_t s = 0u, e = 0u;
-          if (k < rows && zz >= 0 && zz < g.nz && yy >= 0 && yy < g.ny) {
-            const int row = (zz * g.ny + yy) * g.nx;
-            s = g.start[row + xlo];
-            e = g.start[row + xhi + 1];
-          }
-          grid_scan_run(g, s, e, ux, uy, uz, t);
-        }
-        // the three nearest over the lanes' rows (every point lies in exactly one row: no key occurs twice)
-        const unsigned long long g1 = grid_wave_min_u64(t.k1);
-        const unsigned long long c2 = t.k1 == g1 ? t.k2 : t.k1;
-        const unsigned long long g2 = grid_wave_min_u64(c2);
-        const float third = t.k1 == g1 ? (t.k2 == g2 ? t.d3 : grid_key_dist(t.k2)) : (t.k1 == g2 ? grid_key_dist(t.k2) : grid_key_dist(t.k1));
-        GridTop3 m;
-        m.k1 = g1;
-        m.k2 = g2;
-        m.d3 = grid_wave_min_f32(third);
-        int nn, nn2;
-        float rex;
-        const bool settled = grid_settle(m, grid_rho2(g, ux, uy, uz, ucx, ucy, ucz, ur), p.bound2, nn, nn2, rex);  // wave-uniform
-        if (settled) {
-          if (lane == 0) {
-            p.nn[ui] = nn;
-            p.nn2[ui] = nn2;
-            p.rex[ui] = rex;
-          }
-          break;
-        }
-        const float d1 = sqrtf(grid_key_dist(g1));
-        ur = min(max(ur + 1, d1 < 3.0e38f ? grid_ring_for(g, fminf(d1 * 1.00001f, reach), ux, uy, uz, ucx, ucy, ucz) : ur + 1), rcap + 1);
+      const int ui = __shfl(i, l, 64);
+      int nn, nn2;
+      float rex;
+      ring_sum += grid_settle_wave(g, lane, ux, uy, uz, useen, p.bound2, nn, nn2, rex);
+      if (lane == 0) {
+        p.nn[ui] = nn;
+        p.nn2[ui] = nn2;
+        p.rex[ui] = rex;
       }
     }
   }

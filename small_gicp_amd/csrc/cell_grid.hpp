@@ -157,4 +157,128 @@ __device__ __forceinline__ bool grid_ring1_lane(const GridView& g, float qx, flo
   return grid_settle(t, grid_rho2(g, qx, qy, qz, cx, cy, cz, 1), bound2, nn, nn2, rex);
 }
 
+__device__ __forceinline__ unsigned long long grid_wave_min_u64(unsigned long long v) {
+#pragma unroll
+  for (int sft = 32; sft >= 1; sft >>= 1) {
+    const uint32_t lo = __shfl_xor(static_cast<uint32_t>(v), sft, 64), hi = __shfl_xor(static_cast<uint32_t>(v >> 32), sft, 64);
+    const unsigned long long o = (static_cast<unsigned long long>(hi) << 32) | lo;
+    v = o < v ? o : v;
+  }
+  return v;
+}
+__device__ __forceinline__ float grid_wave_min_f32(float v) {
+#pragma unroll
+  for (int sft = 32; sft >= 1; sft >>= 1) v = fminf(v, __shfl_xor(v, sft, 64));
+  return v;
+}
+
+// ring whose block certifies a ball of radius `need` around the query: (r + the distance to the nearest face of its own cell) * h >= need
+__device__ __forceinline__ int grid_ring_for(const GridView& g, float need, float qx, float qy, float qz, int cx, int cy, int cz) {
+  const float fx = qx - fmaf(static_cast<float>(cx), g.h, g.ox), fy = qy - fmaf(static_cast<float>(cy), g.h, g.oy), fz = qz - fmaf(static_cast<float>(cz), g.h, g.oz);
+  const float inside = fminf(fminf(fminf(fx, g.h - fx), fminf(fy, g.h - fy)), fminf(fz, g.h - fz));  // negative for a query outside the grid
+  const float rr = ceilf((need - inside + 2.f * g.eps) * g.inv_h * 1.0001f);
+  return static_cast<int>(fminf(fmaxf(rr, 2.f), 1.0e6f));
+}
+
+// One query per WAVE (all 64 lanes pass the same query): the ring that settles it for certain — as far as the nearest point seen so far
+// (`seen`, +inf: none), or as the whole reach — with its (2r + 1)^2 rows spread over the lanes: every lane looks up and scans its own rows,
+// the lanes' three nearest are merged with wave-wide minima.  Hundreds of mostly empty rows cost a handful of independent loads per lane
+// instead of a serial sweep by one lane.  A block that does not settle the query (a face closer than the arithmetic slack allows) grows and
+// is scanned again; the block that covers the grid settles everything.  Returns the sum of the rings scanned (lane 0; statistics).
+__device__ __forceinline__ unsigned grid_settle_wave(const GridView& g, int lane, float ux, float uy, float uz, float useen, float bound2, int& nn, int& nn2, float& rex) {
+  const float reach = sqrtf(bound2) * 1.00001f;
+  const int rcap = max(max(g.nx, g.ny), g.nz);  // a block never needs to reach beyond the grid
+  const int ucx = grid_cell(ux, g.ox, g.inv_h, g.nx), ucy = grid_cell(uy, g.oy, g.inv_h, g.ny), ucz = grid_cell(uz, g.oz, g.inv_h, g.nz);
+  int ur = min(grid_ring_for(g, fminf(useen * 1.00001f, reach), ux, uy, uz, ucx, ucy, ucz), rcap);
+  unsigned ring_sum = 0;
+  for (;;) {
+    ring_sum += lane == 0 ? static_cast<unsigned>(ur) : 0u;
+    const int W = 2 * ur + 1, rows = W * W;
+    const float inv_w = 1.0f / static_cast<float>(W);
+    const int xlo = max(ucx - ur, 0), xhi = min(ucx + ur, g.nx - 1);
+    GridTop3 t = grid_top3();
+    for (int base = 0; base < rows; base += 64) {
+      const int k = base + lane;
+      int a = static_cast<int>((static_cast<float>(k) + 0.5f) * inv_w);  // k / W for k < 2^20
+      a -= a * W > k ? 1 : 0;
+      a += (a + 1) * W <= k ? 1 : 0;
+      const int zz = ucz + a - ur, yy = ucy + (k - a * W) - ur;
+      uint32_t s = 0u, e = 0u;
+      if (k < rows && zz >= 0 && zz < g.nz && yy >= 0 && yy < g.ny) {
+        const int row = (zz * g.ny + yy) * g.nx;
+        s = g.start[row + xlo];
+        e = g.start[row + xhi + 1];
+      }
+      grid_scan_run(g, s, e, ux, uy, uz, t);
+    }
+    // the three nearest over the lanes' rows (every point lies in exactly one row: no key occurs twice)
+    const unsigned long long g1 = grid_wave_min_u64(t.k1);
+    const unsigned long long c2 = t.k1 == g1 ? t.k2 : t.k1;
+    const unsigned long long g2 = grid_wave_min_u64(c2);
+    const float third = t.k1 == g1 ? (t.k2 == g2 ? t.d3 : grid_key_dist(t.k2)) : (t.k1 == g2 ? grid_key_dist(t.k2) : grid_key_dist(t.k1));
+    GridTop3 m;
+    m.k1 = g1;
+    m.k2 = g2;
+    m.d3 = grid_wave_min_f32(third);
+    if (grid_settle(m, grid_rho2(g, ux, uy, uz, ucx, ucy, ucz, ur), bound2, nn, nn2, rex)) return ring_sum;  // wave-uniform
+    const float d1 = sqrtf(grid_key_dist(g1));
+    ur = min(max(ur + 1, d1 < 3.0e38f ? grid_ring_for(g, fminf(d1 * 1.00001f, reach), ux, uy, uz, ucx, ucy, ucz) : ur + 1), rcap + 1);
+  }
+}
+
+// Ring 1 for ONE query by a GROUP of G lanes (G a power of two, 2 .. 64; the groups of a wave work on different queries, every lane of a
+// group passes the same query).  The candidates of the 9 runs are numbered through (prefix sums of the run lengths) and dealt to the
+// lanes round-robin, four per lane and trip in flight: 300 candidates of a dense wall cost a group of 64 two trips where one lane needs 75,
+// and the latency of a walker — all that matters when a pass has a handful of them — drops from tens of dependent loads to about four.
+// The lanes' three nearest are merged with minima over the group (shuffles on the 64-bit keys; every point lies in exactly one run, so no
+// key occurs twice).  All lanes of the wave must call this together (`has` = this lane's group has a query); the result is uniform
+// within a group.
+__device__ __forceinline__ bool grid_ring1_group(const GridView& g, int G, int gl, bool has, float qx, float qy, float qz, float bound2, int& nn, int& nn2, float& rex, float& seen) {
+  const int cx = grid_cell(qx, g.ox, g.inv_h, g.nx), cy = grid_cell(qy, g.oy, g.inv_h, g.ny), cz = grid_cell(qz, g.oz, g.inv_h, g.nz);
+  uint32_t off[9], pre[10];  // off[r] = start of run r - candidates before it; pre[r] = candidates before run r
+  pre[0] = 0u;
+#pragma unroll
+  for (int r = 0; r < 9; r++) {
+    const int row = ((cz + r / 3 - 1) * g.ny + (cy + r % 3 - 1)) * g.nx + cx;
+    const uint32_t s = has ? g.start[row - 1] : 0u, e = has ? g.start[row + 2] : 0u;  // one address per group: a broadcast load
+    off[r] = s - pre[r];
+    pre[r + 1] = pre[r] + (e - s);
+  }
+  const uint32_t total = pre[9];
+  GridTop3 t = grid_top3();
+  for (uint32_t c0 = static_cast<uint32_t>(gl); __ballot(c0 < total) != 0ull; c0 += 4u * static_cast<uint32_t>(G)) {
+    float4 cand[4];
+    bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const uint32_t c = c0 + static_cast<uint32_t>(u * G);
+      ok[u] = c < total;
+      uint32_t o = off[0];
+#pragma unroll
+      for (int r = 1; r < 9; r++) o = c >= pre[r] ? off[r] : o;
+      cand[u] = g.pts[ok[u] ? c + o : 0u];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) grid_offer(t, ok[u] ? kd_dist2(cand[u].x, cand[u].y, cand[u].z, qx, qy, qz) : INFINITY, ok[u] ? __float_as_uint(cand[u].w) : 0x7fffffffu);
+  }
+  // the three nearest over the group's lanes
+  auto min_u64 = [G](unsigned long long v) {
+    for (int sft = G >> 1; sft >= 1; sft >>= 1) {
+      const uint32_t lo = __shfl_xor(static_cast<uint32_t>(v), sft, 64), hi = __shfl_xor(static_cast<uint32_t>(v >> 32), sft, 64);
+      const unsigned long long o = (static_cast<unsigned long long>(hi) << 32) | lo;
+      v = o < v ? o : v;
+    }
+    return v;
+  };
+  const unsigned long long g1 = min_u64(t.k1);
+  const unsigned long long c2 = t.k1 == g1 ? t.k2 : t.k1;  // (kGridNoKey == kGridNoKey for lanes that saw nothing while the group saw nothing: then g2 = no key as well)
+  const unsigned long long g2 = min_u64(c2);
+  float third = t.k1 == g1 ? (t.k2 == g2 ? t.d3 : grid_key_dist(t.k2)) : (t.k1 == g2 ? grid_key_dist(t.k2) : grid_key_dist(t.k1));
+  for (int sft = G >> 1; sft >= 1; sft >>= 1) third = fminf(third, __shfl_xor(third, sft, 64));
+  GridTop3 m;
+  m.k1 = g1, m.k2 = g2, m.d3 = third;
+  seen = g1 != kGridNoKey ? sqrtf(grid_key_dist(g1)) : INFINITY;
+  return grid_settle(m, grid_rho2(g, qx, qy, qz, cx, cy, cz, 1), bound2, nn, nn2, rex);
+}
+
 }  // namespace sga

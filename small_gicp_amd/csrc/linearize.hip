@@ -986,40 +986,71 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(4))) void
       __syncthreads();
       // spread over the four waves (entry 4 l + w of every 256 goes to lane l of wave w: a fixed assignment): four times the walks in flight
       uint32_t* my_stack = kd_stack + static_cast<size_t>(wave) * static_cast<size_t>(max(q.kd.depth, 1)) * 64;
-      for (int k0 = 0; k0 < total; k0 += kTile) {
-        const int k = k0 + 4 * lane + wave;
-        const bool mine = k < total;
-        const int i = mine ? sh_list[k] : 0;
+      // A handful of walkers (the late passes of a registration): what they cost is the LATENCY of one walk, paid by the whole pass, while
+      // nearly all lanes idle.  Then every walker gets a group of Gw lanes (the largest power of two that serves all of them in one
+      // round: 64 lanes each for <= 4 walkers ... 2 lanes each for <= 128) which scan ring 1 together (grid_ring1_group).
+      int Gw = 1;
+      if ((q.grid_walk & 8) && total > 0 && total <= kTile / 2) {
+        Gw = 64;
+        while (Gw * total > kTile) Gw >>= 1;
+      }
+      const int per_round = kTile / Gw;  // walkers per round of the workgroup
+      for (int k0 = 0; k0 < total; k0 += per_round) {
+        const int sub = lane / Gw, gl = lane & (Gw - 1);
+        const int k = k0 + 4 * sub + wave;  // (Gw = 1: entry 4 l + w of every 256 goes to lane l of wave w)
+        const bool has = k < total, mine = has && gl == 0;
+        const int i = has ? sh_list[k] : 0;
         Real P[1][3] = {{Real(0), Real(0), Real(0)}}, G[1][3] = {{Real(0), Real(0), Real(0)}}, E[1] = {Real(0)};
         Sym3<Real> Mp[1] = {Sym3<Real>{}};
         Sym3<Real> Mh{};
         bool inl = false;
+        bool g_settled = false;
+        int g_nn = -1, g_nn2 = -1;
+        float g_rex = 0.f, g_seen = INFINITY;
+        if (Gw > 1) {  // workgroup-uniform
+          float gx = 0.f, gy = 0.f, gz = 0.f;
+          if (has) {
+            const float4 ps = p.src_pts[i];
+            Real t[3];
+            transform_point<Real>(p.T, Real(ps.x), Real(ps.y), Real(ps.z), t[0], t[1], t[2]);
+            gx = static_cast<float>(t[0]), gy = static_cast<float>(t[1]), gz = static_cast<float>(t[2]);
+          }
+          g_settled = grid_ring1_group(q.grid, Gw, gl, has, gx, gy, gz, q.bound2, g_nn, g_nn2, g_rex, g_seen);
+#ifdef SGA_WALK_SETTLE_WAVE  // measured (round 4): a lone walker ring 1 leaves open gets the settling ring with its rows over the lanes instead of the seeded kd walk: passes with < 100 walkers -4 ... -9 us, passes with thousands +20 us (a point with nothing in reach scans 225 rows), the code in the kernel -1.3 % on every pass
+          if (Gw == 64 && has && !g_settled && (q.grid_walk & 16)) {  // wave-uniform (one walker per wave)
+            grid_settle_wave(q.grid, lane, gx, gy, gz, g_seen, q.bound2, g_nn, g_nn2, g_rex);
+            g_settled = true;
+          }
+#endif
+        }
         if (mine) {
           const float4 ps = p.src_pts[i];
           P[0][0] = ps.x, P[0][1] = ps.y, P[0][2] = ps.z;
           Real t[3];
           transform_point<Real>(p.T, P[0][0], P[0][1], P[0][2], t[0], t[1], t[2]);
           const float fx = static_cast<float>(t[0]), fy = static_cast<float>(t[1]), fz = static_cast<float>(t[2]);
-          // seed: the nearer candidate (the check put it first); slack: what the check left in rex[] — both written by this workgroup
-          const int seed = __hip_atomic_load(&q.nn[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const float slack = -__hip_atomic_load(&q.rex[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           // A walker of a warm pass sits next to a surface (its certificate failed by millimetres): ring 1 of the cell grid settles it
           // with a chain of two dependent loads where the seeded kd walk has a dozen, and its 27 cells give the new certificate a radius
           // of at least a cell.  The rare walker ring 1 does not settle walks the tree.
           int j = -1;
-          bool settled = false;
-          if (q.grid_walk & 1) {  // wave-uniform
-            int g_nn, g_nn2;
-            float g_rex, g_seen;
-            settled = grid_ring1_lane(q.grid, fx, fy, fz, q.bound2, g_nn, g_nn2, g_rex, g_seen);
-            if (settled) {
-              q.nn[i] = g_nn;
-              q.nn2[i] = g_nn2;
-              q.rex[i] = g_rex;
-              j = g_nn;
-            }
+          bool settled = g_settled;
+          if (Gw == 1 && (q.grid_walk & 1)) settled = grid_ring1_lane(q.grid, fx, fy, fz, q.bound2, g_nn, g_nn2, g_rex, g_seen);  // wave-uniform condition
+          if (settled) {
+            q.nn[i] = g_nn;
+            q.nn2[i] = g_nn2;
+            q.rex[i] = g_rex;
+            j = g_nn;
           }
-          if (!settled) j = walk_lane<Real, 64>(q, i, fx, fy, fz, seed, slack, my_stack);
+          if (q.adj_stats != nullptr && (q.grid_walk & 1)) {  // diagnostics (SGA_ADJ_STATS)
+            atomicAdd(&q.adj_stats[0], 1u);
+            if (!settled) atomicAdd(&q.adj_stats[1], 1u);
+          }
+          if (!settled) {
+            // seed: the nearer candidate (the check put it first); slack: what the check left in rex[] — both written by this workgroup
+            const int seed = __hip_atomic_load(&q.nn[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float slack = -__hip_atomic_load(&q.rex[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            j = walk_lane<Real, 64>(q, i, fx, fy, fz, seed, slack, my_stack);
+          }
           if (j >= 0) {
             const float4 m = p.tgt_pts[j];
             const bool within = kd_dist2(m.x, m.y, m.z, fx, fy, fz) < p.bound2;
@@ -1524,7 +1555,7 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
     static const int adj_pass = getenv("SGA_ADJ_PASS") ? atoi(getenv("SGA_ADJ_PASS")) : 1;
     q.adj = (p.kd.adj != nullptr && g_fast_scan && (adj_pass >= 2 || (adj_pass == 1 && !first_pass))) ? 1 : 0;
     static const bool adj_count = getenv("SGA_ADJ_STATS") != nullptr;  // diagnostics: two atomics per wave
-    if (q.adj && adj_count) {
+    if (adj_count && (q.adj || warm)) {  // (warm passes: the walkers of certify_linearize_kernel count how many of them ring 1 of the grid did not settle)
       if (pb->grid_stats.n < 4) {
         SGA_TRY(pb->grid_stats.alloc(4));
         SGA_HIP(hipMemsetAsync(pb->grid_stats.p, 0, 4 * sizeof(uint32_t), ctx->stream));
@@ -1543,8 +1574,10 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
       use_grid = grid_mode >= 2 && rings > 0 && rings <= grid_max_rings &&
                  (grid_mode >= 4 || (!small_warm && (grid_mode == 3 || (!first_pass && pb->grid_open_frac <= grid_max_open))));
       // which walkers try ring 1 of the grid first (SGA_GRID_WALK, bits): 1 those of certify_linearize_kernel, 2 those of the
-      // one-query-per-lane warm pass (search_linearize_kernel<CHECK>), 4 those of the queue-fed kernel
-      static const int grid_walk_bits = getenv("SGA_GRID_WALK") ? atoi(getenv("SGA_GRID_WALK")) : 7;
+      // one-query-per-lane warm pass (search_linearize_kernel<CHECK>), 4 those of the queue-fed kernel, 8 certify_linearize_kernel scans ring 1
+      // with a group of lanes per walker when a workgroup has few of them (grid_ring1_group), 16 a walker that has a wave to itself and is
+      // not settled by ring 1 gets the ring that settles it, rows over the lanes (grid_settle_wave), instead of a kd walk
+      static const int grid_walk_bits = getenv("SGA_GRID_WALK") ? atoi(getenv("SGA_GRID_WALK")) : 15;
       q.grid_walk = grid_walk_bits;
       q.grid = make_grid_view(idx);
       if (first_pass || (!use_grid && !warm)) pb->grid_open_frac = 0.0;  // a kd pass in between: the grid gets another chance afterwards
