@@ -958,7 +958,7 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(4))) void
 // while the other workgroups stream on.  One launch, one partial row per workgroup; the old form (nn_search_queue_kernel: certificate
 // check, queue-fed walks and factors per chunk of 4 tiles in one wave) streams at half this rate and stays for small clouds.
 template <typename Real, int FACTOR, int PTS>
-__global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(4))) void certify_linearize_kernel(const LinParams<Real> p, const NNParams<Real> q) {
+__global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(4))) void certify_linearize_kernel(const LinParams<Real> p, const NNParams<Real> q_arg) {
   extern __shared__ uint32_t kd_stack[];  // 4 x tree depth x 64 words: the traversal stacks of the waves' walks
   __shared__ double sh_acc[kTile / 64][kRow];
   __shared__ unsigned long long sh_failed[kTile / 64][PTS];
@@ -984,6 +984,15 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(4))) void
           total += __popcll(m);
         }
       __syncthreads();
+      // What the walk phase needs of the search parameters (tree, grid, certificate arrays: ~60 scalar registers) is read from the kernel
+      // argument segment HERE, through a pointer the compiler cannot see through — otherwise it loads all of it at the kernel's start,
+      // keeps it live across the streaming part, runs out of scalar registers and re-reads the pose of the streaming part from spilled
+      // lanes (v_readlane: 720 of its 3187 vector instructions).
+      using SearchArgs = const __attribute__((address_space(4))) NNParams<Real>;
+      static_assert(alignof(NNParams<Real>) <= 8 && sizeof(LinParams<Real>) % 8 == 0, "kernel argument layout");
+      SearchArgs* qa = (SearchArgs*)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(LinParams<Real>));
+      asm volatile("" : "+s"(qa));
+      const NNParams<Real>& q = *(const NNParams<Real>*)qa;
       // spread over the four waves (entry 4 l + w of every 256 goes to lane l of wave w: a fixed assignment): four times the walks in flight
       uint32_t* my_stack = kd_stack + static_cast<size_t>(wave) * static_cast<size_t>(max(q.kd.depth, 1)) * 64;
       // A handful of walkers (the late passes of a registration): what they cost is the LATENCY of one walk, paid by the whole pass, while
