@@ -1100,11 +1100,17 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(4))) void
 // 7 waves per SIMD (72 VGPRs): as fast as 8 (64 VGPRs; measured 179 / 190 / 200 against 182 / 185 / 198 us for the cold passes of a C3
 // registration) and without the two registers the 64-VGPR build spills around the walk (20 bytes per lane through scratch memory =
 // 2 x 20 MB of HBM traffic per cold pass).
+// The warm form (CHECK: certificate check, ring 1 of the cell grid for the walkers, then the walk) needs 16 registers more: at 7 waves it
+// spills them around the walk (68 bytes per lane through scratch = 2 x 68 MB of HBM traffic per pass of 1M points, rocprofv3 FETCH_SIZE /
+// WRITE_SIZE), at 6 waves per SIMD (80 VGPRs) it does not.
 #ifndef SGA_SL_WAVES
 #define SGA_SL_WAVES 7
 #endif
+#ifndef SGA_SL_WAVES_WARM
+#define SGA_SL_WAVES_WARM 6
+#endif
 template <typename Real, int FACTOR, bool CHECK>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SGA_SL_WAVES, SGA_SL_WAVES))) void search_linearize_kernel(const NNParams<Real> p, const LinParams<Real> lp) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CHECK ? SGA_SL_WAVES_WARM : SGA_SL_WAVES, CHECK ? SGA_SL_WAVES_WARM : SGA_SL_WAVES))) void search_linearize_kernel(const NNParams<Real> p, const LinParams<Real> lp) {
   extern __shared__ uint32_t kd_stack[];  // max(tree depth, 3) x 64 words: the traversal stacks, then the wave's row of kRow doubles
 #ifdef SGA_KD_TRIPS
   const unsigned long long wave_t0 = wall_clock64();
