@@ -440,6 +440,10 @@ def main():
                 out["policy_c2"] = policy_leg(sga, "PLANE_ICP", None, None, out["plane_icp_c2"]["value"], None, n=100_000)
         if single and not args.no_vgicp:
             out["vgicp_c4"] = vgicp_leg(sga, ctx, tgt, src, args)
+            if not args.no_policy and "value" in out["vgicp_c4"]:
+                # the same VGICP through the reference's Registration<GICPFactor, ParallelReductionHIP, ..., HipAligned<LM>>::align(voxelmap, source, voxelmap):
+                # the target is the reference's own GaussianVoxelMap object, built on the host by the reference's insert()
+                out["policy_c4"] = policy_leg(sga, "VGICP", tgt, src, out["vgicp_c4"]["value"], None)
         if single and args.odom_frames > 1:
             out["kitti_odom"] = odometry_leg(sga, args, None)
     if use_dist and native_comm and world > 1 and args.odom_frames > 1:
@@ -480,7 +484,7 @@ def policy_leg(sga, kind, tgt, src, cabi_rate, cabi_pose, n=None):
         clouds = None
         if tgt is not None:
             clouds = (tgt.xyz(), src.xyz(), sga.api.sym6_from_mats(tgt.covs()), sga.api.sym6_from_mats(src.covs()))
-        r = policy_bench.run(kind, n or len(clouds[0]), reps=5 if kind == "GICP" else 20, clouds=clouds)
+        r = policy_bench.run(kind, n or len(clouds[0]), reps=5 if kind in ("GICP", "VGICP") else 20, clouds=clouds)
         if r is None:
             return {"error": "oracle/_ref/policy_bench did not travel with the repository (built where /root/reference is mounted: make -C oracle/ref)"}
         out = {k: r[k] for k in ("points", "whole_align_iterations_per_s", "inside_the_optimizer_iterations_per_s", "policy_calls_iterations_per_s", "per_align_ms", "lean", "reduction_slot_only_iterations_per_s",

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The benchmark clouds through the reference's Registration<>::align with ParallelReductionHIP + HipAligned<LM> (oracle/_ref/policy_bench,
-built where /root/reference is mounted) — bench.py's policy_c3 / policy_c2 legs call run().  Usage: policy_bench.py [GICP|PLANE_ICP] [points] [reps] [num_gpus]"""
+built where /root/reference is mounted) — bench.py's policy_c3 / policy_c2 legs call run().  Usage: policy_bench.py [GICP|PLANE_ICP|VGICP] [points] [reps] [num_gpus]"""
 import json
 import os
 import subprocess
@@ -24,7 +24,7 @@ def run(kind="GICP", n=1_000_000, reps=5, num_gpus=1, clouds=None, timeout=600):
     if clouds is None:
         target, source, _ = sga.synthetic.registration_pair(n)
         tgt, src = sga.PointCloud(target), sga.PointCloud(source)
-        if kind == "GICP":
+        if kind in ("GICP", "VGICP"):
             sga.estimate_covariances(tgt, None, 20)
             sga.estimate_covariances(src, None, 20)
             ta, sa = sga.api.sym6_from_mats(tgt.covs()), sga.api.sym6_from_mats(src.covs())

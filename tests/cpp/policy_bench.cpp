@@ -3,8 +3,10 @@
 // from the UNMODIFIED reference headers over the Eigen stand-in of oracle/ref/eigen_shim (oracle/ref/Makefile -> oracle/_ref/policy_bench;
 // the binary travels to the GPU box, /root/reference does not).
 //
-//   policy_bench <kind: GICP|PLANE_ICP> <target.f32> <source.f32> <target_attr.f32> <source_attr.f32> <reps> [num_gpus]
-// points: n x 3 float32; attr: n x 6 float32 covariances (xx xy xz yy yz zz) for GICP, n x 3 normals for PLANE_ICP.
+//   policy_bench <kind: GICP|PLANE_ICP|VGICP> <target.f32> <source.f32> <target_attr.f32> <source_attr.f32> <reps> [num_gpus]
+// points: n x 3 float32; attr: n x 6 float32 covariances (xx xy xz yy yz zz) for GICP / VGICP, n x 3 normals for PLANE_ICP.
+// VGICP (registration_helper.cpp:125-137): the target is the reference's own GaussianVoxelMap (0.5 m voxels, built here on the host by the
+// reference's insert()) in the target AND the tree slot.
 // Prints ONE json line: whole-align and inside-the-optimizer iteration rates, what the bracket costs, the pose of the last align.
 #include <chrono>
 #include <cstdio>
@@ -14,6 +16,7 @@
 #include <string>
 #include <vector>
 
+#include <small_gicp/ann/gaussian_voxelmap.hpp>
 #include <small_gicp/factors/gicp_factor.hpp>
 #include <small_gicp/factors/plane_icp_factor.hpp>
 #include <small_gicp/points/point_cloud.hpp>
@@ -56,11 +59,10 @@ static PointCloud make_cloud(const std::vector<float>& xyz, const std::vector<fl
 
 struct NoTree {};  // the policy searches its own index on the device; align() only forwards the tree argument
 
-template <typename Factor>
-static int run(const PointCloud& target, const PointCloud& source, int reps, int num_gpus, const char* kind) {
+template <typename Factor, typename Target, typename Tree>
+static int run(const Target& target, const PointCloud& source, const Tree& tree, int reps, int num_gpus, const char* kind) {
   using Aligned = Registration<Factor, ParallelReductionHIP, NullFactor, DistanceRejector, HipAligned<LevenbergMarquardtOptimizer>>;
   const Eigen::Isometry3d I = Eigen::Isometry3d::Identity();
-  const NoTree tree;
   Aligned reg;
   reg.reduction.num_gpus = num_gpus;
   reg.rejector.max_dist_sq = 1.0;
@@ -139,13 +141,19 @@ int main(int argc, char** argv) {
     return 2;
   }
   const std::string kind = argv[1];
-  const bool gicp = kind == "GICP";
+  const bool gicp = kind == "GICP" || kind == "VGICP";
   const PointCloud target = make_cloud(read_f32(argv[2]), read_f32(argv[4]), gicp);
   const PointCloud source = make_cloud(read_f32(argv[3]), read_f32(argv[5]), gicp);
   const int reps = std::atoi(argv[6]);
   const int num_gpus = argc > 7 ? std::atoi(argv[7]) : 1;
   try {
-    return gicp ? run<GICPFactor>(target, source, reps, num_gpus, "GICP") : run<PointToPlaneICPFactor>(target, source, reps, num_gpus, "PLANE_ICP");
+    const NoTree tree;
+    if (kind == "VGICP") {
+      GaussianVoxelMap voxelmap(0.5);
+      voxelmap.insert(target);
+      return run<GICPFactor>(voxelmap, source, voxelmap, reps, num_gpus, "VGICP");
+    }
+    return gicp ? run<GICPFactor>(target, source, tree, reps, num_gpus, "GICP") : run<PointToPlaneICPFactor>(target, source, tree, reps, num_gpus, "PLANE_ICP");
   } catch (const std::exception& e) {
     std::fprintf(stderr, "policy_bench: %s\n", e.what());
     return 1;
