@@ -84,6 +84,23 @@ def test_two_ranks_share_one_registration_through_rccl(tmp_path, c1_gold):
     assert res[0]["T"] == res[1]["T"]  # both ranks read the same reduced numbers and run the same host LM
 
 
+def test_one_rank_communicator_runs_the_rccl_all_reduce(tmp_path, c1_gold):
+    """What a 1-GPU box CAN execute of the RCCL transport: the same worker with world = 1 — librccl is opened, ncclCommInitRank builds a
+    communicator, and every sga_linearize / sga_error of the registration puts an ncclAllReduce of its accumulator on the library's stream
+    before the hand-off to the host (csrc/comm.hip).  The sums of one rank must come back unchanged: bit-equal to the context without a
+    communicator."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, SGA_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG=os.environ.get("NCCL_DEBUG", "WARN"))
+    p = subprocess.run([sys.executable, str(script), "0", "1", str(tmp_path)], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
+    r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][0][7:])
+    assert r["T"] == r["single"] and r["iterations"] == r["single_iterations"] and r["num_inliers"] == r["single_inliers"]
+    assert 0 < r["lin_inliers"] <= r["num_inliers"] and np.isfinite(r["e"])  # (the linearization at the identity: fewer inliers than at the optimum)
+    dt, dr = pose_error(np.array(r["T"]), np.array(c1_gold["cases"]["GICP"]["T"]))
+    assert dt < 1e-4 and dr < 1e-4
+
+
 # ---- the same N-rank code path with a host transport: runs on ONE device, so it is always exercised ------------------------------
 WORKER_CB = r"""
 import json, os, sys
