@@ -48,7 +48,8 @@
 // DistanceRejector, NullRejector; targets: point clouds (traits::point / normal / cov) and GaussianVoxelMap — VGICP,
 // registration_helper.cpp:125-137: `registration.align(voxelmap, source, voxelmap, init_T)` with GICPFactor.  The map's voxels go to
 // the device in flat order (sga_multi_set_target_voxels), so the voxel ids of target_index (voxel << 32, incremental_voxelmap.hpp:153)
-// are the caller's; search_offsets must be the default 1.  Other voxel contents (FlatContainer) are rejected at compile time.
+// are the caller's; search_offsets must be the default 1.  IncrementalVoxelMap<FlatContainer<...>> (linear iVox, the scan-to-model target)
+// works the same way (sga_multi_set_target_flat_voxels: <= 16 points per voxel, search offsets 1 / 7 / 27); other contents are rejected at compile time.
 // Custom rejectors / factors with host callbacks stay on the CPU reductions (or use sga_problem_set_rejector).
 #pragma once
 
@@ -72,6 +73,7 @@
 #include <Eigen/Geometry>
 
 #include <small_gicp_amd.h>
+#include <small_gicp/ann/flat_container.hpp>
 #include <small_gicp/ann/gaussian_voxelmap.hpp>
 #include <small_gicp/ann/incremental_voxelmap.hpp>
 #include <small_gicp/factors/gicp_factor.hpp>
@@ -225,7 +227,7 @@ struct DeviceState {
   const void *target_addr = nullptr, *source_addr = nullptr;
   std::uint64_t target_fp = 0, source_fp = 0;
   bool has_target = false, has_source = false;
-  bool voxel_target = false;  // target_index of the host factors = voxel id << 32 (incremental_voxelmap.hpp:153)
+  bool voxel_target = false;  // Gaussian voxel map: target_index of the host factors = voxel id << 32 (incremental_voxelmap.hpp:153)
   std::uint64_t generation = 0;  // bumped whenever something is uploaded again
   bool in_align = false;         // between begin_align() and end_align(): linearize() is the device pass and nothing else
   std::vector<std::int64_t> idx;
@@ -307,6 +309,76 @@ inline std::uint64_t fingerprint(const IncrementalVoxelMap<GaussianVoxel>& vm) {
   }
   return h;
 }
+// IncrementalVoxelMap<FlatContainer<N, C>> (linear iVox, the scan-to-model target of odometry_benchmark_small_gicp_model_omp.cpp): every voxel
+// keeps up to max_num_points_in_cell points (flat_container.hpp:21-58); the device holds 16 slots per voxel.
+template <typename T>
+struct is_flat_voxelmap : std::false_type {};
+template <bool N, bool C>
+struct is_flat_voxelmap<IncrementalVoxelMap<FlatContainer<N, C>>> : std::true_type {};
+constexpr size_t kFlatSlots = 16;
+// set_search_offsets(27) APPENDS its 27 offsets to the one the constructor set (incremental_voxelmap.hpp:46,174-182): 28 entries, the
+// query's own voxel first and once more inside the cube — which is the order the device's 27-voxel search follows.
+inline int device_search_offsets(size_t n) {
+  if (n == 1 || n == 7) return static_cast<int>(n);
+  if (n == 28) return 27;
+  throw std::runtime_error("ParallelReductionHIP: the voxel map's search_offsets must be what set_search_offsets(1 | 7 | 27) leaves");
+}
+
+struct PackedFlatVoxels {
+  std::vector<std::int32_t> coord;
+  std::vector<std::uint32_t> count;
+  std::vector<double> pts, cov6;  // n x 16 x 3, n x 16 x 6 (empty without covariances)
+  size_t n = 0;
+};
+template <bool N, bool C>
+PackedFlatVoxels pack_voxels(const IncrementalVoxelMap<FlatContainer<N, C>>& vm) {
+  PackedFlatVoxels out;
+  const size_t n = out.n = vm.flat_voxels.size();
+  out.coord.resize(3 * n);
+  out.count.resize(n);
+  out.pts.assign(3 * kFlatSlots * n, 0.0);
+  if (C) out.cov6.assign(6 * kFlatSlots * n, 0.0);
+  for (size_t i = 0; i < n; i++) {
+    const auto& v = *vm.flat_voxels[i];
+    const size_t m = v.second.points.size();
+    if (m > kFlatSlots) throw std::runtime_error("ParallelReductionHIP: a voxel of the FlatContainer map holds more than 16 points (max_num_points_in_cell): not supported on the device");
+    for (int k = 0; k < 3; k++) out.coord[3 * i + k] = v.first.coord[k];
+    out.count[i] = static_cast<std::uint32_t>(m);
+    for (size_t j = 0; j < m; j++) {
+      for (int k = 0; k < 3; k++) out.pts[3 * (kFlatSlots * i + j) + k] = v.second.points[j][k];
+      if constexpr (C) {
+        const Eigen::Matrix4d& c = v.second.covs[j];
+        double* o = &out.cov6[6 * (kFlatSlots * i + j)];
+        o[0] = c(0, 0), o[1] = c(0, 1), o[2] = c(0, 2), o[3] = c(1, 1), o[4] = c(1, 2), o[5] = c(2, 2);
+      }
+    }
+  }
+  return out;
+}
+template <bool N, bool C>
+std::uint64_t fingerprint(const IncrementalVoxelMap<FlatContainer<N, C>>& vm) {
+  std::uint64_t h = 1469598103934665603ull ^ vm.flat_voxels.size() ^ (static_cast<std::uint64_t>(vm.search_offsets.size()) << 40);
+  auto mix = [&h](double v) {
+    std::uint64_t b;
+    std::memcpy(&b, &v, 8);
+    h = (h ^ b) * 1099511628211ull;
+  };
+  mix(vm.inv_leaf_size);
+  for (const auto& pv : vm.flat_voxels) {
+    const auto& v = *pv;
+    for (int k = 0; k < 3; k++) h = (h ^ static_cast<std::uint32_t>(v.first.coord[k])) * 1099511628211ull;
+    h = (h ^ v.second.points.size()) * 1099511628211ull;
+    for (size_t j = 0; j < v.second.points.size(); j++) {
+      mix(v.second.points[j][0]), mix(v.second.points[j][1]), mix(v.second.points[j][2]);
+      if constexpr (C) {
+        const Eigen::Matrix4d& m = v.second.covs[j];
+        mix(m(0, 0)), mix(m(0, 1)), mix(m(0, 2)), mix(m(1, 1)), mix(m(1, 2)), mix(m(2, 2));
+      }
+    }
+  }
+  return h;
+}
+
 template <typename Target>
 size_t target_size(const Target& t) {
   if constexpr (is_voxelmap<Target>::value) {
@@ -348,11 +420,12 @@ struct ParallelReductionHIP {
   template <typename TargetPointCloud, typename SourcePointCloud>
   void bind(const TargetPointCloud& target, const SourcePointCloud& source, const Eigen::Isometry3d& T) const {
     constexpr bool voxel_target = hip_detail::is_voxelmap<TargetPointCloud>::value;
+    constexpr bool flat_target = hip_detail::is_flat_voxelmap<TargetPointCloud>::value;
     static_assert(
-      !voxel_target || hip_detail::is_gaussian_voxelmap<TargetPointCloud>::value,
-      "ParallelReductionHIP: of the voxel maps only GaussianVoxelMap (one Gaussian per voxel: VGICP, registration_helper.cpp:125-137) is a target the device knows; "
-      "an IncrementalVoxelMap<FlatContainer*> holds several points per voxel — use it as the tree of a CPU reduction, or sga_flatmap_* (small_gicp_amd.h).");
-    if constexpr (voxel_target) {
+      !voxel_target || flat_target || hip_detail::is_gaussian_voxelmap<TargetPointCloud>::value,
+      "ParallelReductionHIP: of the voxel maps only GaussianVoxelMap (one Gaussian per voxel: VGICP, registration_helper.cpp:125-137) and "
+      "IncrementalVoxelMap<FlatContainer<...>> (linear iVox: scan-to-model ICP / GICP) are targets the device knows.");
+    if constexpr (voxel_target && !flat_target) {
       // incremental_voxelmap.hpp:99-119 visits the voxels of search_offsets around the query's own; the device looks into the query's own only (the default)
       if (target.search_offsets.size() != 1) throw std::runtime_error("ParallelReductionHIP: a GaussianVoxelMap target with search_offsets != 1 is not supported");
     }
@@ -374,7 +447,13 @@ struct ParallelReductionHIP {
     // verify_content = false trusts address + size (call rebind() after changing a cloud in place).
     const std::uint64_t tfp = verify_content ? hip_detail::fingerprint(target) : hip_detail::target_size(target), sfp = verify_content ? hip_detail::fingerprint(source) : traits::size(source);
     if (s.target_addr != static_cast<const void*>(&target) || s.target_fp != tfp || !s.has_target) {
-      if constexpr (voxel_target) {
+      if constexpr (flat_target) {
+        // linear iVox: the voxels' points (and covariances) in flat order, 16 slots per voxel; searched over the map's 1 / 7 / 27 offsets
+        const hip_detail::PackedFlatVoxels v = hip_detail::pack_voxels(target);
+        hip_detail::check(
+          sga_multi_set_target_flat_voxels(s.multi, 1.0 / target.inv_leaf_size, v.coord.data(), v.count.data(), v.pts.data(), v.cov6.empty() ? nullptr : v.cov6.data(), hip_detail::device_search_offsets(target.search_offsets.size()), v.n),
+          "sga_multi_set_target_flat_voxels");
+      } else if constexpr (voxel_target) {
         // the voxel map IS the search structure (incremental_voxelmap.hpp:99-119): its voxels in flat order + a hash of their coordinates per device
         const hip_detail::PackedVoxels v = hip_detail::pack_voxels(target);
         hip_detail::check(sga_multi_set_target_voxels(s.multi, 1.0 / target.inv_leaf_size, v.coord.data(), v.mean.data(), v.cov6.data(), v.n), "sga_multi_set_target_voxels");
@@ -383,7 +462,7 @@ struct ParallelReductionHIP {
         // replaces KdTree<PointCloud>(target), ann/kdtree.hpp:250-252: every device builds its own exact index over its copy
         hip_detail::check(sga_multi_set_target_f64(s.multi, c.p.data(), c.nr.empty() ? nullptr : c.nr.data(), c.cv.empty() ? nullptr : c.cv.data(), c.n), "sga_multi_set_target_f64");
       }
-      s.voxel_target = voxel_target;
+      s.voxel_target = voxel_target && !flat_target;  // (a flat map's indices come packed from the device: (voxel << 32) | point)
       s.target_addr = &target;
       s.target_fp = tfp;
       s.has_target = true;

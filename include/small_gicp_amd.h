@@ -98,6 +98,10 @@ int sga_index_build_gaussian_voxelmap(sga_context* ctx, const sga_cloud* points_
  * coords n*3 int32, means n*3 doubles, cov6 n*6 doubles xx,xy,xz,yy,yz,zz; ann/incremental_voxelmap.hpp:39-92): the voxel ids are the
  * caller's.  What lets Registration<GICPFactor, ParallelReductionHIP>::align(voxelmap, source, voxelmap) (registration_helper.cpp:125-137) work. */
 int sga_index_create_voxelmap_from_voxels(sga_context* ctx, double leaf_size, const int32_t* coords, const double* means3, const double* cov6, size_t n, sga_index** out);
+/* A flat voxel map (IncrementalVoxelMap<FlatContainer*>, ann/flat_container.hpp:21-58) from voxels that exist on the host, flat order: coords
+ * n*3, counts n (<= 16 each), points n*16*3 doubles and cov6 n*16*6 doubles (16 slots per voxel, the first counts[v] valid; cov6 may be NULL
+ * for ICP), searched over 1, 7 or 27 voxels.  Target indices are (voxel_id << 32) | point_id with the caller's ids. */
+int sga_index_create_flatmap_from_voxels(sga_context* ctx, double leaf_size, const int32_t* coords, const uint32_t* counts, const double* points3, const double* cov6, int search_offsets, size_t n, sga_index** out);
 /* Re-copy normals / covariances from `cloud` (the cloud the tree was built over) into the index's kd-ordered arrays, e.g. after
  * attributes were estimated or set once the index already existed (reference flow: KdTree first, estimate_covariances second). */
 int sga_index_refresh_attributes(sga_context* ctx, sga_index* index, const sga_cloud* cloud);
@@ -285,6 +289,8 @@ int sga_multi_num_devices(const sga_multi* m);
 int sga_multi_set_target_f64(sga_multi* m, const double* xyzw, const double* normals4, const double* cov4x4, size_t n);
 /* a Gaussian voxel map as the target (see sga_index_create_voxelmap_from_voxels): replicated on every device */
 int sga_multi_set_target_voxels(sga_multi* m, double leaf_size, const int32_t* coords, const double* means3, const double* cov6, size_t n);
+/* a flat voxel map as the target (see sga_index_create_flatmap_from_voxels): replicated on every device */
+int sga_multi_set_target_flat_voxels(sga_multi* m, double leaf_size, const int32_t* coords, const uint32_t* counts, const double* points3, const double* cov6, int search_offsets, size_t n);
 int sga_multi_set_source_f64(sga_multi* m, const double* xyzw, const double* normals4, const double* cov4x4, size_t n, const double init_T[16]);
 /* Reduction::linearize / ::error over all shards (reduction_omp.hpp:24-70), Registration<>::align (registration.hpp:33-43) on the host */
 int sga_multi_linearize(sga_multi* m, const sga_factor_params* params, const double T[16], double H[36], double b[6], double* e, uint64_t* num_inliers);

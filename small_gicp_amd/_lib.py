@@ -84,6 +84,7 @@ SYMBOLS = [
     ("sga_index_build_kdtree", C.c_int, [_vp, _vp, _pvp]),
     ("sga_index_build_gaussian_voxelmap", C.c_int, [_vp, _vp, C.c_double, _pvp]),
     ("sga_index_create_voxelmap_from_voxels", C.c_int, [_vp, C.c_double, C.c_void_p, _dp, _dp, C.c_size_t, _pvp]),
+    ("sga_index_create_flatmap_from_voxels", C.c_int, [_vp, C.c_double, C.c_void_p, C.c_void_p, _dp, _dp, C.c_int, C.c_size_t, _pvp]),
     ("sga_index_refresh_attributes", C.c_int, [_vp, _vp, _vp]),
     ("sga_index_destroy", C.c_int, [_vp]),
     ("sga_index_size", C.c_int, [_vp, C.POINTER(C.c_size_t)]),
@@ -140,6 +141,7 @@ SYMBOLS = [
     ("sga_multi_num_devices", C.c_int, [_vp]),
     ("sga_multi_set_target_f64", C.c_int, [_vp, _dp, _dp, _dp, C.c_size_t]),
     ("sga_multi_set_target_voxels", C.c_int, [_vp, C.c_double, C.c_void_p, _dp, _dp, C.c_size_t]),
+    ("sga_multi_set_target_flat_voxels", C.c_int, [_vp, C.c_double, C.c_void_p, C.c_void_p, _dp, _dp, C.c_int, C.c_size_t]),
     ("sga_multi_set_source_f64", C.c_int, [_vp, _dp, _dp, _dp, C.c_size_t, _dp]),
     ("sga_multi_linearize", C.c_int, [_vp, C.POINTER(FactorParams), _dp, _dp, _dp, _dp, C.POINTER(C.c_uint64)]),
     ("sga_multi_error", C.c_int, [_vp, C.POINTER(FactorParams), _dp, _dp]),

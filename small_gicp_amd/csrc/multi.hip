@@ -123,6 +123,24 @@ int sga_multi_set_target_voxels(sga_multi* m, double leaf, const int32_t* coords
   return SGA_OK;
 }
 
+int sga_multi_set_target_flat_voxels(sga_multi* m, double leaf, const int32_t* coords, const uint32_t* counts, const double* points3, const double* cov6, int search_offsets, size_t n) {
+  if (!m) return fail(SGA_ERR_INVALID, "null argument");
+  m->model_valid = false;
+  for (auto& s : m->shards) {  // the source's problems refer to the old index
+    if (s.problem) sga_problem_destroy(s.problem);
+    s.problem = nullptr;
+    if (s.index) sga_index_destroy(s.index);
+    s.index = nullptr;
+    if (s.target) sga_cloud_destroy(s.target);
+    s.target = nullptr;
+  }
+  m->has_target = false;
+  for (auto& s : m->shards) SGA_TRY(sga_index_create_flatmap_from_voxels(s.ctx, leaf, coords, counts, points3, cov6, search_offsets, n, &s.index));
+  m->n_target = n;
+  m->has_target = true;
+  return SGA_OK;
+}
+
 int sga_multi_set_source_f64(sga_multi* m, const double* xyzw, const double* normals4, const double* cov4x4, size_t n, const double init_T[16]) {
   if (!m || (n > 0 && !xyzw)) return fail(SGA_ERR_INVALID, "null argument");
   if (!m->has_target) return fail(SGA_ERR_INVALID, "sga_multi_set_source_f64 before sga_multi_set_target_f64");

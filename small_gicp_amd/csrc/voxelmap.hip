@@ -361,6 +361,52 @@ int sga_index_create_voxelmap_from_voxels(sga_context* ctx, double leaf, const i
   return SGA_OK;
 }
 
+// A flat voxel map from voxels that already exist on the host: the reference's IncrementalVoxelMap<FlatContainer*> object as it is
+// (flat order; per voxel its points and, for GICP, their covariances: flat_container.hpp:21-58), 16 slots per voxel like
+// sga_flatmap_download.  The scan-to-model target of Registration<GICPFactor, ParallelReductionHIP> (odometry_benchmark_small_gicp_model_omp.cpp).
+int sga_index_create_flatmap_from_voxels(sga_context* ctx, double leaf, const int32_t* coords, const uint32_t* counts, const double* points3, const double* cov6, int search_offsets, size_t n, sga_index** out) {
+  if (!ctx || !out || (n > 0 && (!coords || !counts || !points3))) return fail(SGA_ERR_INVALID, "null argument");
+  if (!(leaf > 0)) return fail(SGA_ERR_INVALID, "leaf size must be positive");
+  if (search_offsets != 1 && search_offsets != 7 && search_offsets != 27) return fail(SGA_ERR_INVALID, "search offsets must be 1, 7 or 27 (incremental_voxelmap.hpp:157-186)");
+  if (n >= (1ull << 27)) return fail(SGA_ERR_INVALID, "too many voxels");
+  for (size_t v = 0; v < n; v++)
+    if (counts[v] > static_cast<uint32_t>(kFlatCap)) return fail(SGA_ERR_UNSUPPORTED, "voxel %zu holds %u points: at most %d per voxel (max_num_points_in_cell)", v, counts[v], kFlatCap);
+  *out = nullptr;
+  SGA_ENTER(ctx);
+  std::unique_ptr<sga_index> idx(new sga_index);
+  idx->kind = SGA_INDEX_FLATMAP;
+  idx->device = ctx->device;
+  idx->leaf = leaf;
+  idx->has_covs = cov6 != nullptr;
+  idx->search_offsets = search_offsets;
+  idx->n = n;
+  if (n > 0) {
+    const size_t slots = n * kFlatCap;
+    DevBuf<double> d_pts, d_cov;
+    SGA_TRY(d_pts.alloc(3 * slots));
+    SGA_TRY(d_cov.alloc(6 * slots));
+    SGA_TRY(idx->vcoords.alloc(3 * n));
+    SGA_TRY(idx->vcounts.alloc(n));
+    SGA_TRY(idx->pts.alloc(slots));
+    SGA_TRY(idx->cov.alloc(slots));
+    SGA_HIP(hipMemcpyAsync(d_pts.p, points3, 3 * slots * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (cov6)
+      SGA_HIP(hipMemcpyAsync(d_cov.p, cov6, 6 * slots * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    else
+      SGA_HIP(hipMemsetAsync(d_cov.p, 0, 6 * slots * sizeof(double), ctx->stream));
+    SGA_HIP(hipMemcpyAsync(idx->vcoords.p, coords, 3 * n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    SGA_HIP(hipMemcpyAsync(idx->vcounts.p, counts, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(fvm_export_kernel, dim3((slots + 255) / 256), dim3(256), 0, ctx->stream, static_cast<uint32_t>(n), idx->vcounts.p, d_pts.p, d_cov.p, idx->pts.p, idx->cov.p);
+    SGA_HIP(hipGetLastError());
+    SGA_TRY(rebuild_hash(ctx, idx.get(), n));
+    SGA_HIP(hipStreamSynchronize(ctx->stream));  // the host buffers are the caller's
+  } else {
+    SGA_TRY(rebuild_hash(ctx, idx.get(), 0));
+  }
+  *out = idx.release();
+  return SGA_OK;
+}
+
 int sga_flatmap_create(sga_context* ctx, double leaf, sga_index** out) {
   SGA_TRY(sga_voxelmap_create(ctx, leaf, out));
   (*out)->kind = SGA_INDEX_FLATMAP;

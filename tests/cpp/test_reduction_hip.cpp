@@ -17,6 +17,7 @@
 #include <type_traits>
 #include <vector>
 
+#include <small_gicp/ann/flat_container.hpp>
 #include <small_gicp/ann/gaussian_voxelmap.hpp>
 #include <small_gicp/ann/kdtree.hpp>
 #include <small_gicp/ann/kdtree_omp.hpp>
@@ -386,6 +387,64 @@ int main(int argc, char** argv) {
       }
       voxelmap->set_search_offsets(1);
       std::printf("CASE {\"name\": \"VGICP: search_offsets = 7 is refused\", \"ok\": %s}\n", threw ? "true" : "false");
+      if (!threw) failures++;
+    }
+  }
+  // ---- scan-to-model GICP (odometry_benchmark_small_gicp_model_omp.cpp:20-47): IncrementalVoxelMap<FlatContainerCov> (linear iVox) as target AND tree ----
+  {
+    using FlatMap = IncrementalVoxelMap<FlatContainerCov>;
+    for (int offsets : {1, 7, 27}) {
+      auto model = std::make_shared<FlatMap>(1.0);
+      model->set_search_offsets(offsets);
+      model->insert(*target);
+      Registration<GICPFactor, ParallelReductionOMP> cpu;
+      cpu.reduction.num_threads = 4;
+      Registration<GICPFactor, ParallelReductionHIP, NullFactor, DistanceRejector, HipAligned<LevenbergMarquardtOptimizer>> hip;
+      hip.rejector.max_dist_sq = cpu.rejector.max_dist_sq;
+      const RegistrationResult rc = cpu.align(*model, *source, *model, I);
+      const RegistrationResult rh = hip.align(*model, *source, *model, I);
+      double dt, dr;
+      pose_error(rc.T_target_source, rh.T_target_source, &dt, &dr);
+      // the packed (voxel, point) indices of the host factors against the CPU reduction's, at the start pose
+      std::vector<GICPFactor> got(source->size()), want(source->size());
+      Registration<GICPFactor, ParallelReductionHIP> plain;
+      plain.reduction.linearize(*model, *source, *model, plain.rejector, I, got);
+      ParallelReductionOMP omp;
+      omp.linearize(*model, *source, *model, plain.rejector, I, want);
+      size_t differ = 0, inl = 0;
+      for (size_t i = 0; i < got.size(); i++) differ += got[i].target_index != want[i].target_index, inl += want[i].target_index != std::numeric_limits<size_t>::max();
+      const long long dinl = std::llabs(static_cast<long long>(rc.num_inliers) - static_cast<long long>(rh.num_inliers));
+      const bool ok = dt < 2e-4 && dr < 2e-4 && rc.converged == rh.converged && std::llabs(static_cast<long long>(rc.iterations) - static_cast<long long>(rh.iterations)) <= 1 && dinl <= 4 && differ <= 4 && inl > source->size() / 2;
+      std::printf("CASE {\"name\": \"scan-to-model GICP: IncrementalVoxelMap<FlatContainerCov>, search_offsets %d\", \"ok\": %s, \"voxels\": %zu, \"dt\": %.3e, \"dr\": %.3e, \"iterations\": [%zu, %zu], \"num_inliers\": [%zu, %zu], \"indices_differing\": %zu}\n",
+                  offsets, ok ? "true" : "false", model->size(), dt, dr, rh.iterations, rc.iterations, rh.num_inliers, rc.num_inliers, differ);
+      if (!ok) failures++;
+    }
+    {  // ICP against a map of bare points (FlatContainerPoints), and a map whose voxels hold too many points for the device
+      auto model = std::make_shared<IncrementalVoxelMap<FlatContainerPoints>>(1.0);
+      model->insert(*target);
+      Registration<ICPFactor, ParallelReductionOMP> cpu;
+      cpu.reduction.num_threads = 4;
+      cpu.rejector.max_dist_sq = 0.25;
+      Registration<ICPFactor, ParallelReductionHIP> hip;
+      hip.rejector.max_dist_sq = 0.25;
+      const RegistrationResult rc = cpu.align(*model, *source, *model, I);
+      const RegistrationResult rh = hip.align(*model, *source, *model, I);
+      double dt, dr;
+      pose_error(rc.T_target_source, rh.T_target_source, &dt, &dr);
+      const bool ok = dt < 2e-4 && dr < 2e-4 && std::llabs(static_cast<long long>(rc.num_inliers) - static_cast<long long>(rh.num_inliers)) <= 4;
+      std::printf("CASE {\"name\": \"scan-to-model ICP: IncrementalVoxelMap<FlatContainerPoints>\", \"ok\": %s, \"dt\": %.3e, \"dr\": %.3e, \"num_inliers\": [%zu, %zu]}\n", ok ? "true" : "false", dt, dr, rh.num_inliers, rc.num_inliers);
+      if (!ok) failures++;
+      auto crowded = std::make_shared<IncrementalVoxelMap<FlatContainerPoints>>(2.0);
+      crowded->voxel_setting.max_num_points_in_cell = 40;
+      crowded->voxel_setting.min_sq_dist_in_cell = 1e-6;
+      crowded->insert(*target);
+      bool threw = false;
+      try {
+        hip.align(*crowded, *source, *crowded, I);
+      } catch (const std::exception&) {
+        threw = true;
+      }
+      std::printf("CASE {\"name\": \"a FlatContainer voxel with more than 16 points is refused\", \"ok\": %s}\n", threw ? "true" : "false");
       if (!threw) failures++;
     }
   }

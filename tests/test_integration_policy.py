@@ -33,15 +33,18 @@ def _syntax_only(tmp_path, body):
     return subprocess.run(["g++", "-std=c++17", "-fopenmp", "-w", "-fsyntax-only", "-I" + os.path.join(ref, "eigen_shim"), "-I/root/reference/include", "-I" + os.path.join(ROOT, "include"), str(src)], capture_output=True, text=True)
 
 
-def test_policy_takes_gaussian_voxelmaps_and_rejects_other_voxel_contents_at_compile_time(tmp_path):
-    """registration_helper.cpp:125-137 runs VGICP as Registration<GICPFactor, Reduction> with a GaussianVoxelMap as target and tree: the HIP
-    policy takes that (tests/cpp/test_reduction_hip.cpp runs it on the GPU).  A voxel map of FlatContainers (several points per voxel,
-    traits::point takes packed indices) would be uploaded as garbage, so it must refuse to compile — with a message that says why."""
+def test_policy_takes_the_reference_voxel_maps_as_targets(tmp_path):
+    """registration_helper.cpp:125-137 runs VGICP as Registration<GICPFactor, Reduction> with a GaussianVoxelMap as target and tree, the model-based
+    odometry (odometry_benchmark_small_gicp_model_omp.cpp) does the same with an IncrementalVoxelMap<FlatContainerCov>: the HIP policy takes
+    both (tests/cpp/test_reduction_hip.cpp runs them on the GPU).  A voxel map of contents it does not know must refuse to compile —
+    traits::point of a voxel map takes packed indices, the generic upload would read garbage — with a message that says why."""
     if not os.path.isdir("/root/reference/include/small_gicp"):
         pytest.skip("no reference tree here (GPU box)")
-    ok = _syntax_only(tmp_path, "int main() { GaussianVoxelMap vm(0.5); PointCloud src; Registration<GICPFactor, ParallelReductionHIP> reg; auto r = reg.align(vm, src, vm); return (int)r.iterations; }\n")
-    assert ok.returncode == 0, ok.stderr[-2000:]
-    bad = _syntax_only(tmp_path, "int main() { IncrementalVoxelMap<FlatContainerCov> vm(0.5); PointCloud src; Registration<GICPFactor, ParallelReductionHIP> reg; auto r = reg.align(vm, src, vm); return (int)r.iterations; }\n")
+    for decl in ("GaussianVoxelMap vm(0.5);", "IncrementalVoxelMap<FlatContainerCov> vm(0.5);", "IncrementalVoxelMap<FlatContainerPoints> vm(0.5);"):
+        ok = _syntax_only(tmp_path, "int main() { %s PointCloud src; Registration<GICPFactor, ParallelReductionHIP> reg; auto r = reg.align(vm, src, vm); return (int)r.iterations; }\n" % decl)
+        assert ok.returncode == 0, (decl, ok.stderr[-2000:])
+    bad = _syntax_only(tmp_path, "struct Blob { struct Setting {}; size_t size() const { return 0; } };\n"
+                                 "int main() { IncrementalVoxelMap<Blob> vm(0.5); PointCloud src; ParallelReductionHIP red; red.bind(vm, src, Eigen::Isometry3d::Identity()); return 0; }\n")
     assert bad.returncode != 0 and "only GaussianVoxelMap" in bad.stderr, bad.stderr[-2000:]
 
 
@@ -54,7 +57,7 @@ def test_registration_with_the_hip_reduction_policy(tmp_path):
         np.ascontiguousarray(d[name][:, :3], dtype="<f4").tofile(tmp_path / (name + ".bin"))
     p = subprocess.run([BIN, str(tmp_path / "target.bin"), str(tmp_path / "source.bin")], capture_output=True, text=True, timeout=600)
     cases = [json.loads(ln[5:]) for ln in p.stdout.splitlines() if ln.startswith("CASE ")]
-    assert p.returncode == 0 and len(cases) >= 26 and all(c["ok"] for c in cases), p.stdout[-3000:] + p.stderr[-2000:]
+    assert p.returncode == 0 and len(cases) >= 31 and all(c["ok"] for c in cases), p.stdout[-3000:] + p.stderr[-2000:]
     for ln in p.stdout.splitlines():
         if ln.startswith("RATE "):
             print("policy rate:", ln[5:])
