@@ -381,6 +381,32 @@ class IncrementalVoxelMapCov:
         idx, d2 = _voxelmap_knn(self, np.asarray(pt, dtype=np.float64).reshape(1, -1), k)
         return idx[0], d2[0]
 
+    @classmethod
+    def from_voxels(cls, leaf_size, coords, counts, points, cov6=None, search_offsets=1, ctx=None):
+        """A map from voxels that exist on the host in the reference's flat order (sga_index_create_flatmap_from_voxels: what
+        ParallelReductionHIP uploads for an IncrementalVoxelMap<FlatContainer*> target): coords (V, 3), counts (V,), points (P, 3) and
+        cov6 (P, 6) with the points of voxel 0 first, then voxel 1, ... like download().  A search target only."""
+        self = cls.__new__(cls)
+        self.leaf = float(leaf_size)
+        self.ctx = ctx or default_context()
+        self.h = C.c_void_p()
+        coords = np.ascontiguousarray(coords, dtype=np.int32).reshape(-1, 3)
+        counts = np.ascontiguousarray(counts, dtype=np.uint32).reshape(-1)
+        points = np.asarray(points, dtype=np.float64).reshape(-1, 3)
+        n = len(coords)
+        if len(counts) != n or int(counts.sum()) != len(points) or (n and counts.max() > cls.FLAT_CAP):
+            raise ValueError("counts must have one entry per voxel (<= %d) and sum to the number of points" % cls.FLAT_CAP)
+        valid = np.arange(cls.FLAT_CAP)[None, :] < counts[:, None]
+        p16 = np.zeros((n, cls.FLAT_CAP, 3))
+        p16[valid] = points
+        c16 = None
+        if cov6 is not None:
+            c16 = np.zeros((n, cls.FLAT_CAP, 6))
+            c16[valid] = np.asarray(cov6, dtype=np.float64).reshape(-1, 6)
+        check(load().sga_index_create_flatmap_from_voxels(self.ctx.h, self.leaf, coords.ctypes.data_as(C.c_void_p), counts.ctypes.data_as(C.c_void_p), _dp(p16), None if c16 is None else _dp(c16),
+                                                          int(search_offsets), n, C.byref(self.h)))
+        return self
+
     def set_setting(self, min_sq_dist_in_cell=0.01, max_num_points_in_cell=10):
         check(load().sga_flatmap_set_setting(self.h, float(min_sq_dist_in_cell), int(max_num_points_in_cell)))
 

@@ -1096,6 +1096,38 @@ def test_voxelmap_from_host_voxels_equals_the_map_they_came_from(gpu_c1):
     assert ne == 0 and ee == 0.0 and not He.any()
 
 
+@pytest.mark.parametrize("offsets", [1, 7, 27])
+def test_flat_voxelmap_from_host_voxels_equals_the_map_they_came_from(gpu_c1, offsets):
+    """sga_index_create_flatmap_from_voxels (the upload of a reference IncrementalVoxelMap<FlatContainerCov>, reduction_hip.hpp): the voxels of
+    a device map, downloaded and handed back, give the same packed correspondences (voxel << 32 | point) and bit-equal sums."""
+    tgt, src, _ = gpu_c1
+    a = sga.IncrementalVoxelMapCov(1.0)
+    a.set_search_offsets(offsets)
+    a.insert(tgt)
+    coords, counts, pts, c6 = a.download()
+    st = sga.make_setting("GICP")
+    T = se3([0.1, 0.2, 1.0], 0.01, [0.2, -0.1, 0.0])
+    pa = sga.Problem(a, src)
+    Ha, ba, ea, na = pa.linearize(st.factor, T)
+    ia, _ = pa.factors()
+    b = sga.IncrementalVoxelMapCov.from_voxels(1.0, coords, counts, pts, c6, search_offsets=offsets)
+    assert b.size() == a.size()
+    pb = sga.Problem(b, src)
+    Hb, bb, eb, nb = pb.linearize(st.factor, T)
+    ib, _ = pb.factors()
+    assert (ia == ib).all() and na == nb > 1000 and (Ha == Hb).all() and (ba == bb).all() and ea == eb
+    assert ((ia[ia >= 0] & 0xFFFFFFFF) < 16).all() and ((ia[ia >= 0] >> 32) < a.size()).all()
+    # without covariances: a target for ICP only
+    c = sga.IncrementalVoxelMapCov.from_voxels(1.0, coords, counts, pts, None, search_offsets=offsets)
+    Hc, bc, ec, nc = sga.Problem(c, src).linearize(sga.make_setting("ICP").factor, T)
+    Hd, bd, ed, nd = sga.Problem(a, src).linearize(sga.make_setting("ICP").factor, T)
+    assert nc == nd and (Hc == Hd).all() and ec == ed
+    with pytest.raises(sga.SgaError):
+        sga.Problem(c, src).linearize(st.factor, T)  # GICP needs the covariances
+    with pytest.raises(sga.SgaError):
+        b.insert(tgt)
+
+
 def test_incremental_single_insert_equals_one_shot_build(gpu_c1):
     """One insert into an empty incremental map == sga_index_build_gaussian_voxelmap (the helper's one-shot path)."""
     import ctypes as C
