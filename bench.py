@@ -497,7 +497,7 @@ def policy_leg(sga, kind, tgt, src, cabi_rate, cabi_pose, n=None):
             out["pose_vs_c_abi"] = {"trans_m": dt, "rot_rad": dr}
         out["note"] = ("whole_align = iterations / wall time of align() incl. the reference's own std::vector<Factor>(n) (registration.hpp:41: 144 B per source point, per_align_ms.reference_factor_vector) and its "
                        "count over the host factors (optimizer.hpp:146); inside_the_optimizer = the reference's optimize() between begin_align and end_align; policy_calls = inside ParallelReductionHIP::linearize / error only; "
-                       "lean = verify_content and sync_inliers off; reduction_slot_only = without HipAligned (content check + factor fill per linearize); upload + index build: first_bind_s, once per cloud")
+                       "lean = verify_content and sync_inliers off; reduction_slot_only = Registration<Factor, ParallelReductionHIP> without HipAligned (since the Registration<> specialisation: the same bracket; before: content check + factor fill per linearize); upload + index build: first_bind_s, once per cloud")
         return out
     except Exception as ex:  # noqa: BLE001
         return {"error": repr(ex)}

@@ -14,17 +14,21 @@
 // device together with the search index and the per-point factor state (registration.hpp:41); every call costs a few kernel
 // launches and one 768-byte result.
 //
-// Two ways to use it.
-//  * Reduction slot only (`Registration<GICPFactor, ParallelReductionHIP>`): nothing else of the reference changes.  The policy cannot
-//    see where an align() begins or ends, so EVERY linearize checks that the clouds it uploaded are still the caller's (a hash over
-//    both clouds, `verify_content`) and fills target_index / source_index of the host `factors` (`sync_inliers`), because the
-//    reference counts them after its loop (optimizer.hpp:146).  Correct and convenient; at 1M points those two per-call passes over
-//    host memory cost several times what the device pass costs.
-//  * Reduction + Optimizer slot (`HipAligned<LevenbergMarquardtOptimizer>` or `HipAligned<GaussNewtonOptimizer>`): the adaptor IS the
-//    reference's optimizer (it derives from it and calls its optimize() unchanged, optimizer.hpp:24-149) bracketed by
-//    reduction.begin_align() — hash / upload / index build once — and reduction.end_align() — the host `factors` filled once, after the
-//    loop, which is when the reference reads them; RegistrationResult::num_inliers is then counted exactly as optimizer.hpp:146 does.
-//    Inside the bracket a linearize is the device pass and nothing else: the rate of the C ABI (bench.py `policy_c3`).
+// How to use it.
+//  * Swap the Reduction type, nothing else: `Registration<GICPFactor, ParallelReductionHIP>`.  This header specialises Registration<> for
+//    its own policy type (bottom of the file): align() is the reference's (registration.hpp:33-43) with the optimizer of the Optimizer
+//    slot — the reference's LevenbergMarquardtOptimizer / GaussNewtonOptimizer, unchanged, all its settings — run between
+//    reduction.begin_align() (hash / upload / index build: once per align) and reduction.end_align() (the host `factors` filled once,
+//    after the loop, which is when the reference reads them, optimizer.hpp:146).  Inside the bracket a linearize is the device pass and
+//    nothing else.  With `reduction.sync_inliers = false` (and sync_factors off) the vector of per-point host factors (registration.hpp:41:
+//    144 bytes per source point, 35 ms per call at 1M points) is not even created and RegistrationResult::num_inliers comes from the
+//    device: a whole align() then runs at the rate of the C ABI (bench.py `policy_c3`: 8.2 k iterations/s at 1M <-> 1M points).
+//  * `HipAligned<Optimizer>` in the Optimizer slot is the same bracket as a type of its own (for code that calls optimizer.optimize()
+//    itself, or Registration<> types written before the specialisation existed).
+//  * reduction.linearize() / error() called directly, outside any align(): the policy cannot see where an align() begins or ends, so EVERY
+//    linearize checks that the clouds it uploaded are still the caller's (a hash over both clouds, `verify_content`) and fills
+//    target_index / source_index of the host `factors` (`sync_inliers`).  Correct and convenient; at 1M points those two per-call passes
+//    over host memory cost several times what the device pass costs.
 //
 // Host factors.  `sync_inliers` (default on) fills target_index / source_index; `sync_factors` (default off) additionally fills
 // GICPFactor::mahalanobis (24 more bytes per point and a recompute kernel).  NOTE for code that inspects the factors itself: with
@@ -82,6 +86,7 @@
 #include <small_gicp/factors/robust_kernel.hpp>
 #include <small_gicp/points/traits.hpp>
 #include <small_gicp/registration/optimizer.hpp>
+#include <small_gicp/registration/registration.hpp>
 #include <small_gicp/registration/registration_result.hpp>
 #include <small_gicp/registration/rejector.hpp>
 
@@ -227,6 +232,7 @@ struct DeviceState {
   const void *target_addr = nullptr, *source_addr = nullptr;
   std::uint64_t target_fp = 0, source_fp = 0;
   bool has_target = false, has_source = false;
+  size_t n_source = 0;  // points of the uploaded source (the host `factors` are filled only if there is one per point)
   bool voxel_target = false;  // Gaussian voxel map: target_index of the host factors = voxel id << 32 (incremental_voxelmap.hpp:153)
   std::uint64_t generation = 0;  // bumped whenever something is uploaded again
   bool in_align = false;         // between begin_align() and end_align(): linearize() is the device pass and nothing else
@@ -475,6 +481,7 @@ struct ParallelReductionHIP {
       hip_detail::check(sga_multi_set_source_f64(s.multi, c.p.data(), c.nr.empty() ? nullptr : c.nr.data(), c.cv.empty() ? nullptr : c.cv.data(), c.n, T.matrix().data()), "sga_multi_set_source_f64");  // registration.hpp:41
       s.source_addr = &source;
       s.source_fp = sfp;
+      s.n_source = c.n;
       s.has_source = true;
       s.generation++;
       pool->uploaded();
@@ -566,7 +573,7 @@ private:
   template <typename Factor>
   void fill_factors(hip_detail::DeviceState& s, std::vector<Factor>& factors) const {
     using Map = hip_detail::factor_map<Factor>;
-    if (!(sync_factors || sync_inliers) || factors.empty()) return;
+    if (!(sync_factors || sync_inliers) || factors.empty() || factors.size() != s.n_source) return;  // (the Registration<> specialisation below hands over a stub vector when no host factors are wanted)
     const size_t n = factors.size();
     s.idx.resize(n);
     constexpr bool is_gicp = Map::kind == SGA_GICP;
@@ -650,6 +657,56 @@ struct HipAligned : public Optimizer {
       return Optimizer::optimize(target, source, target_tree, rejector, criteria, reduction, init_T, factors, general_factor);
     }
   }
+};
+
+namespace hip_detail {
+template <typename T>
+struct is_hip_aligned : std::false_type {};
+template <typename O>
+struct is_hip_aligned<HipAligned<O>> : std::true_type {};
+}  // namespace hip_detail
+
+/// @brief Registration<> with ParallelReductionHIP in the Reduction slot (a partial specialisation of registration/registration.hpp:17-54 for
+/// this repository's own policy type): the reference's align(), with what has to happen once per align() happening once.  Swapping the
+/// Reduction type is then ALL a user does — `Registration<GICPFactor, ParallelReductionHIP>` — and gets
+///  * the optimizer of the Optimizer slot, unchanged, between reduction.begin_align() and reduction.end_align() (what HipAligned<> does;
+///    an Optimizer that already is a HipAligned<> is used as it is);
+///  * the vector of per-point host factors (registration.hpp:41: 144 bytes per source point for GICP, allocated and initialised per call:
+///    35 ms at 1M points, thirty times the device's share of the align) only if something reads it: with reduction.sync_inliers and
+///    reduction.sync_factors both off a one-element stub takes its place and RegistrationResult::num_inliers comes from the device.
+/// Same members, same call, same RegistrationResult.
+template <typename PointFactor, typename GeneralFactor, typename CorrespondenceRejector, typename Optimizer>
+struct Registration<PointFactor, ParallelReductionHIP, GeneralFactor, CorrespondenceRejector, Optimizer> {
+public:
+  template <typename TargetPointCloud, typename SourcePointCloud, typename TargetTree>
+  RegistrationResult
+  align(const TargetPointCloud& target, const SourcePointCloud& source, const TargetTree& target_tree, const Eigen::Isometry3d& init_T = Eigen::Isometry3d::Identity()) const {
+    if (traits::size(target) <= 10) {
+      std::cerr << "warning: target point cloud is too small. |target|=" << traits::size(target) << std::endl;
+    }
+    if (traits::size(source) <= 10) {
+      std::cerr << "warning: source point cloud is too small. |source|=" << traits::size(source) << std::endl;
+    }
+    const bool host_factors = reduction.sync_inliers || reduction.sync_factors;
+    std::vector<PointFactor> factors(host_factors ? traits::size(source) : 1, PointFactor(point_factor));
+    if constexpr (hip_detail::is_hip_aligned<Optimizer>::value) {
+      return optimizer.optimize(target, source, target_tree, rejector, criteria, reduction, init_T, factors, general_factor);
+    } else {
+      HipAligned<Optimizer> bracketed;
+      static_cast<Optimizer&>(bracketed) = optimizer;  // every setting of the caller's optimizer
+      return bracketed.optimize(target, source, target_tree, rejector, criteria, reduction, init_T, factors, general_factor);
+    }
+  }
+
+public:
+  using PointFactorSetting = typename PointFactor::Setting;
+
+  TerminationCriteria criteria;     ///< Termination criteria
+  CorrespondenceRejector rejector;  ///< Correspondence rejector
+  PointFactorSetting point_factor;  ///< Factor setting
+  GeneralFactor general_factor;     ///< General factor
+  ParallelReductionHIP reduction;   ///< Reduction
+  Optimizer optimizer;              ///< Optimizer
 };
 
 }  // namespace small_gicp

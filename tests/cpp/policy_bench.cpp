@@ -94,7 +94,8 @@ static int run(const Target& target, const PointCloud& source, const Tree& tree,
     asm volatile("" ::"r"(factors.data()) : "memory");
   }
   const double factors_s = secs(t0, now());
-  // the lean bracket: no content check (the caller promises not to edit clouds in place), no host factors (num_inliers from the device)
+  // the lean bracket: no content check (the caller promises not to edit clouds in place), no host factors (num_inliers from the device;
+  // the Registration<> specialisation then does not even create the vector of per-point factors)
   Aligned lean;
   lean.reduction.num_gpus = num_gpus;
   lean.reduction.verify_content = lean.reduction.sync_inliers = false;
@@ -113,7 +114,7 @@ static int run(const Target& target, const PointCloud& source, const Tree& tree,
     lean_calls_s += std::get<3>(lean.reduction.last_bracket_seconds());
   }
   const double lean_total_s = secs(t0, now());
-  // the same clouds with the policy in the Reduction slot only (per-call content check + factor fill)
+  // the same clouds with the policy in the Reduction slot only: Registration<Factor, ParallelReductionHIP> (the specialisation in reduction_hip.hpp brackets it like HipAligned<>)
   Registration<Factor, ParallelReductionHIP> plain;
   plain.reduction.num_gpus = num_gpus;
   plain.rejector.max_dist_sq = 1.0;

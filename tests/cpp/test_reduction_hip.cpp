@@ -195,7 +195,8 @@ int main(int argc, char** argv) {
     cpu.reduction.num_threads = 4;
     const auto rc = cpu.align(*target, *source, tree, I);
     auto rh = reg.align(*target, *source, tree, I);
-    const bool ok = rh.num_inliers == 0 && std::llabs(static_cast<long long>(reg.reduction.num_inliers) - static_cast<long long>(rc.num_inliers)) <= 2;
+    // (the Registration<> specialisation puts the device's count into the result; without it the reference's count over untouched factors was 0)
+    const bool ok = rh.num_inliers == reg.reduction.num_inliers && std::llabs(static_cast<long long>(reg.reduction.num_inliers) - static_cast<long long>(rc.num_inliers)) <= 2;
     std::printf("CASE {\"name\": \"sync_inliers = false: count from reduction.num_inliers\", \"ok\": %s, \"reduction_num_inliers\": %zu, \"cpu\": %zu}\n", ok ? "true" : "false", reg.reduction.num_inliers, rc.num_inliers);
     if (!ok) failures++;
   }
@@ -319,6 +320,29 @@ int main(int argc, char** argv) {
     }
     std::printf("CASE {\"name\": \"4 threads align concurrently through one Registration object\", \"ok\": %s, \"worst_pose_error\": %.3e, \"uploads\": %llu}\n", ok ? "true" : "false", worst,
                 static_cast<unsigned long long>(reg.reduction.generation()));
+    if (!ok) failures++;
+  }
+  // ---- the Registration<> specialisation: swapping the Reduction type alone brackets the optimizer; no host factors when nobody reads them ----
+  {
+    Registration<GICPFactor, ParallelReductionOMP> cpu;
+    cpu.reduction.num_threads = 4;
+    const RegistrationResult rc = cpu.align(*target, *source, tree, I);
+    Registration<GICPFactor, ParallelReductionHIP> lean;  // Reduction slot only
+    lean.reduction.sync_inliers = false;                  // -> a one-element stub instead of the vector of per-point factors
+    const RegistrationResult r1 = lean.align(*target, *source, tree, I);
+    const auto uploads = lean.reduction.generation();
+    const RegistrationResult r2 = lean.align(*target, *source, tree, I);
+    double dt, dr;
+    pose_error(rc.T_target_source, r2.T_target_source, &dt, &dr);
+    bool ok = dt < 1e-4 && dr < 1e-4 && rc.iterations == r2.iterations && std::llabs(static_cast<long long>(rc.num_inliers) - static_cast<long long>(r2.num_inliers)) <= 2 && r1.num_inliers == r2.num_inliers &&
+              lean.reduction.generation() == uploads && uploads == 2;
+    // the caller's optimizer settings reach the bracketed optimizer
+    Registration<GICPFactor, ParallelReductionHIP, NullFactor, DistanceRejector, GaussNewtonOptimizer> gn;
+    gn.optimizer.max_iterations = 2;
+    const RegistrationResult r3 = gn.align(*target, *source, tree, I);
+    ok = ok && r3.iterations == 1 && !r3.converged && r3.num_inliers > 5000;
+    std::printf("CASE {\"name\": \"Registration<GICPFactor, ParallelReductionHIP>: bracketed by the specialisation, stub factors with sync_inliers = false\", \"ok\": %s, \"dt\": %.3e, \"num_inliers\": [%zu, %zu], \"uploads\": %llu, \"gn_iterations\": %zu}\n",
+                ok ? "true" : "false", dt, r2.num_inliers, rc.num_inliers, static_cast<unsigned long long>(uploads), r3.iterations);
     if (!ok) failures++;
   }
   // ---- VGICP (registration_helper.cpp:125-137): a GaussianVoxelMap as target AND as tree, through the policy ----
