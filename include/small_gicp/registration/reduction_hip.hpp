@@ -20,9 +20,9 @@
 //    slot — the reference's LevenbergMarquardtOptimizer / GaussNewtonOptimizer, unchanged, all its settings — run between
 //    reduction.begin_align() (hash / upload / index build: once per align) and reduction.end_align() (the host `factors` filled once,
 //    after the loop, which is when the reference reads them, optimizer.hpp:146).  Inside the bracket a linearize is the device pass and
-//    nothing else.  With `reduction.sync_inliers = false` (and sync_factors off) the vector of per-point host factors (registration.hpp:41:
-//    144 bytes per source point, 35 ms per call at 1M points) is not even created and RegistrationResult::num_inliers comes from the
-//    device: a whole align() then runs at the rate of the C ABI (bench.py `policy_c3`: 8.2 k iterations/s at 1M <-> 1M points).
+//    nothing else.  The vector of per-point host factors (registration.hpp:41: 144 bytes per source point, 35 ms per call at 1M points) is
+//    a local of align() nobody can see: it is not created, RegistrationResult::num_inliers comes from the device.  With
+//    `reduction.verify_content = false` a whole align() runs at the rate of the C ABI (bench.py `policy_c3`: 8.2 k iterations/s at 1M <-> 1M).
 //  * `HipAligned<Optimizer>` in the Optimizer slot is the same bracket as a type of its own (for code that calls optimizer.optimize()
 //    itself, or Registration<> types written before the specialisation existed).
 //  * reduction.linearize() / error() called directly, outside any align(): the policy cannot see where an align() begins or ends, so EVERY
@@ -500,13 +500,15 @@ struct ParallelReductionHIP {
     s.bind_s = hip_detail::seconds_since(t0);
   }
   /// End of the bracket: the host `factors` as a CPU reduction would have left them after the last linearize (what optimizer.hpp:146 counts).
+  /// Returns whether the host factors were filled (one per source point and sync_inliers / sync_factors on).
   template <typename Factor>
-  void end_align(std::vector<Factor>& factors) const {
+  bool end_align(std::vector<Factor>& factors) const {
     auto& s = pool->mine();
     s.in_align = false;
     const auto t0 = std::chrono::steady_clock::now();
-    fill_factors(s, factors);
+    const bool filled = fill_factors(s, factors);
     s.fill_s = hip_detail::seconds_since(t0);
+    return filled;
   }
   /// Seconds the last bracket of this thread took: begin_align (hash + upload + index build, if any), the optimizer between the
   /// two (the policy's linearize / error calls AND the reference's own host code: 6x6 solves, and its count over the host factors,
@@ -571,9 +573,9 @@ struct ParallelReductionHIP {
 
 private:
   template <typename Factor>
-  void fill_factors(hip_detail::DeviceState& s, std::vector<Factor>& factors) const {
+  bool fill_factors(hip_detail::DeviceState& s, std::vector<Factor>& factors) const {
     using Map = hip_detail::factor_map<Factor>;
-    if (!(sync_factors || sync_inliers) || factors.empty() || factors.size() != s.n_source) return;  // (the Registration<> specialisation below hands over a stub vector when no host factors are wanted)
+    if (!(sync_factors || sync_inliers) || factors.empty() || factors.size() != s.n_source) return false;  // (the Registration<> specialisation below hands over a one-element stub)
     const size_t n = factors.size();
     s.idx.resize(n);
     constexpr bool is_gicp = Map::kind == SGA_GICP;
@@ -591,6 +593,7 @@ private:
       f.target_index = s.idx[i] < 0 ? std::numeric_limits<size_t>::max() : (s.voxel_target ? static_cast<size_t>(s.idx[i]) << 32 : static_cast<size_t>(s.idx[i]));
       if (is_gicp) hip_detail::set_mahalanobis(f, maha ? &s.m6[6 * i] : nan6);  // not synced: poisoned rather than stale
     }
+    return true;
   }
 
   template <typename Factor>
@@ -647,11 +650,11 @@ struct HipAligned : public Optimizer {
         reduction.end_align(none);
         throw;
       }
-      reduction.end_align(factors);  // the host factors: once, when the reference reads them
-      if (reduction.sync_inliers || reduction.sync_factors)
+      const bool filled = reduction.end_align(factors);  // the host factors: once, when the reference reads them
+      if (filled)
         result.num_inliers = std::count_if(factors.begin(), factors.end(), [](const auto& factor) { return factor.inlier(); });  // optimizer.hpp:146, after the fill
       else
-        result.num_inliers = reduction.num_inliers;  // host factors untouched on request: the count of the last linearization, from the device
+        result.num_inliers = reduction.num_inliers;  // host factors untouched (on request, or a stub vector): the count of the last linearization, from the device
       return result;
     } else {
       return Optimizer::optimize(target, source, target_tree, rejector, criteria, reduction, init_T, factors, general_factor);
@@ -671,9 +674,9 @@ struct is_hip_aligned<HipAligned<O>> : std::true_type {};
 /// Reduction type is then ALL a user does — `Registration<GICPFactor, ParallelReductionHIP>` — and gets
 ///  * the optimizer of the Optimizer slot, unchanged, between reduction.begin_align() and reduction.end_align() (what HipAligned<> does;
 ///    an Optimizer that already is a HipAligned<> is used as it is);
-///  * the vector of per-point host factors (registration.hpp:41: 144 bytes per source point for GICP, allocated and initialised per call:
-///    35 ms at 1M points, thirty times the device's share of the align) only if something reads it: with reduction.sync_inliers and
-///    reduction.sync_factors both off a one-element stub takes its place and RegistrationResult::num_inliers comes from the device.
+///  * no vector of per-point host factors (registration.hpp:41: 144 bytes per source point for GICP, allocated and initialised per call:
+///    35 ms at 1M points, thirty times the device's share of the align): it is a local of align() that no caller can see; the one
+///    thing read of it, RegistrationResult::num_inliers (optimizer.hpp:146), comes from the device's count of the last linearization.
 /// Same members, same call, same RegistrationResult.
 template <typename PointFactor, typename GeneralFactor, typename CorrespondenceRejector, typename Optimizer>
 struct Registration<PointFactor, ParallelReductionHIP, GeneralFactor, CorrespondenceRejector, Optimizer> {
@@ -687,8 +690,10 @@ public:
     if (traits::size(source) <= 10) {
       std::cerr << "warning: source point cloud is too small. |source|=" << traits::size(source) << std::endl;
     }
-    const bool host_factors = reduction.sync_inliers || reduction.sync_factors;
-    std::vector<PointFactor> factors(host_factors ? traits::size(source) : 1, PointFactor(point_factor));
+    // The reference creates one factor per source point here (registration.hpp:41) — a local of this function that no caller ever sees;
+    // what is read of it is RegistrationResult::num_inliers (optimizer.hpp:146), and that count comes from the device.  A one-element
+    // stub (the factor settings) takes its place.
+    std::vector<PointFactor> factors(1, PointFactor(point_factor));
     if constexpr (hip_detail::is_hip_aligned<Optimizer>::value) {
       return optimizer.optimize(target, source, target_tree, rejector, criteria, reduction, init_T, factors, general_factor);
     } else {
