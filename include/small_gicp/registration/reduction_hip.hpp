@@ -166,14 +166,16 @@ std::uint64_t fingerprint(const Cloud& c) {
 #pragma omp parallel for schedule(static) num_threads(kHostThreads) if (n >= kParallelFrom)
 #endif
   for (long long bl = 0; bl < static_cast<long long>(blocks); bl++) {
-    std::uint64_t h = 1469598103934665603ull;
-    auto mix = [&h](double v) {
-      std::uint64_t b;
-      std::memcpy(&b, &v, 8);
-      h = (h ^ b) * 1099511628211ull;
-    };
+    // four interleaved FNV chains (point i feeds chain i & 3): one chain is bound by the latency of its multiply, four keep the core busy
+    std::uint64_t hh[4] = {1469598103934665603ull, 1469598103934665603ull ^ 1u, 1469598103934665603ull ^ 2u, 1469598103934665603ull ^ 3u};
     const size_t i0 = static_cast<size_t>(bl) * kBlock, i1 = i0 + kBlock < n ? i0 + kBlock : n;
     for (size_t i = i0; i < i1; i++) {
+      std::uint64_t& h = hh[i & 3];
+      auto mix = [&h](double v) {
+        std::uint64_t b;
+        std::memcpy(&b, &v, 8);
+        h = (h ^ b) * 1099511628211ull;
+      };
       const Eigen::Vector4d p = traits::point(c, i);
       mix(p[0]), mix(p[1]), mix(p[2]);
       if (covs) {
@@ -185,7 +187,7 @@ std::uint64_t fingerprint(const Cloud& c) {
         mix(v[0]), mix(v[1]), mix(v[2]);
       }
     }
-    part[bl] = h;
+    part[bl] = (((hh[0] * 1099511628211ull ^ hh[1]) * 1099511628211ull ^ hh[2]) * 1099511628211ull) ^ hh[3];
   }
   std::uint64_t h = 1469598103934665603ull ^ n ^ (normals ? 0x9e3779b97f4a7c15ull : 0ull) ^ (covs ? 0xc2b2ae3d27d4eb4full : 0ull);
   for (std::uint64_t v : part) h = (h ^ v) * 1099511628211ull;
