@@ -235,6 +235,7 @@ struct DeviceState {
   std::uint64_t target_fp = 0, source_fp = 0;
   bool has_target = false, has_source = false;
   size_t n_source = 0;  // points of the uploaded source (the host `factors` are filled only if there is one per point)
+  size_t num_inliers = 0;  // of this thread's last linearize
   bool voxel_target = false;  // Gaussian voxel map: target_index of the host factors = voxel id << 32 (incremental_voxelmap.hpp:153)
   std::uint64_t generation = 0;  // bumped whenever something is uploaded again
   bool in_align = false;         // between begin_align() and end_align(): linearize() is the device pass and nothing else
@@ -521,6 +522,8 @@ struct ParallelReductionHIP {
     return {s.bind_s, s.loop_s, s.fill_s, s.calls_s};
   }
   void note_loop_seconds(double v) const { pool->mine().loop_s = v; }
+  /// Inliers of the calling thread's last linearize (the member `num_inliers` is the last write of ANY thread).
+  size_t thread_num_inliers() const { return pool->mine().num_inliers; }
 
   /// reduction.hpp:20-47 / reduction_omp.hpp:24-59
   template <typename TargetPointCloud, typename SourcePointCloud, typename TargetTree, typename CorrespondenceRejector, typename Factor>
@@ -545,6 +548,7 @@ struct ParallelReductionHIP {
       for (int j = 0; j < 6; j++) H(i, j) = H36[6 * i + j];
     }
     num_inliers = inliers;
+    s.num_inliers = inliers;
     // Outside an align bracket the policy cannot know which linearize is the last one: the host factors are filled after each
     // (sync_inliers: indices, 8 bytes per point; sync_factors: the GICP mahalanobis too).  Inside a bracket end_align() does it once.
     if (!s.in_align) fill_factors(s, factors);
@@ -656,7 +660,7 @@ struct HipAligned : public Optimizer {
       if (filled)
         result.num_inliers = std::count_if(factors.begin(), factors.end(), [](const auto& factor) { return factor.inlier(); });  // optimizer.hpp:146, after the fill
       else
-        result.num_inliers = reduction.num_inliers;  // host factors untouched (on request, or a stub vector): the count of the last linearization, from the device
+        result.num_inliers = reduction.thread_num_inliers();  // host factors untouched (on request, or a stub vector): the count of THIS thread's last linearization, from the device
       return result;
     } else {
       return Optimizer::optimize(target, source, target_tree, rejector, criteria, reduction, init_T, factors, general_factor);
