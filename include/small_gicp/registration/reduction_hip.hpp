@@ -194,9 +194,11 @@ std::uint64_t fingerprint(const Cloud& c) {
   return h;
 }
 
-// traits::point / normal / cov (points/traits.hpp:15-78) -> the reference PointCloud layout the C ABI takes (point_cloud.hpp:69-71)
+// traits::point / normal / cov (points/traits.hpp:15-78) -> what the device keeps: fp32 xyz, normals, the six distinct covariance entries
+// (the layout of sga_cloud_create_f32).  Converted here, while the cloud is repacked anyway and on the policy's threads: 48 bytes written
+// per point instead of 192, and no second pass over them inside the library.
 struct PackedCloud {
-  std::vector<double> p, nr, cv;
+  std::vector<float> p, nr, cv;  // n x 3, n x 3, n x 6 (xx xy xz yy yz zz)
   size_t n = 0;
 };
 template <typename Cloud>
@@ -204,24 +206,25 @@ PackedCloud pack(const Cloud& c) {
   PackedCloud out;
   const size_t n = out.n = traits::size(c);
   const bool normals = traits::has_normals(c), covs = traits::has_covs(c);
-  out.p.resize(4 * n);
-  out.nr.resize(normals ? 4 * n : 0);
-  out.cv.resize(covs ? 16 * n : 0);
+  out.p.resize(3 * n);
+  out.nr.resize(normals ? 3 * n : 0);
+  out.cv.resize(covs ? 6 * n : 0);
 #ifdef _OPENMP
 #pragma omp parallel for schedule(static) num_threads(kHostThreads) if (n >= kParallelFrom)
 #endif
   for (long long ii = 0; ii < static_cast<long long>(n); ii++) {
     const size_t i = static_cast<size_t>(ii);
     const Eigen::Vector4d v = traits::point(c, i);
-    for (int k = 0; k < 4; k++) out.p[4 * i + k] = v[k];
+    for (int k = 0; k < 3; k++) out.p[3 * i + k] = static_cast<float>(v[k]);
     if (normals) {
       const Eigen::Vector4d w = traits::normal(c, i);
-      for (int k = 0; k < 4; k++) out.nr[4 * i + k] = w[k];
+      for (int k = 0; k < 3; k++) out.nr[3 * i + k] = static_cast<float>(w[k]);
     }
     if (covs) {
       const Eigen::Matrix4d m = traits::cov(c, i);
-      for (int col = 0; col < 4; col++)
-        for (int row = 0; row < 4; row++) out.cv[16 * i + 4 * col + row] = m(row, col);
+      float* o = &out.cv[6 * i];
+      o[0] = static_cast<float>(m(0, 0)), o[1] = static_cast<float>(m(1, 0)), o[2] = static_cast<float>(m(2, 0));  // (the entries sga_cloud_create_f64 reads: column-major m[0], m[1], m[2], m[5], m[6], m[10])
+      o[3] = static_cast<float>(m(1, 1)), o[4] = static_cast<float>(m(2, 1)), o[5] = static_cast<float>(m(2, 2));
     }
   }
   return out;
@@ -469,7 +472,7 @@ struct ParallelReductionHIP {
       } else {
         const hip_detail::PackedCloud c = hip_detail::pack(target);
         // replaces KdTree<PointCloud>(target), ann/kdtree.hpp:250-252: every device builds its own exact index over its copy
-        hip_detail::check(sga_multi_set_target_f64(s.multi, c.p.data(), c.nr.empty() ? nullptr : c.nr.data(), c.cv.empty() ? nullptr : c.cv.data(), c.n), "sga_multi_set_target_f64");
+        hip_detail::check(sga_multi_set_target_f32(s.multi, c.p.data(), c.nr.empty() ? nullptr : c.nr.data(), c.cv.empty() ? nullptr : c.cv.data(), c.n), "sga_multi_set_target_f32");
       }
       s.voxel_target = voxel_target && !flat_target;  // (a flat map's indices come packed from the device: (voxel << 32) | point)
       s.target_addr = &target;
@@ -481,7 +484,7 @@ struct ParallelReductionHIP {
     }
     if (s.source_addr != static_cast<const void*>(&source) || s.source_fp != sfp || !s.has_source) {
       const hip_detail::PackedCloud c = hip_detail::pack(source);
-      hip_detail::check(sga_multi_set_source_f64(s.multi, c.p.data(), c.nr.empty() ? nullptr : c.nr.data(), c.cv.empty() ? nullptr : c.cv.data(), c.n, T.matrix().data()), "sga_multi_set_source_f64");  // registration.hpp:41
+      hip_detail::check(sga_multi_set_source_f32(s.multi, c.p.data(), c.nr.empty() ? nullptr : c.nr.data(), c.cv.empty() ? nullptr : c.cv.data(), c.n, T.matrix().data()), "sga_multi_set_source_f32");  // registration.hpp:41
       s.source_addr = &source;
       s.source_fp = sfp;
       s.n_source = c.n;

@@ -287,6 +287,9 @@ int sga_multi_create(const int* devices, int num_devices, sga_multi** out);
 int sga_multi_destroy(sga_multi* m);
 int sga_multi_num_devices(const sga_multi* m);
 int sga_multi_set_target_f64(sga_multi* m, const double* xyzw, const double* normals4, const double* cov4x4, size_t n);
+/* the same with fp32 arrays in the layout of sga_cloud_create_f32 (xyz n*3, normals n*3, cov6 n*6: xx xy xz yy yz zz) */
+int sga_multi_set_target_f32(sga_multi* m, const float* xyz, const float* normals3, const float* cov6, size_t n);
+int sga_multi_set_source_f32(sga_multi* m, const float* xyz, const float* normals3, const float* cov6, size_t n, const double init_T[16]);
 /* a Gaussian voxel map as the target (see sga_index_create_voxelmap_from_voxels): replicated on every device */
 int sga_multi_set_target_voxels(sga_multi* m, double leaf_size, const int32_t* coords, const double* means3, const double* cov6, size_t n);
 /* a flat voxel map as the target (see sga_index_create_flatmap_from_voxels): replicated on every device */

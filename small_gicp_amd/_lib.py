@@ -140,6 +140,8 @@ SYMBOLS = [
     ("sga_multi_destroy", C.c_int, [_vp]),
     ("sga_multi_num_devices", C.c_int, [_vp]),
     ("sga_multi_set_target_f64", C.c_int, [_vp, _dp, _dp, _dp, C.c_size_t]),
+    ("sga_multi_set_target_f32", C.c_int, [_vp, _fp, _fp, _fp, C.c_size_t]),
+    ("sga_multi_set_source_f32", C.c_int, [_vp, _fp, _fp, _fp, C.c_size_t, _dp]),
     ("sga_multi_set_target_voxels", C.c_int, [_vp, C.c_double, C.c_void_p, _dp, _dp, C.c_size_t]),
     ("sga_multi_set_target_flat_voxels", C.c_int, [_vp, C.c_double, C.c_void_p, C.c_void_p, _dp, _dp, C.c_int, C.c_size_t]),
     ("sga_multi_set_source_f64", C.c_int, [_vp, _dp, _dp, _dp, C.c_size_t, _dp]),
