@@ -54,6 +54,20 @@ struct Entered {  // SGA_ENTER for a loop over contexts: device + the thread's c
   StreamScope scope;
 };
 
+// before a new target: the problems of the source refer to the old index
+void drop_target(sga_multi* m) {
+  m->model_valid = false;
+  for (auto& s : m->shards) {
+    if (s.problem) sga_problem_destroy(s.problem);
+    s.problem = nullptr;
+    if (s.index) sga_index_destroy(s.index);
+    s.index = nullptr;
+    if (s.target) sga_cloud_destroy(s.target);
+    s.target = nullptr;
+  }
+  m->has_target = false;
+}
+
 int multi_lin_cb(void* user, const double T[16], double H[36], double b[6], double* e, uint64_t* inl);
 int multi_err_cb(void* user, const double T[16], double* e);
 struct MultiReduction {
@@ -86,16 +100,7 @@ int sga_multi_num_devices(const sga_multi* m) { return m ? static_cast<int>(m->s
 
 int sga_multi_set_target_f64(sga_multi* m, const double* xyzw, const double* normals4, const double* cov4x4, size_t n) {
   if (!m || (n > 0 && !xyzw)) return fail(SGA_ERR_INVALID, "null argument");
-  m->model_valid = false;
-  for (auto& s : m->shards) {  // the source's problems refer to the old index
-    if (s.problem) sga_problem_destroy(s.problem);
-    s.problem = nullptr;
-    if (s.index) sga_index_destroy(s.index);
-    s.index = nullptr;
-    if (s.target) sga_cloud_destroy(s.target);
-    s.target = nullptr;
-  }
-  m->has_target = false;
+  drop_target(m);
   for (auto& s : m->shards) {
     SGA_TRY(sga_cloud_create_f64(s.ctx, xyzw, normals4, cov4x4, n, &s.target));
     SGA_TRY(sga_index_build_kdtree(s.ctx, s.target, &s.index));
@@ -110,16 +115,7 @@ int sga_multi_set_target_f64(sga_multi* m, const double* xyzw, const double* nor
 // serial double -> float pass of the f64 entry points (150 ms of a 250 ms first bind at 2 x 1M points).
 int sga_multi_set_target_f32(sga_multi* m, const float* xyz, const float* normals3, const float* cov6, size_t n) {
   if (!m || (n > 0 && !xyz)) return fail(SGA_ERR_INVALID, "null argument");
-  m->model_valid = false;
-  for (auto& s : m->shards) {  // the source's problems refer to the old index
-    if (s.problem) sga_problem_destroy(s.problem);
-    s.problem = nullptr;
-    if (s.index) sga_index_destroy(s.index);
-    s.index = nullptr;
-    if (s.target) sga_cloud_destroy(s.target);
-    s.target = nullptr;
-  }
-  m->has_target = false;
+  drop_target(m);
   for (auto& s : m->shards) {
     SGA_TRY(sga_cloud_create_f32(s.ctx, xyz, normals3, cov6, n, &s.target));
     SGA_TRY(sga_index_build_kdtree(s.ctx, s.target, &s.index));
@@ -153,16 +149,7 @@ int sga_multi_set_source_f32(sga_multi* m, const float* xyz, const float* normal
 
 int sga_multi_set_target_voxels(sga_multi* m, double leaf, const int32_t* coords, const double* means3, const double* cov6, size_t n) {
   if (!m) return fail(SGA_ERR_INVALID, "null argument");
-  m->model_valid = false;
-  for (auto& s : m->shards) {  // the source's problems refer to the old index
-    if (s.problem) sga_problem_destroy(s.problem);
-    s.problem = nullptr;
-    if (s.index) sga_index_destroy(s.index);
-    s.index = nullptr;
-    if (s.target) sga_cloud_destroy(s.target);
-    s.target = nullptr;
-  }
-  m->has_target = false;
+  drop_target(m);
   for (auto& s : m->shards) SGA_TRY(sga_index_create_voxelmap_from_voxels(s.ctx, leaf, coords, means3, cov6, n, &s.index));
   m->n_target = n;
   m->has_target = true;
@@ -171,16 +158,7 @@ int sga_multi_set_target_voxels(sga_multi* m, double leaf, const int32_t* coords
 
 int sga_multi_set_target_flat_voxels(sga_multi* m, double leaf, const int32_t* coords, const uint32_t* counts, const double* points3, const double* cov6, int search_offsets, size_t n) {
   if (!m) return fail(SGA_ERR_INVALID, "null argument");
-  m->model_valid = false;
-  for (auto& s : m->shards) {  // the source's problems refer to the old index
-    if (s.problem) sga_problem_destroy(s.problem);
-    s.problem = nullptr;
-    if (s.index) sga_index_destroy(s.index);
-    s.index = nullptr;
-    if (s.target) sga_cloud_destroy(s.target);
-    s.target = nullptr;
-  }
-  m->has_target = false;
+  drop_target(m);
   for (auto& s : m->shards) SGA_TRY(sga_index_create_flatmap_from_voxels(s.ctx, leaf, coords, counts, points3, cov6, search_offsets, n, &s.index));
   m->n_target = n;
   m->has_target = true;
