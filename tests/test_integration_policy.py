@@ -48,6 +48,16 @@ def test_policy_takes_the_reference_voxel_maps_as_targets(tmp_path):
     assert bad.returncode != 0 and "only GaussianVoxelMap" in bad.stderr, bad.stderr[-2000:]
 
 
+def test_policy_host_side_pieces():
+    """tests/cpp/test_policy_host.cpp: repacking of clouds and of the reference's voxel maps for the C ABI, the content hash (any single entry
+    changed is noticed), the reference's set_search_offsets(27) quirk the device's 27-voxel order follows.  No GPU: runs wherever the binary is."""
+    host = os.path.join(ROOT, "oracle", "_ref", "test_policy_host")
+    if not os.path.exists(host):
+        pytest.skip("oracle/_ref/test_policy_host is not built (make -C oracle/ref where /root/reference is mounted)")
+    p = subprocess.run([host], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "DONE failures=0" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+
+
 @pytest.mark.gpu
 def test_registration_with_the_hip_reduction_policy(tmp_path):
     if not os.path.exists(BIN):
