@@ -75,3 +75,33 @@ def test_registration_with_the_hip_reduction_policy(tmp_path):
     assert len(rates) == 5 and all(r["hip_policy_iterations_per_s"] > 0 and r["uploads"] == 2 for r in rates)  # two uploads: target and source, once
     gicp = cases[0]
     assert gicp["num_inliers"][0] == gicp["reduction_num_inliers"] > 5000  # RegistrationResult::num_inliers is right without patching the optimizer
+
+
+@pytest.mark.gpu
+def test_reference_helper_api_served_by_the_hip_implementation(tmp_path, c1_gold):
+    """integration/registration_helper_hip.cpp defines the functions registration/registration_helper.hpp declares — the reference's compiled
+    helper library (src/small_gicp/registration/registration_helper.cpp) with the MI355X path behind the same symbols.  tests/cpp/
+    test_helper_hip.cpp calls them the way the reference's examples do (the one-call Eigen interface, preprocess_points + align for every
+    registration type, create_gaussian_voxelmap + VGICP); the poses must equal the goldens of config C1 within the 1e-4 m / 1e-4 rad bar."""
+    from conftest import pose_error
+
+    binary = os.path.join(ROOT, "oracle", "_ref", "test_helper_hip")
+    if not os.path.exists(binary):
+        pytest.skip("oracle/_ref/test_helper_hip did not travel with the repository (make -C oracle/ref where /root/reference is mounted)")
+    d = np.load(os.path.join(GOLDEN, "c1_points.npz"))
+    for name in ("target", "source"):
+        np.ascontiguousarray(d[name][:, :3], dtype="<f4").tofile(tmp_path / (name + ".bin"))
+    p = subprocess.run([binary, str(tmp_path / "target.bin"), str(tmp_path / "source.bin")], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    res = {r["name"]: r for r in (json.loads(ln[7:]) for ln in p.stdout.splitlines() if ln.startswith("RESULT "))}
+    assert set(res) == {"points_GICP", "points_VGICP", "ICP", "PLANE_ICP", "GICP", "VGICP"}, p.stdout[-2000:]
+    pre = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("PREPROCESSED ")][0][13:])
+    assert [pre["target"], pre["source"]] == c1_gold["downsampled_sizes"] and pre["tree"] == pre["target"]
+    tree = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("TREE ")][0][5:])
+    assert tree["found"] == 1 and tree["index"] == 0 and tree["sq_dist"] < 1e-12  # the returned KdTree is a working reference tree
+    for name, gold in (("points_GICP", "GICP"), ("GICP", "GICP"), ("ICP", "ICP"), ("PLANE_ICP", "PLANE_ICP"), ("points_VGICP", "VGICP"), ("VGICP", "VGICP")):
+        r, g = res[name], c1_gold["cases"][gold]
+        dt, dr = pose_error(np.array(r["T"]).reshape(4, 4).T, np.array(g["T"]))
+        assert dt < 1e-4 and dr < 1e-4 and bool(r["converged"]) == g["converged"], (name, dt, dr)
+        assert abs(r["iterations"] - g["iterations"]) <= 1 and abs(r["num_inliers"] - g["num_inliers"]) <= 3, (name, r["iterations"], g["iterations"], r["num_inliers"], g["num_inliers"])
+        print("helper %s: dt %.2e dr %.2e iterations %d inliers %d (golden %d)" % (name, dt, dr, r["iterations"], r["num_inliers"], g["num_inliers"]))
