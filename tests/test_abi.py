@@ -37,6 +37,26 @@ def test_no_gpu_fails_loudly():
         sga.PointCloud(np.zeros((10, 3), np.float32))
 
 
+def test_argument_checks_come_before_any_device_work():
+    """Entry points that take host arrays reject null handles and impossible sizes with SGA_ERR_INVALID before they touch a device (so
+    the checks run on a box without a GPU): the from-host-voxels creators and the sga_multi setters added in round 4."""
+    lib = sga.load()
+    out = C.c_void_p()
+    one3 = (C.c_int32 * 3)(0, 0, 0)
+    cnt = (C.c_uint32 * 1)(1)
+    d = (C.c_double * 96)()
+    f = (C.c_float * 6)()
+    INVALID = 1  # SGA_ERR_INVALID
+    assert lib.sga_index_create_voxelmap_from_voxels(None, 1.0, one3, d, d, 1, C.byref(out)) == INVALID
+    assert lib.sga_index_create_flatmap_from_voxels(None, 1.0, one3, cnt, d, d, 1, 1, C.byref(out)) == INVALID
+    assert lib.sga_multi_set_target_voxels(None, 1.0, one3, d, d, 1) == INVALID
+    assert lib.sga_multi_set_target_flat_voxels(None, 1.0, one3, cnt, d, d, 1, 1) == INVALID
+    assert lib.sga_multi_set_target_f32(None, f, None, None, 1) == INVALID
+    assert lib.sga_multi_set_source_f32(None, f, None, None, 1, d) == INVALID
+    assert lib.sga_multi_create(None, 1, C.byref(out)) == INVALID and lib.sga_multi_create((C.c_int * 1)(0), 0, C.byref(out)) == INVALID
+    assert b"" != lib.sga_last_error()
+
+
 def test_defaults_match_reference():
     """registration_helper.hpp:37-49, optimizer.hpp:66,83, termination_criteria.hpp:13, rejector.hpp:20."""
     s = _lib.RegistrationSettingC()
