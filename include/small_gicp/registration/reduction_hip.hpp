@@ -197,8 +197,12 @@ std::uint64_t fingerprint(const Cloud& c) {
 // traits::point / normal / cov (points/traits.hpp:15-78) -> what the device keeps: fp32 xyz, normals, the six distinct covariance entries
 // (the layout of sga_cloud_create_f32).  Converted here, while the cloud is repacked anyway and on the policy's threads: 48 bytes written
 // per point instead of 192, and no second pass over them inside the library.
+// The points are stored RELATIVE to `origin` (the centre of the cloud's bounding box, rounded by the library's own rule,
+// sga_choose_origin): the reference's clouds are double (points/point_cloud.hpp:69-71) and may lie kilometres from the origin — the
+// subtraction happens here, in double, before the cast, so that what fp32 holds is the cloud's shape (small_gicp_amd.h: device frames).
 struct PackedCloud {
   std::vector<float> p, nr, cv;  // n x 3, n x 3, n x 6 (xx xy xz yy yz zz)
+  double origin[3] = {0, 0, 0};
   size_t n = 0;
 };
 template <typename Cloud>
@@ -206,6 +210,19 @@ PackedCloud pack(const Cloud& c) {
   PackedCloud out;
   const size_t n = out.n = traits::size(c);
   const bool normals = traits::has_normals(c), covs = traits::has_covs(c);
+  {
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(kHostThreads) if (n >= kParallelFrom) reduction(min : lo[:3]) reduction(max : hi[:3])
+#endif
+    for (long long ii = 0; ii < static_cast<long long>(n); ii++) {
+      const Eigen::Vector4d v = traits::point(c, static_cast<size_t>(ii));
+      for (int k = 0; k < 3; k++)
+        if (std::isfinite(v[k])) lo[k] = v[k] < lo[k] ? v[k] : lo[k], hi[k] = v[k] > hi[k] ? v[k] : hi[k];
+    }
+    sga_choose_origin(lo, hi, out.origin);
+  }
+  const double o0 = out.origin[0], o1 = out.origin[1], o2 = out.origin[2];
   out.p.resize(3 * n);
   out.nr.resize(normals ? 3 * n : 0);
   out.cv.resize(covs ? 6 * n : 0);
@@ -215,7 +232,7 @@ PackedCloud pack(const Cloud& c) {
   for (long long ii = 0; ii < static_cast<long long>(n); ii++) {
     const size_t i = static_cast<size_t>(ii);
     const Eigen::Vector4d v = traits::point(c, i);
-    for (int k = 0; k < 3; k++) out.p[3 * i + k] = static_cast<float>(v[k]);
+    out.p[3 * i] = static_cast<float>(v[0] - o0), out.p[3 * i + 1] = static_cast<float>(v[1] - o1), out.p[3 * i + 2] = static_cast<float>(v[2] - o2);
     if (normals) {
       const Eigen::Vector4d w = traits::normal(c, i);
       for (int k = 0; k < 3; k++) out.nr[3 * i + k] = static_cast<float>(w[k]);
@@ -472,7 +489,7 @@ struct ParallelReductionHIP {
       } else {
         const hip_detail::PackedCloud c = hip_detail::pack(target);
         // replaces KdTree<PointCloud>(target), ann/kdtree.hpp:250-252: every device builds its own exact index over its copy
-        hip_detail::check(sga_multi_set_target_f32(s.multi, c.p.data(), c.nr.empty() ? nullptr : c.nr.data(), c.cv.empty() ? nullptr : c.cv.data(), c.n), "sga_multi_set_target_f32");
+        hip_detail::check(sga_multi_set_target_f32_origin(s.multi, c.p.data(), c.nr.empty() ? nullptr : c.nr.data(), c.cv.empty() ? nullptr : c.cv.data(), c.n, c.origin), "sga_multi_set_target_f32_origin");
       }
       s.voxel_target = voxel_target && !flat_target;  // (a flat map's indices come packed from the device: (voxel << 32) | point)
       s.target_addr = &target;
@@ -484,7 +501,7 @@ struct ParallelReductionHIP {
     }
     if (s.source_addr != static_cast<const void*>(&source) || s.source_fp != sfp || !s.has_source) {
       const hip_detail::PackedCloud c = hip_detail::pack(source);
-      hip_detail::check(sga_multi_set_source_f32(s.multi, c.p.data(), c.nr.empty() ? nullptr : c.nr.data(), c.cv.empty() ? nullptr : c.cv.data(), c.n, T.matrix().data()), "sga_multi_set_source_f32");  // registration.hpp:41
+      hip_detail::check(sga_multi_set_source_f32_origin(s.multi, c.p.data(), c.nr.empty() ? nullptr : c.nr.data(), c.cv.empty() ? nullptr : c.cv.data(), c.n, c.origin, T.matrix().data()), "sga_multi_set_source_f32_origin");  // registration.hpp:41
       s.source_addr = &source;
       s.source_fp = sfp;
       s.n_source = c.n;

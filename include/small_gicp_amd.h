@@ -70,6 +70,23 @@ void* sga_context_stream(sga_context* ctx); /* the hipStream_t */
 int sga_cloud_create_f32(sga_context* ctx, const float* xyz, const float* normals, const float* cov6, size_t n, sga_cloud** out);
 /* Reference PointCloud layout (points/point_cloud.hpp:69-71): xyzw n*4 doubles, normals n*4 doubles or NULL, covs n*16 doubles (4x4) or NULL */
 int sga_cloud_create_f64(sga_context* ctx, const double* xyzw, const double* normals4, const double* cov4x4, size_t n, sga_cloud** out);
+/* Device frames (round 5).  The reference stores and computes in double (points/point_cloud.hpp:69-71), so clouds kilometres from the origin
+ * (UTM / ENU maps) register to full precision; the device keeps fp32.  Every cloud therefore has an ORIGIN (double[3]) and the device
+ * holds fl32(p - origin), the subtraction done in double: sga_cloud_create_f32 / _f64 choose it themselves (the centre of the bounding
+ * box rounded to a multiple of 128 m — so a cloud centred within 64 m of the origin keeps origin 0 and is stored as before); poses,
+ * H, b, downloaded points, voxel coordinates and kNN queries are always the CALLER's frame, the library converts at its entry points
+ * (pose: t' = R o_source + t - o_target in double; H, b: the 6x6 adjoint of the source shift, so that the twist convention of
+ * util/lie.hpp:73-96 and the LM damping of optimizer.hpp:100-144 are the reference's).  The _origin forms let the caller name the origin:
+ *   sga_cloud_create_f32_origin: xyz_rel are ALREADY relative to origin (true position = xyz_rel + origin; origin NULL = 0) — how an
+ *     fp32 caller hands over a geo-referenced cloud without losing its millimetres;
+ *   sga_cloud_create_f64_origin: absolute doubles, recentred about `origin` (NULL: chosen as above) — ranks that upload their own shard of
+ *     a sharded source name a common origin (the shards' accumulators are added; slices made with sga_cloud_slice share one anyway). */
+int sga_cloud_create_f32_origin(sga_context* ctx, const float* xyz_rel, const float* normals, const float* cov6, size_t n, const double origin[3], sga_cloud** out);
+int sga_cloud_create_f64_origin(sga_context* ctx, const double* xyzw, const double* normals4, const double* cov4x4, size_t n, const double origin[3], sga_cloud** out);
+int sga_cloud_origin(const sga_cloud* cloud, double origin[3]);
+int sga_index_origin(const sga_index* index, double origin[3]);
+/* the library's rule: origin of the device frame for a bounding box (empty / non-finite box: 0) */
+void sga_choose_origin(const double lo[3], const double hi[3], double origin[3]);
 /* A new cloud holding points [first, first + count) of `cloud` with their normals / covariances (device copy): the source shard of one
  * rank when a registration is spread over GPUs (reduction_omp.hpp:32-58 is the loop being partitioned). */
 int sga_cloud_slice(sga_context* ctx, const sga_cloud* cloud, size_t first, size_t count, sga_cloud** out);
@@ -78,6 +95,8 @@ int sga_cloud_size(const sga_cloud* cloud, size_t* n);
 int sga_cloud_has(const sga_cloud* cloud, int* has_normals, int* has_covs);
 /* Any of xyz / normals / cov6 may be NULL. */
 int sga_cloud_download(sga_context* ctx, const sga_cloud* cloud, float* xyz, float* normals, float* cov6);
+/* the same with the points in double (device record + origin, added in double): what a caller far from the origin wants back */
+int sga_cloud_download_f64(sga_context* ctx, const sga_cloud* cloud, double* xyz, float* normals, float* cov6);
 
 /* ---- preprocessing (registration_helper.cpp:22-34 preprocess_points) ----------------------------------------------- */
 /* util/downsampling.hpp:23-78 voxelgrid_sampling: centroid per occupied voxel, output in ascending packed-key order. */
@@ -290,6 +309,9 @@ int sga_multi_set_target_f64(sga_multi* m, const double* xyzw, const double* nor
 /* the same with fp32 arrays in the layout of sga_cloud_create_f32 (xyz n*3, normals n*3, cov6 n*6: xx xy xz yy yz zz) */
 int sga_multi_set_target_f32(sga_multi* m, const float* xyz, const float* normals3, const float* cov6, size_t n);
 int sga_multi_set_source_f32(sga_multi* m, const float* xyz, const float* normals3, const float* cov6, size_t n, const double init_T[16]);
+/* the same with xyz_rel relative to `origin` (see sga_cloud_create_f32_origin): a caller that repacks double clouds subtracts in double while it repacks */
+int sga_multi_set_target_f32_origin(sga_multi* m, const float* xyz_rel, const float* normals3, const float* cov6, size_t n, const double origin[3]);
+int sga_multi_set_source_f32_origin(sga_multi* m, const float* xyz_rel, const float* normals3, const float* cov6, size_t n, const double origin[3], const double init_T[16]);
 /* a Gaussian voxel map as the target (see sga_index_create_voxelmap_from_voxels): replicated on every device */
 int sga_multi_set_target_voxels(sga_multi* m, double leaf_size, const int32_t* coords, const double* means3, const double* cov6, size_t n);
 /* a flat voxel map as the target (see sga_index_create_flatmap_from_voxels): replicated on every device */

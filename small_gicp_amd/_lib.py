@@ -74,11 +74,17 @@ SYMBOLS = [
     ("sga_context_stream", _vp, [_vp]),
     ("sga_cloud_create_f32", C.c_int, [_vp, _fp, _fp, _fp, C.c_size_t, _pvp]),
     ("sga_cloud_create_f64", C.c_int, [_vp, _dp, _dp, _dp, C.c_size_t, _pvp]),
+    ("sga_cloud_create_f32_origin", C.c_int, [_vp, _fp, _fp, _fp, C.c_size_t, _dp, _pvp]),
+    ("sga_cloud_create_f64_origin", C.c_int, [_vp, _dp, _dp, _dp, C.c_size_t, _dp, _pvp]),
+    ("sga_cloud_origin", C.c_int, [_vp, _dp]),
+    ("sga_index_origin", C.c_int, [_vp, _dp]),
+    ("sga_choose_origin", None, [_dp, _dp, _dp]),
     ("sga_cloud_slice", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _pvp]),
     ("sga_cloud_destroy", C.c_int, [_vp]),
     ("sga_cloud_size", C.c_int, [_vp, C.POINTER(C.c_size_t)]),
     ("sga_cloud_has", C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("sga_cloud_download", C.c_int, [_vp, _vp, _fp, _fp, _fp]),
+    ("sga_cloud_download_f64", C.c_int, [_vp, _vp, _dp, _fp, _fp]),
     ("sga_voxelgrid_sampling", C.c_int, [_vp, _vp, C.c_double, _pvp]),
     ("sga_estimate_normals_covariances", C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int]),
     ("sga_index_build_kdtree", C.c_int, [_vp, _vp, _pvp]),
@@ -142,6 +148,8 @@ SYMBOLS = [
     ("sga_multi_set_target_f64", C.c_int, [_vp, _dp, _dp, _dp, C.c_size_t]),
     ("sga_multi_set_target_f32", C.c_int, [_vp, _fp, _fp, _fp, C.c_size_t]),
     ("sga_multi_set_source_f32", C.c_int, [_vp, _fp, _fp, _fp, C.c_size_t, _dp]),
+    ("sga_multi_set_target_f32_origin", C.c_int, [_vp, _fp, _fp, _fp, C.c_size_t, _dp]),
+    ("sga_multi_set_source_f32_origin", C.c_int, [_vp, _fp, _fp, _fp, C.c_size_t, _dp, _dp]),
     ("sga_multi_set_target_voxels", C.c_int, [_vp, C.c_double, C.c_void_p, _dp, _dp, C.c_size_t]),
     ("sga_multi_set_target_flat_voxels", C.c_int, [_vp, C.c_double, C.c_void_p, C.c_void_p, _dp, _dp, C.c_int, C.c_size_t]),
     ("sga_multi_set_source_f64", C.c_int, [_vp, _dp, _dp, _dp, C.c_size_t, _dp]),

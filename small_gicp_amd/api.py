@@ -144,7 +144,6 @@ class PointCloud:
         pts = np.zeros((0, 3), np.float32) if points is None else np.asarray(points)
         if pts.ndim != 2 or pts.shape[1] not in (3, 4):
             raise ValueError("points must be (N,3) or (N,4)")
-        xyz = np.ascontiguousarray(pts[:, :3], dtype=np.float32)
         nrm = None if normals is None else np.ascontiguousarray(np.asarray(normals)[:, :3], dtype=np.float32)
         c6 = None
         if covs is not None:
@@ -152,12 +151,31 @@ class PointCloud:
             c6 = covs if covs.ndim == 2 and covs.shape[1] == 6 else sym6_from_mats(covs)
             c6 = np.ascontiguousarray(c6, dtype=np.float32)
         self.h = C.c_void_p()
-        check(load().sga_cloud_create_f32(self.ctx.h, _fp(xyz), _fp(nrm), _fp(c6), len(xyz), C.byref(self.h)))
+        if pts.dtype == np.float64 and len(pts) > 0:
+            # double input (the reference's PointCloud is double, points/point_cloud.hpp:69-71): the device keeps fp32 records RELATIVE to an
+            # origin (small_gicp_amd.h, "device frames"); the subtraction happens here, in double, so a geo-referenced cloud keeps its millimetres
+            p3 = pts[:, :3]
+            fin = np.isfinite(p3)
+            lo = np.where(fin, p3, np.inf).min(axis=0).astype(np.float64)
+            hi = np.where(fin, p3, -np.inf).max(axis=0).astype(np.float64)
+            origin = np.zeros(3)
+            load().sga_choose_origin(_dp(np.ascontiguousarray(lo)), _dp(np.ascontiguousarray(hi)), _dp(origin))
+            rel = np.ascontiguousarray(p3 - origin if origin.any() else p3, dtype=np.float32)
+            check(load().sga_cloud_create_f32_origin(self.ctx.h, _fp(rel), _fp(nrm), _fp(c6), len(rel), _dp(origin), C.byref(self.h)))
+        else:
+            xyz = np.ascontiguousarray(pts[:, :3], dtype=np.float32)
+            check(load().sga_cloud_create_f32(self.ctx.h, _fp(xyz), _fp(nrm), _fp(c6), len(xyz), C.byref(self.h)))
 
     def __del__(self):
         if getattr(self, "h", None) and self.h.value:
             load().sga_cloud_destroy(self.h)
             self.h = C.c_void_p()
+
+    def origin(self):
+        """Origin of the cloud's device frame (the device holds fl32(p - origin)); zero for clouds centred within 64 m of the origin."""
+        o = np.zeros(3)
+        check(load().sga_cloud_origin(self.h, _dp(o)))
+        return o
 
     def size(self):
         n = C.c_size_t()
@@ -194,9 +212,15 @@ class PointCloud:
     def points(self):
         """(N,4) float64 homogeneous points, like the reference binding."""
         n = self.size()
-        xyz = np.empty((n, 3), np.float32)
-        check(load().sga_cloud_download(self.ctx.h, self.h, _fp(xyz), None, None))
-        return np.concatenate([xyz.astype(np.float64), np.ones((n, 1))], axis=1)
+        xyz = np.empty((n, 3), np.float64)
+        check(load().sga_cloud_download_f64(self.ctx.h, self.h, _dp(xyz), None, None))  # device record + origin, added in double
+        return np.concatenate([xyz, np.ones((n, 1))], axis=1)
+
+    def xyz64(self):
+        n = self.size()
+        xyz = np.empty((n, 3), np.float64)
+        check(load().sga_cloud_download_f64(self.ctx.h, self.h, _dp(xyz), None, None))
+        return xyz
 
     def xyz(self):
         n = self.size()

@@ -163,12 +163,31 @@ struct Ready {
 };
 int mark_ready(sga_context* ctx, Ready& r);            // behind the producing work; no-op unless the context is stream-ordered
 int wait_ready(sga_context* ctx, const Ready& r);      // before consuming on ctx's stream
+
+// ---- device frames (round 5) ---------------------------------------------------------------------------------------------------
+// The reference stores and computes in double (points/point_cloud.hpp:69-71, factors/gicp_factor.hpp:35-73), so clouds kilometres from
+// the origin (UTM / ENU maps) register to full precision.  The device keeps fp32: every cloud / index therefore carries a host-side
+// `origin` (double[3]) and the device holds p' = fl32(p - origin), the subtraction done in double.  origin = kOriginQuantum * round(bbox
+// centre / kOriginQuantum): clouds whose box is centred within 64 m of the origin (every config of BASELINE.json) keep origin 0 and are
+// stored bit for bit as before.  Poses cross the boundary through pose_to_device (t' = R o_s + t - o_t: the same rigid motion between
+// the two device frames, evaluated in double); H and b come back through system_to_caller (the 6x6 adjoint of the source-side shift), so
+// the caller's twist convention (util/lie.hpp:73-96, J = [R skew(p), -R], gicp_factor.hpp:62-66) — and with it the LM damping of
+// optimizer.hpp:100-144, which is not invariant under that adjoint — is exactly the reference's.  Residuals, covariances, normals, the
+// error, the quadratic error model (evaluated between two device-frame poses) do not depend on the frames.
+constexpr double kOriginQuantum = 128.0;
+void choose_origin(const double lo[3], const double hi[3], double origin[3]);  // lo > hi (empty / non-finite box): origin 0
+inline bool origin_is_zero(const double o[3]) { return o[0] == 0.0 && o[1] == 0.0 && o[2] == 0.0; }
+// T, T_dev column-major 4x4; o_s / o_t: origins of the source and target device frames
+void pose_to_device(const double T[16], const double o_s[3], const double o_t[3], double T_dev[16]);
+// H (row-major 6x6, twist order [rx ry rz tx ty tz]) and b of the device frame -> the caller's frame: H = A^T H' A, b = A^T b', A = [[I, 0], [-skew(o_s), I]]
+void system_to_caller(const double o_s[3], double H[36], double b[6]);
 }  // namespace sga
 
 struct sga_cloud {
   int device = 0;
   mutable sga::Ready ready;
   size_t n = 0;
+  double origin[3] = {0, 0, 0};  // the device holds p - origin (see "device frames" above)
   bool has_normals = false, has_covs = false;
   sga::DevBuf<float4> pts;   // w = bitcast(original index)
   sga::DevBuf<float4> nrm;
@@ -183,6 +202,8 @@ struct sga_index {
   int device = 0;
   mutable sga::Ready ready;
   size_t n = 0;  // points (kd-tree) or voxels (voxel map)
+  double origin[3] = {0, 0, 0};  // device frame of the fp32 records (kd-tree: the cloud's; voxel maps: of the exported means / points — voxel
+                                 // coordinates, hash keys and the fp64 state of incremental maps stay in the caller's frame)
   bool has_normals = false, has_covs = false;
   // implicit balanced kd-tree over the target (kd_search.hpp): points in kd order + {threshold, axis} heap
   sga::DevBuf<float4> kd_pts;       // kd order; w = original index bits
@@ -231,6 +252,8 @@ struct sga_problem {
   int device = 0;
   const sga_index* target = nullptr;
   size_t n = 0;  // source points
+  double src_origin[3] = {0, 0, 0};  // device frame of the source records (the target's is target->origin, which an insert into a voxel map may move)
+  bool frame_checked = false;        // sharded contexts: the ranks' source origins were compared (they must agree: the accumulators are summed)
   bool has_normals = false, has_covs = false;
   sga::DevBuf<float4> pts;       // spatially sorted copy of the source; w = original index bits
   sga::DevBuf<sga::Cov8> cov;
@@ -271,6 +294,7 @@ struct sga_problem {
   // custom CorrespondenceRejector on the host (sga_problem_set_rejector): reject flag per source point (caller's order) for the current pass
   sga_rejector_fn rejector_fn = nullptr;
   void* rejector_user = nullptr;
+  const double* caller_T = nullptr;  // the pose as the caller passed it to the linearization being dispatched (what a host rejector is shown)
   sga::DevBuf<unsigned char> reject;
   // the quadratic error model of the last linearization (linearize.hip): valid for trial poses until the next linearization
   bool model_valid = false;

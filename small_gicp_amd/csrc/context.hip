@@ -1,6 +1,8 @@
 // Context (one GPU + one stream), error plumbing and device-resident clouds.
 #include "common.hpp"
 
+#include <cmath>
+
 #include <map>
 #include <mutex>
 
@@ -324,6 +326,44 @@ __global__ void slice_cloud_kernel(const float4* __restrict__ pts, const float4*
   if (cov) ocov[i] = cov[first + i];
 }
 
+// ---- device frames (common.hpp) ----------------------------------------------------------------------------------------------
+void choose_origin(const double lo[3], const double hi[3], double origin[3]) {
+  for (int k = 0; k < 3; k++) {
+    origin[k] = 0.0;
+    if (!(lo[k] <= hi[k])) continue;  // empty or non-finite
+    const double c = 0.5 * (lo[k] + hi[k]);
+    if (c - c != 0.0) continue;
+    origin[k] = kOriginQuantum * std::nearbyint(c / kOriginQuantum);
+  }
+}
+
+void pose_to_device(const double T[16], const double o_s[3], const double o_t[3], double Td[16]) {
+  for (int i = 0; i < 16; i++) Td[i] = T[i];
+  for (int r = 0; r < 3; r++) Td[12 + r] = (T[r] * o_s[0] + T[4 + r] * o_s[1] + T[8 + r] * o_s[2]) + (T[12 + r] - o_t[r]);  // R o_s + (t - o_t)
+}
+
+void system_to_caller(const double o[3], double H[36], double b[6]) {
+  // A = [[I, 0], [X, I]], X = -skew(o):  H = A^T H' A, b = A^T b'  (J = J' A with J' = [R skew(p'), -R], p = p' + o)
+  const double X[3][3] = {{0, o[2], -o[1]}, {-o[2], 0, o[0]}, {o[1], -o[0], 0}};
+  double HA[6][6];  // H' A: columns 0..2 get H'[:, 3..5] X added
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < 6; j++) {
+      double v = H[6 * i + j];
+      if (j < 3)
+        for (int k = 0; k < 3; k++) v += H[6 * i + 3 + k] * X[k][j];
+      HA[i][j] = v;
+    }
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < 6; j++) {
+      double v = HA[i][j];
+      if (i < 3)
+        for (int k = 0; k < 3; k++) v += X[k][i] * HA[3 + k][j];  // (A^T)[i][3 + k] = X[k][i]
+      H[6 * i + j] = v;
+    }
+  for (int i = 0; i < 3; i++)
+    for (int k = 0; k < 3; k++) b[i] += X[k][i] * b[3 + k];
+}
+
 int ensure_temp(sga_context* ctx, size_t bytes) { return ctx->d_temp.reserve(bytes); }
 
 }  // namespace sga
@@ -538,7 +578,10 @@ static int ctx_pinned_stage(sga_context* ctx, size_t bytes, void** out) {
   return SGA_OK;
 }
 
-int sga_cloud_create_f32(sga_context* ctx, const float* xyz, const float* normals, const float* cov6, size_t n, sga_cloud** out) {
+}  // extern "C"
+
+// The cloud whose fp32 coordinates are given RELATIVE to `origin` (true position = xyz_rel + origin): the records go to the device as they are.
+static int cloud_create_rel(sga_context* ctx, const float* xyz, const float* normals, const float* cov6, size_t n, const double origin[3], const double* recentre_by, sga_cloud** out) {
   if (!ctx || !out || (n > 0 && !xyz)) return fail(SGA_ERR_INVALID, "null argument");
   if (n >= (1ull << 31)) return fail(SGA_ERR_INVALID, "cloud too large (%zu points; limit 2^31-1)", n);
   *out = nullptr;
@@ -546,6 +589,7 @@ int sga_cloud_create_f32(sga_context* ctx, const float* xyz, const float* normal
   auto* c = new sga_cloud;
   c->device = ctx->device;
   c->n = n;
+  for (int k = 0; k < 3; k++) c->origin[k] = origin ? origin[k] : 0.0;
   c->has_normals = normals != nullptr;
   c->has_covs = cov6 != nullptr;
   DevBuf<float> sx, sn, sc;
@@ -570,7 +614,12 @@ int sga_cloud_create_f32(sga_context* ctx, const float* xyz, const float* normal
       delete c;
       return rc;
     }
-    std::memcpy(stage, xyz, fx * sizeof(float));
+    if (recentre_by == nullptr) {
+      std::memcpy(stage, xyz, fx * sizeof(float));
+    } else {  // absolute fp32 coordinates far from the origin: the subtraction in double, while the points are staged anyway
+      for (size_t i = 0; i < n; i++)
+        for (int k = 0; k < 3; k++) stage[3 * i + k] = static_cast<float>(static_cast<double>(xyz[3 * i + k]) - recentre_by[k]);
+    }
     if (normals) std::memcpy(stage + fx, normals, fn * sizeof(float));
     if (cov6) std::memcpy(stage + fx + fn, cov6, fc * sizeof(float));
     hipError_t e = hipMemcpyAsync(sx.p, stage, fx * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
@@ -590,11 +639,55 @@ int sga_cloud_create_f32(sga_context* ctx, const float* xyz, const float* normal
   return SGA_OK;
 }
 
-int sga_cloud_create_f64(sga_context* ctx, const double* xyzw, const double* normals4, const double* cov4x4, size_t n, sga_cloud** out) {
+// bounding box over the finite coordinates of n points with `stride` values per point
+template <typename S>
+static void host_bbox(const S* xyz, size_t n, size_t stride, double lo[3], double hi[3]) {
+  for (int k = 0; k < 3; k++) lo[k] = INFINITY, hi[k] = -INFINITY;
+  for (size_t i = 0; i < n; i++)
+    for (int k = 0; k < 3; k++) {
+      const double v = static_cast<double>(xyz[stride * i + k]);
+      if (v - v == 0.0) {  // finite
+        lo[k] = v < lo[k] ? v : lo[k];
+        hi[k] = v > hi[k] ? v : hi[k];
+      }
+    }
+}
+
+namespace sga {
+// absolute fp32 coordinates, recentred about a GIVEN origin (multi.hip: the shards of one source share a device frame)
+int cloud_create_f32_about(sga_context* ctx, const float* xyz, const float* normals, const float* cov6, size_t n, const double origin[3], sga_cloud** out) {
+  return cloud_create_rel(ctx, xyz, normals, cov6, n, origin, origin_is_zero(origin) ? nullptr : origin, out);
+}
+void host_bbox_f32(const float* xyz, size_t n, double lo[3], double hi[3]) { host_bbox(xyz, n, 3, lo, hi); }
+void host_bbox_f64(const double* xyzw, size_t n, double lo[3], double hi[3]) { host_bbox(xyzw, n, 4, lo, hi); }
+}  // namespace sga
+extern "C" {
+
+int sga_cloud_create_f32_origin(sga_context* ctx, const float* xyz_rel, const float* normals, const float* cov6, size_t n, const double origin[3], sga_cloud** out) {
+  return cloud_create_rel(ctx, xyz_rel, normals, cov6, n, origin, nullptr, out);
+}
+
+int sga_cloud_create_f32(sga_context* ctx, const float* xyz, const float* normals, const float* cov6, size_t n, sga_cloud** out) {
+  if (!ctx || !out || (n > 0 && !xyz)) return fail(SGA_ERR_INVALID, "null argument");
+  double lo[3], hi[3], origin[3];
+  host_bbox(xyz, n, 3, lo, hi);
+  choose_origin(lo, hi, origin);
+  return cloud_create_rel(ctx, xyz, normals, cov6, n, origin, origin_is_zero(origin) ? nullptr : origin, out);
+}
+
+int sga_cloud_create_f64_origin(sga_context* ctx, const double* xyzw, const double* normals4, const double* cov4x4, size_t n, const double origin_in[3], sga_cloud** out) {
   if (!ctx || !out || (n > 0 && !xyzw)) return fail(SGA_ERR_INVALID, "null argument");
+  double origin[3] = {0, 0, 0};
+  if (origin_in) {
+    for (int k = 0; k < 3; k++) origin[k] = origin_in[k];
+  } else {
+    double lo[3], hi[3];
+    host_bbox(xyzw, n, 4, lo, hi);
+    choose_origin(lo, hi, origin);
+  }
   std::vector<float> xyz(n * 3), nrm, cov;
   for (size_t i = 0; i < n; i++)
-    for (int k = 0; k < 3; k++) xyz[3 * i + k] = static_cast<float>(xyzw[4 * i + k]);
+    for (int k = 0; k < 3; k++) xyz[3 * i + k] = static_cast<float>(xyzw[4 * i + k] - origin[k]);  // in double, then rounded: what fp32 can hold of the cloud is its shape, not its place
   if (normals4) {
     nrm.resize(n * 3);
     for (size_t i = 0; i < n; i++)
@@ -612,8 +705,26 @@ int sga_cloud_create_f64(sga_context* ctx, const double* xyzw, const double* nor
       cov[6 * i + 5] = static_cast<float>(m[10]);
     }
   }
-  return sga_cloud_create_f32(ctx, xyz.data(), normals4 ? nrm.data() : nullptr, cov4x4 ? cov.data() : nullptr, n, out);
+  return cloud_create_rel(ctx, xyz.data(), normals4 ? nrm.data() : nullptr, cov4x4 ? cov.data() : nullptr, n, origin, nullptr, out);
 }
+
+int sga_cloud_create_f64(sga_context* ctx, const double* xyzw, const double* normals4, const double* cov4x4, size_t n, sga_cloud** out) {
+  return sga_cloud_create_f64_origin(ctx, xyzw, normals4, cov4x4, n, nullptr, out);
+}
+
+int sga_cloud_origin(const sga_cloud* cloud, double origin[3]) {
+  if (!cloud || !origin) return fail(SGA_ERR_INVALID, "null argument");
+  for (int k = 0; k < 3; k++) origin[k] = cloud->origin[k];
+  return SGA_OK;
+}
+
+int sga_index_origin(const sga_index* index, double origin[3]) {
+  if (!index || !origin) return fail(SGA_ERR_INVALID, "null argument");
+  for (int k = 0; k < 3; k++) origin[k] = index->origin[k];
+  return SGA_OK;
+}
+
+void sga_choose_origin(const double lo[3], const double hi[3], double origin[3]) { choose_origin(lo, hi, origin); }
 
 int sga_cloud_slice(sga_context* ctx, const sga_cloud* cloud, size_t first, size_t count, sga_cloud** out) {
   if (!ctx || !cloud || !out) return fail(SGA_ERR_INVALID, "null argument");
@@ -624,6 +735,7 @@ int sga_cloud_slice(sga_context* ctx, const sga_cloud* cloud, size_t first, size
   auto* c = new sga_cloud;
   c->device = ctx->device;
   c->n = count;
+  for (int k = 0; k < 3; k++) c->origin[k] = cloud->origin[k];  // the slice stays in its cloud's device frame: shards of one registration share it
   c->has_normals = cloud->has_normals;
   c->has_covs = cloud->has_covs;
   int rc = c->pts.alloc(count);
@@ -666,24 +778,43 @@ int sga_cloud_has(const sga_cloud* cloud, int* has_normals, int* has_covs) {
   return SGA_OK;
 }
 
-int sga_cloud_download(sga_context* ctx, const sga_cloud* cloud, float* xyz, float* normals, float* cov6) {
+static int cloud_download_impl(sga_context* ctx, const sga_cloud* cloud, float* xyz, double* xyz64, float* normals, float* cov6) {
   if (!ctx || !cloud) return fail(SGA_ERR_INVALID, "null argument");
   if (normals && !cloud->has_normals) return fail(SGA_ERR_INVALID, "cloud has no normals");
   if (cov6 && !cloud->has_covs) return fail(SGA_ERR_INVALID, "cloud has no covariances");
   const size_t n = cloud->n;
   if (n == 0) return SGA_OK;
   SGA_ENTER(ctx);
+  SGA_TRY(wait_ready(ctx, cloud->ready));
   DevBuf<float> sx, sn, sc;
-  if (xyz) SGA_TRY(sx.alloc(n * 3));
+  const bool framed = !origin_is_zero(cloud->origin);
+  std::vector<float> rel;
+  float* xyz_dst = xyz;
+  if (xyz64 || (xyz && framed)) {  // the device frame -> the caller's: the origin is added in double
+    rel.resize(n * 3);
+    xyz_dst = rel.data();
+  }
+  if (xyz_dst) SGA_TRY(sx.alloc(n * 3));
   if (normals) SGA_TRY(sn.alloc(n * 3));
   if (cov6) SGA_TRY(sc.alloc(n * 6));
   hipLaunchKernelGGL(unpack_cloud_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, cloud->pts.p, cloud->nrm.p, cloud->cov.p, n, sx.p, sn.p, sc.p);
   SGA_HIP(hipGetLastError());
-  if (xyz) SGA_HIP(hipMemcpyAsync(xyz, sx.p, n * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  if (xyz_dst) SGA_HIP(hipMemcpyAsync(xyz_dst, sx.p, n * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   if (normals) SGA_HIP(hipMemcpyAsync(normals, sn.p, n * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   if (cov6) SGA_HIP(hipMemcpyAsync(cov6, sc.p, n * 6 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   SGA_HIP(hipStreamSynchronize(ctx->stream));
+  if (!rel.empty())
+    for (size_t i = 0; i < n; i++)
+      for (int k = 0; k < 3; k++) {
+        const double v = static_cast<double>(rel[3 * i + k]) + cloud->origin[k];
+        if (xyz64) xyz64[3 * i + k] = v;
+        if (xyz) xyz[3 * i + k] = static_cast<float>(v);
+      }
   return SGA_OK;
 }
+
+int sga_cloud_download(sga_context* ctx, const sga_cloud* cloud, float* xyz, float* normals, float* cov6) { return cloud_download_impl(ctx, cloud, xyz, nullptr, normals, cov6); }
+
+int sga_cloud_download_f64(sga_context* ctx, const sga_cloud* cloud, double* xyz, float* normals, float* cov6) { return cloud_download_impl(ctx, cloud, nullptr, xyz, normals, cov6); }
 
 }  // extern "C"

@@ -894,11 +894,12 @@ static int build_kdtree(sga_context* ctx, const sga_cloud* cloud, sga_index* idx
 }
 
 // ---- voxel map kernels -------------------------------------------------------------------------------------------------------
-__global__ void voxel_keys_kernel(const float4* __restrict__ pts, size_t n, double inv_leaf, unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals) {
+// (ox, oy, oz): origin of the cloud's device frame — voxel coordinates are those of the CALLER's frame (incremental_voxelmap.hpp:60)
+__global__ void voxel_keys_kernel(const float4* __restrict__ pts, size_t n, double inv_leaf, double ox, double oy, double oz, unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals) {
   const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
   if (i >= n) return;
   const float4 p = pts[i];
-  const int cx = fast_floor_d(static_cast<double>(p.x) * inv_leaf), cy = fast_floor_d(static_cast<double>(p.y) * inv_leaf), cz = fast_floor_d(static_cast<double>(p.z) * inv_leaf);
+  const int cx = fast_floor_d((static_cast<double>(p.x) + ox) * inv_leaf), cy = fast_floor_d((static_cast<double>(p.y) + oy) * inv_leaf), cz = fast_floor_d((static_cast<double>(p.z) + oz) * inv_leaf);
   const bool bad = abs(cx) >= (1 << 20) || abs(cy) >= (1 << 20) || abs(cz) >= (1 << 20);
   keys[i] = bad ? SGA_HASH_EMPTY : voxel_key(cx, cy, cz);  // out-of-range points sort last and are dropped
   vals[i] = static_cast<uint32_t>(i);
@@ -998,6 +999,7 @@ int sga_index_build_kdtree(sga_context* ctx, const sga_cloud* target, sga_index*
   idx->kind = SGA_INDEX_KDTREE;
   idx->device = ctx->device;
   idx->n = n;
+  for (int k = 0; k < 3; k++) idx->origin[k] = target->origin[k];  // the tree lives in its cloud's device frame (common.hpp)
   idx->has_normals = target->has_normals;
   idx->has_covs = target->has_covs;
   SGA_TRY(wait_ready(ctx, target->ready));  // attributes estimated on another context in stream-ordered mode
@@ -1032,6 +1034,8 @@ int sga_index_build_gaussian_voxelmap(sga_context* ctx, const sga_cloud* cloud, 
   idx->leaf = leaf;
   idx->has_covs = true;
   idx->has_normals = false;
+  for (int k = 0; k < 3; k++) idx->origin[k] = cloud->origin[k];  // the means are averages of the cloud's device-frame records
+  SGA_TRY(wait_ready(ctx, cloud->ready));
   uint32_t nvox = 0;
   DevBuf<unsigned long long> keys, keys_sorted;
   DevBuf<uint32_t> vals, order, flags, seg_id, seg_start, seg_first, seg_ids, seg_first_sorted, seg_by_rank;
@@ -1045,7 +1049,7 @@ int sga_index_build_gaussian_voxelmap(sga_context* ctx, const sga_cloud* cloud, 
     SGA_TRY(flags.alloc(n));
     SGA_TRY(seg_id.alloc(n));
     SGA_TRY(d_count.alloc(1));
-    hipLaunchKernelGGL(voxel_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, cloud->pts.p, n, 1.0 / leaf, keys.p, vals.p);
+    hipLaunchKernelGGL(voxel_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, cloud->pts.p, n, 1.0 / leaf, cloud->origin[0], cloud->origin[1], cloud->origin[2], keys.p, vals.p);
     size_t tb = 0;
     SGA_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys.p, keys_sorted.p, vals.p, order.p, n, 0, 64, ctx->stream));
     SGA_TRY(ensure_temp(ctx, tb));
@@ -1132,10 +1136,10 @@ int sga_index_voxelmap_download(sga_context* ctx, const sga_index* index, int32_
   if (counts) SGA_HIP(hipMemcpyAsync(counts, index->vcounts.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   SGA_HIP(hipStreamSynchronize(ctx->stream));
   for (size_t i = 0; i < n; i++) {
-    if (means) {
-      means[3 * i] = hp[i].x;
-      means[3 * i + 1] = hp[i].y;
-      means[3 * i + 2] = hp[i].z;
+    if (means) {  // device frame -> the caller's
+      means[3 * i] = static_cast<float>(static_cast<double>(hp[i].x) + index->origin[0]);
+      means[3 * i + 1] = static_cast<float>(static_cast<double>(hp[i].y) + index->origin[1]);
+      means[3 * i + 2] = static_cast<float>(static_cast<double>(hp[i].z) + index->origin[2]);
     }
     if (cov6) {
       cov6[6 * i] = hc[i].xx;

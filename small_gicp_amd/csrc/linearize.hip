@@ -225,16 +225,19 @@ __device__ __forceinline__ float certify(float rex, float moved, bool has_neighb
 
 // The walk of ONE source point, top-down and seeded, with the fast leaf scan (kd_search.hpp); the rare query it cannot decide (two
 // candidates within 1e-6 of each other, or of the search bound) is searched again with the exact keys.  Stores nn / nn2 / rex.
+// `tid` = the lane's column of kd_stack ([level][BLOCK] words): threadIdx.x in the kernels whose workgroup is BLOCK wide; a kernel that gives
+// every wave of a wider workgroup its own stack passes the lane number (with threadIdx.x there, wave w's rows were shifted by w
+// and a full stack of wave 3 reached past the allocation).
 template <typename Real, int BLOCK>
-__device__ __forceinline__ int walk_lane(const NNParams<Real>& p, int i, float fx, float fy, float fz, int seed, float slack, uint32_t* __restrict__ kd_stack) {
+__device__ __forceinline__ int walk_lane(const NNParams<Real>& p, int i, float fx, float fy, float fz, int seed, float slack, uint32_t* __restrict__ kd_stack, int tid) {
   KdBest nb{};
   bool exact = p.fast == 0;
   if (!exact) {
-    const KdBestFast f = kd_nearest_fast<BLOCK>(p.kd, fx, fy, fz, p.bound2, seed, kd_stack, threadIdx.x, slack);
+    const KdBestFast f = kd_nearest_fast<BLOCK>(p.kd, fx, fy, fz, p.bound2, seed, kd_stack, tid, slack);
     nb = f.best;
     exact = f.ambiguous;
   }
-  if (exact) nb = kd_nearest<BLOCK>(p.kd, fx, fy, fz, p.bound2, seed, kd_stack, threadIdx.x, slack);
+  if (exact) nb = kd_nearest<BLOCK>(p.kd, fx, fy, fz, p.bound2, seed, kd_stack, tid, slack);
   p.nn[i] = nb.idx;
   p.nn2[i] = nb.idx2;
   p.rex[i] = rex_from_r2(nb.r2);
@@ -316,7 +319,7 @@ __device__ __forceinline__ int search_lane(const NNParams<Real>& p, int tile, in
       }
     }
   }
-  return walk_lane<Real, BLOCK>(p, i, fx, fy, fz, seed, CHECK ? slack : 0.f, kd_stack);
+  return walk_lane<Real, BLOCK>(p, i, fx, fy, fz, seed, CHECK ? slack : 0.f, kd_stack, threadIdx.x);
 }
 
 // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed placement; only speed depends on it), and the source is sorted by
@@ -1058,7 +1061,7 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(4))) void
             // seed: the nearer candidate (the check put it first); slack: what the check left in rex[] — both written by this workgroup
             const int seed = __hip_atomic_load(&q.nn[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const float slack = -__hip_atomic_load(&q.rex[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            j = walk_lane<Real, 64>(q, i, fx, fy, fz, seed, slack, my_stack);
+            j = walk_lane<Real, 64>(q, i, fx, fy, fz, seed, slack, my_stack, lane);
           }
           if (j >= 0) {
             const float4 m = p.tgt_pts[j];
@@ -1492,11 +1495,13 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
     p.flat.inv_leaf = 1.0 / idx->leaf;
     p.flat.vnum = idx->vcounts.p;
     p.flat.offsets = idx->search_offsets;
+    for (int k = 0; k < 3; k++) p.flat.org[k] = idx->origin[k];
   } else if (voxel) {
     p.vox.hkeys = idx->hkeys.p;
     p.vox.hvals = idx->hvals.p;
     p.vox.hmask = idx->hmask;
     p.vox.inv_leaf = 1.0 / idx->leaf;
+    for (int k = 0; k < 3; k++) p.vox.org[k] = idx->origin[k];
   } else {
     p.kd = make_kd_view(idx);
   }
@@ -1735,7 +1740,7 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
       int cb_rc;
       {
         StreamScope outside(nullptr);  // user code: objects it destroys (a Python GC run) are not stream-ordered frees of this entry point
-        cb_rc = pb->rejector_fn(pb->rejector_user, T, n, h_idx.data(), h_d2.data(), h_rej.data());
+        cb_rc = pb->rejector_fn(pb->rejector_user, pb->caller_T ? pb->caller_T : T, n, h_idx.data(), h_d2.data(), h_rej.data());  // the rejector sees the CALLER's pose
       }
       if (cb_rc != 0) return fail(SGA_ERR_CALLBACK, "rejector callback failed");
       SGA_HIP(hipMemcpyAsync(pb->reject.p, h_rej.data(), n, hipMemcpyHostToDevice, ctx->stream));
@@ -1968,6 +1973,73 @@ namespace sga {
 
 }  // namespace sga
 
+namespace sga {
+// ---- device frames (common.hpp): what crosses the boundary is converted HERE, everything below works between the two device frames ----
+bool problem_framed(const sga_problem* pb) { return !origin_is_zero(pb->src_origin) || !origin_is_zero(pb->target->origin); }
+// the caller's pose -> the same rigid motion between the source's and the target's device frames; returns Td (or T itself when both origins are 0)
+const double* problem_pose(const sga_problem* pb, const double T[16], double Td[16]) {
+  if (!problem_framed(pb)) return T;
+  pose_to_device(T, pb->src_origin, pb->target->origin, Td);
+  return Td;
+}
+void problem_system_to_caller(const sga_problem* pb, double H[36], double b[6]) {
+  if (!origin_is_zero(pb->src_origin)) system_to_caller(pb->src_origin, H, b);
+}
+// the 30-double accumulator of the asynchronous entry points, in place on the device (one thread: a 6x6 congruence)
+__global__ void frame_accumulator_kernel(double* __restrict__ acc, double ox, double oy, double oz) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double H[36], b[6];
+  int k = 0;
+  for (int i = 0; i < 6; i++)
+    for (int j = i; j < 6; j++) {
+      H[6 * i + j] = H[6 * j + i] = acc[k];
+      k++;
+    }
+  for (int i = 0; i < 6; i++) b[i] = acc[21 + i];
+  const double X[3][3] = {{0, oz, -oy}, {-oz, 0, ox}, {oy, -ox, 0}};  // -skew(o), see system_to_caller (context.hip)
+  double HA[6][6];
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < 6; j++) {
+      double v = H[6 * i + j];
+      if (j < 3)
+        for (int c = 0; c < 3; c++) v += H[6 * i + 3 + c] * X[c][j];
+      HA[i][j] = v;
+    }
+  k = 0;
+  for (int i = 0; i < 6; i++)
+    for (int j = i; j < 6; j++) {
+      double v = HA[i][j];
+      if (i < 3)
+        for (int c = 0; c < 3; c++) v += X[c][i] * HA[3 + c][j];
+      acc[k++] = v;
+    }
+  for (int i = 0; i < 3; i++) {
+    double v = b[i];
+    for (int c = 0; c < 3; c++) v += X[c][i] * b[3 + c];
+    acc[21 + i] = v;
+  }
+}
+// Sharded contexts add the ranks' accumulators: their moments are sums over source points in the SOURCE's device frame, so every rank's
+// shard must live in the same one (slices of one uploaded cloud do: sga_cloud_slice; separately uploaded shards name a common origin:
+// sga_cloud_create_*_origin).  Checked once per problem with one small sum over the ranks: all equal <=> n sum(o^2) == (sum o)^2.
+int problem_check_shard_frames(sga_context* ctx, sga_problem* pb) {
+  if (pb->frame_checked || !ctx->sharded()) return SGA_OK;
+  double h[8] = {pb->src_origin[0], pb->src_origin[1], pb->src_origin[2], pb->src_origin[0] * pb->src_origin[0], pb->src_origin[1] * pb->src_origin[1], pb->src_origin[2] * pb->src_origin[2], 1.0, 0.0};
+  DevBuf<double> d;
+  SGA_TRY(d.alloc(8));
+  SGA_HIP(hipMemcpyAsync(d.p, h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
+  SGA_HIP(hipStreamSynchronize(ctx->stream));
+  SGA_TRY(comm_allreduce_sum(ctx, d.p, 8));
+  SGA_HIP(hipMemcpyAsync(h, d.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+  SGA_HIP(hipStreamSynchronize(ctx->stream));
+  for (int k = 0; k < 3; k++)
+    if (h[6] * h[3 + k] != h[k] * h[k])
+      return fail(SGA_ERR_INVALID, "the source shards of the ranks live in different device frames (origins differ): slice ONE uploaded cloud (sga_cloud_slice) or upload the shards with a common origin (sga_cloud_create_f64_origin)");
+  pb->frame_checked = true;
+  return SGA_OK;
+}
+}  // namespace sga
+
 using namespace sga;
 
 static bool g_error_model = getenv("SGA_ERROR_MODEL") ? atoi(getenv("SGA_ERROR_MODEL")) != 0 : true;
@@ -2010,7 +2082,8 @@ int sga_linearize_per_point(sga_context* ctx, sga_problem* pb, const sga_factor_
   p.corr = pb->corr.p;
   p.hint = pb->hint.p;
   p.maha = pb->maha64.p;
-  p.T = rigid_from_colmajor<double>(T);
+  double Td[16];
+  p.T = rigid_from_colmajor<double>(problem_pose(pb, T, Td));
   p.max_sq = fp->max_dist_sq < 0 ? INFINITY : static_cast<float>(fp->max_dist_sq);
   p.bound2 = p.max_sq < 3.0e38f ? p.max_sq * 1.0000002f : INFINITY;
   p.robust_kind = fp->robust_kind;
@@ -2029,6 +2102,18 @@ int sga_linearize_per_point(sga_context* ctx, sga_problem* pb, const sga_factor_
   SGA_HIP(hipMemcpyAsync(values28, d_vals.p, n * 28 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   SGA_HIP(hipMemcpyAsync(inlier, d_ok.p, n, hipMemcpyDeviceToHost, ctx->stream));
   SGA_HIP(hipStreamSynchronize(ctx->stream));
+  if (!origin_is_zero(pb->src_origin)) {  // per-point systems of the device frame -> the caller's twist convention (common.hpp)
+    for (size_t i = 0; i < n; i++) {
+      double* v = values28 + 28 * i;
+      double Hi[36], bi[6];
+      sga_unpack_accumulator(v, Hi, bi, nullptr, nullptr);  // reads [0, 27) only
+      system_to_caller(pb->src_origin, Hi, bi);
+      int k = 0;
+      for (int r = 0; r < 6; r++)
+        for (int c = r; c < 6; c++) v[k++] = Hi[6 * r + c];
+      for (int r = 0; r < 6; r++) v[21 + r] = bi[r];
+    }
+  }
   return SGA_OK;
 }
 
@@ -2049,14 +2134,24 @@ int sga_linearize_async(sga_context* ctx, sga_problem* pb, const sga_factor_para
   if (!d_out30) return fail(SGA_ERR_INVALID, "null output");
   pb->model_valid = false;  // the cached factor state changes: the synchronous error path must not answer from an older model
   SGA_ENTER(ctx);
-  return fp->math_mode == SGA_MATH_FP64 ? linearize_dispatch<double>(ctx, pb, fp, T, d_out30, nullptr, 0) : linearize_dispatch<float>(ctx, pb, fp, T, d_out30, nullptr, 0);
+  double Tdev[16];
+  const double* Td = problem_pose(pb, T, Tdev);
+  pb->caller_T = T;
+  SGA_TRY(fp->math_mode == SGA_MATH_FP64 ? linearize_dispatch<double>(ctx, pb, fp, Td, d_out30, nullptr, 0) : linearize_dispatch<float>(ctx, pb, fp, Td, d_out30, nullptr, 0));
+  if (!origin_is_zero(pb->src_origin)) {  // the caller reads H / b in its own twist convention (common.hpp: device frames)
+    hipLaunchKernelGGL(frame_accumulator_kernel, dim3(1), dim3(64), 0, ctx->stream, d_out30, pb->src_origin[0], pb->src_origin[1], pb->src_origin[2]);
+    SGA_HIP(hipGetLastError());
+  }
+  return SGA_OK;
 }
 
 int sga_error_async(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, const double T[16], double* d_out1) {
   SGA_TRY(check_args(ctx, pb, fp, T));
   if (!d_out1) return fail(SGA_ERR_INVALID, "null output");
   SGA_ENTER(ctx);
-  return fp->math_mode == SGA_MATH_FP64 ? error_dispatch<double>(ctx, pb, fp, T, d_out1, nullptr, 0) : error_dispatch<float>(ctx, pb, fp, T, d_out1, nullptr, 0);
+  double Tdev[16];
+  const double* Td = problem_pose(pb, T, Tdev);
+  return fp->math_mode == SGA_MATH_FP64 ? error_dispatch<double>(ctx, pb, fp, Td, d_out1, nullptr, 0) : error_dispatch<float>(ctx, pb, fp, Td, d_out1, nullptr, 0);
 }
 
 }  // extern "C"
@@ -2065,7 +2160,11 @@ namespace sga {
 // sga_linearize in two halves, so that one host thread can keep several devices busy (multi.hip): enqueue = the kernels of the pass, the
 // sum over ranks if the context has a communicator, and the hand-off of the result to the host; collect = wait for it (ctx->h_accum
 // then holds `count` doubles: the system, or the system and the error model).
-int linearize_enqueue(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, const double T[16], unsigned long long* seq_out, int* count_out) {
+int linearize_enqueue(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, const double T_caller[16], unsigned long long* seq_out, int* count_out) {
+  double Tdev[16];
+  const double* T = problem_pose(pb, T_caller, Tdev);  // the kernels work between the two device frames (common.hpp)
+  pb->caller_T = T_caller;
+  SGA_TRY(problem_check_shard_frames(ctx, pb));
   const unsigned long long seq = ++ctx->publish_seq;
   const bool direct = !ctx->sharded();
   double* host = direct ? ctx->h_accum_dev : nullptr;
@@ -2104,9 +2203,10 @@ int linearize_collect(sga_context* ctx, sga_problem* pb, const double T[16], uns
       pb->grid_ring_total += static_cast<uint64_t>(ctx->h_accum[kStatsCol + 1]);
     }
   }
-  if (count == kRow) {
+  if (count == kRow) {  // the error model: moments of the source's device frame, evaluated between device-frame poses (sga_error)
+    double Tdev[16];
     memcpy(pb->model, ctx->h_accum, sizeof(pb->model));
-    memcpy(pb->model_T, T, sizeof(pb->model_T));
+    memcpy(pb->model_T, problem_pose(pb, T, Tdev), sizeof(pb->model_T));
     pb->model_valid = true;
   }
   return SGA_OK;
@@ -2124,6 +2224,7 @@ int sga_linearize(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp
   SGA_TRY(linearize_enqueue(ctx, pb, fp, T, &seq, &count));
   SGA_TRY(linearize_collect(ctx, pb, T, seq, count));
   sga_unpack_accumulator(ctx->h_accum, H, b, e, num_inliers);
+  problem_system_to_caller(pb, H, b);
   return SGA_OK;
 }
 
@@ -2172,7 +2273,9 @@ namespace sga {
 double error_model_value(const double* acc96, const double T_lin[16], const double T[16]) { return evaluate_error_model(acc96, T_lin, T); }
 bool error_model_enabled() { return g_error_model; }
 // sga_error's device pass in two halves (see linearize_enqueue)
-int error_enqueue(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, const double T[16], unsigned long long* seq_out) {
+int error_enqueue(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, const double T_caller[16], unsigned long long* seq_out) {
+  double Tdev[16];
+  const double* T = problem_pose(pb, T_caller, Tdev);
   const unsigned long long seq = ++ctx->publish_seq;
   const bool direct = !ctx->sharded();
   double* host = direct ? ctx->h_accum_dev : nullptr;
@@ -2198,7 +2301,8 @@ int sga_error(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, co
   SGA_TRY(check_args(ctx, pb, fp, T));
   if (!e) return fail(SGA_ERR_INVALID, "null output");
   if (pb->model_valid && fp->robust_kind == SGA_ROBUST_NONE && g_error_model) {  // no pass over the cloud: the model of the last linearization
-    *e = evaluate_error_model(pb->model, pb->model_T, T);
+    double Tdev[16];
+    *e = evaluate_error_model(pb->model, pb->model_T, problem_pose(pb, T, Tdev));
     return SGA_OK;
   }
   SGA_ENTER(ctx);

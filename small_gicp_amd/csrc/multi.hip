@@ -17,6 +17,11 @@ int error_enqueue(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp
 int error_collect(sga_context* ctx, unsigned long long seq, double* e);
 double error_model_value(const double* acc96, const double T_lin[16], const double T[16]);
 bool error_model_enabled();
+const double* problem_pose(const sga_problem* pb, const double T[16], double Td[16]);
+void problem_system_to_caller(const sga_problem* pb, double H[36], double b[6]);
+int cloud_create_f32_about(sga_context* ctx, const float* xyz, const float* normals, const float* cov6, size_t n, const double origin[3], sga_cloud** out);
+void host_bbox_f32(const float* xyz, size_t n, double lo[3], double hi[3]);
+void host_bbox_f64(const double* xyzw, size_t n, double lo[3], double hi[3]);
 }  // namespace sga
 
 using namespace sga;
@@ -113,11 +118,16 @@ int sga_multi_set_target_f64(sga_multi* m, const double* xyzw, const double* nor
 // The same two setters with fp32 arrays (xyz n*3, normals n*3, cov6 n*6: the layout of sga_cloud_create_f32): a caller that repacks its
 // clouds anyway (ParallelReductionHIP: from the reference's AoS doubles) converts while it repacks, on its own threads, and spares the
 // serial double -> float pass of the f64 entry points (150 ms of a 250 ms first bind at 2 x 1M points).
-int sga_multi_set_target_f32(sga_multi* m, const float* xyz, const float* normals3, const float* cov6, size_t n) {
+// `relative`: xyz are given relative to `origin` (sga_cloud_create_f32_origin); otherwise absolute, the device frame chosen here — ONE for
+// the whole cloud, so that the shards' accumulators add up (common.hpp: device frames)
+static int multi_set_target_f32(sga_multi* m, const float* xyz, const float* normals3, const float* cov6, size_t n, const double* origin, bool relative) {
   if (!m || (n > 0 && !xyz)) return fail(SGA_ERR_INVALID, "null argument");
   drop_target(m);
   for (auto& s : m->shards) {
-    SGA_TRY(sga_cloud_create_f32(s.ctx, xyz, normals3, cov6, n, &s.target));
+    if (relative)
+      SGA_TRY(sga_cloud_create_f32_origin(s.ctx, xyz, normals3, cov6, n, origin, &s.target));
+    else
+      SGA_TRY(sga_cloud_create_f32(s.ctx, xyz, normals3, cov6, n, &s.target));  // the same data on every device: the same origin
     SGA_TRY(sga_index_build_kdtree(s.ctx, s.target, &s.index));
   }
   m->n_target = n;
@@ -125,11 +135,20 @@ int sga_multi_set_target_f32(sga_multi* m, const float* xyz, const float* normal
   return SGA_OK;
 }
 
-int sga_multi_set_source_f32(sga_multi* m, const float* xyz, const float* normals3, const float* cov6, size_t n, const double init_T[16]) {
+static int multi_set_source_f32(sga_multi* m, const float* xyz, const float* normals3, const float* cov6, size_t n, const double init_T[16], const double* origin_in, bool relative) {
   if (!m || (n > 0 && !xyz)) return fail(SGA_ERR_INVALID, "null argument");
   if (!m->has_target) return fail(SGA_ERR_INVALID, "sga_multi_set_source_f32 before a target was set");
   m->model_valid = false;
   m->has_source = false;
+  double origin[3] = {0, 0, 0};
+  if (relative) {
+    if (origin_in)
+      for (int k = 0; k < 3; k++) origin[k] = origin_in[k];
+  } else {
+    double lo[3], hi[3];
+    host_bbox_f32(xyz, n, lo, hi);
+    sga_choose_origin(lo, hi, origin);
+  }
   const size_t G = m->shards.size();
   for (size_t g = 0; g < G; g++) {
     auto& s = m->shards[g];
@@ -139,12 +158,27 @@ int sga_multi_set_source_f32(sga_multi* m, const float* xyz, const float* normal
     s.source = nullptr;
     s.first = n * g / G;
     s.count = n * (g + 1) / G - s.first;
-    SGA_TRY(sga_cloud_create_f32(s.ctx, xyz + 3 * s.first, normals3 ? normals3 + 3 * s.first : nullptr, cov6 ? cov6 + 6 * s.first : nullptr, s.count, &s.source));
+    const float *px = xyz + 3 * s.first, *pn = normals3 ? normals3 + 3 * s.first : nullptr, *pc = cov6 ? cov6 + 6 * s.first : nullptr;
+    if (relative)
+      SGA_TRY(sga_cloud_create_f32_origin(s.ctx, px, pn, pc, s.count, origin, &s.source));
+    else
+      SGA_TRY(cloud_create_f32_about(s.ctx, px, pn, pc, s.count, origin, &s.source));
     SGA_TRY(sga_problem_create(s.ctx, s.index, s.source, init_T, &s.problem));
   }
   m->n_source = n;
   m->has_source = true;
   return SGA_OK;
+}
+
+int sga_multi_set_target_f32(sga_multi* m, const float* xyz, const float* normals3, const float* cov6, size_t n) { return multi_set_target_f32(m, xyz, normals3, cov6, n, nullptr, false); }
+int sga_multi_set_target_f32_origin(sga_multi* m, const float* xyz_rel, const float* normals3, const float* cov6, size_t n, const double origin[3]) {
+  return multi_set_target_f32(m, xyz_rel, normals3, cov6, n, origin, true);
+}
+int sga_multi_set_source_f32(sga_multi* m, const float* xyz, const float* normals3, const float* cov6, size_t n, const double init_T[16]) {
+  return multi_set_source_f32(m, xyz, normals3, cov6, n, init_T, nullptr, false);
+}
+int sga_multi_set_source_f32_origin(sga_multi* m, const float* xyz_rel, const float* normals3, const float* cov6, size_t n, const double origin[3], const double init_T[16]) {
+  return multi_set_source_f32(m, xyz_rel, normals3, cov6, n, init_T, origin, true);
 }
 
 int sga_multi_set_target_voxels(sga_multi* m, double leaf, const int32_t* coords, const double* means3, const double* cov6, size_t n) {
@@ -170,6 +204,9 @@ int sga_multi_set_source_f64(sga_multi* m, const double* xyzw, const double* nor
   if (!m->has_target) return fail(SGA_ERR_INVALID, "sga_multi_set_source_f64 before sga_multi_set_target_f64");
   m->model_valid = false;
   m->has_source = false;
+  double lo[3], hi[3], origin[3];
+  host_bbox_f64(xyzw, n, lo, hi);
+  sga_choose_origin(lo, hi, origin);  // ONE device frame for all shards: their accumulators are added (common.hpp)
   const size_t G = m->shards.size();
   for (size_t g = 0; g < G; g++) {
     auto& s = m->shards[g];
@@ -179,7 +216,7 @@ int sga_multi_set_source_f64(sga_multi* m, const double* xyzw, const double* nor
     s.source = nullptr;
     s.first = n * g / G;
     s.count = n * (g + 1) / G - s.first;
-    SGA_TRY(sga_cloud_create_f64(s.ctx, xyzw + 4 * s.first, normals4 ? normals4 + 4 * s.first : nullptr, cov4x4 ? cov4x4 + 16 * s.first : nullptr, s.count, &s.source));
+    SGA_TRY(sga_cloud_create_f64_origin(s.ctx, xyzw + 4 * s.first, normals4 ? normals4 + 4 * s.first : nullptr, cov4x4 ? cov4x4 + 16 * s.first : nullptr, s.count, origin, &s.source));
     SGA_TRY(sga_problem_create(s.ctx, s.index, s.source, init_T, &s.problem));
   }
   m->n_source = n;
@@ -209,9 +246,11 @@ int sga_multi_linearize(sga_multi* m, const sga_factor_params* fp, const double 
     for (int c = 0; c < count[g]; c++) acc[c] += s.ctx->h_accum[c];  // shard order: a fixed summation order
   }
   sga_unpack_accumulator(acc, H, b, e, num_inliers);
+  problem_system_to_caller(m->shards[0].problem, H, b);  // all shards share one source frame (the setters see to it)
   if (count[0] == SGA_MODEL_DOUBLES) {
+    double Tdev[16];
     memcpy(m->model, acc, sizeof(acc));
-    memcpy(m->model_T, T, sizeof(m->model_T));
+    memcpy(m->model_T, problem_pose(m->shards[0].problem, T, Tdev), sizeof(m->model_T));  // the model lives between the device frames
     m->model_valid = true;
   }
   return SGA_OK;
@@ -221,7 +260,8 @@ int sga_multi_error(sga_multi* m, const sga_factor_params* fp, const double T[16
   if (!m || !fp || !T || !e) return fail(SGA_ERR_INVALID, "null argument");
   if (!m->has_source) return fail(SGA_ERR_INVALID, "sga_multi_error without clouds");
   if (m->model_valid && fp->robust_kind == SGA_ROBUST_NONE && error_model_enabled()) {
-    *e = error_model_value(m->model, m->model_T, T);
+    double Tdev[16];
+    *e = error_model_value(m->model, m->model_T, problem_pose(m->shards[0].problem, T, Tdev));
     return SGA_OK;
   }
   const size_t G = m->shards.size();

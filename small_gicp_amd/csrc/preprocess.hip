@@ -20,14 +20,16 @@ __device__ __forceinline__ int fast_floor_dd(double x) {
   return n - (x < static_cast<double>(n));
 }
 
-__global__ void downsample_keys_kernel(const float4* __restrict__ pts, size_t n, double inv_leaf, unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals) {
+// (ox, oy, oz): the origin of the cloud's device frame (common.hpp) — the voxel a point falls into is a property of its position in the
+// CALLER's frame, so the origin is added back in double before the floor
+__global__ void downsample_keys_kernel(const float4* __restrict__ pts, size_t n, double inv_leaf, double ox, double oy, double oz, unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals) {
   const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
   if (i >= n) return;
   const float4 p = pts[i];
   // downsampling.hpp:36-49: coord = fast_floor(p * inv_leaf) + 2^20, valid iff 0 <= coord <= 2^21-1, key = x | y<<21 | z<<42
-  const int cx = fast_floor_dd(static_cast<double>(p.x) * inv_leaf) + (1 << 20);
-  const int cy = fast_floor_dd(static_cast<double>(p.y) * inv_leaf) + (1 << 20);
-  const int cz = fast_floor_dd(static_cast<double>(p.z) * inv_leaf) + (1 << 20);
+  const int cx = fast_floor_dd((static_cast<double>(p.x) + ox) * inv_leaf) + (1 << 20);
+  const int cy = fast_floor_dd((static_cast<double>(p.y) + oy) * inv_leaf) + (1 << 20);
+  const int cz = fast_floor_dd((static_cast<double>(p.z) + oz) * inv_leaf) + (1 << 20);
   const int mask = (1 << 21) - 1;
   const bool bad = cx < 0 || cy < 0 || cz < 0 || cx > mask || cy > mask || cz > mask;
   keys[i] = bad ? ~0ull : (static_cast<unsigned long long>(cx) | (static_cast<unsigned long long>(cy) << 21) | (static_cast<unsigned long long>(cz) << 42));
@@ -199,7 +201,7 @@ constexpr int kFeatWindow = 128;
 // kd-ordered attribute arrays and, through the original index kept in pts.w, to the caller's cloud.
 template <int K>  // K > 0: k = K neighbours in registers (kd_knn_own_points); K = 0: any k, list in LDS (kd_knn)
 __global__ __launch_bounds__(kFeatBlock) void local_features_kernel(
-  const KdView g, size_t n, int k, int flags, float4* __restrict__ idx_nrm, Cov8* __restrict__ idx_cov, float4* __restrict__ cloud_nrm, Cov8* __restrict__ cloud_cov) {
+  const KdView g, size_t n, int k, int flags, float4* __restrict__ idx_nrm, Cov8* __restrict__ idx_cov, float4* __restrict__ cloud_nrm, Cov8* __restrict__ cloud_cov, double ox, double oy, double oz) {
   extern __shared__ float sh[];
   __shared__ float4 window[kFeatWindow];  // the kd positions around the wave's own, scanned before the walk
   const int kpad = (k + 3) & ~3;  // kd_knn sweeps the list four slots at a time
@@ -273,7 +275,8 @@ __global__ __launch_bounds__(kFeatBlock) void local_features_kernel(
       double v0[3] = {eg.vec[0][0], eg.vec[0][1], eg.vec[0][2]};
       const double nn = 1.0 / sqrt(v0[0] * v0[0] + v0[1] * v0[1] + v0[2] * v0[2]);
       for (int r = 0; r < 3; r++) v0[r] *= nn;
-      const double dp = static_cast<double>(p.x) * v0[0] + static_cast<double>(p.y) * v0[1] + static_cast<double>(p.z) * v0[2];
+      // the normal looks towards the origin of the CALLER's frame (the sensor, normal_estimation.hpp:20-25): (ox, oy, oz) = the device frame's origin
+      const double dp = (static_cast<double>(p.x) + ox) * v0[0] + (static_cast<double>(p.y) + oy) * v0[1] + (static_cast<double>(p.z) + oz) * v0[2];
       const double sgn = dp > 0 ? -1.0 : 1.0;  // normal_estimation.hpp:20-25
       nrm = make_float4(static_cast<float>(sgn * v0[0]), static_cast<float>(sgn * v0[1]), static_cast<float>(sgn * v0[2]), 0.f);
     }
@@ -330,6 +333,8 @@ int sga_voxelgrid_sampling(sga_context* ctx, const sga_cloud* in, double leaf, s
   const size_t n = in->n;
   std::unique_ptr<sga_cloud> res(new sga_cloud);
   res->device = ctx->device;
+  for (int k = 0; k < 3; k++) res->origin[k] = in->origin[k];  // the centroids stay in the input's device frame
+  SGA_TRY(wait_ready(ctx, in->ready));
   if (n == 0) {  // downsampling.hpp:24-26
     *out = res.release();
     return SGA_OK;
@@ -343,7 +348,7 @@ int sga_voxelgrid_sampling(sga_context* ctx, const sga_cloud* in, double leaf, s
   SGA_TRY(flags.alloc(n));
   SGA_TRY(seg_id.alloc(n));
   const dim3 grid((n + 255) / 256), block(256);
-  hipLaunchKernelGGL(downsample_keys_kernel, grid, block, 0, ctx->stream, in->pts.p, n, 1.0 / leaf, keys.p, vals.p);
+  hipLaunchKernelGGL(downsample_keys_kernel, grid, block, 0, ctx->stream, in->pts.p, n, 1.0 / leaf, in->origin[0], in->origin[1], in->origin[2], keys.p, vals.p);
   size_t tb = 0;
   SGA_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys.p, keys_sorted.p, vals.p, order.p, n, 0, 64, ctx->stream));
   SGA_TRY(ensure_temp(ctx, tb));
@@ -407,6 +412,8 @@ int sga_estimate_normals_covariances(sga_context* ctx, sga_cloud* cloud, const s
   } else {
     if (index->kind != SGA_INDEX_KDTREE) return fail(SGA_ERR_INVALID, "a kd-tree index is required");
     if (index->n != n) return fail(SGA_ERR_INVALID, "index was built over a cloud of %zu points, got %zu", index->n, n);
+    for (int a = 0; a < 3; a++)
+      if (index->origin[a] != cloud->origin[a]) return fail(SGA_ERR_INVALID, "the index was not built over this cloud (their device frames differ)");
     SGA_TRY(wait_ready(ctx, index->ready));  // built on another context that returned before its kernels had run
   }
   SGA_TRY(wait_ready(ctx, cloud->ready));
@@ -423,11 +430,11 @@ int sga_estimate_normals_covariances(sga_context* ctx, sga_cloud* cloud, const s
     Cov8* icov = temp ? nullptr : index->cov.p;
     // the reference's two neighbourhood sizes (registration_helper.cpp:60-61 k = 10, the benchmarks' k = 20) keep the list in registers
     if (k == 20)
-      hipLaunchKernelGGL((local_features_kernel<20>), fgrid, fblock, shmem, ctx->stream, kv, n, k, flags, inrm, icov, cloud->nrm.p, cloud->cov.p);
+      hipLaunchKernelGGL((local_features_kernel<20>), fgrid, fblock, shmem, ctx->stream, kv, n, k, flags, inrm, icov, cloud->nrm.p, cloud->cov.p, cloud->origin[0], cloud->origin[1], cloud->origin[2]);
     else if (k == 10)
-      hipLaunchKernelGGL((local_features_kernel<10>), fgrid, fblock, shmem, ctx->stream, kv, n, k, flags, inrm, icov, cloud->nrm.p, cloud->cov.p);
+      hipLaunchKernelGGL((local_features_kernel<10>), fgrid, fblock, shmem, ctx->stream, kv, n, k, flags, inrm, icov, cloud->nrm.p, cloud->cov.p, cloud->origin[0], cloud->origin[1], cloud->origin[2]);
     else
-      hipLaunchKernelGGL((local_features_kernel<0>), fgrid, fblock, shmem, ctx->stream, kv, n, k, flags, inrm, icov, cloud->nrm.p, cloud->cov.p);
+      hipLaunchKernelGGL((local_features_kernel<0>), fgrid, fblock, shmem, ctx->stream, kv, n, k, flags, inrm, icov, cloud->nrm.p, cloud->cov.p, cloud->origin[0], cloud->origin[1], cloud->origin[2]);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && !ctx->stream_ordered) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) rc = fail(SGA_ERR_HIP, "local_features_kernel: %s", hipGetErrorString(e));

@@ -152,9 +152,9 @@ __global__ void voxel_knn_kernel(
     idx[j] = -1;
     d2[j] = INFINITY;
   }
-  const int cx = fast_floor_d(static_cast<double>(qx) * v.inv_leaf);
-  const int cy = fast_floor_d(static_cast<double>(qy) * v.inv_leaf);
-  const int cz = fast_floor_d(static_cast<double>(qz) * v.inv_leaf);
+  const int cx = fast_floor_d((static_cast<double>(qx) + v.org[0]) * v.inv_leaf);
+  const int cy = fast_floor_d((static_cast<double>(qy) + v.org[1]) * v.inv_leaf);
+  const int cz = fast_floor_d((static_cast<double>(qz) + v.org[2]) * v.inv_leaf);
   int found = 0;
   auto push = [&](long long index, float d) {
     if (d > max_sq || d >= d2[k - 1]) return;
@@ -260,6 +260,7 @@ int sga_problem_create_from_index(sga_context* ctx, const sga_index* target, con
   const size_t n = source->n;
   SGA_TRY(problem_alloc_state(ctx, pb.get(), n, source->has_covs, /*own_arrays=*/false));
   if (n > 0) {
+    for (int k = 0; k < 3; k++) pb->src_origin[k] = source->origin[k];
     pb->pts_view = source->kd_pts.p;  // borrowed: the source index outlives the problem
     pb->cov_view = source->has_covs ? source->cov.p : nullptr;
     for (int k = 0; k < 3; k++) {
@@ -279,11 +280,13 @@ int sga_problem_create(sga_context* ctx, const sga_index* target, const sga_clou
   SGA_TRY(wait_ready(ctx, target->ready));  // inputs produced on another context in stream-ordered mode (common.hpp: Ready)
   SGA_TRY(wait_ready(ctx, source->ready));
   static const double I16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-  const double* T = init_T ? init_T : I16;
+  double T[16];
+  pose_to_device(init_T ? init_T : I16, source->origin, target->origin, T);  // the sort keys are computed from device-frame records (common.hpp)
   std::unique_ptr<sga_problem> pb(new sga_problem);
   pb->device = ctx->device;
   pb->target = target;
   pb->n = source->n;
+  for (int k = 0; k < 3; k++) pb->src_origin[k] = source->origin[k];
   pb->has_normals = source->has_normals;
   pb->has_covs = source->has_covs;
   const size_t n = source->n;
@@ -397,11 +400,20 @@ static int index_knn_impl(sga_context* ctx, const sga_index* index, const float*
   if (k < 1 || k > 128) return fail(SGA_ERR_INVALID, "k must be in [1,128]");
   if (m == 0) return SGA_OK;
   SGA_ENTER(ctx);
+  SGA_TRY(wait_ready(ctx, index->ready));
   std::vector<float> qf;
-  if (!queries) {  // double queries: the search itself runs on their fp32 roundings
+  std::vector<double> qd;
+  const bool framed = !origin_is_zero(index->origin);
+  if (!queries || framed) {  // double queries: the search itself runs on their fp32 roundings — in the index's device frame (common.hpp)
     qf.resize(m * 3);
-    for (size_t i = 0; i < m * 3; i++) qf[i] = static_cast<float>(queries64[i]);
+    if (queries64 && framed) qd.resize(m * 3);
+    for (size_t i = 0; i < m * 3; i++) {
+      const double v = (queries64 ? queries64[i] : static_cast<double>(queries[i])) - index->origin[i % 3];
+      qf[i] = static_cast<float>(v);
+      if (!qd.empty()) qd[i] = v;
+    }
     queries = qf.data();
+    if (!qd.empty()) queries64 = qd.data();
   }
   DevBuf<float> d_q, d_d;
   DevBuf<double> d_q64, d_d64;
@@ -418,7 +430,7 @@ static int index_knn_impl(sga_context* ctx, const sga_index* index, const float*
   }
   const float max_sq = max_sq_dist < 0 ? INFINITY : static_cast<float>(max_sq_dist);
   if (index->kind == SGA_INDEX_VOXELMAP || index->kind == SGA_INDEX_FLATMAP) {
-    const FlatView v{index->hkeys.p, index->hvals.p, index->hmask, 1.0 / index->leaf, index->vcounts.p, index->search_offsets};
+    const FlatView v{index->hkeys.p, index->hvals.p, index->hmask, 1.0 / index->leaf, index->vcounts.p, index->search_offsets, {index->origin[0], index->origin[1], index->origin[2]}};
     if (index->n == 0 || index->hkeys.p == nullptr) {  // an empty map: nothing found
       SGA_HIP(hipMemsetAsync(d_i.p, 0xff, m * k * sizeof(long long), ctx->stream));
       std::vector<float> inf(m * k, INFINITY);

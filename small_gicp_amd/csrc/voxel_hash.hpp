@@ -27,6 +27,7 @@ struct VoxelView {
   const uint32_t* __restrict__ hvals;
   uint32_t hmask;
   double inv_leaf;
+  double org[3];  // origin of the device frame the queries and the stored means live in (common.hpp): voxel coordinates are the CALLER's
 };
 
 // util/fast_floor.hpp:12-15 on doubles (the reference floors pt * inv_leaf_size in double)
@@ -37,9 +38,9 @@ __device__ __forceinline__ int fast_floor_d(double x) {
 
 // returns voxel id or -1
 __device__ __forceinline__ int voxel_lookup(const VoxelView& v, float qx, float qy, float qz) {
-  const int cx = fast_floor_d(static_cast<double>(qx) * v.inv_leaf);
-  const int cy = fast_floor_d(static_cast<double>(qy) * v.inv_leaf);
-  const int cz = fast_floor_d(static_cast<double>(qz) * v.inv_leaf);
+  const int cx = fast_floor_d((static_cast<double>(qx) + v.org[0]) * v.inv_leaf);
+  const int cy = fast_floor_d((static_cast<double>(qy) + v.org[1]) * v.inv_leaf);
+  const int cz = fast_floor_d((static_cast<double>(qz) + v.org[2]) * v.inv_leaf);
   if (abs(cx) >= (1 << 20) || abs(cy) >= (1 << 20) || abs(cz) >= (1 << 20)) return -1;
   const unsigned long long key = voxel_key(cx, cy, cz);
   uint32_t slot = voxel_hash(key) & v.hmask;
@@ -62,6 +63,7 @@ struct FlatView {
   double inv_leaf;
   const uint32_t* __restrict__ vnum;  // points per voxel
   int offsets;                        // 1, 7, 27
+  double org[3];                      // origin of the device frame (see VoxelView)
 };
 
 __device__ __forceinline__ int flat_voxel_at(const FlatView& v, int cx, int cy, int cz) {
@@ -80,9 +82,9 @@ __device__ __forceinline__ int flat_voxel_at(const FlatView& v, int cx, int cy, 
 // returns the slot (voxel * kFlatCap + i) of the nearest stored point or -1; t = that point
 template <typename Real>
 __device__ __forceinline__ int flat_nearest(const FlatView& v, const float4* __restrict__ pts, Real qx, Real qy, Real qz, float4& t) {
-  const int cx = fast_floor_d(static_cast<double>(qx) * v.inv_leaf);
-  const int cy = fast_floor_d(static_cast<double>(qy) * v.inv_leaf);
-  const int cz = fast_floor_d(static_cast<double>(qz) * v.inv_leaf);
+  const int cx = fast_floor_d((static_cast<double>(qx) + v.org[0]) * v.inv_leaf);
+  const int cy = fast_floor_d((static_cast<double>(qy) + v.org[1]) * v.inv_leaf);
+  const int cz = fast_floor_d((static_cast<double>(qz) + v.org[2]) * v.inv_leaf);
   Real best = static_cast<Real>(INFINITY);
   int j = -1;
   auto scan = [&](int ox, int oy, int oz) {

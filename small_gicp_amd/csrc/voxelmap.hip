@@ -14,6 +14,7 @@
 // (voxel_hash.hpp), rebuilt when it gets half full or after an LRU sweep.
 #include "common.hpp"
 
+#include <cmath>
 #include <memory>
 #include <rocprim/rocprim.hpp>
 
@@ -171,10 +172,11 @@ __global__ void ivm_compact_kernel(
   lru_out[w] = lru_in[v];
 }
 
-__global__ void ivm_export_kernel(uint32_t n, const double* __restrict__ mean64, const double* __restrict__ cov64, float4* __restrict__ means, Cov8* __restrict__ mcov) {
+// (ox, oy, oz): origin of the map's device frame (common.hpp) — the fp64 state is the caller's frame, the fp32 records the kernels read are not
+__global__ void ivm_export_kernel(uint32_t n, const double* __restrict__ mean64, const double* __restrict__ cov64, double ox, double oy, double oz, float4* __restrict__ means, Cov8* __restrict__ mcov) {
   const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= n) return;
-  means[v] = make_float4(static_cast<float>(mean64[3 * v]), static_cast<float>(mean64[3 * v + 1]), static_cast<float>(mean64[3 * v + 2]), __uint_as_float(v));
+  means[v] = make_float4(static_cast<float>(mean64[3 * v] - ox), static_cast<float>(mean64[3 * v + 1] - oy), static_cast<float>(mean64[3 * v + 2] - oz), __uint_as_float(v));
   Cov8 o;
   o.xx = static_cast<float>(cov64[6 * v]);
   o.xy = static_cast<float>(cov64[6 * v + 1]);
@@ -255,7 +257,7 @@ __global__ void fvm_compact_kernel(
 }
 
 // fp32 records read by the factor kernels: slot = voxel * kFlatCap + i, w = slot
-__global__ void fvm_export_kernel(uint32_t n, const uint32_t* __restrict__ counts, const double* __restrict__ fpts64, const double* __restrict__ fcov64, float4* __restrict__ pts, Cov8* __restrict__ cov) {
+__global__ void fvm_export_kernel(uint32_t n, const uint32_t* __restrict__ counts, const double* __restrict__ fpts64, const double* __restrict__ fcov64, double ox, double oy, double oz, float4* __restrict__ pts, Cov8* __restrict__ cov) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t v = t / kFlatCap, j = t % kFlatCap;
   if (v >= n) return;
@@ -263,7 +265,7 @@ __global__ void fvm_export_kernel(uint32_t n, const uint32_t* __restrict__ count
     pts[t] = make_float4(INFINITY, INFINITY, INFINITY, __uint_as_float(t));
     return;
   }
-  pts[t] = make_float4(static_cast<float>(fpts64[3 * static_cast<size_t>(t)]), static_cast<float>(fpts64[3 * static_cast<size_t>(t) + 1]), static_cast<float>(fpts64[3 * static_cast<size_t>(t) + 2]), __uint_as_float(t));
+  pts[t] = make_float4(static_cast<float>(fpts64[3 * static_cast<size_t>(t)] - ox), static_cast<float>(fpts64[3 * static_cast<size_t>(t) + 1] - oy), static_cast<float>(fpts64[3 * static_cast<size_t>(t) + 2] - oz), __uint_as_float(t));
   Cov8 o;
   const double* c = fcov64 + 6 * static_cast<size_t>(t);
   o.xx = static_cast<float>(c[0]);
@@ -274,6 +276,17 @@ __global__ void fvm_export_kernel(uint32_t n, const uint32_t* __restrict__ count
   o.zz = static_cast<float>(c[5]);
   o.pad0 = o.pad1 = 0.f;
   cov[t] = o;
+}
+
+// origin of a device frame centred on n host points (3 doubles each)
+static void host_origin(const double* xyz, size_t n, double origin[3]) {
+  double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (size_t i = 0; i < n; i++)
+    for (int k = 0; k < 3; k++) {
+      const double x = xyz[3 * i + k];
+      if (x - x == 0.0) lo[k] = x < lo[k] ? x : lo[k], hi[k] = x > hi[k] ? x : hi[k];
+    }
+  choose_origin(lo, hi, origin);
 }
 
 template <typename T>
@@ -350,7 +363,8 @@ int sga_index_create_voxelmap_from_voxels(sga_context* ctx, double leaf, const i
     SGA_HIP(hipMemcpyAsync(d_cov.p, cov6, 6 * n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     SGA_HIP(hipMemcpyAsync(idx->vcoords.p, coords, 3 * n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     SGA_HIP(hipMemsetAsync(idx->vcounts.p, 0, n * sizeof(uint32_t), ctx->stream));  // (the number of points behind a voxel is not part of what the registration reads)
-    hipLaunchKernelGGL(ivm_export_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, static_cast<uint32_t>(n), d_mean.p, d_cov.p, idx->pts.p, idx->cov.p);
+    host_origin(means3, n, idx->origin);
+    hipLaunchKernelGGL(ivm_export_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, static_cast<uint32_t>(n), d_mean.p, d_cov.p, idx->origin[0], idx->origin[1], idx->origin[2], idx->pts.p, idx->cov.p);
     SGA_HIP(hipGetLastError());
     SGA_TRY(rebuild_hash(ctx, idx.get(), n));
     SGA_HIP(hipStreamSynchronize(ctx->stream));  // the host buffers are the caller's
@@ -396,7 +410,17 @@ int sga_index_create_flatmap_from_voxels(sga_context* ctx, double leaf, const in
       SGA_HIP(hipMemsetAsync(d_cov.p, 0, 6 * slots * sizeof(double), ctx->stream));
     SGA_HIP(hipMemcpyAsync(idx->vcoords.p, coords, 3 * n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     SGA_HIP(hipMemcpyAsync(idx->vcounts.p, counts, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(fvm_export_kernel, dim3((slots + 255) / 256), dim3(256), 0, ctx->stream, static_cast<uint32_t>(n), idx->vcounts.p, d_pts.p, d_cov.p, idx->pts.p, idx->cov.p);
+    {  // the device frame: centred on the valid points
+      double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+      for (size_t v = 0; v < n; v++)
+        for (uint32_t j = 0; j < counts[v]; j++)
+          for (int k = 0; k < 3; k++) {
+            const double x = points3[3 * (v * kFlatCap + j) + k];
+            if (x - x == 0.0) lo[k] = x < lo[k] ? x : lo[k], hi[k] = x > hi[k] ? x : hi[k];
+          }
+      choose_origin(lo, hi, idx->origin);
+    }
+    hipLaunchKernelGGL(fvm_export_kernel, dim3((slots + 255) / 256), dim3(256), 0, ctx->stream, static_cast<uint32_t>(n), idx->vcounts.p, d_pts.p, d_cov.p, idx->origin[0], idx->origin[1], idx->origin[2], idx->pts.p, idx->cov.p);
     SGA_HIP(hipGetLastError());
     SGA_TRY(rebuild_hash(ctx, idx.get(), n));
     SGA_HIP(hipStreamSynchronize(ctx->stream));  // the host buffers are the caller's
@@ -451,10 +475,10 @@ int sga_flatmap_download(sga_context* ctx, const sga_index* index, int32_t* coor
   if (counts) SGA_HIP(hipMemcpyAsync(counts, index->vcounts.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   SGA_HIP(hipStreamSynchronize(ctx->stream));
   for (size_t i = 0; i < n * kFlatCap; i++) {
-    if (points) {
-      points[3 * i] = hp[i].x;
-      points[3 * i + 1] = hp[i].y;
-      points[3 * i + 2] = hp[i].z;
+    if (points) {  // device frame -> the caller's (empty slots hold +inf and stay +inf)
+      points[3 * i] = static_cast<float>(static_cast<double>(hp[i].x) + index->origin[0]);
+      points[3 * i + 1] = static_cast<float>(static_cast<double>(hp[i].y) + index->origin[1]);
+      points[3 * i + 2] = static_cast<float>(static_cast<double>(hp[i].z) + index->origin[2]);
     }
     if (cov6) {
       cov6[6 * i] = hc[i].xx;
@@ -482,10 +506,21 @@ int sga_voxelmap_insert(sga_context* ctx, sga_index* idx, const sga_cloud* cloud
   if (cloud->n > 0 && !cloud->has_covs) return fail(SGA_ERR_INVALID, "GaussianVoxelMap needs point covariances");
   if (cloud->device != ctx->device || idx->device != ctx->device) return fail(SGA_ERR_INVALID, "cloud / map live on another device");
   SGA_ENTER(ctx);
+  SGA_TRY(wait_ready(ctx, cloud->ready));
+  SGA_TRY(wait_ready(ctx, idx->ready));
+  // The cloud's records live in its device frame (p' = p - o_c, common.hpp); the map's fp64 state, voxel coordinates and hash keys are the
+  // CALLER's frame, exactly the reference's doubles: the kernels move a record by R p' + (R o_c + t).
   Pose12 T;
   for (int r = 0; r < 3; r++) {
     for (int c = 0; c < 3; c++) T.r[3 * r + c] = T16 ? T16[4 * c + r] : (r == c ? 1.0 : 0.0);
     T.t[r] = T16 ? T16[12 + r] : 0.0;
+  }
+  for (int r = 0; r < 3; r++) T.t[r] += T.r[3 * r] * cloud->origin[0] + T.r[3 * r + 1] * cloud->origin[1] + T.r[3 * r + 2] * cloud->origin[2];
+  // The fp32 records the factor kernels read are re-exported after every insert anyway: their device frame follows the inserted scan (the
+  // moved origin of the cloud's frame, quantised), so a map that walks kilometres (scan-to-model odometry) keeps sub-millimetre records.
+  if (cloud->n > 0) {
+    const double lo[3] = {T.t[0], T.t[1], T.t[2]};
+    choose_origin(lo, lo, idx->origin);
   }
   const size_t n = cloud->n;
   const uint32_t n_old = static_cast<uint32_t>(idx->n);
@@ -620,9 +655,9 @@ int sga_voxelmap_insert(sga_context* ctx, sga_index* idx, const sga_cloud* cloud
   }
   if (idx->n > 0) {
     if (idx->kind == SGA_INDEX_FLATMAP)
-      hipLaunchKernelGGL(fvm_export_kernel, dim3((idx->n * kFlatCap + 255) / 256), dim3(256), 0, ctx->stream, static_cast<uint32_t>(idx->n), idx->vcounts.p, idx->fpts64.p, idx->fcov64.p, idx->pts.p, idx->cov.p);
+      hipLaunchKernelGGL(fvm_export_kernel, dim3((idx->n * kFlatCap + 255) / 256), dim3(256), 0, ctx->stream, static_cast<uint32_t>(idx->n), idx->vcounts.p, idx->fpts64.p, idx->fcov64.p, idx->origin[0], idx->origin[1], idx->origin[2], idx->pts.p, idx->cov.p);
     else
-      hipLaunchKernelGGL(ivm_export_kernel, dim3((idx->n + 255) / 256), dim3(256), 0, ctx->stream, static_cast<uint32_t>(idx->n), idx->vmean64.p, idx->vcov64.p, idx->pts.p, idx->cov.p);
+      hipLaunchKernelGGL(ivm_export_kernel, dim3((idx->n + 255) / 256), dim3(256), 0, ctx->stream, static_cast<uint32_t>(idx->n), idx->vmean64.p, idx->vcov64.p, idx->origin[0], idx->origin[1], idx->origin[2], idx->pts.p, idx->cov.p);
   }
   SGA_HIP(hipGetLastError());
   SGA_HIP(hipStreamSynchronize(ctx->stream));

@@ -1,0 +1,279 @@
+"""The reference's coordinate range: PointCloud stores Vector4d (points/point_cloud.hpp:69-71) and every factor works in
+double (factors/gicp_factor.hpp:35-73), so clouds kilometres from the origin (UTM / ENU maps) register to full precision.  The device
+keeps fp32 records — RELATIVE to a per-cloud origin, subtracted in double when the cloud is uploaded (small_gicp_amd.h: device frames).
+These tests move config C1 far from the origin and compare with the reference compiled here (oracle/_ref) or the oracle, both run in
+double on the very same double inputs.
+
+Metrics.  A rotation error d_theta shows up in the translation column of T_target_source multiplied by the distance of the data from
+the origin (at 2.2e5 m a rotation error of 1e-9 rad is 2e-4 m of "translation").  Two numbers are therefore checked:
+  * AT THE DATA: the displacement |T_gpu c - T_ref c| of the cloud's centre c, and the angle of R_gpu^T R_ref — the error of the
+    registration where the points are: 1e-4 m / 1e-4 rad (BASELINE.json north_star), the bar;
+  * the literal pose error of conftest.pose_error (translation of T_gpu^-1 T_ref): printed, and bounded by the lever arm.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import small_gicp_amd as sga
+from conftest import pose_error
+
+pytestmark = pytest.mark.gpu
+
+SHIFTS = [(1e4, -1e4, 50.0), (1e5, 2e5, 300.0)]
+
+
+def rot(axis, ang):
+    from scipy.spatial.transform import Rotation
+
+    return Rotation.from_rotvec(np.asarray(axis, dtype=np.float64) / np.linalg.norm(axis) * ang).as_matrix()
+
+
+def se3(axis, ang, t):
+    T = np.eye(4)
+    T[:3, :3] = rot(axis, ang)
+    T[:3, 3] = t
+    return T
+
+
+def shift_pose(T, s_src, s_tgt):
+    """The rigid motion T between clouds, after the source moved by s_src and the target by s_tgt: q + s_tgt = R (p + s_src) + t'."""
+    out = T.copy()
+    out[:3, 3] = T[:3, 3] + np.asarray(s_tgt) - T[:3, :3] @ np.asarray(s_src)
+    return out
+
+
+def at_data_error(T, T_ref, centre):
+    c = np.append(np.asarray(centre, dtype=np.float64), 1.0)
+    dt = float(np.linalg.norm((T @ c - T_ref @ c)[:3]))
+    R = T[:3, :3].T @ T_ref[:3, :3]
+    dr = float(np.arcsin(min(1.0, 0.5 * np.linalg.norm([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]]))))  # (arccos of the trace resolves 1e-8 rad at best)
+    return dt, dr
+
+
+def adjoint(o):
+    """A with J = J' A for the source shift o (J = [R skew(p), -R], p = p' + o): H = A^T H' A, b = A^T b'."""
+    X = -np.array([[0, -o[2], o[1]], [o[2], 0, -o[0]], [-o[1], o[0], 0]], dtype=np.float64)
+    A = np.eye(6)
+    A[3:, :3] = X
+    return A
+
+
+@pytest.fixture(scope="module")
+def c1_double(c1_oracle_clouds):
+    tc, sc = c1_oracle_clouds
+    tp, tn, tcv = tc.get()
+    sp, sn, scv = sc.get()
+    return dict(tp=tp, tn=tn, tc=tcv, sp=sp, sn=sn, sc=scv)
+
+
+@pytest.mark.parametrize("shift", SHIFTS)
+@pytest.mark.parametrize("mode", ["fp32", "fp64"])
+def test_shifted_c1_registers_like_the_double_reference(orc, c1_double, shift, mode):
+    """C1 moved as a whole (target and source by the same vector): the oracle in double on the shifted doubles, the device on its
+    recentred fp32 records, through the Python layer (double arrays -> sga_cloud_create_f32_origin)."""
+    d = c1_double
+    s = np.asarray(shift)
+    ot = orc.Cloud(d["tp"] + s, d["tn"], d["tc"])
+    os_ = orc.Cloud(d["sp"] + s, d["sn"], d["sc"], tree=False)
+    ores = orc.align(ot, os_, orc.default_setting(factor_kind=orc.GICP, num_threads=4))
+    obase = orc.align(orc.Cloud(d["tp"], d["tn"], d["tc"]), orc.Cloud(d["sp"], d["sn"], d["sc"], tree=False), orc.default_setting(factor_kind=orc.GICP, num_threads=4))
+    tgt = sga.PointCloud(d["tp"] + s, d["tn"], d["tc"])
+    src = sga.PointCloud(d["sp"] + s, d["sn"], d["sc"])
+    assert np.abs(tgt.origin() - s).max() <= 64.0 + 45.0 and (tgt.origin() % 128.0 == 0).all()
+    assert np.abs(tgt.points()[:, :3] - (d["tp"] + s)).max() < 2e-5  # the round trip through the device frame keeps the millimetres (fp32 at 1e5 m: 8 mm)
+    tree = sga.KdTree(tgt)
+    res = sga.Problem(tree, src).align(sga.make_setting("GICP", math_mode=mode))
+    centre = d["sp"].mean(axis=0) + s
+    dt, dr = at_data_error(res.T_target_source, ores.T_target_source, centre)
+    lt, lr = pose_error(res.T_target_source, ores.T_target_source)
+    print("shift %s %s: at the data %.2e m %.2e rad; literal pose error %.2e m (lever %.1e m); iterations %d / %d (unshifted %d)" % (shift, mode, dt, dr, lt, np.linalg.norm(s), res.iterations, ores.iterations, obase.iterations))
+    assert dt < 1e-4 and dr < 1e-4, (dt, dr)
+    # Iteration counts.  In the CALLER's frame the normal equations of a cloud 2e5 m from the origin have a condition number ~5e10 times
+    # the unshifted one (H_rr ~ |o|^2 H_tt): the reference's own LM, in double, then needs 7 iterations where the unshifted problem needs 2 —
+    # every step's rotation carries ~1e-8 rad of solve noise, i.e. millimetres at the data, the size of translation_eps.  Which noisy step
+    # first passes the termination test is not reproducible by any other arithmetic; at 1.4e4 m (3 iterations) it still is.
+    if np.linalg.norm(s) < 5e4:
+        assert res.iterations == ores.iterations
+    else:
+        assert abs(int(res.iterations) - int(ores.iterations)) <= 3
+    assert res.converged == ores.converged
+    assert abs(int(res.num_inliers) - int(ores.num_inliers)) <= 2
+    assert abs(res.error - ores.error) <= (1e-4 if np.linalg.norm(s) < 5e4 else 2e-3) * abs(ores.error)  # (two different noisy stopping points, see above)
+    assert lt <= 1e-4 + 2.0 * dr * np.linalg.norm(s)  # what the lever arm allows, no more
+    # H and b in the caller's twist convention: entry by entry against the double result, on the scale sqrt(H_ii H_jj)
+    Ho = ores.H
+    sc = np.sqrt(np.outer(np.diag(Ho), np.diag(Ho)))
+    assert (np.abs(res.H - Ho) / sc).max() <= 2e-4, (np.abs(res.H - Ho) / sc).max()
+
+
+@pytest.mark.parametrize("shift", [(12800.0, -25600.0, 128.0), (1e5, 2e5, 300.0)])
+def test_linearize_in_a_shifted_frame_is_the_adjoint_of_the_unshifted_one(c1_f32, shift):
+    """Moving both clouds by s must change nothing but the frame: e equal, H = A^T H0 A, b = A^T b0 with the adjoint of the source
+    shift; the error at trial poses equal.  For a shift of whole multiples of 128 m the device records are the unshifted ones bit for
+    bit, so the comparison isolates the conversions at the boundary (pose in, system out)."""
+    d = c1_f32
+    s = np.asarray(shift)
+    t0 = sga.PointCloud(d["tp"], d["tn"], d["tc"])
+    s0 = sga.PointCloud(d["sp"], d["sn"], d["sc"])
+    t1 = sga.PointCloud(d["tp"].astype(np.float64) + s, d["tn"], d["tc"])
+    s1 = sga.PointCloud(d["sp"].astype(np.float64) + s, d["sn"], d["sc"])
+    exact = (s % 128.0 == 0).all()
+    if exact:
+        assert (t1.origin() == s).all() and (s1.origin() == s).all()
+    p0, p1 = sga.Problem(sga.KdTree(t0), s0), sga.Problem(sga.KdTree(t1), s1)
+    A = adjoint(s)
+    for name in ("GICP", "PLANE_ICP", "ICP"):
+        for mode in ("fp32", "fp64"):
+            st = sga.make_setting(name, math_mode=mode)
+            for T in (np.eye(4), se3([0.1, 0.2, 1.0], np.deg2rad(0.7), [0.49, 0.12, -0.02]), se3([1, -1, 0.3], np.deg2rad(5.0), [-0.4, 0.3, 0.2])):
+                Ts = shift_pose(T, s, s)
+                H0, b0, e0, n0 = p0.linearize(st.factor, T)
+                H1, b1, e1, n1 = p1.linearize(st.factor, Ts)
+                rel = (2e-6 if mode == "fp32" else 1e-9) if exact else 5e-4  # exact shifts: the pose reaches the kernels through one more rounding; inexact ones: the fp32 records differ by their rounding
+                assert abs(int(n0) - int(n1)) <= (0 if exact else 3)
+                assert abs(e1 - e0) <= rel * abs(e0), (name, mode, e0, e1)
+                Hm = A.T @ H0 @ A
+                sc = np.sqrt(np.outer(np.diag(Hm), np.diag(Hm)))
+                assert (np.abs(H1 - Hm) / sc).max() <= max(rel, 1e-9), (name, mode, (np.abs(H1 - Hm) / sc).max())
+                bm = A.T @ b0
+                bsc = np.sqrt(np.diag(Hm) * max(e0, 1e-30))
+                assert (np.abs(b1 - bm) / bsc).max() <= max(10 * rel, 1e-8), (name, mode, (np.abs(b1 - bm) / bsc).max())
+                Tq = T @ se3([0, 0, 1], 1e-3, [1e-3, -2e-3, 5e-4])
+                ea, eb = p0.error(st.factor, Tq), p1.error(st.factor, shift_pose(Tq, s, s))
+                assert abs(ea - eb) <= max(rel, 1e-8) * abs(ea), (name, mode, ea, eb)
+
+
+def test_target_in_a_map_frame_source_in_the_sensor_frame(orc, c1_double):
+    """The usual scan-to-map case: the target is geo-referenced (kilometres), the source is a scan in its sensor's frame; the pose carries
+    the kilometres.  Against the oracle in double."""
+    d = c1_double
+    s = np.array([431500.0, 5411200.0, 212.0])  # UTM-like
+    ot = orc.Cloud(d["tp"] + s, d["tn"], d["tc"])
+    os_ = orc.Cloud(d["sp"], d["sn"], d["sc"], tree=False)
+    T0 = shift_pose(np.eye(4), np.zeros(3), s)
+    ores = orc.align(ot, os_, orc.default_setting(factor_kind=orc.GICP, num_threads=4), T0)
+    tgt = sga.PointCloud(d["tp"] + s, d["tn"], d["tc"])
+    src = sga.PointCloud(d["sp"], d["sn"], d["sc"])
+    assert (src.origin() == 0).all() and np.abs(tgt.origin() - s).max() < 128.0
+    res = sga.Problem(sga.KdTree(tgt), src, T0).align(sga.make_setting("GICP"), T0)
+    dt, dr = at_data_error(res.T_target_source, ores.T_target_source, d["sp"].mean(axis=0))
+    lt, _ = pose_error(res.T_target_source, ores.T_target_source)
+    print("map frame: at the data %.2e m %.2e rad, literal %.2e m, iterations %d / %d" % (dt, dr, lt, res.iterations, ores.iterations))
+    # the source sits at its own origin: no lever arm, the literal error is the error at the data
+    assert dt < 1e-4 and dr < 1e-4 and lt < 1e-4 and res.iterations == ores.iterations and abs(int(res.num_inliers) - int(ores.num_inliers)) <= 2
+
+
+def test_c_abi_f64_entry_recentres(c1_double):
+    """sga_cloud_create_f64 (the reference's PointCloud layout, doubles): the origin is chosen inside the library, the download in double
+    returns the input to the fp32 resolution of the RELATIVE coordinates, preprocessing (voxel grid, covariances) sees the caller's frame."""
+    lib = sga._lib.load()
+    ctx = sga.default_context()
+    d = c1_double
+    s = np.array([1e5, 2e5, 300.0])
+    n = len(d["tp"])
+    xyzw = np.ones((n, 4))
+    xyzw[:, :3] = d["tp"] + s
+    h = C.c_void_p()
+    sga._lib.check(lib.sga_cloud_create_f64(ctx.h, xyzw.ctypes.data_as(C.POINTER(C.c_double)), None, None, n, C.byref(h)))
+    cloud = sga.PointCloud(ctx=ctx, _handle=h)
+    assert (cloud.origin() % 128.0 == 0).all() and np.abs(cloud.origin() - s).max() < 128.0
+    assert np.abs(cloud.xyz64() - xyzw[:, :3]).max() < 1e-5
+    # voxel grid: the partition of the CALLER's frame (downsampling.hpp:36-49): equal to the CPU oracle's on the shifted doubles
+    from oracle import orc
+
+    raw = np.load(os.path.join(os.path.dirname(__file__), "golden", "c1_points.npz"))["target"].astype(np.float64) + s
+    g = sga.PointCloud(raw)
+    down = sga.voxelgrid_sampling(g, 0.25)
+    ref = orc.voxelgrid_sampling(raw, 0.25)
+    assert down.size() == len(ref)
+    assert np.abs(down.xyz64() - ref).max() < 2e-5
+    # normals look towards the caller's origin (normal_estimation.hpp:20-25), covariances are translation invariant
+    # (the oracle runs on the same points moved BACK: at 2e5 m its own double-precision covariance sums, sum p p^T - mean sum p^T,
+    # normal_estimation.hpp:85-86, cancel to ~5e-6 m^2 and 2 % of its normals are off by more than 1e-3 — the device, working in the
+    # recentred frame, is the more exact of the two there)
+    oc = orc.Cloud(ref - s)
+    oc.estimate_normals_covariances(10, 4)
+    sga.estimate_normals_covariances(down, None, 10)
+    _, on, ocv = oc.get()
+    gn = down.normals()[:, :3]
+    agree = (np.abs((gn * on).sum(axis=1)) > 1.0 - 1e-6).mean()
+    assert agree > 0.995, agree
+    assert ((gn * (down.xyz64())).sum(axis=1) <= 1e-6).all()
+    gc = down.covs()[:, :3, :3]
+    assert (np.abs(gc - ocv).reshape(len(gc), -1).max(axis=1) < 1e-4).mean() > 0.995
+
+
+def test_single_process_shards_share_one_frame(c1_double):
+    """sga_multi_*: the shards of a source are slices of the caller's array — with bounding boxes of their own; they must share ONE device
+    frame, or their accumulators (moments about the frame's origin) would not add up.  Two and three logical shards == one problem."""
+    d = c1_double
+    s = np.array([1e5, 2e5, 300.0])
+    tgt, src = (d["tp"] + s, d["tn"], d["tc"]), (d["sp"] + s, d["sn"], d["sc"])
+    one = sga.Problem(sga.KdTree(sga.PointCloud(*tgt)), sga.PointCloud(*src))
+    st = sga.make_setting("GICP", math_mode="fp64")
+    T = shift_pose(se3([0.1, 0.2, 1.0], np.deg2rad(0.7), [0.49, 0.12, -0.02]), s, s)
+    H1, b1, e1, n1 = one.linearize(st.factor, T)
+    Tq = shift_pose(se3([0.1, 0.2, 1.0], np.deg2rad(0.7), [0.49, 0.12, -0.02]) @ se3([0, 0, 1], 1e-3, [1e-3, -2e-3, 5e-4]), s, s)
+    eq1 = one.error(st.factor, Tq)
+    r1 = one.align(st)
+    for shards in (2, 3):
+        m = sga.MultiProblem([0] * shards, tgt, src)
+        H, b, e, n = m.linearize(st.factor, T)
+        sc = np.sqrt(np.outer(np.diag(H1), np.diag(H1)))
+        assert n == n1 and abs(e - e1) <= 1e-10 * abs(e1) and (np.abs(H - H1) / sc).max() <= 1e-9, (shards, (np.abs(H - H1) / sc).max())
+        assert abs(m.error(st.factor, Tq) - eq1) <= 1e-9 * abs(e1)
+        r = m.align(st)
+        dt, dr = at_data_error(r.T_target_source, r1.T_target_source, d["sp"].mean(axis=0) + s)
+        assert dt < 1e-7 and dr < 1e-9 and r.iterations == r1.iterations, (shards, dt, dr)
+
+
+def test_knn_queries_in_the_callers_frame(c1_double):
+    d = c1_double
+    s = np.array([1e5, 2e5, 300.0])
+    tree = sga.KdTree(sga.PointCloud(d["tp"] + s))
+    base = sga.KdTree(sga.PointCloud(d["tp"]))
+    q = d["sp"][:500]
+    i1, d1 = tree.batch_knn_search(q + s, 5)
+    i0, d0 = base.batch_knn_search(q, 5)
+    assert (i1 == i0).mean() > 0.995 and np.abs(d1 - d0).max() < 1e-4
+
+
+def test_scan_to_model_chain_walks_five_kilometres(orc, c1_double):
+    """Scan-to-model over a Gaussian voxel map whose poses walk 5 km (incremental_voxelmap.hpp:55-119): scans in the sensor frame, the
+    map in the world frame.  Every step inserts the previous scan at its pose and registers the next one against the map; the map's
+    fp32 records follow the inserted scan (their device frame is re-chosen per insert), so the last step is as exact as the first.
+    Against the oracle's VoxelMap in double, step by step."""
+    d = c1_double
+    scan_t, scan_s = (d["tp"], d["tn"], d["tc"]), (d["sp"], d["sn"], d["sc"])
+    gv, ov = sga.GaussianVoxelMap(1.0), orc.VoxelMap(None, 1.0)
+    gv.set_lru(1, 2)
+    ov.set_lru(1, 2)
+    gt, gs = sga.PointCloud(*scan_t), sga.PointCloud(*scan_s)
+    ot, os_ = orc.Cloud(*scan_t), orc.Cloud(*scan_s, tree=False)
+    step = np.array([231.7, 122.3, 1.9])
+    worst = (0.0, 0.0)
+    st = sga.make_setting("GICP")
+    for k in range(21):
+        P = se3([0.05, 0.02, 1.0], 0.011 * k, step * k)
+        gv.insert(gt, P)
+        ov.insert(ot, P)
+        assert gv.size() == len(ov)
+        res = sga.Problem(gv, gs, P).align(st, P)
+        ores = orc.align(ov, os_, orc.default_setting(factor_kind=orc.GICP, num_threads=4), P)
+        dt, dr = at_data_error(res.T_target_source, ores.T_target_source, d["sp"].mean(axis=0))
+        worst = (max(worst[0], dt), max(worst[1], dr))
+        assert dt < 1e-4 and dr < 1e-4 and res.iterations == ores.iterations, (k, dt, dr, res.iterations, ores.iterations)
+        assert abs(int(res.num_inliers) - int(ores.num_inliers)) <= 3, (k, res.num_inliers, ores.num_inliers)
+    assert np.linalg.norm(step * 20) > 5000.0
+    print("scan-to-model over %.1f km: worst step %.2e m %.2e rad" % (np.linalg.norm(step * 20) / 1000.0, worst[0], worst[1]))
+
+
+def test_origin_zero_keeps_the_records(c1_f32):
+    """Clouds centred within 64 m of the origin keep origin 0: nothing about the existing configurations changes."""
+    d = c1_f32
+    c = sga.PointCloud(d["tp"], d["tn"], d["tc"])
+    assert (c.origin() == 0).all() and (c.xyz() == d["tp"]).all()
+    c64 = sga.PointCloud(d["tp"].astype(np.float64), d["tn"], d["tc"])
+    assert (c64.origin() == 0).all() and (c64.xyz() == d["tp"]).all()
