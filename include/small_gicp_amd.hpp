@@ -94,10 +94,19 @@ struct PointCloud {
   template <typename T, size_t D>
   explicit PointCloud(const std::vector<std::array<T, D>>& pts, int device = 0) : ctx(default_context(device)) {
     static_assert(D == 3 || D == 4, "points must be 3- or 4-vectors");
+    // double points may lie kilometres from the origin (points/point_cloud.hpp:69-71): the cloud's origin is subtracted in double before the
+    // cast (small_gicp_amd.h: device frames); float points are what they are and go through the library's own recentring
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, origin[3] = {0, 0, 0};
+    for (size_t i = 0; i < pts.size(); i++)
+      for (int k = 0; k < 3; k++) {
+        const double v = static_cast<double>(pts[i][k]);
+        if (v - v == 0.0) lo[k] = v < lo[k] ? v : lo[k], hi[k] = v > hi[k] ? v : hi[k];
+      }
+    sga_choose_origin(lo, hi, origin);
     std::vector<float> xyz(pts.size() * 3);
     for (size_t i = 0; i < pts.size(); i++)
-      for (int k = 0; k < 3; k++) xyz[3 * i + k] = static_cast<float>(pts[i][k]);
-    check(sga_cloud_create_f32(ctx, xyz.data(), nullptr, nullptr, pts.size(), &h), "sga_cloud_create_f32");
+      for (int k = 0; k < 3; k++) xyz[3 * i + k] = static_cast<float>(static_cast<double>(pts[i][k]) - origin[k]);
+    check(sga_cloud_create_f32_origin(ctx, xyz.data(), nullptr, nullptr, pts.size(), origin, &h), "sga_cloud_create_f32_origin");
   }
   /// xyz n*3 floats [+ normals n*3] [+ cov6 n*6 (xx,xy,xz,yy,yz,zz)]
   PointCloud(const float* xyz, const float* normals, const float* cov6, size_t n, int device = 0) : ctx(default_context(device)) { check(sga_cloud_create_f32(ctx, xyz, normals, cov6, n, &h), "sga_cloud_create_f32"); }
@@ -150,14 +159,15 @@ private:
   void sync_host() const {
     if (host_valid) return;
     const size_t n = size();
-    host_xyz.assign(3 * n, 0.f);
+    host_xyz.assign(3 * n, 0.0);
     host_nrm.assign(has_normals() ? 3 * n : 0, 0.f);
     host_cov.assign(has_covs() ? 6 * n : 0, 0.f);
-    check(sga_cloud_download(ctx, h, host_xyz.data(), host_nrm.empty() ? nullptr : host_nrm.data(), host_cov.empty() ? nullptr : host_cov.data()), "sga_cloud_download");
+    check(sga_cloud_download_f64(ctx, h, host_xyz.data(), host_nrm.empty() ? nullptr : host_nrm.data(), host_cov.empty() ? nullptr : host_cov.data()), "sga_cloud_download_f64");  // device record + origin, in double
     host_valid = true;
   }
   mutable bool host_valid = false;
-  mutable std::vector<float> host_xyz, host_nrm, host_cov;
+  mutable std::vector<double> host_xyz;
+  mutable std::vector<float> host_nrm, host_cov;
 };
 
 /// ann/kdtree.hpp:248-291 KdTree<PointCloud>: exact nearest-neighbour index over a cloud (GPU kd-tree).

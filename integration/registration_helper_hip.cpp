@@ -13,12 +13,20 @@
 //   align (voxel map)       registration_helper.cpp:125-137 VGICP: the voxel map as target and tree through the same policy
 // setting.num_threads keeps its meaning for the host parts (tree build); the reduction itself runs on `SGA_HELPER_GPUS` devices (default 1).
 //
+// Device residency (round 5).  A cloud is uploaded ONCE: preprocess_points keeps what it built on the device — the downsampled cloud with its
+// normals / covariances and the exact search index the covariance estimation needed anyway — in a side table keyed by the PointCloud it
+// returns (weak ownership: the entry dies with the cloud; a cloud edited afterwards is recognised by its content hash and goes through the
+// general policy path).  align(clouds + tree) of two such clouds then runs on those device objects (sga_problem / sga_align: no upload, no
+// second tree); align(points ...) never leaves the device between the raw points and the result: no download, no host tree.
+//
 // Compiled and run by this repository's tests against the unmodified reference headers (oracle/ref/Makefile -> oracle/_ref/test_helper_hip).
 #include <small_gicp/registration/registration_helper.hpp>
 
 #include <cstdlib>
 #include <iostream>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <vector>
 
@@ -81,22 +89,99 @@ RegistrationResult run(const Target& target, const PointCloud& source, const Tre
   return registration.align(target, source, tree, init_T);
 }
 
+// ---- what preprocess_points leaves on the device ------------------------------------------------------------------------------
+struct DeviceCloud {
+  CloudHandle cloud;  // downsampled, with normals and covariances
+  IndexHandle index;  // exact nearest-neighbour index over it (attributes in kd order)
+  size_t n = 0;
+};
+
+// raw points (the reference's layout: Vector4d, contiguous) -> voxel grid -> index -> normals + covariances; nothing comes back to the host
+std::shared_ptr<DeviceCloud> device_preprocess(const PointCloud& points, double downsampling_resolution, int num_neighbors) {
+  sga_context* ctx = thread_context();
+  auto dc = std::make_shared<DeviceCloud>();
+  CloudHandle raw;
+  static_assert(sizeof(Eigen::Vector4d) == 4 * sizeof(double), "PointCloud::points is n x 4 doubles (points/point_cloud.hpp:69)");
+  must(sga_cloud_create_f64(ctx, points.size() ? &points.points[0][0] : nullptr, nullptr, nullptr, points.size(), &raw.c), "sga_cloud_create_f64");  // recentred in double (device frames)
+  must(sga_voxelgrid_sampling(ctx, raw.c, downsampling_resolution, &dc->cloud.c), "sga_voxelgrid_sampling");  // util/downsampling.hpp:23-78
+  must(sga_index_build_kdtree(ctx, dc->cloud.c, &dc->index.i), "sga_index_build_kdtree");                     // KdTree<PointCloud>(points), registration_helper.cpp:30-31
+  must(sga_estimate_normals_covariances(ctx, dc->cloud.c, dc->index.i, num_neighbors, 3), "sga_estimate_normals_covariances");  // util/normal_estimation.hpp:65-92 (fills the index's copies too)
+  must(sga_cloud_size(dc->cloud.c, &dc->n), "sga_cloud_size");
+  return dc;
+}
+
+// side table: host cloud returned by preprocess_points -> its device twin
+struct Resident {
+  std::weak_ptr<PointCloud> host;
+  std::shared_ptr<DeviceCloud> device;
+  std::uint64_t fingerprint = 0;
+};
+std::mutex g_resident_mutex;
+std::map<const PointCloud*, Resident> g_resident;
+
+void remember(const PointCloud::Ptr& host, const std::shared_ptr<DeviceCloud>& device) {
+  std::lock_guard<std::mutex> lock(g_resident_mutex);
+  for (auto it = g_resident.begin(); it != g_resident.end();) it = it->second.host.expired() ? g_resident.erase(it) : std::next(it);  // clouds that are gone take their device twins along
+  g_resident[host.get()] = Resident{host, device, hip_detail::fingerprint(*host)};
+}
+std::shared_ptr<DeviceCloud> resident(const PointCloud& cloud) {
+  std::shared_ptr<DeviceCloud> dev;
+  {
+    std::lock_guard<std::mutex> lock(g_resident_mutex);
+    const auto it = g_resident.find(&cloud);
+    if (it == g_resident.end() || it->second.host.expired() || it->second.device->n != cloud.size()) return nullptr;
+    dev = it->second.device;
+    if (it->second.fingerprint != hip_detail::fingerprint(cloud)) return nullptr;  // edited since: the general path uploads what the caller holds now
+  }
+  return dev;
+}
+
+RegistrationResult to_result(const sga_result& r) {
+  Eigen::Isometry3d T = Eigen::Isometry3d::Identity();
+  for (int c = 0; c < 4; c++)
+    for (int rr = 0; rr < 3; rr++) T.matrix()(rr, c) = r.T_target_source[4 * c + rr];
+  RegistrationResult out(T);
+  out.converged = r.converged != 0;
+  out.iterations = r.iterations;
+  out.num_inliers = r.num_inliers;
+  for (int i = 0; i < 6; i++) {
+    out.b(i) = r.b[i];
+    for (int j = 0; j < 6; j++) out.H(i, j) = r.H[6 * i + j];
+  }
+  out.error = r.error;
+  return out;
+}
+
+// Registration<Factor, ...>::align on objects that already live on the device (registration_helper.cpp:89-120 for the settings)
+RegistrationResult device_align(const sga_index* target, const sga_cloud* source, size_t n_target, size_t n_source, int factor_kind, bool set_rejector, const Eigen::Isometry3d& init_T, const RegistrationSetting& setting) {
+  if (n_target <= 10) std::cerr << "warning: target point cloud is too small. |target|=" << n_target << std::endl;  // registration.hpp:34-39
+  if (n_source <= 10) std::cerr << "warning: source point cloud is too small. |source|=" << n_source << std::endl;
+  sga_registration_setting st;
+  sga_registration_setting_default(&st);
+  st.factor.factor_kind = factor_kind;
+  st.factor.max_dist_sq = set_rejector ? setting.max_correspondence_distance * setting.max_correspondence_distance : 1.0;  // DistanceRejector's default, rejector.hpp:20
+  st.optimizer = SGA_LEVENBERG_MARQUARDT;
+  st.max_iterations = setting.max_iterations;
+  st.rotation_eps = setting.rotation_eps;
+  st.translation_eps = setting.translation_eps;
+  st.verbose = setting.verbose ? 1 : 0;
+  double T16[16];
+  for (int c = 0; c < 4; c++)
+    for (int r = 0; r < 4; r++) T16[4 * c + r] = init_T.matrix()(r, c);
+  sga_result res;
+  must(sga_align(thread_context(), target, source, T16, &st, &res), "sga_align");
+  return to_result(res);
+}
+
 }  // namespace
 
 std::pair<PointCloud::Ptr, std::shared_ptr<KdTree<PointCloud>>> preprocess_points(const PointCloud& points, double downsampling_resolution, int num_neighbors, int num_threads) {
   sga_context* ctx = thread_context();
-  const size_t n_in = points.size();
-  std::vector<float> xyz(3 * n_in);
-  for (size_t i = 0; i < n_in; i++)
-    for (int k = 0; k < 3; k++) xyz[3 * i + k] = static_cast<float>(points.point(i)[k]);
-  CloudHandle raw, down;
-  must(sga_cloud_create_f32(ctx, xyz.data(), nullptr, nullptr, n_in, &raw.c), "sga_cloud_create_f32");
-  must(sga_voxelgrid_sampling(ctx, raw.c, downsampling_resolution, &down.c), "sga_voxelgrid_sampling");                 // util/downsampling.hpp:23-78
-  must(sga_estimate_normals_covariances(ctx, down.c, nullptr, num_neighbors, 3), "sga_estimate_normals_covariances");  // util/normal_estimation.hpp:65-92
-  size_t n = 0;
-  must(sga_cloud_size(down.c, &n), "sga_cloud_size");
-  std::vector<float> p(3 * n), nr(3 * n), c6(6 * n);
-  must(sga_cloud_download(ctx, down.c, p.data(), nr.data(), c6.data()), "sga_cloud_download");
+  const std::shared_ptr<DeviceCloud> dc = device_preprocess(points, downsampling_resolution, num_neighbors);
+  const size_t n = dc->n;
+  std::vector<double> p(3 * n);
+  std::vector<float> nr(3 * n), c6(6 * n);
+  must(sga_cloud_download_f64(ctx, dc->cloud.c, p.data(), nr.data(), c6.data()), "sga_cloud_download_f64");
   auto out = std::make_shared<PointCloud>();
   out->resize(n);
   for (size_t i = 0; i < n; i++) {
@@ -109,6 +194,7 @@ std::pair<PointCloud::Ptr, std::shared_ptr<KdTree<PointCloud>>> preprocess_point
   }
   // the tree the return type promises (callers may search it themselves); the registrations below do not read it
   auto tree = num_threads == 1 ? std::make_shared<KdTree<PointCloud>>(out) : std::make_shared<KdTree<PointCloud>>(out, KdTreeBuilderOMP(num_threads));
+  remember(out, dc);  // align(*out, ...) finds the cloud and its index on the device
   return {out, tree};
 }
 
@@ -132,10 +218,18 @@ GaussianVoxelMap::Ptr create_gaussian_voxelmap(const PointCloud& points, double 
 template <typename T, int D>
 RegistrationResult
 align(const std::vector<Eigen::Matrix<T, D, 1>>& target, const std::vector<Eigen::Matrix<T, D, 1>>& source, const Eigen::Isometry3d& init_T, const RegistrationSetting& setting) {
-  const auto tgt = preprocess_points(target, setting.downsampling_resolution, 10, setting.num_threads);
-  const auto src = preprocess_points(source, setting.downsampling_resolution, 10, setting.num_threads);
-  if (setting.type == RegistrationSetting::VGICP) return align(*create_gaussian_voxelmap(*tgt.first, setting.voxel_resolution), *src.first, init_T, setting);
-  return align(*tgt.first, *src.first, *tgt.second, init_T, setting);
+  // registration_helper.cpp:57-79 without leaving the device: raw points up, result down — no host copy of the preprocessed clouds, no host tree
+  const std::shared_ptr<DeviceCloud> tgt = device_preprocess(PointCloud(target), setting.downsampling_resolution, 10);
+  const std::shared_ptr<DeviceCloud> src = device_preprocess(PointCloud(source), setting.downsampling_resolution, 10);
+  if (setting.type == RegistrationSetting::VGICP) {
+    IndexHandle voxelmap;  // create_gaussian_voxelmap, registration_helper.cpp:50-54
+    must(sga_index_build_gaussian_voxelmap(thread_context(), tgt->cloud.c, setting.voxel_resolution, &voxelmap.i), "sga_index_build_gaussian_voxelmap");
+    size_t voxels = 0;
+    must(sga_index_size(voxelmap.i, &voxels), "sga_index_size");
+    return device_align(voxelmap.i, src->cloud.c, voxels, src->n, SGA_GICP, false, init_T, setting);  // (the rejector stays at its default there, registration_helper.cpp:130-135)
+  }
+  const int kind = setting.type == RegistrationSetting::ICP ? SGA_ICP : (setting.type == RegistrationSetting::PLANE_ICP ? SGA_PLANE_ICP : SGA_GICP);
+  return device_align(tgt->index.i, src->cloud.c, tgt->n, src->n, kind, true, init_T, setting);
 }
 
 template RegistrationResult
@@ -149,6 +243,14 @@ align(const std::vector<Eigen::Matrix<double, 4, 1>>&, const std::vector<Eigen::
 
 RegistrationResult
 align(const PointCloud& target, const PointCloud& source, const KdTree<PointCloud>& target_tree, const Eigen::Isometry3d& init_T, const RegistrationSetting& setting) {
+  if (setting.type != RegistrationSetting::VGICP && helper_gpus() == 1) {
+    // both clouds came out of preprocess_points and were not edited since: their device twins (cloud, index) are still there
+    const std::shared_ptr<DeviceCloud> t = resident(target), sdev = t ? resident(source) : nullptr;
+    if (t && sdev) {
+      const int kind = setting.type == RegistrationSetting::ICP ? SGA_ICP : (setting.type == RegistrationSetting::PLANE_ICP ? SGA_PLANE_ICP : SGA_GICP);
+      return device_align(t->index.i, sdev->cloud.c, t->n, sdev->n, kind, true, init_T, setting);
+    }
+  }
   switch (setting.type) {
     case RegistrationSetting::ICP:
       return run<ICPFactor>(target, source, target_tree, init_T, setting, true);

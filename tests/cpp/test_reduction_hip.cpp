@@ -472,6 +472,41 @@ int main(int argc, char** argv) {
       if (!threw) failures++;
     }
   }
+  // ---- the reference's coordinate range (points/point_cloud.hpp:69-71: Vector4d): C1 moved kilometres from the origin.  The CPU reduction
+  // works on the doubles; the policy subtracts the cloud's origin in double while it repacks (hip_detail::pack) and the device keeps fp32
+  // records relative to it.  Error measured AT THE DATA (displacement of the source's centre, angle of the relative rotation): in the
+  // translation column of T a rotation error appears multiplied by the distance from the origin.
+  for (int far = 0; far < 2; far++) {
+    const Eigen::Vector4d shift = far ? Eigen::Vector4d(1e5, 2e5, 300.0, 0.0) : Eigen::Vector4d(1e4, -1e4, 50.0, 0.0);
+    auto tgt2 = std::make_shared<PointCloud>(*target);
+    auto src2 = std::make_shared<PointCloud>(*source);
+    Eigen::Vector4d centre = Eigen::Vector4d::Zero();
+    for (size_t i = 0; i < tgt2->size(); i++) tgt2->point(i) += shift;
+    for (size_t i = 0; i < src2->size(); i++) {
+      src2->point(i) += shift;
+      centre += src2->point(i);
+    }
+    centre /= static_cast<double>(src2->size());
+    centre[3] = 1.0;
+    KdTree<PointCloud> tree2(tgt2, KdTreeBuilderOMP(4));
+    Registration<GICPFactor, ParallelReductionOMP> cpu;
+    cpu.reduction.num_threads = 1;  // (a fixed summation order: at these condition numbers the order of the per-thread sums changes the LM path)
+    Registration<GICPFactor, ParallelReductionHIP> hip;
+    const RegistrationResult rc = cpu.align(*tgt2, *src2, tree2, I);
+    const RegistrationResult rh = hip.align(*tgt2, *src2, tree2, I);
+    const double dt = ((rc.T_target_source * centre) - (rh.T_target_source * centre)).norm();
+    const Eigen::Matrix3d R = rc.T_target_source.linear().transpose() * rh.T_target_source.linear();
+    const double dr = std::asin(std::min(1.0, 0.5 * std::sqrt((R(2, 1) - R(1, 2)) * (R(2, 1) - R(1, 2)) + (R(0, 2) - R(2, 0)) * (R(0, 2) - R(2, 0)) + (R(1, 0) - R(0, 1)) * (R(1, 0) - R(0, 1)))));
+    double lt, lr;
+    pose_error(rc.T_target_source, rh.T_target_source, &lt, &lr);
+    // iteration counts: equal while the caller-frame normal equations are still well enough conditioned for the reference's own LM to be
+    // reproducible (1.4e4 m); at 2.2e5 m its steps carry millimetres of solve noise and the count depends on it (tests/test_coordinate_range.py)
+    const long long dit = std::llabs(static_cast<long long>(rc.iterations) - static_cast<long long>(rh.iterations));
+    const bool ok = dt < 1e-4 && dr < 1e-4 && rc.converged == rh.converged && dit <= (far ? 3 : 0) && std::llabs(static_cast<long long>(rc.num_inliers) - static_cast<long long>(rh.num_inliers)) <= 2;
+    std::printf("CASE {\"name\": \"GICP, clouds moved by (%g, %g, %g)\", \"ok\": %s, \"dt_at_the_data\": %.3e, \"dr\": %.3e, \"dt_of_T\": %.3e, \"iterations\": [%zu, %zu], \"num_inliers\": [%zu, %zu], \"converged\": [%d, %d]}\n", shift[0], shift[1], shift[2],
+                ok ? "true" : "false", dt, dr, lt, rh.iterations, rc.iterations, rh.num_inliers, rc.num_inliers, rh.converged ? 1 : 0, rc.converged ? 1 : 0);
+    if (!ok) failures++;
+  }
   // ---- iterations/s THROUGH the policy (what a small_gicp user who swaps the Reduction gets), default settings of the policy ----
   using Plain = Registration<GICPFactor, ParallelReductionHIP>;
   using Aligned = Registration<GICPFactor, ParallelReductionHIP, NullFactor, DistanceRejector, HipAligned<LevenbergMarquardtOptimizer>>;

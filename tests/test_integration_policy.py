@@ -67,7 +67,7 @@ def test_registration_with_the_hip_reduction_policy(tmp_path):
         np.ascontiguousarray(d[name][:, :3], dtype="<f4").tofile(tmp_path / (name + ".bin"))
     p = subprocess.run([BIN, str(tmp_path / "target.bin"), str(tmp_path / "source.bin")], capture_output=True, text=True, timeout=600)
     cases = [json.loads(ln[5:]) for ln in p.stdout.splitlines() if ln.startswith("CASE ")]
-    assert p.returncode == 0 and len(cases) >= 32 and all(c["ok"] for c in cases), p.stdout[-3000:] + p.stderr[-2000:]
+    assert p.returncode == 0 and len(cases) >= 34 and all(c["ok"] for c in cases), p.stdout[-3000:] + p.stderr[-2000:]
     for ln in p.stdout.splitlines():
         if ln.startswith("RATE "):
             print("policy rate:", ln[5:])
@@ -97,6 +97,10 @@ def test_reference_helper_api_served_by_the_hip_implementation(tmp_path, c1_gold
     assert set(res) == {"points_GICP", "points_VGICP", "ICP", "PLANE_ICP", "GICP", "VGICP"}, p.stdout[-2000:]
     pre = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("PREPROCESSED ")][0][13:])
     assert [pre["target"], pre["source"]] == c1_gold["downsampled_sizes"] and pre["tree"] == pre["target"]
+    edited = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("EDITED ")][0][7:])
+    assert abs(edited["dx"] + 0.05) < 2e-3, edited  # a cloud edited after preprocess_points is NOT served from its device twin
+    timing = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("TIMING ")][0][7:])
+    print("helper timing:", timing)
     tree = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("TREE ")][0][5:])
     assert tree["found"] == 1 and tree["index"] == 0 and tree["sq_dist"] < 1e-12  # the returned KdTree is a working reference tree
     for name, gold in (("points_GICP", "GICP"), ("GICP", "GICP"), ("ICP", "ICP"), ("PLANE_ICP", "PLANE_ICP"), ("points_VGICP", "VGICP"), ("VGICP", "VGICP")):
