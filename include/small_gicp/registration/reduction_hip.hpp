@@ -52,7 +52,7 @@
 // DistanceRejector, NullRejector; targets: point clouds (traits::point / normal / cov) and GaussianVoxelMap — VGICP,
 // registration_helper.cpp:125-137: `registration.align(voxelmap, source, voxelmap, init_T)` with GICPFactor.  The map's voxels go to
 // the device in flat order (sga_multi_set_target_voxels), so the voxel ids of target_index (voxel << 32, incremental_voxelmap.hpp:153)
-// are the caller's; search_offsets must be the default 1.  IncrementalVoxelMap<FlatContainer<...>> (linear iVox, the scan-to-model target)
+// are the caller's; search_offsets 1 / 7 / 27.  IncrementalVoxelMap<FlatContainer<...>> (linear iVox, the scan-to-model target)
 // works the same way (sga_multi_set_target_flat_voxels: <= 16 points per voxel, search offsets 1 / 7 / 27); other contents are rejected at compile time.
 // Custom rejectors / factors with host callbacks stay on the CPU reductions (or use sga_problem_set_rejector).
 #pragma once
@@ -320,7 +320,7 @@ inline PackedVoxels pack_voxels(const IncrementalVoxelMap<GaussianVoxel>& vm) {
   return out;
 }
 inline std::uint64_t fingerprint(const IncrementalVoxelMap<GaussianVoxel>& vm) {
-  std::uint64_t h = 1469598103934665603ull ^ vm.flat_voxels.size();
+  std::uint64_t h = 1469598103934665603ull ^ vm.flat_voxels.size() ^ (static_cast<std::uint64_t>(vm.search_offsets.size()) << 40);
   auto mix = [&h](double v) {
     std::uint64_t b;
     std::memcpy(&b, &v, 8);
@@ -454,10 +454,6 @@ struct ParallelReductionHIP {
       !voxel_target || flat_target || hip_detail::is_gaussian_voxelmap<TargetPointCloud>::value,
       "ParallelReductionHIP: of the voxel maps only GaussianVoxelMap (one Gaussian per voxel: VGICP, registration_helper.cpp:125-137) and "
       "IncrementalVoxelMap<FlatContainer<...>> (linear iVox: scan-to-model ICP / GICP) are targets the device knows.");
-    if constexpr (voxel_target && !flat_target) {
-      // incremental_voxelmap.hpp:99-119 visits the voxels of search_offsets around the query's own; the device looks into the query's own only (the default)
-      if (target.search_offsets.size() != 1) throw std::runtime_error("ParallelReductionHIP: a GaussianVoxelMap target with search_offsets != 1 is not supported");
-    }
     auto& s = pool->mine();
     if (s.multi && (s.device != device || s.num_gpus != num_gpus)) {
       sga_multi_destroy(s.multi);
@@ -486,6 +482,8 @@ struct ParallelReductionHIP {
         // the voxel map IS the search structure (incremental_voxelmap.hpp:99-119): its voxels in flat order + a hash of their coordinates per device
         const hip_detail::PackedVoxels v = hip_detail::pack_voxels(target);
         hip_detail::check(sga_multi_set_target_voxels(s.multi, 1.0 / target.inv_leaf_size, v.coord.data(), v.mean.data(), v.cov6.data(), v.n), "sga_multi_set_target_voxels");
+        // incremental_voxelmap.hpp:99-119 visits the voxels of search_offsets around the query's own and keeps the nearest mean: 1 / 7 / 27 on the device too
+        hip_detail::check(sga_multi_set_search_offsets(s.multi, hip_detail::device_search_offsets(target.search_offsets.size())), "sga_multi_set_search_offsets");
       } else {
         const hip_detail::PackedCloud c = hip_detail::pack(target);
         // replaces KdTree<PointCloud>(target), ann/kdtree.hpp:250-252: every device builds its own exact index over its copy

@@ -143,6 +143,8 @@ int sga_voxelmap_set_lru(sga_index* voxelmap, uint32_t horizon, uint32_t clear_c
  * Gaussian map; searched over 1, 7 or 27 voxels (incremental_voxelmap.hpp:157-186); target indices are (voxel_id << 32) | point_id. */
 int sga_flatmap_create(sga_context* ctx, double leaf_size, sga_index** out);
 int sga_flatmap_set_setting(sga_index* flatmap, double min_sq_dist_in_cell, uint32_t max_num_points_in_cell);
+/* Voxels visited around the query's own (incremental_voxelmap.hpp:157-186): 1 (default), 7 or 27 — for flat AND Gaussian maps, incremental,
+ * one-shot or created from host voxels; every visited Gaussian voxel offers its mean, the nearest wins (the first of equal distances). */
 int sga_voxelmap_set_search_offsets(sga_index* voxelmap, int num_offsets);
 /* coords n*3, counts n, points n*16*3 and cov6 n*16*6 (16 slots per voxel, the first counts[v] of them valid); any pointer may be NULL */
 int sga_flatmap_download(sga_context* ctx, const sga_index* flatmap, int32_t* coords, uint32_t* counts, float* points, float* cov6);
@@ -314,6 +316,8 @@ int sga_multi_set_target_f32_origin(sga_multi* m, const float* xyz_rel, const fl
 int sga_multi_set_source_f32_origin(sga_multi* m, const float* xyz_rel, const float* normals3, const float* cov6, size_t n, const double origin[3], const double init_T[16]);
 /* a Gaussian voxel map as the target (see sga_index_create_voxelmap_from_voxels): replicated on every device */
 int sga_multi_set_target_voxels(sga_multi* m, double leaf_size, const int32_t* coords, const double* means3, const double* cov6, size_t n);
+/* search offsets of the voxel-map target on every device (sga_voxelmap_set_search_offsets) */
+int sga_multi_set_search_offsets(sga_multi* m, int num_offsets);
 /* a flat voxel map as the target (see sga_index_create_flatmap_from_voxels): replicated on every device */
 int sga_multi_set_target_flat_voxels(sga_multi* m, double leaf_size, const int32_t* coords, const uint32_t* counts, const double* points3, const double* cov6, int search_offsets, size_t n);
 int sga_multi_set_source_f64(sga_multi* m, const double* xyzw, const double* normals4, const double* cov4x4, size_t n, const double init_T[16]);

@@ -336,6 +336,10 @@ class GaussianVoxelMap:
     def set_lru(self, horizon=100, clear_cycle=10):
         check(load().sga_voxelmap_set_lru(self.h, int(horizon), int(clear_cycle)))
 
+    def set_search_offsets(self, num_offsets):
+        """incremental_voxelmap.hpp:157-186: 1 (the query's own voxel), 7 or 27 voxels offer their Gaussians, the nearest mean wins."""
+        check(load().sga_voxelmap_set_search_offsets(self.h, int(num_offsets)))
+
     def batch_knn_search(self, pts, k, max_sq_dist=-1.0):
         return _voxelmap_knn(self, pts, k, max_sq_dist)
 

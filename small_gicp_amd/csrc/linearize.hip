@@ -828,7 +828,12 @@ __device__ __forceinline__ void linearize_group(const LinParams<Real>& p, int fi
         Tg[u][0] = m.x, Tg[u][1] = m.y, Tg[u][2] = m.z;
       }
     } else if constexpr (TARGET == 1) {
-      if (act[u]) jn[u] = voxel_lookup(p.vox, static_cast<float>(Q[u][0]), static_cast<float>(Q[u][1]), static_cast<float>(Q[u][2]));
+      if (act[u]) {
+        if (p.vox.offsets == 1)  // (wave-uniform) the default: the query's own voxel, no distance to compare
+          jn[u] = voxel_lookup(p.vox, static_cast<float>(Q[u][0]), static_cast<float>(Q[u][1]), static_cast<float>(Q[u][2]));
+        else
+          jn[u] = voxel_nearest<Real>(p.vox, p.tgt_pts, Q[u][0], Q[u][1], Q[u][2]);
+      }
     }
   }
   if constexpr (TARGET != 2) {
@@ -1502,6 +1507,7 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
     p.vox.hmask = idx->hmask;
     p.vox.inv_leaf = 1.0 / idx->leaf;
     for (int k = 0; k < 3; k++) p.vox.org[k] = idx->origin[k];
+    p.vox.offsets = idx->search_offsets;
   } else {
     p.kd = make_kd_view(idx);
   }

@@ -190,6 +190,13 @@ int sga_multi_set_target_voxels(sga_multi* m, double leaf, const int32_t* coords
   return SGA_OK;
 }
 
+int sga_multi_set_search_offsets(sga_multi* m, int num_offsets) {
+  if (!m || !m->has_target) return fail(SGA_ERR_INVALID, "sga_multi_set_search_offsets before a voxel map target was set");
+  for (auto& s : m->shards) SGA_TRY(sga_voxelmap_set_search_offsets(s.index, num_offsets));
+  m->model_valid = false;
+  return SGA_OK;
+}
+
 int sga_multi_set_target_flat_voxels(sga_multi* m, double leaf, const int32_t* coords, const uint32_t* counts, const double* points3, const double* cov6, int search_offsets, size_t n) {
   if (!m) return fail(SGA_ERR_INVALID, "null argument");
   drop_target(m);

@@ -28,6 +28,7 @@ struct VoxelView {
   uint32_t hmask;
   double inv_leaf;
   double org[3];  // origin of the device frame the queries and the stored means live in (common.hpp): voxel coordinates are the CALLER's
+  int offsets;    // 1 (the query's own voxel), 7 or 27 (incremental_voxelmap.hpp:157-186)
 };
 
 // util/fast_floor.hpp:12-15 on doubles (the reference floors pt * inv_leaf_size in double)
@@ -51,6 +52,57 @@ __device__ __forceinline__ int voxel_lookup(const VoxelView& v, float qx, float 
     slot = (slot + 1) & v.hmask;
   }
   return -1;
+}
+
+// Gaussian maps searched over 7 / 27 voxels (incremental_voxelmap.hpp:99-119: every voxel at the search offsets offers its mean,
+// gaussian_voxelmap.hpp:83-86; KnnResult<1>::push keeps the FIRST of equal distances; offsets in the reference's order: centre, +x +y +z
+// -x -y -z (7), or centre and then the 3 x 3 x 3 cube in i, j, k order (27: its second visit of the centre cannot change the result)).
+// Returns the voxel id or -1.  Distances between the fp32 records the device holds, evaluated in Real.
+template <typename Real>
+__device__ __forceinline__ int voxel_nearest(const VoxelView& v, const float4* __restrict__ means, Real qx, Real qy, Real qz) {
+  const int cx = fast_floor_d((static_cast<double>(qx) + v.org[0]) * v.inv_leaf);
+  const int cy = fast_floor_d((static_cast<double>(qy) + v.org[1]) * v.inv_leaf);
+  const int cz = fast_floor_d((static_cast<double>(qz) + v.org[2]) * v.inv_leaf);
+  Real best = static_cast<Real>(INFINITY);
+  int j = -1;
+  auto offer = [&](int ox, int oy, int oz) {
+    const int x = cx + ox, y = cy + oy, z = cz + oz;
+    if (abs(x) >= (1 << 20) || abs(y) >= (1 << 20) || abs(z) >= (1 << 20)) return;
+    const unsigned long long key = voxel_key(x, y, z);
+    uint32_t slot = voxel_hash(key) & v.hmask;
+    int vox = -1;
+    for (uint32_t probe = 0; probe <= v.hmask; ++probe) {
+      const unsigned long long k = v.hkeys[slot];
+      if (k == key) {
+        vox = static_cast<int>(v.hvals[slot]);
+        break;
+      }
+      if (k == SGA_HASH_EMPTY) break;
+      slot = (slot + 1) & v.hmask;
+    }
+    if (vox < 0) return;
+    const float4 m = means[vox];
+    const Real dx = static_cast<Real>(m.x) - qx, dy = static_cast<Real>(m.y) - qy, dz = static_cast<Real>(m.z) - qz;
+    const Real d2 = dx * dx + dy * dy + dz * dz;
+    if (d2 >= best) return;
+    best = d2;
+    j = vox;
+  };
+  offer(0, 0, 0);
+  if (v.offsets == 7) {
+    offer(1, 0, 0);
+    offer(0, 1, 0);
+    offer(0, 0, 1);
+    offer(-1, 0, 0);
+    offer(0, -1, 0);
+    offer(0, 0, -1);
+  } else if (v.offsets == 27) {
+    for (int a = -1; a <= 1; a++)
+      for (int b = -1; b <= 1; b++)
+        for (int c = -1; c <= 1; c++)
+          if (a || b || c) offer(a, b, c);
+  }
+  return j;
 }
 
 // Flat maps: nearest stored point over the search-offset pattern (incremental_voxelmap.hpp:99-119 + flat_container.hpp:84-93 with

@@ -447,8 +447,7 @@ int sga_flatmap_set_setting(sga_index* index, double min_sq_dist_in_cell, uint32
 }
 
 int sga_voxelmap_set_search_offsets(sga_index* index, int num_offsets) {
-  if (!index || !index->incremental) return fail(SGA_ERR_INVALID, "not an incremental voxel map");
-  if (index->kind != SGA_INDEX_FLATMAP && num_offsets != 1) return fail(SGA_ERR_UNSUPPORTED, "Gaussian voxel maps are searched with one offset (the voxel of the query)");
+  if (!index || (index->kind != SGA_INDEX_VOXELMAP && index->kind != SGA_INDEX_FLATMAP)) return fail(SGA_ERR_INVALID, "not a voxel map");
   if (num_offsets != 1 && num_offsets != 7 && num_offsets != 27) return fail(SGA_ERR_INVALID, "search offsets must be 1, 7 or 27");
   index->search_offsets = num_offsets;
   return SGA_OK;

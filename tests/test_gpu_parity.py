@@ -1063,6 +1063,49 @@ def test_incremental_voxelmap_matches_oracle(orc, c1_f32, gpu_c1):
     assert dt < POSE_TOL_T and dr < POSE_TOL_R and res.iterations == ores.iterations and res.num_inliers == ores.num_inliers, (dt, dr)
 
 
+@pytest.mark.parametrize("offsets", [7, 27])
+def test_gaussian_voxelmap_searched_over_7_and_27_voxels(orc, c1_f32, gpu_c1, offsets):
+    """incremental_voxelmap.hpp:99-119 with set_search_offsets(7 | 27) for a GaussianVoxelMap: every voxel at the offsets offers its mean and
+    the nearest wins (SURVEY a8 "7/27 selectable"; VERDICT r4 missing #2).  Linearization at two poses and the whole VGICP registration
+    against the oracle with the same offsets; the one-shot map, the incremental map and the map made from host voxels agree."""
+    d = c1_f32
+    tgt, src, _ = gpu_c1
+    ot, os_ = orc.Cloud(d["tp"], d["tn"], d["tc"]), orc.Cloud(d["sp"], d["sn"], d["sc"], tree=False)
+    ov = orc.VoxelMap(ot, 1.0)
+    ov.set_search_offsets(offsets)
+    gv = sga.GaussianVoxelMap(1.0)
+    gv.insert(tgt)
+    gv.set_search_offsets(offsets)
+    st = sga.make_setting("GICP")
+    os_set = orc.default_setting(factor_kind=orc.GICP, num_threads=1)
+    pb = sga.Problem(gv, src)
+    f = orc.Factors(len(os_))
+    wide = 0
+    for T in (np.eye(4), se3([0.1, 0.2, 1.0], np.deg2rad(0.7), [0.49, 0.12, -0.02])):
+        H, b, e, n = pb.linearize(st.factor, T)
+        Ho, bo, eo, no = orc.linearize(ov, os_, os_set, T, f)
+        assert abs(int(n) - int(no)) <= 3, (n, no)
+        assert np.abs(H - Ho).max() <= 5e-4 * np.abs(Ho).max() and abs(e - eo) <= 5e-4 * abs(eo), (np.abs(H - Ho).max() / np.abs(Ho).max(), e, eo)
+        ti, _ = pb.factors()
+        oti, _ = f.get(is_voxelmap=True)
+        assert (ti == oti).mean() > 0.999, (ti == oti).mean()  # voxel ids (first-insertion order on both sides), -1 = no correspondence
+        one = sga.GaussianVoxelMap(1.0)
+        one.insert(tgt)
+        H1, _, _, n1 = sga.Problem(one, src).linearize(st.factor, T)
+        wide += int(n) - int(n1)
+    assert wide > 100  # the wider search does find neighbours the query's own voxel does not offer
+    res = sga.Problem(gv, src).align(st)
+    ores = orc.align(ov, os_, os_set)
+    dt, dr = pose_error(res.T_target_source, ores.T_target_source)
+    assert dt < POSE_TOL_T and dr < POSE_TOL_R and res.iterations == ores.iterations and abs(int(res.num_inliers) - int(ores.num_inliers)) <= 3, (dt, dr, res.iterations, ores.iterations)
+    coords, means, c6, _ = gv.download()
+    hv = sga.GaussianVoxelMap.from_voxels(1.0, coords, means, c6)
+    hv.set_search_offsets(offsets)
+    H2, b2, e2, n2 = sga.Problem(hv, src).linearize(st.factor, np.eye(4))
+    H3, b3, e3, n3 = sga.Problem(gv, src).linearize(st.factor, np.eye(4))
+    assert n2 == n3 and (H2 == H3).all() and e2 == e3
+
+
 def test_voxelmap_from_host_voxels_equals_the_map_they_came_from(gpu_c1):
     """sga_index_create_voxelmap_from_voxels (the upload of a reference GaussianVoxelMap object, reduction_hip.hpp): the voxels of a device
     map, downloaded and handed back in the same order, give the same correspondences (voxel ids) and the same sums; handed back in a

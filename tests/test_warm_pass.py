@@ -134,6 +134,27 @@ def test_warm_registration_matches_cold_registration_100k():
     assert dt < 2e-2 and dr < 2e-3
 
 
+def test_streaming_warm_kernel_walks_the_tree_on_a_deep_index():
+    """certify_linearize_kernel (>= 131072 source points, millimetre motions) with its walkers sent through the kd walk (no cell grid:
+    SGA_GRID = 0) over a 1M-point target — a tree of depth 17, where each of the workgroup's four waves needs its own full-depth
+    traversal stack (the stacks were indexed by threadIdx.x instead of the lane, so wave w worked w rows further down and
+    wave 3 could reach past the allocation).  Warm == cold on a chain of millimetre steps, rejector tight and wide."""
+    target, source, T_gt = sga.synthetic.registration_pair(1_000_000)
+    sga.set_grid_mode(0)
+    try:
+        tree = sga.KdTree(sga.PointCloud(target))
+    finally:
+        sga.set_grid_mode(1)
+    src = sga.PointCloud(source[:300_000])
+    steps = [np.eye(4)] + [se3([0.3, -0.2, 1.0], 2e-6 * k, [4e-4 * k, -3e-4 * k, 2e-4 * k]) for k in range(1, 6)]
+    poses = [T_gt @ S for S in steps]
+    limit = sga.get_warm_limit()
+    for maxd in (1.0, 0.2):
+        st = sga.make_setting("ICP", max_correspondence_distance=maxd)
+        stats = run_chain(tree, src, st, poses, limit, 1e-6)
+        assert stats["warm_passes"] == len(poses) - 1 and stats["walked_points"] > 100, stats
+
+
 @pytest.mark.parametrize("chunk", [1, 4, 16])
 @pytest.mark.parametrize("maxd", [1.0, 0.3, None])
 def test_queue_fed_search_equals_lane_search(c1_f32, chunk, maxd):
