@@ -39,7 +39,8 @@
 // Threads.  Registration<>::align is const and the reference runs it from many threads at once
 // (src/benchmark/odometry_benchmark_small_gicp_tbb_flow.cpp:81-96).  Every calling thread gets its own device context, stream and
 // uploaded clouds (looked up by thread id in a pool shared by the copies of one policy object), so concurrent align() calls on one
-// Registration — or on copies of it — are independent, on the host and on the GPU.
+// Registration — or on copies of it — are independent, on the host and on the GPU.  A thread that ends takes its state along (device
+// memory does not grow with the number of short-lived threads that ever called align()).
 //
 // Several GPUs in one process: `num_gpus` > 1 (the analogue of ParallelReductionOMP::num_threads, reduction_omp.hpp:22,72) shards the
 // source over devices `device` .. `device + num_gpus - 1` with the target replicated (sga_multi_*, small_gicp_amd.h); the sums of the
@@ -54,7 +55,8 @@
 // the device in flat order (sga_multi_set_target_voxels), so the voxel ids of target_index (voxel << 32, incremental_voxelmap.hpp:153)
 // are the caller's; search_offsets 1 / 7 / 27.  IncrementalVoxelMap<FlatContainer<...>> (linear iVox, the scan-to-model target)
 // works the same way (sga_multi_set_target_flat_voxels: <= 16 points per voxel, search offsets 1 / 7 / 27); other contents are rejected at compile time.
-// Custom rejectors / factors with host callbacks stay on the CPU reductions (or use sga_problem_set_rejector).
+// Any other rejector type (registration/rejector.hpp:11-28 is a duck-typed slot) decides on the host through the device's batch callback
+// (sga_multi_set_rejector: nearest neighbours down, verdicts up, once per linearization — correct, not fast; point-cloud targets).
 #pragma once
 
 #include <cmath>
@@ -62,6 +64,9 @@
 #include <cstring>
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <iostream>
 #include <limits>
 #include <map>
 #include <memory>
@@ -130,6 +135,29 @@ struct factor_map<RobustFactor<Cauchy, F>> {
 
 inline double max_dist_sq_of(const DistanceRejector& r) { return r.max_dist_sq; }
 inline double max_dist_sq_of(const NullRejector&) { return -1.0; }  // sga_factor_params: < 0 = no rejector
+template <typename Rejector>
+inline double max_dist_sq_of(const Rejector&) { return -1.0; }  // any other rejector decides on the host (batch callback): the device searches without a bound
+template <typename Rejector>
+struct is_builtin_rejector : std::integral_constant<bool, std::is_same<Rejector, DistanceRejector>::value || std::is_same<Rejector, NullRejector>::value> {};
+
+// A user-defined CorrespondenceRejector (registration/rejector.hpp:11-28 is a duck-typed slot: bool operator()(target, source, T,
+// target_index, source_index, sq_dist), true = reject) decides on the host: once per linearization and shard the device hands over the
+// nearest neighbour of every source point and gets the verdicts back (sga_multi_set_rejector).  Correct, not fast.
+template <typename Target, typename Source, typename Rejector>
+struct RejectorCall {
+  const Target* target;
+  const Source* source;
+  const Rejector* rejector;
+  static int invoke(void* user, const double T16[16], size_t first, size_t n, const std::int64_t* target_index, const float* sq_dist, unsigned char* reject) {
+    const auto* c = static_cast<const RejectorCall*>(user);
+    Eigen::Isometry3d T = Eigen::Isometry3d::Identity();
+    for (int col = 0; col < 4; col++)
+      for (int r = 0; r < 3; r++) T.matrix()(r, col) = T16[4 * col + r];
+    for (size_t i = 0; i < n; i++)
+      reject[i] = target_index[i] < 0 ? 1 : ((*c->rejector)(*c->target, *c->source, T, static_cast<size_t>(target_index[i]), first + i, static_cast<double>(sq_dist[i])) ? 1 : 0);
+    return 0;
+  }
+};
 
 inline void set_mahalanobis(GICPFactor& f, const float* m6) {
   f.mahalanobis.setZero();
@@ -151,6 +179,8 @@ inline void check(int rc, const char* what) {
 // OpenMP team (every hardware thread, spinning between regions) costs more than these loops and fights the registration's own threads.
 constexpr int kHostThreads = 8;
 constexpr size_t kParallelFrom = 65536;
+// the content hash streams 160 bytes per point (points + 4 x 4 covariances): bound by memory bandwidth, which one socket's 8 threads do not saturate
+inline int hash_threads(size_t n) { return n >= 8 * kParallelFrom ? 2 * kHostThreads : kHostThreads; }  // (target and source are hashed side by side during an align)
 
 // identity of a cloud's CONTENT: size, attributes and EVERY point / normal / covariance entry (FNV-1a per block of 4096 points, the
 // block hashes combined in order; OpenMP over the blocks).  One streaming pass over the host data — cheap next to the repack and
@@ -163,7 +193,7 @@ std::uint64_t fingerprint(const Cloud& c) {
   const size_t blocks = (n + kBlock - 1) / kBlock;
   std::vector<std::uint64_t> part(blocks);
 #ifdef _OPENMP
-#pragma omp parallel for schedule(static) num_threads(kHostThreads) if (n >= kParallelFrom)
+#pragma omp parallel for schedule(static) num_threads(hash_threads(n)) if (n >= kParallelFrom)
 #endif
   for (long long bl = 0; bl < static_cast<long long>(blocks); bl++) {
     // four interleaved FNV chains (point i feeds chain i & 3): one chain is bound by the latency of its multiply, four keep the core busy
@@ -247,6 +277,76 @@ PackedCloud pack(const Cloud& c) {
   return out;
 }
 
+// One helper thread per device state: hashes the caller's clouds WHILE the registration already runs on the cached upload (begin_align).
+// A persistent thread, because the OpenMP team of a thread lives with it: a fresh thread per align would create a fresh team every time.
+class HashWorker {
+public:
+  ~HashWorker() {
+    {
+      std::lock_guard<std::mutex> lock(m_);
+      quit_ = true;
+    }
+    cv_.notify_all();
+    if (worker_.joinable()) worker_.join();
+  }
+  void start(std::function<int()> job) {
+    std::lock_guard<std::mutex> lock(m_);
+    if (!worker_.joinable()) worker_ = std::thread([this] { run(); });
+    job_ = std::move(job);
+    pending_ = true;
+    done_ = false;
+    cv_.notify_all();
+  }
+  bool pending() const { return pending_; }
+  int wait() {  // the job's verdict; 1 also when it threw
+    std::unique_lock<std::mutex> lock(m_);
+    cv_.wait(lock, [this] { return done_; });
+    pending_ = false;
+    return result_;
+  }
+
+private:
+  void run() {
+    std::unique_lock<std::mutex> lock(m_);
+    for (;;) {
+      cv_.wait(lock, [this] { return quit_ || (pending_ && !done_ && job_); });
+      if (quit_) return;
+      std::function<int()> job = std::move(job_);
+      job_ = nullptr;
+      lock.unlock();
+      int r = 1;
+      try {
+        r = job();
+      } catch (...) {
+        r = 1;
+      }
+      lock.lock();
+      result_ = r;
+      done_ = true;
+      cv_.notify_all();
+    }
+  }
+  std::mutex m_;
+  std::condition_variable cv_;
+  std::thread worker_;
+  std::function<int()> job_;
+  bool pending_ = false, done_ = false, quit_ = false;
+  int result_ = 0;
+};
+// target and source are hashed side by side (two teams): bit 0 = the target changed, bit 1 = the source
+class Verifier {
+public:
+  void start(std::function<int()> target_changed, std::function<int()> source_changed) {
+    t_.start(std::move(target_changed));
+    s_.start(std::move(source_changed));
+  }
+  bool pending() const { return t_.pending() || s_.pending(); }
+  int wait() { return (t_.wait() ? 1 : 0) | (s_.wait() ? 2 : 0); }
+
+private:
+  HashWorker t_, s_;
+};
+
 // What one calling thread keeps on the device(s): contexts + streams, the uploaded clouds, the search index, the factor state.
 struct DeviceState {
   int device = 0, num_gpus = 1;
@@ -255,6 +355,10 @@ struct DeviceState {
   std::uint64_t target_fp = 0, source_fp = 0;
   bool has_target = false, has_source = false;
   size_t n_source = 0;  // points of the uploaded source (the host `factors` are filled only if there is one per point)
+  size_t n_target = 0;
+  double last_max_dist_sq = 1.0;  // of this thread's last linearize (error() evaluates with the same rejector)
+  bool custom_rejector = false;   // a host rejector is installed on the device problems
+  Verifier verifier;              // begin_align: the content hash of cached clouds runs beside the registration
   size_t num_inliers = 0;  // of this thread's last linearize
   bool voxel_target = false;  // Gaussian voxel map: target_index of the host factors = voxel id << 32 (incremental_voxelmap.hpp:153)
   std::uint64_t generation = 0;  // bumped whenever something is uploaded again
@@ -271,21 +375,54 @@ struct DeviceState {
 // The states of all threads that use (copies of) one policy object.  A thread's state is created on its first call and lives as long
 // as the pool (TBB / OpenMP worker threads are persistent; a thread that is gone leaves its state behind until the last copy of the
 // policy dies).
-struct StatePool {
+struct StatePool;
+// A thread that ends takes its states along (contexts, streams, uploaded clouds, indices: ~0.3 GB at 1M <-> 1M): callers that run align()
+// from short-lived threads (std::async) would otherwise grow device memory without bound.
+struct ThreadStates {
+  std::vector<std::weak_ptr<StatePool>> pools;
+  ~ThreadStates();
+};
+inline ThreadStates& thread_states() {
+  static thread_local ThreadStates t;
+  return t;
+}
+struct StatePool : std::enable_shared_from_this<StatePool> {
   std::mutex mutex;
   std::map<std::thread::id, std::unique_ptr<DeviceState>> per_thread;
   std::uint64_t generation_total = 0;  // uploads of all threads (under the mutex)
   DeviceState& mine() {
     std::lock_guard<std::mutex> lock(mutex);
     auto& slot = per_thread[std::this_thread::get_id()];
-    if (!slot) slot.reset(new DeviceState);
+    if (!slot) {
+      slot.reset(new DeviceState);
+      thread_states().pools.push_back(weak_from_this());  // dropped again when this thread ends
+    }
     return *slot;
+  }
+  size_t states() {
+    std::lock_guard<std::mutex> lock(mutex);
+    return per_thread.size();
   }
   void uploaded() {
     std::lock_guard<std::mutex> lock(mutex);
     generation_total++;
   }
 };
+
+inline ThreadStates::~ThreadStates() {
+  for (auto& w : pools)
+    if (auto p = w.lock()) {
+      std::unique_ptr<DeviceState> mine;
+      {
+        std::lock_guard<std::mutex> lock(p->mutex);
+        auto it = p->per_thread.find(std::this_thread::get_id());
+        if (it != p->per_thread.end()) {
+          mine = std::move(it->second);
+          p->per_thread.erase(it);
+        }
+      }
+    }  // (the state is destroyed outside the pool's lock)
+}
 
 // A voxel map in the target slot (VGICP, registration_helper.cpp:125-137) is not a point cloud: traits::point(i) takes packed
 // (voxel, point) indices (incremental_voxelmap.hpp:153-155).  A GaussianVoxelMap goes to the device as it is — its voxels in flat
@@ -320,22 +457,41 @@ inline PackedVoxels pack_voxels(const IncrementalVoxelMap<GaussianVoxel>& vm) {
   return out;
 }
 inline std::uint64_t fingerprint(const IncrementalVoxelMap<GaussianVoxel>& vm) {
-  std::uint64_t h = 1469598103934665603ull ^ vm.flat_voxels.size() ^ (static_cast<std::uint64_t>(vm.search_offsets.size()) << 40);
-  auto mix = [&h](double v) {
-    std::uint64_t b;
-    std::memcpy(&b, &v, 8);
-    h = (h ^ b) * 1099511628211ull;
-  };
-  mix(vm.inv_leaf_size);
-  for (const auto& pv : vm.flat_voxels) {
-    const auto& v = *pv;
-    h = (h ^ static_cast<std::uint32_t>(v.first.coord[0])) * 1099511628211ull;
-    h = (h ^ static_cast<std::uint32_t>(v.first.coord[1])) * 1099511628211ull;
-    h = (h ^ static_cast<std::uint32_t>(v.first.coord[2])) * 1099511628211ull;
-    mix(v.second.mean[0]), mix(v.second.mean[1]), mix(v.second.mean[2]);
-    const Eigen::Matrix4d& m = v.second.cov;
-    mix(m(0, 0)), mix(m(0, 1)), mix(m(0, 2)), mix(m(1, 1)), mix(m(1, 2)), mix(m(2, 2));
+  // blocks of 1024 voxels hashed in parallel (the voxels hang off shared_ptrs: one thread chasing 165 000 of them took 1 ms), combined in order
+  const size_t n = vm.flat_voxels.size();
+  constexpr size_t kBlock = 1024;
+  const size_t blocks = (n + kBlock - 1) / kBlock;
+  std::vector<std::uint64_t> part(blocks);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(kHostThreads) if (n >= 16 * kBlock)
+#endif
+  for (long long bl = 0; bl < static_cast<long long>(blocks); bl++) {
+    std::uint64_t h = 1469598103934665603ull ^ static_cast<std::uint64_t>(bl);
+    auto mix = [&h](double v) {
+      std::uint64_t b;
+      std::memcpy(&b, &v, 8);
+      h = (h ^ b) * 1099511628211ull;
+    };
+    const size_t i0 = static_cast<size_t>(bl) * kBlock, i1 = i0 + kBlock < n ? i0 + kBlock : n;
+    for (size_t i = i0; i < i1; i++) {
+      const auto& v = *vm.flat_voxels[i];
+      h = (h ^ static_cast<std::uint32_t>(v.first.coord[0])) * 1099511628211ull;
+      h = (h ^ static_cast<std::uint32_t>(v.first.coord[1])) * 1099511628211ull;
+      h = (h ^ static_cast<std::uint32_t>(v.first.coord[2])) * 1099511628211ull;
+      mix(v.second.mean[0]), mix(v.second.mean[1]), mix(v.second.mean[2]);
+      const Eigen::Matrix4d& m = v.second.cov;
+      mix(m(0, 0)), mix(m(0, 1)), mix(m(0, 2)), mix(m(1, 1)), mix(m(1, 2)), mix(m(2, 2));
+    }
+    part[bl] = h;
   }
+  std::uint64_t h = 1469598103934665603ull ^ n ^ (static_cast<std::uint64_t>(vm.search_offsets.size()) << 40);
+  {
+    std::uint64_t b;
+    const double il = vm.inv_leaf_size;
+    std::memcpy(&b, &il, 8);
+    h = (h ^ b) * 1099511628211ull;
+  }
+  for (std::uint64_t v : part) h = (h ^ v) * 1099511628211ull;
   return h;
 }
 // IncrementalVoxelMap<FlatContainer<N, C>> (linear iVox, the scan-to-model target of odometry_benchmark_small_gicp_model_omp.cpp): every voxel
@@ -417,6 +573,10 @@ size_t target_size(const Target& t) {
   }
 }
 
+inline bool& warned_about_shared_devices() {
+  static bool warned = false;
+  return warned;
+}
 inline double seconds_since(const std::chrono::steady_clock::time_point& t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
 
 }  // namespace hip_detail
@@ -439,6 +599,9 @@ struct ParallelReductionHIP {
     s.target_addr = s.source_addr = nullptr;
   }
 
+  /// Device states alive (one per thread that has used this policy or a copy of it and has not ended yet).
+  size_t device_states() const { return pool->states(); }
+
   /// Uploads so far, over all threads (diagnostic: a loop that re-registers unchanged objects must not re-upload them).
   std::uint64_t generation() const {
     std::lock_guard<std::mutex> lock(pool->mutex);
@@ -447,7 +610,7 @@ struct ParallelReductionHIP {
 
   /// Hash / upload / index what is not on the device(s) yet.  Called by every linearize() outside an align bracket.
   template <typename TargetPointCloud, typename SourcePointCloud>
-  void bind(const TargetPointCloud& target, const SourcePointCloud& source, const Eigen::Isometry3d& T) const {
+  void bind(const TargetPointCloud& target, const SourcePointCloud& source, const Eigen::Isometry3d& T, bool defer_verification = false) const {
     constexpr bool voxel_target = hip_detail::is_voxelmap<TargetPointCloud>::value;
     constexpr bool flat_target = hip_detail::is_flat_voxelmap<TargetPointCloud>::value;
     static_assert(
@@ -466,11 +629,29 @@ struct ParallelReductionHIP {
       std::vector<int> devices(static_cast<size_t>(s.num_gpus));
       int visible = sga_device_count();
       for (int g = 0; g < s.num_gpus; g++) devices[g] = visible > 0 ? (device + g) % visible : device + g;  // more shards than devices: logical shards share a device
+      if (visible > 0 && device + s.num_gpus > visible) {
+        bool& warned = hip_detail::warned_about_shared_devices();
+        if (!warned) std::cerr << "warning: ParallelReductionHIP: devices " << device << " .. " << device + s.num_gpus - 1 << " requested, " << visible << " visible: the shards share devices (logical shards)" << std::endl;
+        warned = true;
+      }
       hip_detail::check(sga_multi_create(devices.data(), s.num_gpus, &s.multi), "sga_multi_create");
     }
     // content check (one streaming pass over both clouds, ~0.2 ms per 100k points): an object refilled in place is uploaded again.
     // verify_content = false trusts address + size (call rebind() after changing a cloud in place).
-    const std::uint64_t tfp = verify_content ? hip_detail::fingerprint(target) : hip_detail::target_size(target), sfp = verify_content ? hip_detail::fingerprint(source) : traits::size(source);
+    // Inside an align bracket, for large clouds whose objects (address, size) are the ones already on the device: the registration starts
+    // on the cached upload at once and the hash runs beside it on the state's helper thread; end of the bracket: equal -> done, different ->
+    // upload what the caller holds now and register again (HipAligned::optimize).  A refilled cloud costs one wasted registration,
+    // an unchanged one no longer waits 1.7 - 2.3 ms (2 x 1M points) for a hash before ten 0.12 ms iterations.
+    const size_t nt = hip_detail::target_size(target), ns = traits::size(source);
+    const bool same_objects = s.has_target && s.has_source && s.target_addr == static_cast<const void*>(&target) && s.source_addr == static_cast<const void*>(&source) && s.n_target == nt && s.n_source == ns;
+    if (verify_content && defer_verification && same_objects && nt + ns >= hip_detail::kParallelFrom) {
+      const std::uint64_t want_t = s.target_fp, want_s = s.source_fp;
+      const TargetPointCloud* tp = &target;
+      const SourcePointCloud* sp = &source;
+      s.verifier.start([tp, want_t] { return hip_detail::fingerprint(*tp) != want_t ? 1 : 0; }, [sp, want_s] { return hip_detail::fingerprint(*sp) != want_s ? 1 : 0; });
+      return;
+    }
+    const std::uint64_t tfp = verify_content ? hip_detail::fingerprint(target) : nt, sfp = verify_content ? hip_detail::fingerprint(source) : ns;
     if (s.target_addr != static_cast<const void*>(&target) || s.target_fp != tfp || !s.has_target) {
       if constexpr (flat_target) {
         // linear iVox: the voxels' points (and covariances) in flat order, 16 slots per voxel; searched over the map's 1 / 7 / 27 offsets
@@ -492,6 +673,7 @@ struct ParallelReductionHIP {
       s.voxel_target = voxel_target && !flat_target;  // (a flat map's indices come packed from the device: (voxel << 32) | point)
       s.target_addr = &target;
       s.target_fp = tfp;
+      s.n_target = nt;
       s.has_target = true;
       s.has_source = false;
       s.generation++;
@@ -513,12 +695,22 @@ struct ParallelReductionHIP {
   template <typename TargetPointCloud, typename SourcePointCloud>
   void begin_align(const TargetPointCloud& target, const SourcePointCloud& source, const Eigen::Isometry3d& init_T) const {
     const auto t0 = std::chrono::steady_clock::now();
-    bind(target, source, init_T);
+    bind(target, source, init_T, /*defer_verification=*/true);
     auto& s = pool->mine();
     hip_detail::check(sga_multi_reset_search_state(s.multi), "sga_multi_reset_search_state");  // a registration's result must not depend on earlier ones
     s.in_align = true;
     s.calls_s = 0.0;
     s.bind_s = hip_detail::seconds_since(t0);
+  }
+  /// The verdict of the content check begin_align() started beside the registration (true when none was pending).  False: the clouds were
+  /// edited in place since their upload — the caller (HipAligned::optimize) forgets them and registers again.
+  bool verified() const {
+    auto& s = pool->mine();
+    if (!s.verifier.pending()) return true;
+    const int changed = s.verifier.wait();
+    if (changed & 1) s.target_addr = nullptr;
+    if (changed & 2) s.source_addr = nullptr;
+    return changed == 0;
   }
   /// End of the bracket: the host `factors` as a CPU reduction would have left them after the last linearize (what optimizer.hpp:146 counts).
   /// Returns whether the host factors were filled (one per source point and sync_inliers / sync_factors on).
@@ -556,11 +748,24 @@ struct ParallelReductionHIP {
     const auto call_t0 = std::chrono::steady_clock::now();
     if (!s.in_align) bind(target, source, T);
     sga_factor_params fp = params<Factor>(factors, hip_detail::max_dist_sq_of(rejector));
+    s.last_max_dist_sq = fp.max_dist_sq;
+    // any rejector type other than the two the device evaluates itself decides on the host, through the batch callback
+    hip_detail::RejectorCall<TargetPointCloud, SourcePointCloud, CorrespondenceRejector> call{&target, &source, &rejector};
+    if constexpr (!hip_detail::is_builtin_rejector<CorrespondenceRejector>::value) {
+      static_assert(!hip_detail::is_voxelmap<TargetPointCloud>::value, "ParallelReductionHIP: a user-defined rejector needs a point-cloud target (the device reports nearest neighbours of a kd-tree)");
+      hip_detail::check(sga_multi_set_rejector(s.multi, &decltype(call)::invoke, &call), "sga_multi_set_rejector");
+      s.custom_rejector = true;
+    } else if (s.custom_rejector) {
+      hip_detail::check(sga_multi_set_rejector(s.multi, nullptr, nullptr), "sga_multi_set_rejector");
+      s.custom_rejector = false;
+    }
     Eigen::Matrix<double, 6, 6> H;
     Eigen::Matrix<double, 6, 1> b;
     double H36[36], b6[6], e = 0.0;
     std::uint64_t inliers = 0;
     hip_detail::check(sga_multi_linearize(s.multi, &fp, T.matrix().data(), H36, b6, &e, &inliers), "sga_multi_linearize");
+    if constexpr (!hip_detail::is_builtin_rejector<CorrespondenceRejector>::value)
+      hip_detail::check(sga_multi_set_rejector(s.multi, nullptr, nullptr), "sga_multi_set_rejector"), s.custom_rejector = false;  // `call` dies with this frame
     for (int i = 0; i < 6; i++) {
       b(i) = b6[i];
       for (int j = 0; j < 6; j++) H(i, j) = H36[6 * i + j];
@@ -580,7 +785,7 @@ struct ParallelReductionHIP {
     auto& s = pool->mine();
     if (!s.multi || !s.has_source) throw std::runtime_error("ParallelReductionHIP::error before linearize");
     const auto call_t0 = std::chrono::steady_clock::now();
-    sga_factor_params fp = params<Factor>(factors, last_max_dist_sq);
+    sga_factor_params fp = params<Factor>(factors, s.last_max_dist_sq);
     double e = 0.0;
     hip_detail::check(sga_multi_error(s.multi, &fp, T.matrix().data(), &e), "sga_multi_error");
     s.calls_s += hip_detail::seconds_since(call_t0);
@@ -630,11 +835,9 @@ private:
     fp.robust_c = factors.empty() ? 1.0 : Map::width(factors.front());
     fp.max_dist_sq = max_dist_sq;
     fp.math_mode = fp64_math ? SGA_MATH_FP64 : SGA_MATH_FP32;
-    last_max_dist_sq = max_dist_sq;
     return fp;
   }
 
-  mutable double last_max_dist_sq = 1.0;
   std::shared_ptr<hip_detail::StatePool> pool;  // shared by copies of the policy (Registration<> objects are copied freely); one state per calling thread
 };
 
@@ -663,13 +866,23 @@ struct HipAligned : public Optimizer {
     std::vector<Factor>& factors,
     GeneralFactor& general_factor) const {
     if constexpr (std::is_same<typename std::remove_cv<Reduction>::type, ParallelReductionHIP>::value) {
-      reduction.begin_align(target, source, init_T);  // hash / upload / index: once
+      reduction.begin_align(target, source, init_T);  // hash / upload / index: once (the hash of clouds already on the device: beside the registration)
       RegistrationResult result(init_T);
       const auto t0 = std::chrono::steady_clock::now();
       try {
         result = Optimizer::optimize(target, source, target_tree, rejector, criteria, reduction, init_T, factors, general_factor);  // registration/optimizer.hpp, as it is
+        if (!reduction.verified()) {
+          // the caller refilled a cloud in place since its upload (every odometry loop does): what was registered is the old content.
+          // Upload what the caller holds now and register again; the wasted pass is what the unchanged case no longer waits for.
+          std::vector<Factor> none;
+          reduction.end_align(none);
+          reduction.begin_align(target, source, init_T);  // (addresses forgotten by verified(): hashes, uploads, no deferral)
+          result = Optimizer::optimize(target, source, target_tree, rejector, criteria, reduction, init_T, factors, general_factor);
+          (void)reduction.verified();
+        }
         reduction.note_loop_seconds(hip_detail::seconds_since(t0));
       } catch (...) {
+        (void)reduction.verified();  // (never leave a check running over clouds that may go away)
         std::vector<Factor> none;
         reduction.end_align(none);
         throw;

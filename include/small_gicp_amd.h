@@ -316,6 +316,10 @@ int sga_multi_set_target_f32_origin(sga_multi* m, const float* xyz_rel, const fl
 int sga_multi_set_source_f32_origin(sga_multi* m, const float* xyz_rel, const float* normals3, const float* cov6, size_t n, const double origin[3], const double init_T[16]);
 /* a Gaussian voxel map as the target (see sga_index_create_voxelmap_from_voxels): replicated on every device */
 int sga_multi_set_target_voxels(sga_multi* m, double leaf_size, const int32_t* coords, const double* means3, const double* cov6, size_t n);
+/* A custom CorrespondenceRejector for the whole registration (see sga_problem_set_rejector): the batch callback is invoked once per shard and
+ * linearization with the shard's range [first, first + n) of the caller's source order; fn = NULL restores the built-in rejectors. */
+typedef int (*sga_multi_rejector_fn)(void* user, const double T[16], size_t first, size_t n, const int64_t* target_index, const float* sq_dist, unsigned char* reject);
+int sga_multi_set_rejector(sga_multi* m, sga_multi_rejector_fn fn, void* user);
 /* search offsets of the voxel-map target on every device (sga_voxelmap_set_search_offsets) */
 int sga_multi_set_search_offsets(sga_multi* m, int num_offsets);
 /* a flat voxel map as the target (see sga_index_create_flatmap_from_voxels): replicated on every device */

@@ -152,6 +152,7 @@ SYMBOLS = [
     ("sga_multi_set_source_f32_origin", C.c_int, [_vp, _fp, _fp, _fp, C.c_size_t, _dp, _dp]),
     ("sga_multi_set_target_voxels", C.c_int, [_vp, C.c_double, C.c_void_p, _dp, _dp, C.c_size_t]),
     ("sga_multi_set_search_offsets", C.c_int, [_vp, C.c_int]),
+    ("sga_multi_set_rejector", C.c_int, [_vp, C.c_void_p, _vp]),
     ("sga_multi_set_target_flat_voxels", C.c_int, [_vp, C.c_double, C.c_void_p, C.c_void_p, _dp, _dp, C.c_int, C.c_size_t]),
     ("sga_multi_set_source_f64", C.c_int, [_vp, _dp, _dp, _dp, C.c_size_t, _dp]),
     ("sga_multi_linearize", C.c_int, [_vp, C.POINTER(FactorParams), _dp, _dp, _dp, _dp, C.POINTER(C.c_uint64)]),

@@ -35,7 +35,10 @@ struct sga_multi {
     sga_cloud* source = nullptr;
     sga_problem* problem = nullptr;
     size_t first = 0, count = 0;  // its range of the caller's source order
+    sga_multi* owner = nullptr;   // for the rejector trampoline
   };
+  sga_multi_rejector_fn rejector_fn = nullptr;
+  void* rejector_user = nullptr;
   std::vector<Shard> shards;
   size_t n_target = 0, n_source = 0;
   bool has_target = false, has_source = false;
@@ -75,6 +78,17 @@ void drop_target(sga_multi* m) {
 
 int multi_lin_cb(void* user, const double T[16], double H[36], double b[6], double* e, uint64_t* inl);
 int multi_err_cb(void* user, const double T[16], double* e);
+// a shard's problem asks about ITS source points: the caller is told where they start in its own order
+int shard_rejector(void* user, const double T[16], size_t n, const int64_t* target_index, const float* sq_dist, unsigned char* reject) {
+  auto* s = static_cast<sga_multi::Shard*>(user);
+  return s->owner->rejector_fn(s->owner->rejector_user, T, s->first, n, target_index, sq_dist, reject);
+}
+void install_rejector(sga_multi* m) {
+  for (auto& s : m->shards) {
+    s.owner = m;
+    if (s.problem) (void)sga_problem_set_rejector(s.problem, m->rejector_fn ? shard_rejector : nullptr, &s);
+  }
+}
 struct MultiReduction {
   sga_multi* m;
   const sga_factor_params* fp;
@@ -167,6 +181,7 @@ static int multi_set_source_f32(sga_multi* m, const float* xyz, const float* nor
   }
   m->n_source = n;
   m->has_source = true;
+  if (m->rejector_fn) install_rejector(m);  // (a rejector set earlier stays in force for the new problems)
   return SGA_OK;
 }
 
@@ -187,6 +202,16 @@ int sga_multi_set_target_voxels(sga_multi* m, double leaf, const int32_t* coords
   for (auto& s : m->shards) SGA_TRY(sga_index_create_voxelmap_from_voxels(s.ctx, leaf, coords, means3, cov6, n, &s.index));
   m->n_target = n;
   m->has_target = true;
+  return SGA_OK;
+}
+
+int sga_multi_set_rejector(sga_multi* m, sga_multi_rejector_fn fn, void* user) {
+  if (!m) return fail(SGA_ERR_INVALID, "null argument");
+  if (fn && m->has_target && m->shards[0].index && m->shards[0].index->kind != SGA_INDEX_KDTREE) return fail(SGA_ERR_UNSUPPORTED, "host rejectors need a kd-tree target");
+  m->rejector_fn = fn;
+  m->rejector_user = user;
+  m->model_valid = false;
+  install_rejector(m);
   return SGA_OK;
 }
 
@@ -228,6 +253,7 @@ int sga_multi_set_source_f64(sga_multi* m, const double* xyzw, const double* nor
   }
   m->n_source = n;
   m->has_source = true;
+  if (m->rejector_fn) install_rejector(m);  // (a rejector set earlier stays in force for the new problems)
   return SGA_OK;
 }
 

@@ -470,6 +470,42 @@ int main(int argc, char** argv) {
       if (!threw) failures++;
     }
   }
+  // ---- a user-defined CorrespondenceRejector (rejector.hpp:11-28 is a duck-typed slot; example 03_registration_template.cpp): decides on the host
+  {
+    struct EveryOtherRejector {
+      double max_dist_sq = 0.5;
+      bool operator()(const PointCloud&, const PointCloud&, const Eigen::Isometry3d&, size_t target_index, size_t source_index, double sq_dist) const {
+        return sq_dist > max_dist_sq || ((target_index + source_index) % 3 == 0);
+      }
+    };
+    Registration<GICPFactor, ParallelReductionOMP, NullFactor, EveryOtherRejector> cpu;
+    cpu.reduction.num_threads = 4;
+    Registration<GICPFactor, ParallelReductionHIP, NullFactor, EveryOtherRejector> hip;
+    const RegistrationResult rc = cpu.align(*target, *source, tree, I);
+    const RegistrationResult rh = hip.align(*target, *source, tree, I);
+    double dt, dr;
+    pose_error(rc.T_target_source, rh.T_target_source, &dt, &dr);
+    const bool ok = dt < 1e-4 && dr < 1e-4 && rc.iterations == rh.iterations && std::llabs(static_cast<long long>(rc.num_inliers) - static_cast<long long>(rh.num_inliers)) <= 2 && rh.num_inliers < source->size() * 3 / 4;
+    std::printf("CASE {\"name\": \"user-defined rejector type through the batch callback\", \"ok\": %s, \"dt\": %.3e, \"dr\": %.3e, \"iterations\": [%zu, %zu], \"num_inliers\": [%zu, %zu]}\n", ok ? "true" : "false", dt, dr, rh.iterations,
+                rc.iterations, rh.num_inliers, rc.num_inliers);
+    if (!ok) failures++;
+    // the built-in rejector afterwards: the callback is gone again
+    Registration<GICPFactor, ParallelReductionHIP> plain;
+    run_case("GICP after a custom rejector (built-in rejector restored)", *target, *source, tree, plain, I);
+  }
+  // ---- short-lived threads: a thread that ends takes its device state along
+  {
+    Registration<GICPFactor, ParallelReductionHIP> reg;
+    reg.align(*target, *source, tree, I);
+    const size_t before = reg.reduction.device_states();
+    for (int r = 0; r < 3; r++) {
+      std::thread t([&] { reg.align(*target, *source, tree, I); });
+      t.join();
+    }
+    const bool ok = before == 1 && reg.reduction.device_states() == 1;
+    std::printf("CASE {\"name\": \"device states of ended threads are released\", \"ok\": %s, \"states\": [%zu, %zu]}\n", ok ? "true" : "false", before, reg.reduction.device_states());
+    if (!ok) failures++;
+  }
   // ---- the reference's coordinate range (points/point_cloud.hpp:69-71: Vector4d): C1 moved kilometres from the origin.  The CPU reduction
   // works on the doubles; the policy subtracts the cloud's origin in double while it repacks (hip_detail::pack) and the device keeps fp32
   // records relative to it.  Error measured AT THE DATA (displacement of the source's centre, angle of the relative rotation): in the
@@ -534,6 +570,27 @@ int main(int argc, char** argv) {
     auto big_t = make(1, Eigen::Isometry3d::Identity());
     auto big_s = make(2, M.inverse());
     KdTree<PointCloud> big_tree(big_t, KdTreeBuilderOMP(8));
+    {
+      // clouds large enough for the DEFERRED content check (the hash runs beside the registration on the cached upload): unchanged objects are
+      // not uploaded again; a source refilled in place is noticed at the end of the bracket and registered again from what the caller holds now
+      Registration<GICPFactor, ParallelReductionHIP> hip;
+      Registration<GICPFactor, ParallelReductionOMP> cpu;
+      cpu.reduction.num_threads = 16;
+      const RegistrationResult h1 = hip.align(*big_t, *big_s, big_tree, I);
+      const auto uploads = hip.reduction.generation();
+      const RegistrationResult h2 = hip.align(*big_t, *big_s, big_tree, I);
+      bool ok = hip.reduction.generation() == uploads && (h1.T_target_source.matrix() - h2.T_target_source.matrix()).norm() == 0.0;
+      for (size_t i = 0; i < big_s->size(); i++) big_s->point(i)[0] = static_cast<float>(big_s->point(i)[0] + 0.05);
+      const RegistrationResult h3 = hip.align(*big_t, *big_s, big_tree, I);
+      const RegistrationResult c3 = cpu.align(*big_t, *big_s, big_tree, I);
+      double dt, dr;
+      pose_error(c3.T_target_source, h3.T_target_source, &dt, &dr);
+      ok = ok && hip.reduction.generation() == uploads + 1 && dt < 1e-4 && dr < 1e-4 && c3.iterations == h3.iterations && std::abs(h3.T_target_source.translation()[0] - h1.T_target_source.translation()[0] + 0.05) < 5e-3;
+      for (size_t i = 0; i < big_s->size(); i++) big_s->point(i)[0] = static_cast<float>(big_s->point(i)[0] - 0.05);
+      std::printf("CASE {\"name\": \"deferred content check: unchanged clouds stay, a refilled source is registered again\", \"ok\": %s, \"dt\": %.3e, \"dr\": %.3e, \"iterations\": [%zu, %zu], \"uploads\": [%llu, %llu]}\n", ok ? "true" : "false", dt, dr,
+                  h3.iterations, c3.iterations, static_cast<unsigned long long>(uploads), static_cast<unsigned long long>(hip.reduction.generation()));
+      if (!ok) failures++;
+    }
     rate<Plain>("synthetic planes (~100k after 0.25 m voxel grid)", *big_t, *big_s, big_tree, 20);
     rate<Plain>("synthetic planes, verify_content = sync_inliers = false", *big_t, *big_s, big_tree, 20, true);
     rate<Aligned>("synthetic planes, HipAligned<LM>", *big_t, *big_s, big_tree, 20);
