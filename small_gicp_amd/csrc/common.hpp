@@ -302,4 +302,6 @@ struct sga_problem {
   double model_T[16] = {0};      // its pose
   // reduction scratch
   sga::DevBuf<double> partials;  // partial rows + the stage rows of reduce_rows_kernel
+  sga::DevBuf<uint32_t> row_flags;  // row collectors (linearize.hip): row r of the current pass is complete once row_flags[r] == flag_seq
+  uint32_t flag_seq = 0;
 };

@@ -106,6 +106,101 @@ __device__ __forceinline__ void fused_tail(const FusedTail& f, const double* __r
   }
 }
 
+// ---- row collectors -------------------------------------------------------------------------------------------------------------
+// producer side: the row has been written with write-through stores (agent-scope relaxed atomic stores) by this wave / workgroup; once they
+// have left the CU the flag follows, one plain write-through store — nobody reads-modifies-writes anything
+__device__ __forceinline__ void publish_row_flag(uint32_t* __restrict__ flags, int row, uint32_t seq) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if ((threadIdx.x & 63u) == 0u) __hip_atomic_store(&flags[row], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// collector side, executed by wave 0 of collector workgroup g of G (the other waves of a wider workgroup leave at once).  Collector g adds
+// rows g, g + G, g + 2G, ... in that order (eight at a time once their flags are up), then the collectors meet at a ticket exactly like the
+// workgroups of reduce_rows_kernel, and the last one adds the G stage rows in order, derives and hands over.  The arithmetic depends on the
+// row indices only, never on who arrived when: bit-reproducible.  sh: >= kCols doubles of LDS.
+// xcd_order: the producers take their rows in the XCD-aware order of search_tile_of_block (slot b -> row (b % 8) * per_xcd + b / 8); the
+// collectors then walk the SLOTS in launch order, which is the order in which the rows become ready (walking the row indices would park a
+// collector behind the last-started tiles of the first XCD share until the kernel is nearly over).  The order of the additions is still a
+// function of the row count alone.
+__device__ __forceinline__ int row_of_slot(int b, int nrows, bool xcd_order) {
+  const int per_xcd = nrows >> 3;
+  return (xcd_order && b < 8 * per_xcd) ? (b & 7) * per_xcd + (b >> 3) : b;
+}
+__device__ __forceinline__ void collect_rows_wave(
+  const double* __restrict__ partials, int nrows, const uint32_t* __restrict__ flags, uint32_t flag_seq, double* __restrict__ stage, int g, int G, const FusedTail& f, double* __restrict__ sh, bool xcd_order) {
+  const int lane = threadIdx.x & 63;
+  constexpr int kBatch = 8;
+  const int c1 = lane + 64;  // second column of this lane (rows have kRow = 96 of them)
+  double a0 = 0.0, a1 = 0.0;
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  bool timed_out = false;
+  for (int r = g; r < nrows && !timed_out; r += G * kBatch) {
+    const int mine = r + lane * G;  // lane k < kBatch watches the flag of the batch's k-th row
+    const bool watch = lane < kBatch && mine < nrows;
+    const int mine_row = row_of_slot(watch ? mine : 0, nrows, xcd_order);
+    for (unsigned spins = 0;; spins++) {
+      const uint32_t fl = watch ? __hip_atomic_load(&flags[mine_row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : flag_seq;
+      if (__ballot(fl != flag_seq) == 0ull) break;
+      __builtin_amdgcn_s_sleep(8);
+      if ((spins & 1023u) == 1023u && __builtin_readcyclecounter() - t0 > 4000000000ull) {  // ~2 s at the shader clock: a producer died; fail loudly on the host
+        timed_out = true;
+        break;
+      }
+    }
+    double v0[kBatch], v1[kBatch];
+#pragma unroll
+    for (int k = 0; k < kBatch; k++) {
+      const bool ok = r + k * G < nrows;
+      const int row = row_of_slot(ok ? r + k * G : 0, nrows, xcd_order);
+      v0[k] = ok ? __hip_atomic_load(&partials[static_cast<size_t>(row) * kRow + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+      v1[k] = (ok && c1 < kRow) ? __hip_atomic_load(&partials[static_cast<size_t>(row) * kRow + c1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < kBatch; k++) a0 += v0[k], a1 += v1[k];
+  }
+  if (lane == 63) a1 = timed_out ? 1.0 : 0.0;  // column 127 (rows end at 96): the collectors' give-up count rides along to the one that hands over
+  __hip_atomic_store(&stage[g * kCols + lane], a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(&stage[g * kCols + c1], a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  unsigned ticket = 0;
+  if (lane == 0) ticket = __hip_atomic_fetch_add(f.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);  // release this collector's stage row, acquire the earlier ones
+  ticket = __shfl(ticket, 0);
+  if (ticket != static_cast<unsigned>(G - 1)) return;  // wave-uniform
+  double t0s = 0.0, t1s = 0.0;
+  for (int k0 = 0; k0 < G; k0 += kBatch) {
+    double v0[kBatch], v1[kBatch];
+#pragma unroll
+    for (int k = 0; k < kBatch; k++) {
+      const bool ok = k0 + k < G;
+      v0[k] = ok ? __hip_atomic_load(&stage[(k0 + k) * kCols + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+      v1[k] = ok ? __hip_atomic_load(&stage[(k0 + k) * kCols + c1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < kBatch; k++) t0s += v0[k], t1s += v1[k];
+  }
+  const bool gave_up = __shfl(t1s, 63) != 0.0;
+  sh[lane] = t0s;
+  sh[c1] = t1s;
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const int cc = lane + 64 * h;
+    if (cc < f.out_n) {
+      const double t = is_derived_col(cc) ? derived_entry(cc, sh) : sh[cc];  // moment form: H_rr, H_rt, b_r from the totals
+      const double r = cc < kModelCols ? t : 0.0;
+      f.out[cc] = r;
+      if (f.host != nullptr) f.host[cc] = r;
+    }
+  }
+  if (lane == 0) __hip_atomic_store(f.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch on this stream
+  if (f.host != nullptr) {
+    __threadfence_system();
+    // (a timed-out collection publishes a sequence number nobody waits for: the host's wait ends in its own error path)
+    if (lane == 0) __hip_atomic_store(reinterpret_cast<unsigned long long*>(f.host + kSeqWord), gave_up ? ~0ull : f.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 template <typename Real>
 struct LinParams {
   const float4* __restrict__ src_pts;
@@ -130,6 +225,16 @@ struct LinParams {
   Real robust_c;
   double* __restrict__ partials;
   FusedTail tail;
+  // Row collectors (round 5): the last `collectors` workgroups of a fused search / certify launch do not produce a row but ADD the rows of
+  // the others while those still run — they poll one flag per row (plain write-through stores by the producers: no atomics, which is what
+  // sank the arrival-counter forms), add the rows in a fixed order, and the last of them derives the system and hands it to the host.
+  // No reduce_rows_kernel, no launch gap behind the slowest wave: the result is on the host ~5 us after the last row instead of ~14.
+  int collectors;                      // 0: none (reduce_rows_kernel follows)
+  int producers;                       // workgroups [0, producers) produce rows, [producers, producers + collectors) collect them
+  int collect_rows;                    // rows to add (one per producer)
+  uint32_t* __restrict__ row_flags;    // row r is complete once row_flags[r] == flag_seq
+  uint32_t flag_seq;
+  double* __restrict__ collect_stage;  // collectors x kCols doubles
   // warm pass with the certificate check inside the factor kernel (certify_linearize_kernel): the certificate of the previous
   // linearization pose T_prev is checked per point on the way through; a point whose certificate fails contributes nothing to the
   // streaming part, is flagged (rex[i] = -(exploration slack) < 0) and walks at the end of its workgroup's step
@@ -143,8 +248,8 @@ struct LinParams {
 
 // XCD-aware tile schedule: workgroup b runs on XCD b % 8 (observed placement; used for L2 affinity only).  Each XCD
 // gets one contiguous 1/8th of the (spatially sorted) tiles so that neighbouring tiles share an L2.
-__device__ __forceinline__ void tile_schedule(int num_tiles, int& first, int& stride, int& end) {
-  const int nblocks = gridDim.x;
+__device__ __forceinline__ void tile_schedule(int num_tiles, int& first, int& stride, int& end, int nblocks = 0) {
+  if (nblocks == 0) nblocks = gridDim.x;  // (launches with row collectors pass the number of producer workgroups)
   if (nblocks % 8 == 0 && num_tiles >= nblocks) {
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd_blocks = nblocks >> 3;
     const int t0 = static_cast<int>((static_cast<long long>(num_tiles) * xcd) >> 3);
@@ -324,8 +429,9 @@ __device__ __forceinline__ int search_lane(const NNParams<Real>& p, int tile, in
 
 // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed placement; only speed depends on it), and the source is sorted by
 // target leaf, so giving each XCD one contiguous eighth of the tiles makes its L2 hold one eighth of the target instead of all of it
-__device__ __forceinline__ int search_tile_of_block() {
-  const int nblk = gridDim.x, per_xcd = nblk >> 3, b = blockIdx.x;
+__device__ __forceinline__ int search_tile_of_block(int nblk = 0) {
+  if (nblk == 0) nblk = gridDim.x;  // (launches with row collectors pass the number of producer workgroups)
+  const int per_xcd = nblk >> 3, b = blockIdx.x;
   return b < 8 * per_xcd ? (b & 7) * per_xcd + (b >> 3) : b;
 }
 
@@ -390,10 +496,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 6))) void
   __shared__ int q_idx[kQueueCap];        // source point
   __shared__ uint32_t q_leaf[kQueueCap];  // start group (heap node of depth gdepth)
   const int lane = threadIdx.x;
+  if constexpr (FACTOR >= 0) {
+    if (lp.collectors > 0 && static_cast<int>(blockIdx.x) >= lp.producers) {  // workgroup-uniform: a row collector (LinParams)
+      collect_rows_wave(lp.partials, lp.collect_rows, lp.row_flags, lp.flag_seq, lp.collect_stage, static_cast<int>(blockIdx.x) - lp.producers, lp.collectors, lp.tail, reinterpret_cast<double*>(kd_stack), true);
+      return;
+    }
+  }
   const int D = p.kd.gdepth;  // the walk's unit is the group (kd_search.hpp)
   const int num_tiles = (p.n + 63) >> 6;
   // XCD-aware chunk order (workgroup b runs on XCD b % 8): each XCD gets one contiguous eighth of the chunks
-  const int nblk = gridDim.x, per_xcd = nblk >> 3, b = blockIdx.x;
+  const int nblk = (FACTOR >= 0 && lp.collectors > 0) ? lp.producers : static_cast<int>(gridDim.x), per_xcd = nblk >> 3, b = blockIdx.x;
   const int chunk = b < 8 * per_xcd ? (b & 7) * per_xcd + (b >> 3) : b;
   int tile = chunk * p.chunk_tiles;
   const int tile_end = min(tile + p.chunk_tiles, num_tiles);
@@ -566,7 +678,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 6))) void
     else
       for (int t0 = chunk * p.chunk_tiles; t0 < tile_end; t0 += 4) linearize_group<Real, FACTOR, 0, 4, true>(lp, t0 * 64 + lane, 64, limit, row, lane);
     __syncthreads();
-    for (int c = lane; c < kRow; c += 64) lp.partials[static_cast<size_t>(chunk) * kRow + c] = row[c];
+    if (lp.collectors > 0) {  // wave-uniform
+      for (int c = lane; c < kRow; c += 64) __hip_atomic_store(&lp.partials[static_cast<size_t>(chunk) * kRow + c], row[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      publish_row_flag(lp.row_flags, chunk, lp.flag_seq);
+    } else {
+      for (int c = lane; c < kRow; c += 64) lp.partials[static_cast<size_t>(chunk) * kRow + c] = row[c];
+    }
   }
 #ifdef SGA_KD_TRIPS
   if (lane == 0) {  // [12] staging, [13] walks, [14] factor stage, [15] waves; [11] latest end - earliest start is derived from the wave times
@@ -972,11 +1089,15 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(4))) void
   __shared__ unsigned long long sh_failed[kTile / 64][PTS];
   __shared__ int sh_list[PTS * kTile];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (p.collectors > 0 && static_cast<int>(blockIdx.x) >= p.producers) {  // workgroup-uniform: a row collector (LinParams); its first wave does the work
+    if (wave == 0) collect_rows_wave(p.partials, p.collect_rows, p.row_flags, p.flag_seq, p.collect_stage, static_cast<int>(blockIdx.x) - p.producers, p.collectors, p.tail, &sh_acc[0][0], false);
+    return;
+  }
   for (int c = lane; c < kRow; c += 64) sh_acc[wave][c] = 0.0;
   double* acc_row = sh_acc[wave];
 
   int tile, stride, tile_end;
-  tile_schedule(p.num_tiles, tile, stride, tile_end);
+  tile_schedule(p.num_tiles, tile, stride, tile_end, p.collectors > 0 ? p.producers : 0);
   for (; tile < tile_end; tile += stride) {
     const int base = tile * PTS * kTile;
     linearize_group<Real, FACTOR, 0, PTS, false, true>(p, base + static_cast<int>(threadIdx.x), kTile, p.n, acc_row, lane, sh_failed[wave]);
@@ -1092,10 +1213,15 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(4))) void
     double t = 0.0;
 #pragma unroll
     for (int w = 0; w < kTile / 64; w++) t += sh_acc[w][threadIdx.x];
-    if (p.tail.enabled)
+    if (p.tail.enabled || p.collectors > 0)
       __hip_atomic_store(&p.partials[static_cast<size_t>(blockIdx.x) * kRow + threadIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else
       p.partials[static_cast<size_t>(blockIdx.x) * kRow + threadIdx.x] = t;
+  }
+  if (p.collectors > 0) {  // workgroup-uniform: the row's two waves wait for their stores, then ONE flag store says the row is there
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&p.row_flags[blockIdx.x], p.flag_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (p.tail.enabled) fused_tail(p.tail, p.partials, gridDim.x, kModelCols, kRow, true);  // small grids: the last workgroup adds the rows and hands the result over
 }
@@ -1124,7 +1250,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CHECK ? SGA_
   const unsigned long long wave_t0 = wall_clock64();
 #endif
   const int lane = threadIdx.x;
-  const int slot = search_tile_of_block();
+  if (lp.collectors > 0 && static_cast<int>(blockIdx.x) >= lp.producers) {  // workgroup-uniform: this wave adds the rows of the others (LinParams: row collectors)
+    collect_rows_wave(lp.partials, lp.collect_rows, lp.row_flags, lp.flag_seq, lp.collect_stage, static_cast<int>(blockIdx.x) - lp.producers, lp.collectors, lp.tail, reinterpret_cast<double*>(kd_stack), true);
+    return;
+  }
+  const int slot = search_tile_of_block(lp.collectors > 0 ? lp.producers : 0);
   const int tile = p.tile_order != nullptr ? static_cast<int>(p.tile_order[slot]) : slot;  // wave-uniform
   const unsigned long long cost_t0 = p.tile_cost != nullptr ? wall_clock64() : 0ull;
   const int i = tile * 64 + lane;
@@ -1164,7 +1294,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CHECK ? SGA_
   __syncthreads();
   if (inliers > 0) accumulate_moments<Real, 1>(P, Mp, G, E, inliers, row, lane);
   __syncthreads();
-  for (int c = lane; c < kRow; c += 64) lp.partials[static_cast<size_t>(tile) * kRow + c] = row[c];
+  if (lp.collectors > 0) {  // wave-uniform
+    for (int c = lane; c < kRow; c += 64) __hip_atomic_store(&lp.partials[static_cast<size_t>(tile) * kRow + c], row[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    publish_row_flag(lp.row_flags, tile, lp.flag_seq);
+  } else {
+    for (int c = lane; c < kRow; c += 64) lp.partials[static_cast<size_t>(tile) * kRow + c] = row[c];
+  }
   if (p.tile_cost != nullptr && lane == 0) p.tile_cost[tile] = static_cast<uint32_t>(wall_clock64() - cost_t0);
 #ifdef SGA_KD_TRIPS
   if (blockIdx.x < 32768 && lane == 0) {
@@ -1388,6 +1523,29 @@ static size_t partial_rows(size_t n) { return std::max<size_t>(kMaxBlocks, (n + 
 static void launch_reduce(sga_context* ctx, const double* partials, int nrows, int ncols, int row_stride, double* stage, double* out, int out_n, double* host, unsigned long long seq, bool derive = false, const uint32_t* stats = nullptr) {
   const int groups = nrows > 256 ? std::min(kReduceGroups, std::max(8, nrows / 128)) : 1;  // <= 256 rows: one workgroup, no hand-off between workgroups
   hipLaunchKernelGGL(reduce_rows_kernel, dim3(groups), dim3(kReduceSlices * kCols), 0, ctx->stream, partials, nrows, ncols, row_stride, stage, ctx->d_ticket.p, out, out_n, host, seq, derive ? 1 : 0, stats);
+}
+
+// Row collectors (LinParams): how many of them a launch with `rows` producer rows gets; 0 = none (SGA_COLLECT=0: reduce_rows_kernel as before)
+// (SGA_COLLECT, bits: 1 the one-query-per-lane search kernel, 2 the queue-fed kernel, 4 the streaming warm kernel)
+static int g_collect = getenv("SGA_COLLECT") ? atoi(getenv("SGA_COLLECT")) : 0;
+static int collectors_for(int rows, int kind) { return (g_collect & kind) == 0 || rows < 1 ? 0 : std::min(kReduceGroups, std::max(4, rows / 64)); }
+template <typename Real>
+static int arm_collectors(sga_context* ctx, sga_problem* pb, LinParams<Real>& p, int rows, int kind, double* d_out, int out_n, double* host, unsigned long long seq) {
+  p.collectors = collectors_for(rows, kind);
+  if (p.collectors == 0) return SGA_OK;
+  if (pb->row_flags.n < partial_rows(pb->n)) {
+    SGA_TRY(pb->row_flags.alloc(partial_rows(pb->n)));
+    SGA_HIP(hipMemsetAsync(pb->row_flags.p, 0, pb->row_flags.n * sizeof(uint32_t), ctx->stream));
+    pb->flag_seq = 0;
+  }
+  if (++pb->flag_seq == 0u) pb->flag_seq = 1u;  // (0 is what the flags start from)
+  p.producers = rows;
+  p.collect_rows = rows;
+  p.row_flags = pb->row_flags.p;
+  p.flag_seq = pb->flag_seq;
+  p.collect_stage = pb->partials.p + partial_rows(pb->n) * kRow;
+  p.tail = FusedTail{0, ctx->d_ticket.p, d_out, out_n, host, seq};
+  return SGA_OK;
 }
 
 static bool g_lazy_maha = getenv("SGA_LAZY_MAHA") ? atoi(getenv("SGA_LAZY_MAHA")) != 0 : true;
@@ -1648,6 +1806,7 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
       const bool cfuse = cblocks <= g_fuse_max;
       pc.tail = FusedTail{cfuse ? 1 : 0, ctx->d_ticket.p, d_out30, out_n, host, seq};
       split_fused_tail = cfuse;
+      if (!cfuse) SGA_TRY(arm_collectors(ctx, pb, p, cblocks, 4, d_out30, out_n, host, seq));
       p.cert_nn = pb->hint.p;
       p.cert_nn2 = pb->hint2.p;
       p.cert_rex = pb->rex.p;
@@ -1659,9 +1818,9 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
 #define SGA_CERTIFY(F)                                                                                                                      \
   do {                                                                                                                                      \
     if (spts == kLinPts)                                                                                                                    \
-      hipLaunchKernelGGL((certify_linearize_kernel<Real, F, kLinPts>), dim3(cblocks), dim3(kTile), lds, ctx->stream, p, q);                 \
+      hipLaunchKernelGGL((certify_linearize_kernel<Real, F, kLinPts>), dim3(cblocks + p.collectors), dim3(kTile), lds, ctx->stream, p, q);  \
     else                                                                                                                                    \
-      hipLaunchKernelGGL((certify_linearize_kernel<Real, F, 1>), dim3(cblocks), dim3(kTile), lds, ctx->stream, p, q);                       \
+      hipLaunchKernelGGL((certify_linearize_kernel<Real, F, 1>), dim3(cblocks + p.collectors), dim3(kTile), lds, ctx->stream, p, q);        \
   } while (0)
       switch (fp->factor_kind) {
         case SGA_GICP: SGA_CERTIFY(SGA_GICP); break;
@@ -1675,6 +1834,10 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
       // every search wave evaluates the factors of its own tile: one partial row per tile of 64 points, summed by reduce_rows_kernel
       p.tail.enabled = 0;
       fused_rows = static_cast<int>(sgrid.x);
+      // (not when this pass starts its tiles in the order the previous one recorded: the collectors walk the launch slots, and the sum must not depend on timings)
+      const bool ordered = g_lpt != 0 && sgrid.x >= 8192 && order_tiles_before == sgrid.x && pb->order_stream == ctx->stream && (g_lpt == 2 || warm);
+      SGA_TRY(arm_collectors(ctx, pb, p, ordered ? 0 : fused_rows, 1, d_out30, out_n, host, seq));
+      const dim3 cgrid(sgrid.x + p.collectors);
       if (g_lpt != 0 && sgrid.x >= 8192) {  // fewer tiles than wave slots: all waves start at once, the order means nothing
         SGA_TRY(pb->tile_cost.reserve(sgrid.x));
         SGA_TRY(pb->tile_order.reserve(sgrid.x));
@@ -1687,16 +1850,16 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
       const size_t lds = std::max<size_t>(words, 3) * 64 * sizeof(uint32_t) + lds_pad;
       switch (fp->factor_kind) {
         case SGA_GICP:
-          if (warm) hipLaunchKernelGGL((search_linearize_kernel<Real, SGA_GICP, true>), sgrid, sblock, lds, ctx->stream, q, p);
-          else hipLaunchKernelGGL((search_linearize_kernel<Real, SGA_GICP, false>), sgrid, sblock, lds, ctx->stream, q, p);
+          if (warm) hipLaunchKernelGGL((search_linearize_kernel<Real, SGA_GICP, true>), cgrid, sblock, lds, ctx->stream, q, p);
+          else hipLaunchKernelGGL((search_linearize_kernel<Real, SGA_GICP, false>), cgrid, sblock, lds, ctx->stream, q, p);
           break;
         case SGA_PLANE_ICP:
-          if (warm) hipLaunchKernelGGL((search_linearize_kernel<Real, SGA_PLANE_ICP, true>), sgrid, sblock, lds, ctx->stream, q, p);
-          else hipLaunchKernelGGL((search_linearize_kernel<Real, SGA_PLANE_ICP, false>), sgrid, sblock, lds, ctx->stream, q, p);
+          if (warm) hipLaunchKernelGGL((search_linearize_kernel<Real, SGA_PLANE_ICP, true>), cgrid, sblock, lds, ctx->stream, q, p);
+          else hipLaunchKernelGGL((search_linearize_kernel<Real, SGA_PLANE_ICP, false>), cgrid, sblock, lds, ctx->stream, q, p);
           break;
         default:
-          if (warm) hipLaunchKernelGGL((search_linearize_kernel<Real, SGA_ICP, true>), sgrid, sblock, lds, ctx->stream, q, p);
-          else hipLaunchKernelGGL((search_linearize_kernel<Real, SGA_ICP, false>), sgrid, sblock, lds, ctx->stream, q, p);
+          if (warm) hipLaunchKernelGGL((search_linearize_kernel<Real, SGA_ICP, true>), cgrid, sblock, lds, ctx->stream, q, p);
+          else hipLaunchKernelGGL((search_linearize_kernel<Real, SGA_ICP, false>), cgrid, sblock, lds, ctx->stream, q, p);
           break;
       }
     } else if (queue) {
@@ -1711,10 +1874,12 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
       if (fused_search) {  // the chunk's wave evaluates the factors as well: one partial row per chunk
         p.tail.enabled = 0;
         fused_rows = static_cast<int>(qgrid.x);
+        SGA_TRY(arm_collectors(ctx, pb, p, fused_rows, 2, d_out30, out_n, host, seq));
+        const dim3 cgrid(qgrid.x + p.collectors);
         switch (fp->factor_kind) {
-          case SGA_GICP: hipLaunchKernelGGL((nn_search_queue_kernel<Real, true, SGA_GICP>), qgrid, sblock, lds, ctx->stream, q, p); break;
-          case SGA_PLANE_ICP: hipLaunchKernelGGL((nn_search_queue_kernel<Real, true, SGA_PLANE_ICP>), qgrid, sblock, lds, ctx->stream, q, p); break;
-          default: hipLaunchKernelGGL((nn_search_queue_kernel<Real, true, SGA_ICP>), qgrid, sblock, lds, ctx->stream, q, p); break;
+          case SGA_GICP: hipLaunchKernelGGL((nn_search_queue_kernel<Real, true, SGA_GICP>), cgrid, sblock, lds, ctx->stream, q, p); break;
+          case SGA_PLANE_ICP: hipLaunchKernelGGL((nn_search_queue_kernel<Real, true, SGA_PLANE_ICP>), cgrid, sblock, lds, ctx->stream, q, p); break;
+          default: hipLaunchKernelGGL((nn_search_queue_kernel<Real, true, SGA_ICP>), cgrid, sblock, lds, ctx->stream, q, p); break;
         }
       } else if (warm)
         hipLaunchKernelGGL((nn_search_queue_kernel<Real, true>), qgrid, sblock, lds, ctx->stream, q, p);
@@ -1773,8 +1938,8 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
       }
     }
   }
-  if (fused_search && split_fused_tail) {
-    // (done inside the kernel)
+  if (fused_search && (split_fused_tail || p.collectors > 0)) {
+    // (done inside the kernel: fused tail of a small grid, or the launch's row collectors)
   } else if (fused_search) {
     launch_reduce(ctx, pb->partials.p, fused_rows, ncols, kRow, pb->partials.p + partial_rows(pb->n) * kRow, d_out30, out_n, host, seq, true);
   }

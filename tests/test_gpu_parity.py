@@ -1348,8 +1348,9 @@ def test_incremental_maps_edge_cases():
         with pytest.raises(sga.SgaError):
             m.set_lru(10, 0)
     g = sga.GaussianVoxelMap(1.0)
+    g.set_search_offsets(7)  # (round 5: Gaussian maps are searched over 1 / 7 / 27 voxels too)
     with pytest.raises(sga.SgaError):
-        sga._lib.check(sga._lib.load().sga_voxelmap_set_search_offsets(g.h, 7))
+        g.set_search_offsets(9)
     f = sga.IncrementalVoxelMapCov(1.0)
     for bad in (0, 5, 28):
         with pytest.raises(sga.SgaError):
