@@ -124,6 +124,9 @@ int sga_index_create_flatmap_from_voxels(sga_context* ctx, double leaf_size, con
 /* Re-copy normals / covariances from `cloud` (the cloud the tree was built over) into the index's kd-ordered arrays, e.g. after
  * attributes were estimated or set once the index already existed (reference flow: KdTree first, estimate_covariances second). */
 int sga_index_refresh_attributes(sga_context* ctx, sga_index* index, const sga_cloud* cloud);
+/* A deep copy of an index on ctx's device, which may differ from the source's (peer copy): a replicated target reaches the other GPUs of a
+ * sharded registration without being built once per GPU. */
+int sga_index_clone(sga_context* ctx, const sga_index* src, sga_index** out);
 int sga_index_destroy(sga_index* index);
 /* Number of target points (kd-tree) or voxels (voxel map): traits::size(target). */
 int sga_index_size(const sga_index* index, size_t* n);

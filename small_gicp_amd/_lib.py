@@ -92,6 +92,7 @@ SYMBOLS = [
     ("sga_index_create_voxelmap_from_voxels", C.c_int, [_vp, C.c_double, C.c_void_p, _dp, _dp, C.c_size_t, _pvp]),
     ("sga_index_create_flatmap_from_voxels", C.c_int, [_vp, C.c_double, C.c_void_p, C.c_void_p, _dp, _dp, C.c_int, C.c_size_t, _pvp]),
     ("sga_index_refresh_attributes", C.c_int, [_vp, _vp, _vp]),
+    ("sga_index_clone", C.c_int, [_vp, _vp, _pvp]),
     ("sga_index_destroy", C.c_int, [_vp]),
     ("sga_index_size", C.c_int, [_vp, C.POINTER(C.c_size_t)]),
     ("sga_index_voxelmap_download", C.c_int, [_vp, _vp, C.POINTER(C.c_int32), _fp, _fp, C.POINTER(C.c_uint32)]),

@@ -120,9 +120,11 @@ int sga_multi_num_devices(const sga_multi* m) { return m ? static_cast<int>(m->s
 int sga_multi_set_target_f64(sga_multi* m, const double* xyzw, const double* normals4, const double* cov4x4, size_t n) {
   if (!m || (n > 0 && !xyzw)) return fail(SGA_ERR_INVALID, "null argument");
   drop_target(m);
-  for (auto& s : m->shards) {
-    SGA_TRY(sga_cloud_create_f64(s.ctx, xyzw, normals4, cov4x4, n, &s.target));
-    SGA_TRY(sga_index_build_kdtree(s.ctx, s.target, &s.index));
+  {  // built ONCE, on the first device; the other shards get copies of the finished index (sga_index_clone: peer copies)
+    auto& s0 = m->shards[0];
+    SGA_TRY(sga_cloud_create_f64(s0.ctx, xyzw, normals4, cov4x4, n, &s0.target));
+    SGA_TRY(sga_index_build_kdtree(s0.ctx, s0.target, &s0.index));
+    for (size_t g = 1; g < m->shards.size(); g++) SGA_TRY(sga_index_clone(m->shards[g].ctx, s0.index, &m->shards[g].index));
   }
   m->n_target = n;
   m->has_target = true;
@@ -137,12 +139,15 @@ int sga_multi_set_target_f64(sga_multi* m, const double* xyzw, const double* nor
 static int multi_set_target_f32(sga_multi* m, const float* xyz, const float* normals3, const float* cov6, size_t n, const double* origin, bool relative) {
   if (!m || (n > 0 && !xyz)) return fail(SGA_ERR_INVALID, "null argument");
   drop_target(m);
-  for (auto& s : m->shards) {
+  {  // built ONCE, on the first device; the other shards get copies of the finished index (sga_index_clone: peer copies) — a first bind
+     // of G devices costs one build + G - 1 copies instead of G builds one after the other
+    auto& s0 = m->shards[0];
     if (relative)
-      SGA_TRY(sga_cloud_create_f32_origin(s.ctx, xyz, normals3, cov6, n, origin, &s.target));
+      SGA_TRY(sga_cloud_create_f32_origin(s0.ctx, xyz, normals3, cov6, n, origin, &s0.target));
     else
-      SGA_TRY(sga_cloud_create_f32(s.ctx, xyz, normals3, cov6, n, &s.target));  // the same data on every device: the same origin
-    SGA_TRY(sga_index_build_kdtree(s.ctx, s.target, &s.index));
+      SGA_TRY(sga_cloud_create_f32(s0.ctx, xyz, normals3, cov6, n, &s0.target));
+    SGA_TRY(sga_index_build_kdtree(s0.ctx, s0.target, &s0.index));
+    for (size_t g = 1; g < m->shards.size(); g++) SGA_TRY(sga_index_clone(m->shards[g].ctx, s0.index, &m->shards[g].index));
   }
   m->n_target = n;
   m->has_target = true;
@@ -199,7 +204,8 @@ int sga_multi_set_source_f32_origin(sga_multi* m, const float* xyz_rel, const fl
 int sga_multi_set_target_voxels(sga_multi* m, double leaf, const int32_t* coords, const double* means3, const double* cov6, size_t n) {
   if (!m) return fail(SGA_ERR_INVALID, "null argument");
   drop_target(m);
-  for (auto& s : m->shards) SGA_TRY(sga_index_create_voxelmap_from_voxels(s.ctx, leaf, coords, means3, cov6, n, &s.index));
+  SGA_TRY(sga_index_create_voxelmap_from_voxels(m->shards[0].ctx, leaf, coords, means3, cov6, n, &m->shards[0].index));
+  for (size_t g = 1; g < m->shards.size(); g++) SGA_TRY(sga_index_clone(m->shards[g].ctx, m->shards[0].index, &m->shards[g].index));
   m->n_target = n;
   m->has_target = true;
   return SGA_OK;
@@ -225,7 +231,8 @@ int sga_multi_set_search_offsets(sga_multi* m, int num_offsets) {
 int sga_multi_set_target_flat_voxels(sga_multi* m, double leaf, const int32_t* coords, const uint32_t* counts, const double* points3, const double* cov6, int search_offsets, size_t n) {
   if (!m) return fail(SGA_ERR_INVALID, "null argument");
   drop_target(m);
-  for (auto& s : m->shards) SGA_TRY(sga_index_create_flatmap_from_voxels(s.ctx, leaf, coords, counts, points3, cov6, search_offsets, n, &s.index));
+  SGA_TRY(sga_index_create_flatmap_from_voxels(m->shards[0].ctx, leaf, coords, counts, points3, cov6, search_offsets, n, &m->shards[0].index));
+  for (size_t g = 1; g < m->shards.size(); g++) SGA_TRY(sga_index_clone(m->shards[g].ctx, m->shards[0].index, &m->shards[g].index));
   m->n_target = n;
   m->has_target = true;
   return SGA_OK;
@@ -268,7 +275,17 @@ int sga_multi_linearize(sga_multi* m, const sga_factor_params* fp, const double 
     auto& s = m->shards[g];
     SGA_HIP(hipSetDevice(s.device));
     Entered in(s.ctx);
-    SGA_TRY(linearize_enqueue(s.ctx, s.problem, fp, T, &seq[g], &count[g]));
+    const int rc = linearize_enqueue(s.ctx, s.problem, fp, T, &seq[g], &count[g]);
+    if (rc != SGA_OK) {  // the passes already enqueued on the earlier shards are collected before the error is reported
+      const std::string why = sga_last_error();
+      for (size_t k = 0; k < g; k++) {
+        auto& e = m->shards[k];
+        (void)hipSetDevice(e.device);
+        Entered in2(e.ctx);
+        (void)linearize_collect(e.ctx, e.problem, T, seq[k], count[k]);
+      }
+      return fail(rc, "%s", why.c_str());
+    }
   }
   double acc[SGA_MODEL_DOUBLES] = {0};
   for (size_t g = 0; g < G; g++) {

@@ -205,3 +205,31 @@ def test_single_process_shards_equal_one_problem(shards):
         r1, rm = one.align(st, np.eye(4)), multi.align(st, np.eye(4))
         assert r1.iterations == rm.iterations and r1.num_inliers == rm.num_inliers and r1.converged == rm.converged
         assert np.abs(r1.T_target_source - rm.T_target_source).max() < (1e-10 if mode == "fp64" else 1e-6)
+
+
+@pytest.mark.gpu
+def test_replicated_target_is_built_once_and_copied():
+    """sga_multi_set_target_*: the search index of the replicated target is built on the first device and COPIED to the others
+    (sga_index_clone: peer copies) — a first bind over G devices costs one build + G - 1 copies, not G builds one after the other.
+    Here G logical shards on device 0: the bind of 4 shards must stay close to the bind of 1, and the copies must search like the original."""
+    import time
+
+    import small_gicp_amd as sga
+
+    target, source, T_gt = sga.synthetic.registration_pair(400_000)
+    st = sga.make_setting("ICP")
+
+    def bind(G):
+        t0 = time.perf_counter()
+        m = sga.MultiProblem([0] * G, (target, None, None), (source, None, None))
+        return m, time.perf_counter() - t0
+
+    bind(1)  # warm-up: allocator pools, kernel resolution
+    m1, t1 = bind(1)
+    m4, t4 = bind(4)
+    print("first bind: 1 shard %.1f ms, 4 shards %.1f ms (%.2fx)" % (1e3 * t1, 1e3 * t4, t4 / t1))
+    assert t4 < 2.0 * t1, (t1, t4)  # (what remains above 1x: the four source shards are uploaded, sorted and paired one after the other; four builds took 3.4x)
+    H1, b1, e1, n1 = m1.linearize(st.factor, T_gt)
+    H4, b4, e4, n4 = m4.linearize(st.factor, T_gt)
+    assert n1 == n4 and abs(e1 - e4) <= 1e-6 * abs(e1) and np.abs(H1 - H4).max() <= 1e-6 * np.abs(H1).max()
+    assert (m1.factors() == m4.factors()).all()  # the copies of the index return the neighbours of the original
