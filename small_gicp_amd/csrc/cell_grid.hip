@@ -77,7 +77,10 @@ int build_cell_grid(sga_context* ctx, sga_index* idx) {
   const size_t min_points = static_cast<size_t>(std::max(16ll, g_grid_min_points));
   static const double cell_override = getenv("SGA_GRID_CELL") ? atof(getenv("SGA_GRID_CELL")) : 0.0;
   static const double fill = getenv("SGA_GRID_FILL") ? atof(getenv("SGA_GRID_FILL")) : 2.2;
-  static const double max_cells = getenv("SGA_GRID_MAX_CELLS") ? atof(getenv("SGA_GRID_MAX_CELLS")) : 96e6;
+  // the dense header array: at most 48 cells per target point (C3: 25 per point at its natural edge of 0.162 m) and never more than 96 M
+  // cells = 384 MB — a sparse cloud in a huge box gets larger cells instead of a header a hundred times its size
+  static const double max_cells_env = getenv("SGA_GRID_MAX_CELLS") ? atof(getenv("SGA_GRID_MAX_CELLS")) : 0.0;
+  const double max_cells = max_cells_env > 0.0 ? max_cells_env : std::min(96e6, std::max(1.0e6, 48.0 * static_cast<double>(idx->n)));
   idx->grid_h = 0.f;
   const size_t n = idx->n;
   if (mode == 0 || n < min_points || n >= (1ull << 31) || ctx->stream_ordered) return SGA_OK;
@@ -341,7 +344,11 @@ template int grid_search_pass<double>(sga_context*, const sga_index*, const floa
 // rings needed to cover `reach` metres, or -1 if the index has no grid
 int grid_rings_for(const sga_index* idx, double reach) {
   if (idx->grid_h <= 0.f) return -1;
-  return static_cast<int>(std::ceil(reach / idx->grid_h)) + 1;
+  const double rings = std::ceil(reach / idx->grid_h) + 1.0;
+  // grid_settle_wave numbers the (2r + 1)^2 rows of a ring block through one integer decoded with a float reciprocal (exact below 2^20):
+  // a reach that needs more rows than that is not a grid's job — the caller walks the kd-tree
+  if ((2.0 * rings + 1.0) * (2.0 * rings + 1.0) > 1048576.0) return -1;
+  return static_cast<int>(rings);
 }
 
 }  // namespace sga

@@ -149,6 +149,9 @@ struct sga_context {
 // estimation returns while its kernels are still in flight on the producing context's stream.  The object remembers that stream and an
 // event recorded behind the work; an entry point that consumes the object on ANOTHER stream first makes its stream wait for the event
 // (sga::wait_ready), so outputs never race with a half-built input whichever context consumes them.  (Same stream: stream order suffices.)
+// Producers that return early in stream-ordered mode: sga_index_build_kdtree, sga_estimate_normals_covariances, sga_index_clone; every
+// entry point that takes a cloud or an index waits (problem creation, index build, estimation, refresh, voxel grid, voxel-map insert, kNN,
+// downloads, clone).  All other producers (voxel grid, voxel-map insert / build, uploads) synchronise their stream before they return.
 namespace sga {
 struct Ready {
   hipEvent_t event = nullptr;

@@ -381,6 +381,8 @@ int sga_index_refresh_attributes(sga_context* ctx, sga_index* index, const sga_c
   if (index->kind != SGA_INDEX_KDTREE) return fail(SGA_ERR_INVALID, "not a kd-tree index");
   if (index->n != cloud->n) return fail(SGA_ERR_INVALID, "index was built over a cloud of %zu points, got %zu", index->n, cloud->n);
   SGA_ENTER(ctx);
+  SGA_TRY(wait_ready(ctx, index->ready));  // produced on another context in stream-ordered mode (common.hpp: Ready)
+  SGA_TRY(wait_ready(ctx, cloud->ready));
   const size_t n = index->n;
   if (cloud->has_normals && index->nrm.n < n) SGA_TRY(index->nrm.alloc(n));
   if (cloud->has_covs && index->cov.n < n) SGA_TRY(index->cov.alloc(n));

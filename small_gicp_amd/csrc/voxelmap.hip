@@ -460,6 +460,7 @@ int sga_flatmap_download(sga_context* ctx, const sga_index* index, int32_t* coor
   const size_t n = index->n;
   if (n == 0) return SGA_OK;
   SGA_ENTER(ctx);
+  SGA_TRY(wait_ready(ctx, index->ready));
   std::vector<float4> hp;
   std::vector<Cov8> hc;
   if (points) {

@@ -794,7 +794,11 @@ def test_c4_matches_reference(c3, c3_cpu):
     for mode in ("fp32", "fp64"):  # the voxel means and covariances themselves are rounded to fp32 on the device: both modes to 2e-5
         H, b, e, n = pb.linearize(sga.make_setting("GICP", math_mode=mode).factor, T)
         assert np.abs(H - Ho).max() <= FP32_REL * np.abs(Ho).max(), (mode, np.abs(H - Ho).max() / np.abs(Ho).max())
-        assert abs(e - eo) <= FP32_REL * eo and abs(int(n) - int(no)) <= 100
+        ti, _ = pb.factors()
+        oti, _ = f.get(is_voxelmap=True)
+        differ = int((ti != oti).sum())
+        print("C4 %s: %d of %d voxel assignments differ from the CPU's (queries within fp32 rounding of a voxel face), inliers %d / %d" % (mode, differ, len(ti), n, no))
+        assert abs(e - eo) <= FP32_REL * eo and abs(int(n) - int(no)) <= 4 and differ <= 20, (n, no, differ)  # observed: 7 / 5 assignments, 1 / 0 inliers
     res = pb.align(sga.make_setting("GICP"))
     if c3_cpu["ref"] is not None:
         r = c3_cpu["ref"].align(c3_cpu["rtc"], c3_cpu["rsc"], c3_cpu["ref"].VGICP, 0.5, 1.0, threads)
