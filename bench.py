@@ -446,6 +446,12 @@ def main():
                 out["policy_c4"] = policy_leg(sga, "VGICP", tgt, src, out["vgicp_c4"]["value"], None)
         if single and args.odom_frames > 1:
             out["kitti_odom"] = odometry_leg(sga, args, None)
+        if single and not args.no_policy:
+            out["helper_c1"] = helper_leg(sga, "c1")
+            if args.odom_frames > 1:
+                out["helper_c5"] = helper_leg(sga, "c5")
+        if world > 1:
+            out["scaling_model"] = scaling_model(world, per_rank)
     if use_dist and native_comm and world > 1 and args.odom_frames > 1:
         r = odometry_leg(sga, args, (rank, world, ctx))
         # the other way to spread C5 over the GPUs: whole frame pairs per rank, no collective
@@ -469,6 +475,61 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def helper_leg(sga, which):
+    """ms per call of the reference's HELPER API (registration/registration_helper.hpp) served by integration/registration_helper_hip.cpp
+    (oracle/_ref/test_helper_hip: the reference-side binding compiled against the unmodified reference headers — not the oracle):
+    align(points ...) = raw points up, result down, nothing else crosses PCIe (downsampling 0.25 m, k = 10, GICP); align(clouds + tree) on
+    clouds that came out of preprocess_points = their device twins, no upload; preprocess_points = device pipeline + download + the host
+    KdTree its return type promises.  c1 = data/target.ply <-> source.ply (69k points each); c5 = two consecutive KITTI-shaped scans (~125k points each)."""
+    import subprocess
+    import tempfile
+
+    binary = os.path.join(ROOT, "oracle", "_ref", "test_helper_hip")
+    if not os.path.exists(binary):
+        return {"skipped": "oracle/_ref/test_helper_hip is not built (make -C oracle/ref where /root/reference is mounted)"}
+    try:
+        if which == "c1":
+            d = np.load(os.path.join(ROOT, "tests", "golden", "c1_points.npz"))
+            clouds = (d["target"][:, :3], d["source"][:, :3])
+        else:
+            clouds = (sga.synthetic.kitti_like_scan(0)[0][:, :3], sga.synthetic.kitti_like_scan(1)[0][:, :3])
+        with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+            paths = []
+            for name, a in zip(("target", "source"), clouds):
+                paths.append(os.path.join(tmp, name + ".bin"))
+                np.ascontiguousarray(a, dtype="<f4").tofile(paths[-1])
+            p = subprocess.run([binary, paths[0], paths[1], "20"], capture_output=True, text=True, timeout=600)
+        for ln in p.stdout.splitlines():
+            if ln.startswith("TIMING "):
+                r = json.loads(ln[7:])
+                r["unit"] = "ms per call, 20 calls after the first"
+                return r
+        return {"error": "no TIMING line: rc %d %s" % (p.returncode, p.stderr[-300:])}
+    except Exception as ex:  # noqa: BLE001
+        return {"error": repr(ex)}
+
+
+def scaling_model(world, per_rank):
+    """What the design predicts for ONE 1M <-> 1M registration sharded over N GPUs (profiles/r04_shard_model.txt: one GPU
+    doing the work of one rank of N): K1 per pass of a 1 / N source slice + 6.5 us of host work + the all-reduce.  Printed beside the
+    measurement so that the first real multi-GPU run is a one-line comparison; `with_measured_collective` replaces the assumed 20 us by
+    this run's own per_rank.collective_avg_us."""
+    k1 = {1: 128.6, 2: 95.7, 4: 72.3, 8: 62.1}
+    host_us, assumed = 6.5, 20.0
+    n = min(k1, key=lambda g: abs(g - world))
+    out = {"shard_k1_us": k1, "host_us": host_us, "assumed_allreduce_us": assumed,
+           "predicted_iterations_per_s": {str(g): 1e6 / (v + host_us + (assumed if g > 1 else 0.0)) for g, v in k1.items()},
+           "note": "a pass over an N-th of the source still costs half a pass (search chains, launch, row reduction, hand-off do not shrink with the shard): one job saturates near 1.5x at 8 GPUs; "
+                   "weak scaling (--scaling weak) and frame pairs per rank (kitti_odom_frame_pairs_per_rank) are the modes that scale"}
+    try:
+        coll = [r.get("collective_avg_us") for r in (per_rank or []) if r and r.get("collective_avg_us")]
+        if coll:
+            out["with_measured_collective"] = {"collective_avg_us": max(coll), "predicted_iterations_per_s": 1e6 / (k1[n] + host_us + max(coll))}
+    except Exception:  # noqa: BLE001
+        pass
+    return out
 
 
 def policy_leg(sga, kind, tgt, src, cabi_rate, cabi_pose, n=None):

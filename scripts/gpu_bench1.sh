@@ -20,3 +20,11 @@ j=json.load(open('gpurun_out/bench_2r.json'))
 print('value', j['value'], 'n_gpus', j['n_gpus'], 'per_rank', json.dumps(j.get('per_rank')), 'shard', j.get('sharded_vs_unsharded'))
 print('odom', {k:v for k,v in j.get('kitti_odom',{}).items() if 'ms' in k}, 'pairs', j.get('kitti_odom_frame_pairs_per_rank'))
 PY
+python - <<'PY'
+import json
+j=json.load(open('gpurun_out/bench_default.json'))
+print('helper_c1', j.get('helper_c1'), 'helper_c5', j.get('helper_c5'))
+print('policy_c4', json.dumps(j.get('policy_c4'))[:500])
+j=json.load(open('gpurun_out/bench_2r.json'))
+print('scaling_model', json.dumps(j.get('scaling_model'))[:700])
+PY
