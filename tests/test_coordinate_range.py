@@ -277,3 +277,126 @@ def test_origin_zero_keeps_the_records(c1_f32):
     assert (c.origin() == 0).all() and (c.xyz() == d["tp"]).all()
     c64 = sga.PointCloud(d["tp"].astype(np.float64), d["tn"], d["tc"])
     assert (c64.origin() == 0).all() and (c64.xyz() == d["tp"]).all()
+
+
+def _hip():
+    lib = C.CDLL("libamdhip64.so")
+    lib.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    lib.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    lib.hipFree.argtypes = [C.c_void_p]
+    return lib
+
+
+def _like(H0, b0, e0, H1, b1, e1, A, rel, what):
+    """(H1, b1, e1) of the shifted problem == the adjoint image of the unshifted (H0, b0, e0)."""
+    assert abs(e1 - e0) <= rel * max(abs(e0), 1e-30), (what, e0, e1)
+    Hm, bm = A.T @ H0 @ A, A.T @ b0
+    sc = np.sqrt(np.outer(np.diag(Hm), np.diag(Hm))) + 1e-300
+    assert (np.abs(H1 - Hm) / sc).max() <= rel, (what, (np.abs(H1 - Hm) / sc).max())
+    bsc = np.sqrt(np.diag(Hm) * max(e0, 1e-30)) + 1e-300
+    assert (np.abs(b1 - bm) / bsc).max() <= 10 * rel, (what, (np.abs(b1 - bm) / bsc).max())
+
+
+def test_every_kind_of_entry_point_converts_frames(c1_f32):
+    """Both clouds moved by whole multiples of 128 m: their device records are the unshifted ones bit for bit, so whatever an entry point
+    returns must be the unshifted answer seen from the shifted frame — exactly, up to the one rounding of the pose conversion.  Walks
+    through the entry points test_shifted_* does not: per-point systems, the asynchronous form, the host rejector, a source given by its own
+    index, one-shot / incremental / host-voxel Gaussian maps with 1 and 7 offsets and their kNN, flat maps and their kNN."""
+    d = c1_f32
+    s = np.array([12800.0, -25600.0, 128.0])
+    t0, s0 = sga.PointCloud(d["tp"], d["tn"], d["tc"]), sga.PointCloud(d["sp"], d["sn"], d["sc"])
+    t1, s1 = sga.PointCloud(d["tp"].astype(np.float64) + s, d["tn"], d["tc"]), sga.PointCloud(d["sp"].astype(np.float64) + s, d["sn"], d["sc"])
+    assert (t1.origin() == s).all() and (s1.origin() == s).all()
+    A = adjoint(s)
+    T = se3([0.1, 0.2, 1.0], np.deg2rad(0.7), [0.49, 0.12, -0.02])
+    Ts = shift_pose(T, s, s)
+    st = sga.make_setting("GICP", math_mode="fp64")
+    k0, k1 = sga.KdTree(t0), sga.KdTree(t1)
+    p0, p1 = sga.Problem(k0, s0), sga.Problem(k1, s1)
+    # ---- per-point systems (src/python/factors.cpp:52-101 through sga_linearize_per_point)
+    ok0, H0, b0, e0 = p0.linearize_per_point(st.factor, T)
+    ok1, H1, b1, e1 = p1.linearize_per_point(st.factor, Ts)
+    assert (ok0 == ok1).all() and np.abs(e1 - e0).max() <= 1e-9 * np.abs(e0).max()
+    Hm = np.einsum("ji,njk,kl->nil", A, H0, A)
+    bm = b0 @ A
+    assert np.abs(H1 - Hm).max() <= 1e-9 * np.abs(Hm).max() and np.abs(b1 - bm).max() <= 1e-9 * np.abs(bm).max()
+    # ---- the asynchronous form: the 30-double accumulator stays on the device; what the caller unpacks is its own frame's system
+    hip = _hip()
+    dptr = C.c_void_p()
+    assert hip.hipMalloc(C.byref(dptr), 30 * 8) == 0
+    try:
+        Hs, bs, es, ns = p1.linearize(st.factor, Ts)
+        p1.linearize_async(st.factor, Ts, dptr.value)
+        p1.ctx.synchronize()
+        acc = np.zeros(30)
+        assert hip.hipMemcpy(acc.ctypes.data_as(C.c_void_p), dptr, 30 * 8, 2) == 0
+        Ha, ba, ea, na = sga.unpack_accumulator(acc)
+        assert na == ns and abs(ea - es) <= 1e-12 * abs(es) and np.abs(Ha - Hs).max() <= 1e-10 * np.abs(Hs).max() and np.abs(ba - bs).max() <= 1e-9 * np.abs(bs).max()
+    finally:
+        hip.hipFree(dptr)
+    # ---- a host rejector sees the CALLER's pose and the caller's indices
+    seen = []
+
+    def rej(Tcb, idx, d2):
+        seen.append(Tcb.copy())
+        return (d2 > 0.25) | (idx % 5 == 0)
+
+    p0.set_rejector(rej)
+    p1.set_rejector(rej)
+    Hr0, br0, er0, nr0 = p0.linearize(st.factor, T)
+    Hr1, br1, er1, nr1 = p1.linearize(st.factor, Ts)
+    p0.set_rejector(None)
+    p1.set_rejector(None)
+    assert np.abs(seen[-1] - Ts).max() == 0.0 and nr0 == nr1 and 0 < nr1 < len(d["sp"])
+    _like(Hr0, br0, er0, Hr1, br1, er1, A, 1e-9, "rejector")
+    # ---- the source given by its own index (the odometry loop, sga_problem_create_from_index)
+    q0, q1 = sga.Problem(k0, sga.KdTree(s0)), sga.Problem(k1, sga.KdTree(s1))
+    a, b = q0.linearize(st.factor, T), q1.linearize(st.factor, Ts)
+    assert a[3] == b[3] and (q0.factors()[0] == q1.factors()[0]).all()
+    _like(a[0], a[1], a[2], b[0], b[1], b[2], A, 1e-9, "source index")
+    # ---- Gaussian voxel maps: incremental, one-shot, from host voxels; 1 and 7 offsets; kNN
+    lib = sga._lib.load()
+    for offsets in (1, 7):
+        maps = []
+        for tgt, shift in ((t0, np.zeros(3)), (t1, s)):
+            inc = sga.GaussianVoxelMap(1.0)
+            inc.insert(tgt)
+            h = C.c_void_p()
+            sga._lib.check(lib.sga_index_build_gaussian_voxelmap(tgt.ctx.h, tgt.h, 1.0, C.byref(h)))
+            one = sga.GaussianVoxelMap.__new__(sga.GaussianVoxelMap)
+            one.leaf, one.ctx, one.h = 1.0, tgt.ctx, h
+            coords, means, c6, _ = inc.download()
+            host = sga.GaussianVoxelMap.from_voxels(1.0, coords, means.astype(np.float64) if not shift.any() else (inc.download()[1].astype(np.float64)), c6)
+            for m in (inc, one, host):
+                m.set_search_offsets(offsets)
+            maps.append((inc, one, host))
+        c_base, c_far = maps[0][0].download()[0], maps[1][0].download()[0]
+        assert (c_far - c_base == np.array([12800, -25600, 128])).all()  # voxel coordinates are the CALLER's (leaf 1 m)
+        for which in (0, 1):  # incremental and one-shot builds (the host-voxel map of the far cloud went through float32 means: checked on the near one)
+            r0 = sga.Problem(maps[0][which], s0).linearize(st.factor, T)
+            r1 = sga.Problem(maps[1][which], s1).linearize(st.factor, Ts)
+            assert r0[3] == r1[3] > 4000, (offsets, which, r0[3], r1[3])
+            _like(r0[0], r0[1], r0[2], r1[0], r1[1], r1[2], A, 1e-9, ("voxel map", offsets, which))
+        rh = sga.Problem(maps[0][2], s0).linearize(st.factor, T)
+        ri = sga.Problem(maps[0][0], s0).linearize(st.factor, T)
+        assert rh[3] == ri[3] and rh[2] == ri[2]
+        i0, d0 = maps[0][0].batch_knn_search(d["sp"][:300].astype(np.float64), 3)
+        i1, d1 = maps[1][0].batch_knn_search(d["sp"][:300].astype(np.float64) + s, 3)
+        assert (i0 == i1).all() and np.abs(np.where(np.isfinite(d0), d0 - d1, 0.0)).max() < 1e-6
+    # ---- flat maps (linear iVox): inserted with a pose, searched over 7 voxels, kNN
+    P = se3([0, 0, 1], 0.05, [1.5, -2.0, 0.25])
+    f0, f1 = sga.IncrementalVoxelMapCov(1.0), sga.IncrementalVoxelMapCov(1.0)
+    f0.set_search_offsets(7)
+    f1.set_search_offsets(7)
+    f0.insert(t0, P)
+    f1.insert(t1, shift_pose(P, s, s))
+    assert f0.size() == f1.size() and (f1.download()[0] - f0.download()[0] == np.array([12800, -25600, 128])).all() and (f1.download()[1] == f0.download()[1]).all()
+    Tp, Tps = P @ T, shift_pose(P @ T, s, s)
+    r0, r1 = sga.Problem(f0, s0, Tp), sga.Problem(f1, s1, Tps)
+    a, b = r0.linearize(st.factor, Tp), r1.linearize(st.factor, Tps)
+    assert a[3] == b[3] > 4000 and (r0.factors()[0] == r1.factors()[0]).all()
+    _like(a[0], a[1], a[2], b[0], b[1], b[2], A, 1e-7, "flat map")  # (the map's device frame follows the inserted scan: its records are rounded about another origin than the unshifted map's)
+    qs = (d["sp"][:300].astype(np.float64) @ Tp[:3, :3].T + Tp[:3, 3])
+    i0, d0 = f0.batch_knn_search(qs, 4)
+    i1, d1 = f1.batch_knn_search(qs + s, 4)
+    assert (i0 == i1).mean() > 0.995 and np.abs(np.where(np.isfinite(d0) & (i0 == i1), d0 - d1, 0.0)).max() < 1e-4
