@@ -1,8 +1,8 @@
 """The reference's coordinate range: PointCloud stores Vector4d (points/point_cloud.hpp:69-71) and every factor works in
 double (factors/gicp_factor.hpp:35-73), so clouds kilometres from the origin (UTM / ENU maps) register to full precision.  The device
 keeps fp32 records — RELATIVE to a per-cloud origin, subtracted in double when the cloud is uploaded (small_gicp_amd.h: device frames).
-These tests move config C1 far from the origin and compare with the reference compiled here (oracle/_ref) or the oracle, both run in
-double on the very same double inputs.
+These tests move config C1 far from the origin and compare with the oracle run in double on the very same double inputs — on ONE thread:
+at these condition numbers the order of the reference's per-thread sums changes its LM path from run to run.
 
 Metrics.  A rotation error d_theta shows up in the translation column of T_target_source multiplied by the distance of the data from
 the origin (at 2.2e5 m a rotation error of 1e-9 rad is 2e-4 m of "translation").  Two numbers are therefore checked:
@@ -77,8 +77,8 @@ def test_shifted_c1_registers_like_the_double_reference(orc, c1_double, shift, m
     s = np.asarray(shift)
     ot = orc.Cloud(d["tp"] + s, d["tn"], d["tc"])
     os_ = orc.Cloud(d["sp"] + s, d["sn"], d["sc"], tree=False)
-    ores = orc.align(ot, os_, orc.default_setting(factor_kind=orc.GICP, num_threads=4))
-    obase = orc.align(orc.Cloud(d["tp"], d["tn"], d["tc"]), orc.Cloud(d["sp"], d["sn"], d["sc"], tree=False), orc.default_setting(factor_kind=orc.GICP, num_threads=4))
+    ores = orc.align(ot, os_, orc.default_setting(factor_kind=orc.GICP, num_threads=1))
+    obase = orc.align(orc.Cloud(d["tp"], d["tn"], d["tc"]), orc.Cloud(d["sp"], d["sn"], d["sc"], tree=False), orc.default_setting(factor_kind=orc.GICP, num_threads=1))
     tgt = sga.PointCloud(d["tp"] + s, d["tn"], d["tc"])
     src = sga.PointCloud(d["sp"] + s, d["sn"], d["sc"])
     assert np.abs(tgt.origin() - s).max() <= 64.0 + 45.0 and (tgt.origin() % 128.0 == 0).all()
@@ -153,7 +153,7 @@ def test_target_in_a_map_frame_source_in_the_sensor_frame(orc, c1_double):
     ot = orc.Cloud(d["tp"] + s, d["tn"], d["tc"])
     os_ = orc.Cloud(d["sp"], d["sn"], d["sc"], tree=False)
     T0 = shift_pose(np.eye(4), np.zeros(3), s)
-    ores = orc.align(ot, os_, orc.default_setting(factor_kind=orc.GICP, num_threads=4), T0)
+    ores = orc.align(ot, os_, orc.default_setting(factor_kind=orc.GICP, num_threads=1), T0)
     tgt = sga.PointCloud(d["tp"] + s, d["tn"], d["tc"])
     src = sga.PointCloud(d["sp"], d["sn"], d["sc"])
     assert (src.origin() == 0).all() and np.abs(tgt.origin() - s).max() < 128.0
@@ -261,7 +261,7 @@ def test_scan_to_model_chain_walks_five_kilometres(orc, c1_double):
         ov.insert(ot, P)
         assert gv.size() == len(ov)
         res = sga.Problem(gv, gs, P).align(st, P)
-        ores = orc.align(ov, os_, orc.default_setting(factor_kind=orc.GICP, num_threads=4), P)
+        ores = orc.align(ov, os_, orc.default_setting(factor_kind=orc.GICP, num_threads=1), P)
         dt, dr = at_data_error(res.T_target_source, ores.T_target_source, d["sp"].mean(axis=0))
         worst = (max(worst[0], dt), max(worst[1], dr))
         assert dt < 1e-4 and dr < 1e-4 and res.iterations == ores.iterations, (k, dt, dr, res.iterations, ores.iterations)
@@ -382,7 +382,8 @@ def test_every_kind_of_entry_point_converts_frames(c1_f32):
         assert rh[3] == ri[3] and rh[2] == ri[2]
         i0, d0 = maps[0][0].batch_knn_search(d["sp"][:300].astype(np.float64), 3)
         i1, d1 = maps[1][0].batch_knn_search(d["sp"][:300].astype(np.float64) + s, 3)
-        assert (i0 == i1).all() and np.abs(np.where(np.isfinite(d0), d0 - d1, 0.0)).max() < 1e-6
+        fin = np.isfinite(d0)
+        assert (i0 == i1).all() and (np.isfinite(d1) == fin).all() and np.abs(d0[fin] - d1[fin]).max() < 1e-6
     # ---- flat maps (linear iVox): inserted with a pose, searched over 7 voxels, kNN
     P = se3([0, 0, 1], 0.05, [1.5, -2.0, 0.25])
     f0, f1 = sga.IncrementalVoxelMapCov(1.0), sga.IncrementalVoxelMapCov(1.0)
