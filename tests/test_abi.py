@@ -54,7 +54,36 @@ def test_argument_checks_come_before_any_device_work():
     assert lib.sga_multi_set_target_f32(None, f, None, None, 1) == INVALID
     assert lib.sga_multi_set_source_f32(None, f, None, None, 1, d) == INVALID
     assert lib.sga_multi_create(None, 1, C.byref(out)) == INVALID and lib.sga_multi_create((C.c_int * 1)(0), 0, C.byref(out)) == INVALID
+    # round 5: origins, clones, rejectors, search offsets
+    assert lib.sga_cloud_create_f32_origin(None, f, None, None, 1, d, C.byref(out)) == INVALID
+    assert lib.sga_cloud_create_f64_origin(None, d, None, None, 1, d, C.byref(out)) == INVALID
+    assert lib.sga_cloud_origin(None, d) == INVALID and lib.sga_index_origin(None, d) == INVALID
+    assert lib.sga_cloud_download_f64(None, None, d, None, None) == INVALID
+    assert lib.sga_index_clone(None, None, C.byref(out)) == INVALID
+    assert lib.sga_multi_set_target_f32_origin(None, f, None, None, 1, d) == INVALID
+    assert lib.sga_multi_set_source_f32_origin(None, f, None, None, 1, d, d) == INVALID
+    assert lib.sga_multi_set_rejector(None, None, None) == INVALID and lib.sga_multi_set_search_offsets(None, 7) == INVALID
+    assert lib.sga_voxelmap_set_search_offsets(None, 7) == INVALID
     assert b"" != lib.sga_last_error()
+
+
+def test_origin_rule_and_frame_conversions_on_the_host():
+    """sga_choose_origin (small_gicp_amd.h, device frames): the bounding-box centre rounded to a multiple of 128 m — 0 for everything centred
+    within 64 m of the origin (so the BASELINE configs are stored as before), 0 for empty / non-finite boxes."""
+    lib = sga.load()
+
+    def origin(lo, hi):
+        o = (C.c_double * 3)()
+        lib.sga_choose_origin((C.c_double * 3)(*lo), (C.c_double * 3)(*hi), o)
+        return list(o)
+
+    assert origin([-50, -50, -1], [50, 50, 10]) == [0.0, 0.0, 0.0]
+    assert origin([10, -100, 0], [117.9, 27.9, 5]) == [0.0, 0.0, 0.0]      # centres (63.95, -36.05, 2.5)
+    assert origin([10, -100, 0], [118.1, -28.1, 5]) == [128.0, -128.0, 0.0]  # centres (64.05, -64.05, 2.5)
+    assert origin([99990, 199990, 290], [100040, 200080, 310]) == [99968.0, 200064.0, 256.0]  # centres (100015, 200035, 300)
+    assert origin([1, 1, 1], [-1, -1, -1]) == [0.0, 0.0, 0.0]
+    assert origin([float("inf")] * 3, [float("-inf")] * 3) == [0.0, 0.0, 0.0]
+    assert origin([float("nan"), 0, 0], [1, 1, 1])[0] == 0.0
 
 
 def test_defaults_match_reference():
