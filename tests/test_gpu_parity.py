@@ -704,6 +704,33 @@ def test_c2_plane_icp_100k_matches_oracle(orc):
     assert dt < 0.02 and dr < 2e-3
 
 
+def test_c3_in_a_geo_referenced_frame_is_c3(c3):
+    """Config C3 with both clouds moved by (25 600, -51 200, 128) m — whole multiples of 128 m, so the device records are the unshifted ones
+    bit for bit (small_gicp_amd.h: device frames) and the whole 10-pass registration (cold, warm, queue-fed and streaming kernels, their
+    motion thresholds, the certificates, the error model) must reproduce itself: the same passes, the same inliers, the pose conjugated by
+    the shift.  The C1-sized frame tests are in tests/test_coordinate_range.py; this is the benchmark's size."""
+    s = np.array([25600.0, -51200.0, 128.0])
+    tgt, src = c3["tgt"], c3["src"]
+    tc, sc = tgt.covs()[:, :3, :3], src.covs()[:, :3, :3]
+    tgt2 = sga.PointCloud(tgt.xyz().astype(np.float64) + s, None, tc)
+    src2 = sga.PointCloud(src.xyz().astype(np.float64) + s, None, sc)
+    assert (tgt2.origin() == s).all() and (src2.origin() == s).all()
+    st = sga.make_setting("GICP", max_iterations=10, rotation_eps=0.0, translation_eps=0.0)  # the benchmark's protocol: ten iterations
+    p1, p2 = sga.Problem(c3["tree"], src), sga.Problem(sga.KdTree(tgt2), src2)
+    r1, r2 = p1.align(st), p2.align(st)
+    T1s = r1.T_target_source.copy()
+    T1s[:3, 3] = r1.T_target_source[:3, 3] + s - r1.T_target_source[:3, :3] @ s
+    c = np.append(src.xyz().astype(np.float64).mean(axis=0) + s, 1.0)
+    d = float(np.linalg.norm((T1s @ c - r2.T_target_source @ c)[:3]))
+    print("C3 in a frame 57 km from the origin: %.2e m at the data from the unshifted registration, iterations %d / %d, inliers %d / %d, passes %s" % (d, r2.iterations, r1.iterations, r2.num_inliers, r1.num_inliers, p2.pass_stats()))
+    assert r1.iterations == r2.iterations and r1.num_inliers == r2.num_inliers and d < 1e-6
+    s1, s2 = p1.pass_stats(), p2.pass_stats()
+    assert s1["cold_passes"] == s2["cold_passes"] and s1["warm_passes"] == s2["warm_passes"]
+    differ = int((p1.factors()[0] != p2.factors()[0]).sum())
+    print("correspondences differing between the two frames: %d of 1M (the pose reaches the kernels through one more rounding)" % differ)
+    assert differ <= 10  # observed: 1
+
+
 # ---- configs C3 and C4 at their full size against the reference itself ------------------------------------------------------------
 @pytest.fixture(scope="module")
 def c3_cpu(c3):
