@@ -401,3 +401,23 @@ def test_every_kind_of_entry_point_converts_frames(c1_f32):
     i0, d0 = f0.batch_knn_search(qs, 4)
     i1, d1 = f1.batch_knn_search(qs + s, 4)
     assert (i0 == i1).mean() > 0.995 and np.abs(np.where(np.isfinite(d0) & (i0 == i1), d0 - d1, 0.0)).max() < 1e-4
+
+
+def test_float32_clouds_far_from_the_origin_are_recentred_too(orc, c1_f32):
+    """sga_cloud_create_f32 (fp32 input): what the caller holds is already rounded to fp32 — at 1e4 m to a millimetre — but the reference
+    would compute in double ON those values; so does the device, on their offsets from the cloud's origin (subtracted in double: exact here,
+    the differences of nearby fp32 numbers are fp32 numbers).  Against the oracle in double on the same fp32 values."""
+    d = c1_f32
+    s = np.array([1e4, -1e4, 50.0])
+    tp = (d["tp"].astype(np.float64) + s).astype(np.float32)
+    sp = (d["sp"].astype(np.float64) + s).astype(np.float32)
+    tgt, src = sga.PointCloud(tp, d["tn"], d["tc"]), sga.PointCloud(sp, d["sn"], d["sc"])
+    assert (tgt.origin() % 128.0 == 0).all() and np.abs(tgt.origin() - s).max() < 128.0
+    assert (tgt.xyz() == tp).all() and np.abs(tgt.xyz64() - tp.astype(np.float64)).max() == 0.0  # the round trip is exact
+    ot = orc.Cloud(tp.astype(np.float64), d["tn"], d["tc"])
+    os_ = orc.Cloud(sp.astype(np.float64), d["sn"], d["sc"], tree=False)
+    ores = orc.align(ot, os_, orc.default_setting(factor_kind=orc.GICP, num_threads=1))
+    res = sga.Problem(sga.KdTree(tgt), src).align(sga.make_setting("GICP"))
+    dt, dr = at_data_error(res.T_target_source, ores.T_target_source, sp.astype(np.float64).mean(axis=0))
+    print("fp32 clouds at 1.4e4 m: %.2e m %.2e rad at the data, iterations %d / %d" % (dt, dr, res.iterations, ores.iterations))
+    assert dt < 1e-4 and dr < 1e-4 and res.iterations == ores.iterations and abs(int(res.num_inliers) - int(ores.num_inliers)) <= 2

@@ -139,6 +139,28 @@ for math in ("fp64", "fp32"):
                      num_inliers=int(res.num_inliers), single_inliers=int(s.num_inliers), lin_inliers=int(ninl), error=res.error, single_error=s.error)
 out["counts"] = sorted(set(calls))
 out["collectives"] = len(calls)
+# shards uploaded SEPARATELY live in device frames of their own unless they name a common origin: their accumulators must not be added
+import ctypes as C
+lib = sga._lib.load()
+def shard_cloud(origin):
+    xyz = src.xyz64()[lo:hi] + np.array([3000.0, -2000.0, 0.0])
+    p4 = np.ones((len(xyz), 4)); p4[:, :3] = xyz
+    c4 = np.zeros((len(xyz), 4, 4)); c4[:, :3, :3] = src.covs()[lo:hi, :3, :3]
+    h = C.c_void_p()
+    o = np.ascontiguousarray(origin, dtype=np.float64)
+    sga._lib.check(lib.sga_cloud_create_f64_origin(ctx.h, p4.ctypes.data_as(C.POINTER(C.c_double)), None, np.ascontiguousarray(c4).ctypes.data_as(C.POINTER(C.c_double)), len(xyz), o.ctypes.data_as(C.POINTER(C.c_double)), C.byref(h)))
+    return sga.PointCloud(ctx=ctx, _handle=h)
+T_far = np.eye(4); T_far[:3, 3] = [-3000.0, 2000.0, 0.0]
+st = sga.make_setting("GICP", math_mode="fp64")
+same = sga.Problem(tree, shard_cloud([2944.0, -2048.0, 0.0]), T_far)     # both ranks name the same origin: accepted
+Hs, bs, es, ns = same.linearize(st.factor, T_far)
+out["common_origin_inliers"] = int(ns)
+try:
+    bad = sga.Problem(tree, shard_cloud([2944.0 + 128.0 * rank, -2048.0, 0.0]), T_far)  # origins differ between the ranks: refused, loudly, on every rank
+    bad.linearize(st.factor, T_far)
+    out["differing_origins"] = "accepted"
+except sga.SgaError as ex:
+    out["differing_origins"] = str(ex)
 json.dump(out, open(os.path.join(os.environ["SGA_TMP"], "result_%d.json" % rank), "w"))  # (the ranks share one stdout: lines could interleave)
 dist.barrier()
 dist.destroy_process_group()
@@ -156,6 +178,8 @@ def test_two_ranks_share_one_registration_through_the_callback_transport(tmp_pat
     res = [json.load(open(tmp_path / ("result_%d.json" % r))) for r in range(2)]
     g = c1_gold["cases"]["GICP"]
     for r in res:
+        assert "different device frames" in r["differing_origins"], r["differing_origins"]
+        assert abs(r["common_origin_inliers"] - r["fp64"]["lin_inliers"]) <= 2  # the shifted shards with a common origin: the registration problem of the unshifted ones
         assert r["counts"] == [8, 96], r["counts"]              # one collective per linearization (system + error-model moments), + once per problem the 8 doubles that compare the ranks' source frames
         for math, tol in (("fp64", 1e-9), ("fp32", 1e-5)):
             m = r[math]
@@ -171,7 +195,7 @@ def test_two_ranks_share_one_registration_through_the_callback_transport(tmp_pat
     assert res[0]["fp64"]["T"] == res[1]["fp64"]["T"] and res[0]["fp32"]["T"] == res[1]["fp32"]["T"]  # same reduced numbers, same host LM on both ranks
     # collectives: one per linearization only (iterations + 1 per align, + the explicit linearize)
     it = res[0]["fp64"]["iterations"] + res[0]["fp32"]["iterations"]
-    assert res[0]["collectives"] <= it + 2 + 2 + 4 + 2, res[0]["collectives"]  # (+ 2: the frame check of the two problems)
+    assert res[0]["collectives"] <= it + 2 + 2 + 4 + 2 + 3, res[0]["collectives"]  # (+ 2: the frame check of the two problems; + 3: the two origin cases at the end)
 
 
 @pytest.mark.gpu
