@@ -18,9 +18,9 @@ all-reduces ONE accumulator of 96 doubles per linearization (21 H, 6 b, e, inlie
 with RCCL on its own stream (csrc/comm.hip); the trial errors of the LM steps are evaluated on every rank's host from the reduced
 moments — no collective per error pass; every rank runs the same host LM on the reduced numbers.  value = iterations/s of that one
 job.  Rank 0 also runs the unsharded registration and the bench asserts that the N-rank pose equals it (1e-9 in fp64 per-pair
-arithmetic, 1e-5 in the timed fp32 arithmetic).  If the native communicator cannot be created the run FAILS unless --allow-fallback
-is given; with it the torch.distributed callback path (30 doubles per linearization + 1 per error pass) is measured and the JSON says
-"fallback": true.  --scaling weak: every rank owns an independent 1M-point source (value = N x the job's iteration rate).
+arithmetic, 1e-5 in the timed fp32 arithmetic).  If the native communicator cannot be created the torch.distributed callback path (30 doubles per
+linearization + 1 per error pass, still one rank per GPU, the all-reduce through torch's RCCL) is measured instead, the JSON says
+"fallback": true with "fallback_reason", and stderr says so; --require-native makes that case fail instead.  --scaling weak: every rank owns an independent 1M-point source (value = N x the job's iteration rate).
 
 Extra objects on the JSON line: "roofline" (K1 = search + factor kernel of one linearize pass, algorithmic bytes / HIP-event time vs
 8 TB/s; traffic = FETCH_SIZE / WRITE_SIZE of one registration re-run under rocprofv3 when it is on the box), "cpu_baseline" (the
@@ -64,7 +64,8 @@ def parse():
     ap.add_argument("--no-plane", action="store_true", help="skip the point-to-plane (config C2) leg")
     ap.add_argument("--no-policy", action="store_true", help="skip the legs through the reference's Registration<> with ParallelReductionHIP + HipAligned<LM> (oracle/_ref/policy_bench)")
     ap.add_argument("--no-traffic", action="store_true", help="do not re-run one registration under rocprofv3 for the HBM traffic of K1")
-    ap.add_argument("--allow-fallback", action="store_true", help="N > 1: if the native RCCL communicator cannot be created, measure the torch.distributed callback path instead of failing")
+    ap.add_argument("--require-native", action="store_true", help="N > 1: fail if the library's own RCCL communicator cannot be created (default: measure the torch.distributed callback path, flagged \"fallback\": true)")
+    ap.add_argument("--allow-fallback", action="store_true", help="(the default since round 5; kept for old command lines)")
     ap.add_argument("--no-fp64", action="store_true", help="skip the fp64-math repetition of the headline")
     ap.add_argument("--sustain-s", type=float, default=3.0, help="extra (reported separately) sustained run of the same steps for this many seconds; 0 = skip")
     ap.add_argument("--force-dist", action="store_true", help="use the torch.distributed/RCCL path even at world size 1 (validation)")
@@ -193,6 +194,7 @@ def main():
 
     native_comm = False
     transport = None
+    fallback_reason = None
     if use_dist:
         # native path: the library all-reduces its accumulators with RCCL on its own stream (no Python in the iteration loop);
         # torch.distributed only carries the 128-byte communicator id, the barriers and the max-over-ranks of the wall time
@@ -208,15 +210,18 @@ def main():
                 ctx.comm_init_callback(world, rank, _host_allreduce)
                 transport = "host callback over gloo (sga_comm_init_callback; --oversubscribe testing mode)"
             else:
+                if os.environ.get("SGA_BENCH_FORCE_FALLBACK"):  # exercises the branch below on a box where the communicator would work
+                    raise RuntimeError("SGA_BENCH_FORCE_FALLBACK is set")
                 ids = [sga.Context.comm_unique_id() if rank == 0 else None]
                 dist.broadcast_object_list(ids, src=0)
                 ctx.comm_init(world, rank, ids[0])
                 transport = "native ncclAllReduce (RCCL) on the library stream"
             native_comm = True
         except Exception as ex:  # noqa: BLE001
-            if not (args.allow_fallback or args.oversubscribe):
-                raise SystemExit("bench: native RCCL communicator unavailable (%r); the callback path is a different (slower) protocol — pass --allow-fallback to measure it instead" % (ex,))
-            print("bench: native RCCL communicator unavailable (%r); falling back to torch.distributed callbacks (--allow-fallback)" % (ex,), file=sys.stderr)
+            if args.require_native and not args.oversubscribe:
+                raise SystemExit("bench: native RCCL communicator unavailable (%r) and --require-native was given" % (ex,))
+            fallback_reason = repr(ex)
+            print("bench: native RCCL communicator unavailable (%r); MEASURING THE torch.distributed CALLBACK PROTOCOL instead (\"fallback\": true in the JSON line)" % (ex,), file=sys.stderr)
 
     host_tensors = args.oversubscribe  # gloo fallback reduces on the host
     if use_dist and not native_comm:
@@ -355,6 +360,7 @@ def main():
             "unit": "iterations/s",
             "n_gpus": world,
             "fallback": bool(use_dist and not native_comm),
+            "fallback_reason": fallback_reason,
             "steps": steps_done,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / steps_done,
