@@ -42,7 +42,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ALG_BYTES_PER_POINT = {"linearize_gicp": 100, "error_gicp": 52, "linearize_plane_icp": 40}
+ALG_BYTES_PER_POINT = {"linearize_gicp": 100, "error_gicp": 52, "linearize_plane_icp": 40,
+                       # VGICP pass = the factor kernel alone: source point 16 + source covariance 32 + hash slot 8 + 4 + voxel mean 16 + voxel covariance 32 + correspondence 4
+                       "linearize_vgicp": 112}
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PROFILE_ALIGNS = 5  # registrations profiled pass by pass after the timed region (3 cold + 7 warm passes each on C3)
 ITERS_PER_ALIGN = 10
@@ -746,7 +748,10 @@ def vgicp_leg(sga, ctx, tgt, src, args):
         el = time.perf_counter() - t0
         kms = ctx.kernel_ms()
         ctx.set_profiling(False)
-        return {"value": steps / el, "unit": "iterations/s", "ms_per_step": 1e3 * el / steps, "voxelmap_build_s": build_s, "linearize_kernel_avg_us": kms["linearize_ms"] * 1e3, "error_kernel_avg_us": kms["error_ms"] * 1e3,
+        lin_us = kms["linearize_ms"] * 1e3
+        gbs = ALG_BYTES_PER_POINT["linearize_vgicp"] * src.size() / (lin_us * 1e-6) / 1e9 if lin_us > 0 else None  # whole pass (kernel + row reduction + launch gap); the kernel alone: profiles/*_c4_c2_kernel_stats.csv
+        return {"value": steps / el, "unit": "iterations/s", "ms_per_step": 1e3 * el / steps, "voxelmap_build_s": build_s, "linearize_kernel_avg_us": lin_us, "error_kernel_avg_us": kms["error_ms"] * 1e3,
+                "alg_bytes_per_point": ALG_BYTES_PER_POINT["linearize_vgicp"], "achieved_GBs": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS if gbs else None,
                 "workload": "C4: VGICP, GaussianVoxelMap(0.5 m) of the 1M-point target, 1M source points"}
     except Exception as ex:  # noqa: BLE001
         return {"error": repr(ex)}
