@@ -618,6 +618,11 @@ struct ParallelReductionHIP {
       "ParallelReductionHIP: of the voxel maps only GaussianVoxelMap (one Gaussian per voxel: VGICP, registration_helper.cpp:125-137) and "
       "IncrementalVoxelMap<FlatContainer<...>> (linear iVox: scan-to-model ICP / GICP) are targets the device knows.");
     auto& s = pool->mine();
+    if (s.verifier.pending()) {  // a bracket that was never closed (begin_align twice): its check first — the helper threads take one job at a time
+      const int changed = s.verifier.wait();
+      if (changed & 1) s.target_addr = nullptr;
+      if (changed & 2) s.source_addr = nullptr;
+    }
     if (s.multi && (s.device != device || s.num_gpus != num_gpus)) {
       sga_multi_destroy(s.multi);
       s.multi = nullptr;
