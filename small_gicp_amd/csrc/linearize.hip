@@ -479,7 +479,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
 constexpr int kQueueCap = 128;        // entries; a tile is staged while at most kQueueCap - 64 are waiting
 constexpr int kPathRecords = 10;      // pair records fetched at once by kd_push_path: covers depth 20 (8 M points); deeper trees take a second batch
 
-template <typename Real, int FACTOR, int TARGET, int PTS, bool FRESH_NN = false, bool CERT = false>
+template <typename Real, int FACTOR, int TARGET, int PTS, bool FRESH_NN = false, bool CERT = false, bool STAGED = false>
 __device__ __forceinline__ void linearize_group(const LinParams<Real>& p, int first, int stride, int limit, double* __restrict__ acc_row, int lane, unsigned long long* __restrict__ failed_masks = nullptr);
 template <typename Real, int FACTOR>
 __device__ __forceinline__ bool pair_moments(const LinParams<Real>& p, int i, int j, bool within_bound, Real qx, Real qy, Real qz, Real tx, Real ty, Real tz, Sym3<Real>& Mp, Real* g, Real& e, Sym3<Real>& M_out);
@@ -902,13 +902,29 @@ __device__ __forceinline__ void accumulate_moments(const Real (&P)[PTS][3], cons
   }
 }
 
+// The kernel's FIRST argument (a LinParams) read again from the kernel-argument segment through a pointer the compiler cannot see through:
+// the scalar loads of the fields a stage uses are issued in that stage and their registers die with it.  Without this the compiler loads
+// every field at the kernel's start and keeps all of them for its whole length — more than the 100 scalar registers a wave has, so it
+// parks them in the lanes of vector registers and fetches them back one v_readlane at a time (certify_linearize_kernel: 448 of its ~3 200
+// vector instructions per wave).  Only valid inside a kernel whose first parameter is the LinParams<Real> passed by value.
+template <typename Real>
+__device__ __forceinline__ const LinParams<Real>& kernarg_lin_params() {
+  using Args = const __attribute__((address_space(4))) LinParams<Real>;
+  Args* a = (Args*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(a));
+  return *(const LinParams<Real>*)a;
+}
+
 // The factor stage as a kernel of its own.  TARGET: 0 kd-tree (the neighbours come from the search kernel), 1 Gaussian voxel map, 2 flat voxel map (the lookup of a
 // voxel target happens right here).  Streaming + two gathers; a lane handles PTS points (PTS x kTile consecutive points per
 // workgroup step), their products are added up in registers, reduced with DPP inside the wave, in fp64 across waves.
 // The factors of PTS points per lane — points first, first + stride, ... below `limit` — added to the wave's row.
 // FRESH_NN: hint[] was written earlier in this very kernel (by any lane of this wave): read it past the vector L1.
-template <typename Real, int FACTOR, int TARGET, int PTS, bool FRESH_NN, bool CERT>
-__device__ __forceinline__ void linearize_group(const LinParams<Real>& p, int first, int stride, int limit, double* __restrict__ acc_row, int lane, unsigned long long* __restrict__ failed_masks) {
+// STAGED (the caller is a kernel whose first argument is `p0` itself): every stage reads the parameters it uses afresh (kernarg_lin_params).
+template <typename Real, int FACTOR, int TARGET, int PTS, bool FRESH_NN, bool CERT, bool STAGED>
+__device__ __forceinline__ void linearize_group(const LinParams<Real>& p0, int first, int stride, int limit, double* __restrict__ acc_row, int lane, unsigned long long* __restrict__ failed_masks) {
+#define SGA_STAGE_PARAMS(name) const LinParams<Real>& name = STAGED ? kernarg_lin_params<Real>() : p0
+  SGA_STAGE_PARAMS(p);
   Real P[PTS][3], G[PTS][3], E[PTS];
   Sym3<Real> Mp[PTS];
   int inliers = 0;
@@ -931,6 +947,8 @@ __device__ __forceinline__ void linearize_group(const LinParams<Real>& p, int fi
   }
   Real Q[PTS][3], Tg[PTS][3];
   bool within[PTS];
+  {
+  SGA_STAGE_PARAMS(p);
 #pragma unroll
   for (int u = 0; u < PTS; u++) {
     P[u][0] = ps4[u].x, P[u][1] = ps4[u].y, P[u][2] = ps4[u].z;  // multiplied by zero M' / g when the point is no inlier
@@ -953,6 +971,7 @@ __device__ __forceinline__ void linearize_group(const LinParams<Real>& p, int fi
       }
     }
   }
+  }
   if constexpr (TARGET != 2) {
     float4 m4[PTS];
     if constexpr (CERT && TARGET == 0) {
@@ -961,18 +980,22 @@ __device__ __forceinline__ void linearize_group(const LinParams<Real>& p, int fi
       // below the exclusion radius minus the point's motion; otherwise the point is flagged for the walkers' kernel and skipped here.
       int c2[PTS];
       float rx[PTS];
-#pragma unroll
-      for (int u = 0; u < PTS; u++) {
-        const int i = first + u * stride;
-        c2[u] = act[u] ? p.cert_nn2[i] : -1;
-        rx[u] = act[u] ? p.cert_rex[i] : 0.f;
-      }
       float4 m4b[PTS];
+      {
+        SGA_STAGE_PARAMS(p);
 #pragma unroll
-      for (int u = 0; u < PTS; u++) {
-        m4[u] = jn[u] >= 0 ? p.tgt_pts[jn[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
-        m4b[u] = c2[u] >= 0 ? p.tgt_pts[c2[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int u = 0; u < PTS; u++) {
+          const int i = first + u * stride;
+          c2[u] = act[u] ? p.cert_nn2[i] : -1;
+          rx[u] = act[u] ? p.cert_rex[i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < PTS; u++) {
+          m4[u] = jn[u] >= 0 ? p.tgt_pts[jn[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
+          m4b[u] = c2[u] >= 0 ? p.tgt_pts[c2[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
       }
+      SGA_STAGE_PARAMS(p);
 #pragma unroll
       for (int u = 0; u < PTS; u++) {
         const int i = first + u * stride;
@@ -1008,6 +1031,7 @@ __device__ __forceinline__ void linearize_group(const LinParams<Real>& p, int fi
 #pragma unroll
       for (int u = 0; u < PTS; u++) m4[u] = jn[u] >= 0 ? p.tgt_pts[jn[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    SGA_STAGE_PARAMS(p);
 #pragma unroll
     for (int u = 0; u < PTS; u++) {
       Tg[u][0] = m4[u].x, Tg[u][1] = m4[u].y, Tg[u][2] = m4[u].z;
@@ -1023,6 +1047,8 @@ __device__ __forceinline__ void linearize_group(const LinParams<Real>& p, int fi
   }
   Sym3<Real> Mh[PTS];  // the mahalanobis matrices, stored after the last load
   bool inl[PTS];
+  {
+  SGA_STAGE_PARAMS(p);
 #pragma unroll
   for (int u = 0; u < PTS; u++) {
     const int i = first + u * stride;
@@ -1033,14 +1059,16 @@ __device__ __forceinline__ void linearize_group(const LinParams<Real>& p, int fi
     if (act[u]) inl[u] = pair_moments<Real, FACTOR>(p, i, jn[u], within[u], Q[u][0], Q[u][1], Q[u][2], Tg[u][0], Tg[u][1], Tg[u][2], Mp[u], G[u], E[u], Mh[u]);
     inliers += __popcll(__ballot(inl[u]));
   }
+  }
+  SGA_STAGE_PARAMS(pw);
 #pragma unroll
   for (int u = 0; u < PTS; u++) {
     const int i = first + u * stride;
     if (act[u]) {
-      p.corr[i] = inl[u] ? jn[u] : -1;
+      pw.corr[i] = inl[u] ? jn[u] : -1;
       if constexpr (FACTOR == SGA_GICP) {
-        if (inl[u] && p.store_maha) {  // only robust factors read it back (error kernel); otherwise it is recomputed on demand
-          Real* m = p.maha + static_cast<size_t>(i) * 6;
+        if (inl[u] && pw.store_maha) {  // only robust factors read it back (error kernel); otherwise it is recomputed on demand
+          Real* m = pw.maha + static_cast<size_t>(i) * 6;
           m[0] = Mh[u].xx, m[1] = Mh[u].xy, m[2] = Mh[u].xz, m[3] = Mh[u].yy, m[4] = Mh[u].yz, m[5] = Mh[u].zz;
         }
       }
@@ -1048,6 +1076,7 @@ __device__ __forceinline__ void linearize_group(const LinParams<Real>& p, int fi
   }
   if (inliers == 0) return;  // wave-uniform
   accumulate_moments<Real, PTS>(P, Mp, G, E, inliers, acc_row, lane);
+#undef SGA_STAGE_PARAMS
 }
 
 template <typename Real, int FACTOR, int TARGET, int PTS>
@@ -1100,7 +1129,7 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(4))) void
   tile_schedule(p.num_tiles, tile, stride, tile_end, p.collectors > 0 ? p.producers : 0);
   for (; tile < tile_end; tile += stride) {
     const int base = tile * PTS * kTile;
-    linearize_group<Real, FACTOR, 0, PTS, false, true>(p, base + static_cast<int>(threadIdx.x), kTile, p.n, acc_row, lane, sh_failed[wave]);
+    linearize_group<Real, FACTOR, 0, PTS, false, true, true>(p, base + static_cast<int>(threadIdx.x), kTile, p.n, acc_row, lane, sh_failed[wave]);
     __syncthreads();
     {  // the walkers of this step: point of (sub-step u, wave w, lane l) = base + u * kTile + w * 64 + l; every wave counts them, wave 0 lists them
       int total = 0;
