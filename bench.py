@@ -553,18 +553,19 @@ def policy_leg(sga, kind, tgt, src, cabi_rate, cabi_pose, n=None):
         clouds = None
         if tgt is not None:
             clouds = (tgt.xyz(), src.xyz(), sga.api.sym6_from_mats(tgt.covs()), sga.api.sym6_from_mats(src.covs()))
-        r = policy_bench.run(kind, n or len(clouds[0]), reps=5 if kind in ("GICP", "VGICP") else 20, clouds=clouds)
+        r = policy_bench.run(kind, n or len(clouds[0]), reps=15 if kind in ("GICP", "VGICP") else 20, clouds=clouds)
         if r is None:
             return {"error": "oracle/_ref/policy_bench did not travel with the repository (built where /root/reference is mounted: make -C oracle/ref)"}
-        out = {k: r[k] for k in ("points", "whole_align_iterations_per_s", "inside_the_optimizer_iterations_per_s", "policy_calls_iterations_per_s", "per_align_ms", "lean", "reduction_slot_only_iterations_per_s",
-                                 "first_align_s", "first_bind_s", "num_inliers")}
+        out = {k: r[k] for k in ("points", "whole_align_iterations_per_s", "whole_align_median_iterations_per_s", "align_ms", "inside_the_optimizer_iterations_per_s", "policy_calls_iterations_per_s", "per_align_ms", "lean",
+                                 "reduction_slot_only_iterations_per_s", "first_align_s", "first_bind_s", "num_inliers")}
         out["c_abi_iterations_per_s"] = cabi_rate
         out["policy_calls_over_c_abi"] = r["policy_calls_iterations_per_s"] / cabi_rate if cabi_rate else None
         if cabi_pose is not None:
             T = np.array(r["T"]).reshape(4, 4).T
             dt, dr = pose_error(T, cabi_pose)
             out["pose_vs_c_abi"] = {"trans_m": dt, "rot_rad": dr}
-        out["note"] = ("whole_align = iterations / wall time of align() incl. the reference's own std::vector<Factor>(n) (registration.hpp:41: 144 B per source point, per_align_ms.reference_factor_vector) and its "
+        out["note"] = ("whole_align = iterations / wall time of the timed align() calls (their mean; align_ms lists every one of them and whole_align_median is the rate of the median call: on a two-socket host the "
+                       "first calls of a run sometimes take 2 - 5 ms — the content check streams 320 MB of host memory beside the registration and waits for the operating system's page migration) incl. the reference's own std::vector<Factor>(n) (registration.hpp:41: 144 B per source point, per_align_ms.reference_factor_vector) and its "
                        "count over the host factors (optimizer.hpp:146); inside_the_optimizer = the reference's optimize() between begin_align and end_align; policy_calls = inside ParallelReductionHIP::linearize / error only; "
                        "lean = verify_content and sync_inliers off; reduction_slot_only = Registration<Factor, ParallelReductionHIP> without HipAligned (since the Registration<> specialisation: the same bracket; before: content check + factor fill per linearize); upload + index build: first_bind_s, once per cloud")
         return out

@@ -8,6 +8,7 @@
 // VGICP (registration_helper.cpp:125-137): the target is the reference's own GaussianVoxelMap (0.5 m voxels, built here on the host by the
 // reference's insert()) in the target AND the tree slot.
 // Prints ONE json line: whole-align and inside-the-optimizer iteration rates, what the bracket costs, the pose of the last align.
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -80,13 +81,19 @@ static int run(const Target& target, const PointCloud& source, const Tree& tree,
   size_t iters = 0;
   double bind_s = 0.0, loop_s = 0.0, fill_s = 0.0, calls_s = 0.0;
   t0 = now();
+  std::vector<double> each_ms;
   for (int r = 0; r < reps; r++) {
+    const auto a0 = now();
     res = reg.align(target, source, tree, I);
+    each_ms.push_back(1e3 * secs(a0, now()));
     iters += res.iterations + 1;
     const auto b = reg.reduction.last_bracket_seconds();
     bind_s += std::get<0>(b), loop_s += std::get<1>(b), fill_s += std::get<2>(b), calls_s += std::get<3>(b);
   }
   const double total_s = secs(t0, now());
+  std::vector<double> sorted_ms = each_ms;
+  std::sort(sorted_ms.begin(), sorted_ms.end());
+  const double median_ms = sorted_ms[sorted_ms.size() / 2];
   // what the reference's align() itself spends per call before the optimizer runs: std::vector<Factor>(n) (registration.hpp:41)
   t0 = now();
   {
@@ -128,9 +135,13 @@ static int run(const Target& target, const PointCloud& source, const Tree& tree,
     "POLICY {\"kind\": \"%s\", \"points\": [%zu, %zu], \"num_gpus\": %d, \"reps\": %d, \"iterations\": %zu, \"first_align_s\": %.4f, \"first_bind_s\": %.4f, "
     "\"whole_align_iterations_per_s\": %.1f, \"inside_the_optimizer_iterations_per_s\": %.1f, \"policy_calls_iterations_per_s\": %.1f, \"per_align_ms\": {\"total\": %.3f, \"content_check\": %.3f, \"optimizer\": %.3f, "
     "\"optimizer_policy_calls\": %.3f, \"factor_fill\": %.3f, \"reference_factor_vector\": %.3f}, \"lean\": {\"whole_align_iterations_per_s\": %.1f, \"inside_the_optimizer_iterations_per_s\": %.1f, "
-    "\"policy_calls_iterations_per_s\": %.1f}, \"reduction_slot_only_iterations_per_s\": %.1f, \"num_inliers\": %zu, \"converged\": %d, \"T\": [",
+    "\"policy_calls_iterations_per_s\": %.1f}, \"reduction_slot_only_iterations_per_s\": %.1f, \"num_inliers\": %zu, \"converged\": %d, \"whole_align_median_iterations_per_s\": %.1f, ",
     kind, target.size(), source.size(), num_gpus, reps, iters, first_s, first_bind_s, iters / total_s, iters / loop_s, iters / calls_s, 1e3 * total_s / reps, 1e3 * bind_s / reps, 1e3 * loop_s / reps, 1e3 * calls_s / reps,
-    1e3 * fill_s / reps, 1e3 * factors_s, liters / lean_total_s, liters / lean_loop_s, liters / lean_calls_s, piters / plain_s, res.num_inliers, res.converged ? 1 : 0);
+    1e3 * fill_s / reps, 1e3 * factors_s, liters / lean_total_s, liters / lean_loop_s, liters / lean_calls_s, piters / plain_s, res.num_inliers, res.converged ? 1 : 0,
+    (static_cast<double>(iters) / reps) / (1e-3 * median_ms));
+  std::printf("\"align_ms\": [");
+  for (size_t k = 0; k < each_ms.size(); k++) std::printf("%s%.3f", k ? ", " : "", each_ms[k]);
+  std::printf("], \"T\": [");
   for (int k = 0; k < 16; k++) std::printf("%s%.12g", k ? ", " : "", res.T_target_source.matrix().data()[k]);
   std::printf("]}\n");
   return 0;
