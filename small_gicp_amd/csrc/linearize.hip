@@ -244,6 +244,7 @@ struct LinParams {
   uint32_t* __restrict__ cert_walked;
   Rigid<Real> T_prev;
   float cert_within2, cert_slack_min, cert_slack_max;
+  float cert_pad;  // headroom of the certificate check (see certify)
 };
 
 // XCD-aware tile schedule: workgroup b runs on XCD b % 8 (observed placement; used for L2 affinity only).  Each XCD
@@ -302,6 +303,7 @@ struct NNParams {
   float bound2;      // the walks find neighbours with kd_dist2 < bound2 (the rejector's reach + kSearchMargin)
   float within2;     // a neighbour counts for the rejector only if kd_dist2 < within2
   float slack_min, slack_max;  // exploration slack of a re-walk = clamp(motion, slack_min, slack_max) (SGA_SLACK_MIN / SGA_SLACK_MAX)
+  float cert_pad;    // headroom of the certificate check as a share of the point's motion (see certify; SGA_CERT_PAD)
   int* __restrict__ nn;
   int* __restrict__ nn2;   // the runner-up of every walk: second candidate of the certificate
   float* __restrict__ rex;
@@ -321,9 +323,17 @@ struct NNParams {
 };
 
 // Returns the shrunken radius (relative to the new pose) or a negative value if the certificate fails.
-__device__ __forceinline__ float certify(float rex, float moved, bool has_neighbour, float d2_new, float within2) {
+// Headroom (round 5): the DECISION asks for pad * moved metres more than the certificate needs, the radius handed on is the true one.
+// A point that is sent into the walk although its certificate holds is found again exactly, so nothing but the number of walkers
+// depends on it.  Why: the steps of an LM run shrink geometrically, and a certificate that survives this pass by less than the motion
+// still to come fails in one of the LATE passes — where the streaming kernel pays for the tail of a single walk —
+// whereas this pass walks thousands of points anyway and the re-walk (exploration slack = this pass's motion) buys a certificate that
+// lasts.  Measured on C3 (profiles/r05_cert_pad.txt): walkers of the passes after 1.7 / 0.29 / 0.05 mm 14 021 / 2 625 / 413 -> 2 091 /
+// 89 / 6 at pad 0.6, those passes 128 / 96 / 68 -> 92 / 78 / 62 us.  pad = 0: the plain check, bit for bit.
+__device__ __forceinline__ float certify(float rex, float moved, bool has_neighbour, float d2_new, float within2, float pad) {
   const float lim = rex - moved * 1.000001f;
-  const float lim2 = lim > 0.f ? lim * lim * 0.999995f : -1.f;
+  const float lim_d = lim - moved * pad;
+  const float lim2 = lim_d > 0.f ? lim_d * lim_d * 0.999995f : -1.f;
   const bool ok = has_neighbour ? d2_new < lim2 : lim2 > within2;  // no neighbour within reach before: still none
   return ok ? lim * 0.9999995f : -1.f;
 }
@@ -374,7 +384,7 @@ __device__ __forceinline__ int search_lane(const NNParams<Real>& p, int tile, in
     // the nearer of the two candidates (the canonical rule again: equidistant -> lower position)
     const bool swap = cand2 >= 0 && (d2 < d1 || (d2 == d1 && cand2 < seed));
     const int best = swap ? cand2 : seed;
-    const float r = certify(p.rex[i], moved, best >= 0, swap ? d2 : d1, p.within2);
+    const float r = certify(p.rex[i], moved, best >= 0, swap ? d2 : d1, p.within2, p.cert_pad);
     if (r >= 0.f) {
       p.rex[i] = r;
       if (swap) {
@@ -551,7 +561,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 6))) void
           }
           const bool swap = cand2 >= 0 && (d2 < d1 || (d2 == d1 && cand2 < seed));  // the canonical rule: equidistant -> lower position
           const int best = swap ? cand2 : seed;
-          const float r = certify(p.rex[i], moved, best >= 0, swap ? d2 : d1, p.within2);
+          const float r = certify(p.rex[i], moved, best >= 0, swap ? d2 : d1, p.within2, p.cert_pad);
           if (r >= 0.f) {
             p.rex[i] = r;
             if (swap) {
@@ -1009,7 +1019,7 @@ __device__ __forceinline__ void linearize_group(const LinParams<Real>& p0, int f
           const float d2 = c2[u] >= 0 ? kd_dist2(m4b[u].x, m4b[u].y, m4b[u].z, fx, fy, fz) : INFINITY;
           const bool swap = c2[u] >= 0 && (d2 < d1 || (d2 == d1 && c2[u] < jn[u]));  // the canonical rule: equidistant -> lower position
           const int best = swap ? c2[u] : jn[u];
-          const float r = certify(rx[u], moved, best >= 0, swap ? d2 : d1, p.cert_within2);
+          const float r = certify(rx[u], moved, best >= 0, swap ? d2 : d1, p.cert_within2, p.cert_pad);
           failed = !(r >= 0.f);
           // settled: the shrunken radius; failed: the flag of the walkers' kernel, which is also the exploration slack of the re-walk
           p.cert_rex[i] = failed ? -fminf(fmaxf(moved, p.cert_slack_min), p.cert_slack_max) : r;
@@ -1651,6 +1661,8 @@ static bool g_fuse_search = getenv("SGA_FUSE_SEARCH") ? atoi(getenv("SGA_FUSE_SE
 static const int g_lpt = getenv("SGA_LPT") ? atoi(getenv("SGA_LPT")) : 1;
 static const float g_slack_min = getenv("SGA_SLACK_MIN") ? static_cast<float>(atof(getenv("SGA_SLACK_MIN"))) : 3e-4f;
 static const float g_slack_max = getenv("SGA_SLACK_MAX") ? static_cast<float>(atof(getenv("SGA_SLACK_MAX"))) : 0.02f;
+// headroom of the certificate check (certify): a point walks unless its certificate survives PAD x its own motion beyond what this pass needs
+static const float g_cert_pad = getenv("SGA_CERT_PAD") ? static_cast<float>(atof(getenv("SGA_CERT_PAD"))) : 0.6f;
 static double g_queue_delta = getenv("SGA_QUEUE_DELTA") ? atof(getenv("SGA_QUEUE_DELTA")) : 0.02;
 // 1 (default): the one-query-per-lane search kernels walk with the fast leaf scan (32-bit keys, packed fp32; exact repeat of the
 // queries it cannot decide); 0: the exact 64-bit keys throughout.  Results do not depend on it.
@@ -1757,6 +1769,7 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
     q.T = p.T;
     q.within2 = p.bound2;
     q.slack_min = g_slack_min, q.slack_max = g_slack_max;
+    q.cert_pad = std::max(g_cert_pad, 0.f);
     q.bound2 = p.bound2 * (1.f + kSearchMargin) * (1.f + kSearchMargin);
     q.nn = pb->hint.p;
     q.nn2 = pb->hint2.p;
@@ -1843,6 +1856,7 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
       p.T_prev = q.T_prev;
       p.cert_within2 = q.within2;
       p.cert_slack_min = q.slack_min, p.cert_slack_max = q.slack_max;
+      p.cert_pad = q.cert_pad;
       const size_t lds = std::max<size_t>(words, 1) * 64 * sizeof(uint32_t) * (kTile / 64);
 #define SGA_CERTIFY(F)                                                                                                                      \
   do {                                                                                                                                      \
