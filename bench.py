@@ -520,16 +520,16 @@ def helper_leg(sga, which):
 
 
 def scaling_model(world, per_rank):
-    """What the design predicts for ONE 1M <-> 1M registration sharded over N GPUs (profiles/r04_shard_model.txt: one GPU
+    """What the design predicts for ONE 1M <-> 1M registration sharded over N GPUs (profiles/r05_shard_model.txt: one GPU
     doing the work of one rank of N): K1 per pass of a 1 / N source slice + 6.5 us of host work + the all-reduce.  Printed beside the
     measurement so that the first real multi-GPU run is a one-line comparison; `with_measured_collective` replaces the assumed 20 us by
     this run's own per_rank.collective_avg_us."""
-    k1 = {1: 128.6, 2: 95.7, 4: 72.3, 8: 62.1}
+    k1 = {1: 120.9, 2: 86.2, 4: 77.6, 8: 53.2}  # us per pass, measured on the round's final build
     host_us, assumed = 6.5, 20.0
     n = min(k1, key=lambda g: abs(g - world))
     out = {"shard_k1_us": k1, "host_us": host_us, "assumed_allreduce_us": assumed,
            "predicted_iterations_per_s": {str(g): 1e6 / (v + host_us + (assumed if g > 1 else 0.0)) for g, v in k1.items()},
-           "note": "a pass over an N-th of the source still costs half a pass (search chains, launch, row reduction, hand-off do not shrink with the shard): one job saturates near 1.5x at 8 GPUs; "
+           "note": "a pass over an N-th of the source still costs half a pass (search chains, launch, row reduction, hand-off do not shrink with the shard): one job saturates near 1.6x at 8 GPUs; "
                    "weak scaling (--scaling weak) and frame pairs per rank (kitti_odom_frame_pairs_per_rank) are the modes that scale"}
     try:
         coll = [r.get("collective_avg_us") for r in (per_rank or []) if r and r.get("collective_avg_us")]
