@@ -251,3 +251,56 @@ def test_fast_leaf_scan_equals_exact_scan_on_adversarial_inputs(tmp_path):
         assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     p = subprocess.run([sys.executable, script, "--compare", str(tmp_path / "f1.npz"), str(tmp_path / "f0.npz")], capture_output=True, text=True, timeout=120)
     assert p.returncode == 0, p.stdout[-3000:]
+
+
+_HEADROOM_CHAIN = r"""
+import hashlib, json
+import numpy as np
+from scipy.spatial.transform import Rotation
+import small_gicp_amd as sga
+
+target, source, T_gt = sga.synthetic.registration_pair(150_000)  # >= 131 072 source points: the streaming warm kernel takes the millimetre passes
+tgt, src = sga.PointCloud(target), sga.PointCloud(source)
+sga.estimate_covariances(tgt, None, 10)
+sga.estimate_covariances(src, None, 10)
+pb = sga.Problem(sga.KdTree(tgt), src)
+st = sga.make_setting("GICP", max_correspondence_distance=1.0)
+rv = Rotation.from_matrix(T_gt[:3, :3]).as_rotvec()
+h, sums = hashlib.sha256(), []
+for f in (0.0, 0.6, 0.9, 0.98, 0.996, 0.9992, 0.99985, 0.99997, 1.0, 1.0):
+    T = np.eye(4)
+    T[:3, :3] = Rotation.from_rotvec(rv * f).as_matrix()
+    T[:3, 3] = T_gt[:3, 3] * f
+    H, b, e, n = pb.linearize(st.factor, T)
+    h.update(np.ascontiguousarray(pb.factors()[0]).tobytes())
+    sums.append([float(e), int(n), float(np.abs(H).max())])
+s = pb.pass_stats()
+print("RESULT " + json.dumps({"hash": h.hexdigest(), "sums": sums, "warm": s["warm_passes"], "walked": s["walked_points"]}))
+"""
+
+
+def test_certificate_headroom_changes_nothing_but_the_walkers():
+    """SGA_CERT_PAD (linearize.hip: certify) only decides which points of a warm pass search again — every one of them is found again exactly —
+    so a pose chain shaped like an LM run gives the same correspondences on every pass whatever the value: the plain check (0), the default,
+    and a value that sends nearly every point into the walk.  The switch is read when the library loads, hence one process per value."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for pad in ("0", "0.6", "5"):
+        env = dict(os.environ, SGA_CERT_PAD=pad, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        r = subprocess.run([sys.executable, "-c", _HEADROOM_CHAIN], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (pad, r.stdout[-2000:], r.stderr[-2000:])
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1]
+        out[pad] = json.loads(line[len("RESULT "):])
+    print({k: (v["warm"], v["walked"]) for k, v in out.items()})
+    ref = out["0"]
+    assert ref["warm"] >= 4, ref
+    for pad, v in out.items():
+        assert v["hash"] == ref["hash"], (pad, "correspondences differ")
+        assert v["warm"] == ref["warm"]
+        for (e, n, hm), (e0, n0, hm0) in zip(v["sums"], ref["sums"]):
+            assert n == n0 and abs(e - e0) <= 1e-6 * abs(e0) and abs(hm - hm0) <= 1e-6 * hm0, (pad, e, e0, n, n0)
+    assert out["5"]["walked"] > out["0"]["walked"], out  # (the large value does send more points into the walk)
