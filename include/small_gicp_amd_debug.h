@@ -28,6 +28,12 @@ int sga_problem_get_grid_stats(const sga_problem* pb, uint64_t out[6]);
  * no grid (default 65536; applies to indices built afterwards).  Negative arguments keep the current value.
  * Environment: SGA_GRID, SGA_GRID_MIN_POINTS. */
 void sga_set_grid_mode(int mode, long long min_points);
+/* The host arithmetic of the frame check of sharded registrations (linearize.hip: problem_check_shard_frames), exposed so that it can be
+ * tested without a device: pack() turns a source origin into the SGA_FRAME_CHECK_DOUBLES values a rank contributes to the all-reduce,
+ * agree() says whether the ranks whose contributions were summed all named the same origin (exact for any origin, up to 1024 ranks). */
+#define SGA_FRAME_CHECK_DOUBLES 32
+void sga_debug_shard_frame_pack(const double origin[3], double out[SGA_FRAME_CHECK_DOUBLES]);
+int sga_debug_shard_frame_agree(const double sum[SGA_FRAME_CHECK_DOUBLES]);
 /* Diagnostics build only (make trips): loop-trip counters of the kd walk and the start / end clock of every search wave. */
 int sga_debug_kd_trips(unsigned long long* out16);
 int sga_debug_kd_wave_times(unsigned long long* out, int waves);

@@ -135,6 +135,8 @@ SYMBOLS = [
     ("sga_problem_get_sorted_points", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("sga_problem_get_grid_stats", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     ("sga_set_grid_mode", None, [C.c_int, C.c_longlong]),
+    ("sga_debug_shard_frame_pack", None, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    ("sga_debug_shard_frame_agree", C.c_int, [C.POINTER(C.c_double)]),
     ("sga_debug_kd_trips", C.c_int, [C.c_void_p]),
     ("sga_debug_kd_wave_times", C.c_int, [C.c_void_p, C.c_int]),
     ("sga_set_search_mode", None, [C.c_int, C.c_int, C.c_int]),

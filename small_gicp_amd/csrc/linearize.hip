@@ -2236,19 +2236,45 @@ __global__ void frame_accumulator_kernel(double* __restrict__ acc, double ox, do
 // Sharded contexts add the ranks' accumulators: their moments are sums over source points in the SOURCE's device frame, so every rank's
 // shard must live in the same one (slices of one uploaded cloud do: sga_cloud_slice; separately uploaded shards name a common origin:
 // sga_cloud_create_*_origin).  Checked once per problem with one small sum over the ranks: all equal <=> n sum(o^2) == (sum o)^2.
+// The ranks of a sharded registration must share ONE source frame (their accumulators are added).  Compared with one all-reduce of sums
+// that are EXACT for any number of ranks and any origin (n * sum(o^2) == (sum o)^2 on the doubles themselves rounds differently
+// on both sides for 3+ ranks and non-round origins): every origin coordinate is cut into four 16-bit pieces of its bit pattern, each an
+// integer < 2^16, and the ranks add the pieces p and their squares p^2.  All of those sums are integers below 2^53 for up to 2^10 ranks, so
+// they do not depend on the order of the additions, every rank reads the same numbers and takes the same decision, and by the equality case
+// of Cauchy-Schwarz  n * sum(p^2) == (sum p)^2  holds iff all ranks hold the same piece.
+constexpr int kFrameCheckDoubles = SGA_FRAME_CHECK_DOUBLES;
+void shard_frame_pack(const double origin[3], double out[kFrameCheckDoubles]) {
+  for (int k = 0; k < 3; k++) {
+    const double o = origin[k] + 0.0;  // -0.0 and +0.0 are one origin
+    unsigned long long bits;
+    memcpy(&bits, &o, sizeof(bits));
+    for (int j = 0; j < 4; j++) {
+      const double piece = static_cast<double>((bits >> (16 * j)) & 0xffffull);
+      out[4 * k + j] = piece;
+      out[12 + 4 * k + j] = piece * piece;
+    }
+  }
+  out[24] = 1.0;  // the number of ranks
+  for (int i = 25; i < kFrameCheckDoubles; i++) out[i] = 0.0;
+}
+bool shard_frame_agree(const double sum[kFrameCheckDoubles]) {
+  for (int i = 0; i < 12; i++)
+    if (sum[24] * sum[12 + i] != sum[i] * sum[i]) return false;
+  return true;
+}
 int problem_check_shard_frames(sga_context* ctx, sga_problem* pb) {
   if (pb->frame_checked || !ctx->sharded()) return SGA_OK;
-  double h[8] = {pb->src_origin[0], pb->src_origin[1], pb->src_origin[2], pb->src_origin[0] * pb->src_origin[0], pb->src_origin[1] * pb->src_origin[1], pb->src_origin[2] * pb->src_origin[2], 1.0, 0.0};
+  double h[kFrameCheckDoubles];
+  shard_frame_pack(pb->src_origin, h);
   DevBuf<double> d;
-  SGA_TRY(d.alloc(8));
+  SGA_TRY(d.alloc(kFrameCheckDoubles));
   SGA_HIP(hipMemcpyAsync(d.p, h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
   SGA_HIP(hipStreamSynchronize(ctx->stream));
-  SGA_TRY(comm_allreduce_sum(ctx, d.p, 8));
+  SGA_TRY(comm_allreduce_sum(ctx, d.p, kFrameCheckDoubles));
   SGA_HIP(hipMemcpyAsync(h, d.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
   SGA_HIP(hipStreamSynchronize(ctx->stream));
-  for (int k = 0; k < 3; k++)
-    if (h[6] * h[3 + k] != h[k] * h[k])
-      return fail(SGA_ERR_INVALID, "the source shards of the ranks live in different device frames (origins differ): slice ONE uploaded cloud (sga_cloud_slice) or upload the shards with a common origin (sga_cloud_create_f64_origin)");
+  if (!shard_frame_agree(h))
+    return fail(SGA_ERR_INVALID, "the source shards of the ranks live in different device frames (origins differ): slice ONE uploaded cloud (sga_cloud_slice) or upload the shards with a common origin (sga_cloud_create_f64_origin)");
   pb->frame_checked = true;
   return SGA_OK;
 }
@@ -2259,6 +2285,9 @@ using namespace sga;
 static bool g_error_model = getenv("SGA_ERROR_MODEL") ? atoi(getenv("SGA_ERROR_MODEL")) != 0 : true;
 
 extern "C" {
+
+void sga_debug_shard_frame_pack(const double origin[3], double out[SGA_FRAME_CHECK_DOUBLES]) { shard_frame_pack(origin, out); }
+int sga_debug_shard_frame_agree(const double sum[SGA_FRAME_CHECK_DOUBLES]) { return shard_frame_agree(sum) ? 1 : 0; }
 
 void sga_unpack_accumulator(const double acc[SGA_ACCUM_DOUBLES], double H[36], double b[6], double* e, uint64_t* num_inliers) {
   int k = 0;

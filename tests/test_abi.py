@@ -211,3 +211,47 @@ def test_small_gicp_module_name_exports_the_reference_surface():
     q = inspect.signature(small_gicp.preprocess_points).parameters
     assert q["num_neighbors"].default == 10 and q["downsampling_resolution"].default == 0.25
     assert small_gicp.DistanceRejector().max_dist_sq == 1.0
+
+
+def test_shard_frame_check_is_exact_for_any_rank_count():
+    """the ranks of a sharded registration compare their source origins through ONE sum over the ranks
+    (linearize.hip: problem_check_shard_frames).  The sums must be exact whatever the origin and the number of ranks: identical
+    origins are accepted (n = 1 .. 9, origins up to 1e6 m with fractional parts), a single deviating rank — by one ulp — is refused,
+    and every rank takes the same decision (the decision is a function of the summed values alone).  The sums are integers below 2^53:
+    their value does not depend on the order in which a transport adds them (checked by summing in shuffled orders)."""
+    lib = sga.load()
+    N = 32
+
+    def pack(o):
+        o = np.ascontiguousarray(o, dtype=np.float64)
+        out = np.zeros(N)
+        lib.sga_debug_shard_frame_pack(o.ctypes.data_as(C.POINTER(C.c_double)), out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out
+
+    def agree(total):
+        total = np.ascontiguousarray(total, dtype=np.float64)
+        return bool(lib.sga_debug_shard_frame_agree(total.ctypes.data_as(C.POINTER(C.c_double))))
+
+    rng = np.random.default_rng(7)
+    for n in range(1, 10):
+        for _ in range(200):
+            o = rng.uniform(-1e6, 1e6, 3)
+            if rng.random() < 0.2:
+                o = np.round(o / 128.0) * 128.0  # the library's own origins
+            rows = [pack(o) for _ in range(n)]
+            for _ in range(3):  # any order of the additions gives the same doubles
+                rng.shuffle(rows)
+                tot = np.zeros(N)
+                for r in rows:
+                    tot = tot + r
+                assert agree(tot), (n, o)
+            if n >= 2:
+                bad = o.copy()
+                k = rng.integers(3)
+                bad[k] = np.nextafter(bad[k], np.inf) if rng.random() < 0.5 else bad[k] + 128.0 * rng.integers(1, 5)
+                rows[rng.integers(n)] = pack(bad)
+                assert not agree(np.sum(rows, axis=0)), (n, o, bad)
+    assert agree(pack([0.0, -0.0, 0.0]) + pack([-0.0, 0.0, 0.0]))  # one origin
+    # 1024 ranks at the largest piece value: still exact
+    big = pack([-np.nextafter(0.0, 1.0)] * 3)  # (bit pattern with high pieces set)
+    assert agree(big * 1024)

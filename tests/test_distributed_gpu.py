@@ -155,6 +155,10 @@ st = sga.make_setting("GICP", math_mode="fp64")
 same = sga.Problem(tree, shard_cloud([2944.0, -2048.0, 0.0]), T_far)     # both ranks name the same origin: accepted
 Hs, bs, es, ns = same.linearize(st.factor, T_far)
 out["common_origin_inliers"] = int(ns)
+# a common origin that is NOT a round number (ADVICE r5: n * sum(o^2) == (sum o)^2 on the doubles rejected such origins for 3+ ranks)
+odd = sga.Problem(tree, shard_cloud([2943.7312345678, -2047.9001, 0.123456789]), T_far)
+Ho, bo, eo, no = odd.linearize(st.factor, T_far)
+out["odd_origin_inliers"] = int(no)
 try:
     bad = sga.Problem(tree, shard_cloud([2944.0 + 128.0 * rank, -2048.0, 0.0]), T_far)  # origins differ between the ranks: refused, loudly, on every rank
     bad.linearize(st.factor, T_far)
@@ -167,20 +171,22 @@ dist.destroy_process_group()
 """
 
 
-def test_two_ranks_share_one_registration_through_the_callback_transport(tmp_path, c1_gold):
-    """sga_comm_init_callback: the real kernels, the 96-double accumulator and the per-rank error model with two ranks on device 0."""
+@pytest.mark.parametrize("world", [2, 3])
+def test_two_ranks_share_one_registration_through_the_callback_transport(tmp_path, c1_gold, world):
+    """sga_comm_init_callback: the real kernels, the 96-double accumulator and the per-rank error model with two (and three) ranks on device 0."""
     script = tmp_path / "worker_cb.py"
     script.write_text(WORKER_CB)
     env = dict(os.environ, SGA_ROOT=ROOT, SGA_TMP=str(tmp_path), MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29741", str(script)]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1", "--master-port", str(29739 + world), str(script)]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
-    res = [json.load(open(tmp_path / ("result_%d.json" % r))) for r in range(2)]
+    res = [json.load(open(tmp_path / ("result_%d.json" % r))) for r in range(world)]
     g = c1_gold["cases"]["GICP"]
     for r in res:
         assert "different device frames" in r["differing_origins"], r["differing_origins"]
         assert abs(r["common_origin_inliers"] - r["fp64"]["lin_inliers"]) <= 2  # the shifted shards with a common origin: the registration problem of the unshifted ones
-        assert r["counts"] == [8, 96], r["counts"]              # one collective per linearization (system + error-model moments), + once per problem the 8 doubles that compare the ranks' source frames
+        assert abs(r["odd_origin_inliers"] - r["fp64"]["lin_inliers"]) <= 2     # ... and with a common origin that is no round number
+        assert r["counts"] == [32, 96], r["counts"]             # one collective per linearization (system + error-model moments), + once per problem the 32 doubles that compare the ranks' source frames
         for math, tol in (("fp64", 1e-9), ("fp32", 1e-5)):
             m = r[math]
             dt, dr = pose_error(np.array(m["T"]), np.array(m["single"]))
@@ -192,10 +198,11 @@ def test_two_ranks_share_one_registration_through_the_callback_transport(tmp_pat
             assert abs(m["error"] - m["single_error"]) <= 1e-6 * abs(m["single_error"])
             dt, dr = pose_error(np.array(m["T"]), np.array(g["T"]))
             assert dt < 1e-4 and dr < 1e-4
-    assert res[0]["fp64"]["T"] == res[1]["fp64"]["T"] and res[0]["fp32"]["T"] == res[1]["fp32"]["T"]  # same reduced numbers, same host LM on both ranks
+    for r in res[1:]:
+        assert res[0]["fp64"]["T"] == r["fp64"]["T"] and res[0]["fp32"]["T"] == r["fp32"]["T"]  # same reduced numbers, same host LM on every rank
     # collectives: one per linearization only (iterations + 1 per align, + the explicit linearize)
     it = res[0]["fp64"]["iterations"] + res[0]["fp32"]["iterations"]
-    assert res[0]["collectives"] <= it + 2 + 2 + 4 + 2 + 3, res[0]["collectives"]  # (+ 2: the frame check of the two problems; + 3: the two origin cases at the end)
+    assert res[0]["collectives"] <= it + 2 + 2 + 4 + 2 + 5, res[0]["collectives"]  # (+ 2: the frame check of the two problems; + 5: the three origin cases at the end)
 
 
 @pytest.mark.gpu
