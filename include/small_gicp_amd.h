@@ -66,7 +66,15 @@ int sga_context_synchronize(sga_context* ctx);
 void* sga_context_stream(sga_context* ctx); /* the hipStream_t */
 
 /* ---- clouds (points/traits.hpp:15-78 accessor protocol: size / point / normal / cov) --------------------------------- */
-/* fp32 input: xyz n*3, normals n*3 or NULL, cov6 n*6 or NULL */
+/* Pinned host memory for the caller's scans (round 6).  The reference's drivers hold every scan in host memory before they time a frame
+ * (benchmark/benchmark_odom.hpp:36-47, odometry_benchmark.cpp: the points are read into std::vector<Eigen::Vector4f> first); a caller of
+ * this library that reads its scans into memory from sga_host_alloc (or any hipHostMalloc / hipHostRegister'd buffer) spares the upload
+ * its only CPU pass: sga_cloud_create_f32 recognises such arrays and lets the device read them in place.  Ordinary (pageable) arrays
+ * work as before: they are copied once into the context's pinned staging ring. */
+int sga_host_alloc(size_t bytes, void** out);
+int sga_host_free(void* p);
+/* fp32 input: xyz n*3, normals n*3 or NULL, cov6 n*6 or NULL.  The arrays are free for reuse when the call returns (in stream-ordered
+ * mode too: a pageable array has been copied, a pinned one has been read). */
 int sga_cloud_create_f32(sga_context* ctx, const float* xyz, const float* normals, const float* cov6, size_t n, sga_cloud** out);
 /* Reference PointCloud layout (points/point_cloud.hpp:69-71): xyzw n*4 doubles, normals n*4 doubles or NULL, covs n*16 doubles (4x4) or NULL */
 int sga_cloud_create_f64(sga_context* ctx, const double* xyzw, const double* normals4, const double* cov4x4, size_t n, sga_cloud** out);

@@ -28,6 +28,10 @@ int sga_problem_get_grid_stats(const sga_problem* pb, uint64_t out[6]);
  * no grid (default 65536; applies to indices built afterwards).  Negative arguments keep the current value.
  * Environment: SGA_GRID, SGA_GRID_MIN_POINTS. */
 void sga_set_grid_mode(int mode, long long min_points);
+/* Normal / covariance estimation: clouds of at most max_points points search their neighbours with one wave per query (csrc/knn_wave.hpp:
+ * the form for clouds that do not fill the chip), larger ones with one query per lane.  Both are exact; the tests compare them.
+ * Default 32768 (environment: SGA_KNN_WAVE_MAX); 0 = never. */
+void sga_set_knn_wave_max(long long max_points);
 /* The host arithmetic of the frame check of sharded registrations (linearize.hip: problem_check_shard_frames), exposed so that it can be
  * tested without a device: pack() turns a source origin into the SGA_FRAME_CHECK_DOUBLES values a rank contributes to the all-reduce,
  * agree() says whether the ranks whose contributions were summed all named the same origin (exact for any origin, up to 1024 ranks). */

@@ -28,6 +28,8 @@ from .api import (  # noqa: F401
     set_warm_limit,
     make_setting,
     optimize,
+    pinned_copy,
+    pinned_empty,
     preprocess_points,
     unpack_accumulator,
     voxelgrid_sampling,

@@ -133,6 +133,41 @@ def mats_from_sym6(c6):
     return m
 
 
+class _PinnedBlock:
+    """Owner of one sga_host_alloc block (freed when the last array viewing it is gone)."""
+
+    def __init__(self, nbytes):
+        self.p = C.c_void_p()
+        check(load().sga_host_alloc(int(nbytes), C.byref(self.p)))
+        self.nbytes = int(nbytes)
+
+    def __del__(self):
+        if getattr(self, "p", None) and self.p.value:
+            load().sga_host_free(self.p)
+            self.p = C.c_void_p()
+
+
+def pinned_empty(shape, dtype=np.float32):
+    """A numpy array in pinned host memory (sga_host_alloc).  Scans read into such arrays are uploaded without a CPU copy: the device reads
+    them in place (PointCloud(points) recognises them) — what a driver that preloads its scans into host memory should use
+    (benchmark/benchmark_odom.hpp:36-47 keeps every scan in host memory before the timed loop).  The block is freed with the last array
+    that views it."""
+    dt = np.dtype(dtype)
+    count = int(np.prod(shape)) if np.ndim(shape) else int(shape)
+    block = _PinnedBlock(max(1, count * dt.itemsize))
+    buf = (C.c_char * block.nbytes).from_address(block.p.value)
+    buf._sga_block = block  # np.frombuffer keeps `buf` alive, `buf` keeps the block
+    return np.frombuffer(buf, dtype=dt, count=count).reshape(shape)
+
+
+def pinned_copy(a, dtype=np.float32):
+    """`a` copied into pinned host memory (C-contiguous, `dtype`)."""
+    a = np.asarray(a)
+    out = pinned_empty(a.shape, dtype)
+    out[...] = a
+    return out
+
+
 class PointCloud:
     """Device-resident point cloud (points [+ normals] [+ covariances]); mirrors small_gicp.PointCloud."""
 
@@ -163,7 +198,8 @@ class PointCloud:
             rel = np.ascontiguousarray(p3 - origin if origin.any() else p3, dtype=np.float32)
             check(load().sga_cloud_create_f32_origin(self.ctx.h, _fp(rel), _fp(nrm), _fp(c6), len(rel), _dp(origin), C.byref(self.h)))
         else:
-            xyz = np.ascontiguousarray(pts[:, :3], dtype=np.float32)
+            # (an (N,3) float32 C-contiguous array — e.g. one from pinned_empty — goes down as it is: no copy on this side)
+            xyz = pts if (pts.shape[1] == 3 and pts.dtype == np.float32 and pts.flags.c_contiguous) else np.ascontiguousarray(pts[:, :3], dtype=np.float32)
             check(load().sga_cloud_create_f32(self.ctx.h, _fp(xyz), _fp(nrm), _fp(c6), len(xyz), C.byref(self.h)))
 
     def __del__(self):

@@ -110,8 +110,27 @@ struct sga_context {
   sga::DevBuf<unsigned> d_ticket; // arrival counter of the reduction kernel (linearize.hip), zero between launches
   double* h_accum = nullptr;      // pinned + device-mapped: [0, 128) a result, word 128 = sequence number of the last published result
   double* h_accum_dev = nullptr;  // device address of h_accum
-  void* h_stage = nullptr;        // pinned staging buffer for uploads (context.hip), grow-only
-  size_t h_stage_bytes = 0;
+  // pinned, device-mapped staging ring for uploads from pageable memory (context.hip): the pack kernel reads a slot over PCIe while
+  // the host fills the next one; a slot is reused once the event recorded behind its reader has completed
+  struct StageSlot {
+    void* host = nullptr;
+    void* dev = nullptr;
+    size_t bytes = 0;
+    hipEvent_t done = nullptr;
+    bool busy = false;
+  };
+  static constexpr int kStageSlots = 3;
+  StageSlot stage[kStageSlots];
+  unsigned stage_next = 0;
+  // notes (notes.hpp): small results handed to the host through mapped memory
+  unsigned long long* h_notes = nullptr;      // kNoteSlots x kNoteWords words behind h_accum
+  unsigned long long* h_notes_dev = nullptr;
+  unsigned long long note_seq = 0;
+  // voxel grid (preprocess.hip: ds_segments_kernel): look-back status words, {arrival counter, runs, valid points}, launch epoch
+  sga::DevBuf<unsigned long long> vg_status;
+  sga::DevBuf<uint32_t> vg_scratch;
+  unsigned vg_epoch = 0;
+  sga::DevBuf<int> d_box;         // bounding-box accumulator of box_reduce_publish: identity values + arrival counter between launches
   int* h_scratch = nullptr;       // 16 pinned ints behind h_accum: small asynchronous read-backs (bounding boxes)
   unsigned long long publish_seq = 0;
   sga::DevBuf<uint8_t> d_temp;    // rocPRIM temp storage (grow-only)
@@ -191,6 +210,9 @@ struct sga_cloud {
   mutable sga::Ready ready;
   size_t n = 0;
   double origin[3] = {0, 0, 0};  // the device holds p - origin (see "device frames" above)
+  // bounding box of the finite records (device frame), when the producer knows it for free (uploads): lets the voxel grid sort short keys
+  bool has_box = false;
+  float box_lo[3] = {0, 0, 0}, box_hi[3] = {0, 0, 0};
   bool has_normals = false, has_covs = false;
   sga::DevBuf<float4> pts;   // w = bitcast(original index)
   sga::DevBuf<float4> nrm;
@@ -273,6 +295,7 @@ struct sga_problem {
   sga::DevBuf<float> rex;        // exclusion radius around the query (kd_search.hpp): every target point but the two candidates lies beyond it
   sga::DevBuf<int> dbg_leaves;   // diagnostics (sga_problem_set_search_stats): leaves scanned per source point in the last pass
   sga::DevBuf<uint32_t> walked;  // statistics, one counter per 64 source points: lanes of warm passes that had to walk
+  bool state_fresh = false;      // hint / hint2 / corr still hold the "none" problem_state_init_kernel wrote: the first registration skips its own reset
   double T_prev[16] = {0};       // pose of the last linearization (column-major), valid iff prev_valid
   bool prev_valid = false;
   int prev_math = 0;

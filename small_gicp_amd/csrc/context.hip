@@ -1,7 +1,13 @@
 // Context (one GPU + one stream), error plumbing and device-resident clouds.
 #include "common.hpp"
+#include "notes.hpp"
 
+#include <chrono>
 #include <cmath>
+#include <thread>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 #include <map>
 #include <mutex>
@@ -272,22 +278,74 @@ static void dev_cache_context_destroyed(int device, hipStream_t stream) {
   }
 }
 
-__global__ void pack_cloud_f32_kernel(const float* __restrict__ xyz, const float* __restrict__ nrm, const float* __restrict__ cov6, size_t n, float4* __restrict__ pts, float4* __restrict__ onrm, Cov8* __restrict__ ocov) {
-  const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
-  if (i >= n) return;
-  pts[i] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], __uint_as_float(static_cast<uint32_t>(i)));
-  if (nrm) onrm[i] = make_float4(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2], 0.f);
-  if (cov6) {
-    Cov8 c;
-    c.xx = cov6[6 * i];
-    c.xy = cov6[6 * i + 1];
-    c.xz = cov6[6 * i + 2];
-    c.yy = cov6[6 * i + 3];
-    c.yz = cov6[6 * i + 4];
-    c.zz = cov6[6 * i + 5];
-    c.pad0 = c.pad1 = 0.f;
-    ocov[i] = c;
+// Upload: xyz (3 floats per point, AoS), optional normals (3) and covariances (6, symmetric) -> the 16 / 16 / 32-byte device records.
+// The inputs may live in pinned HOST memory (the staging ring, or the caller's own pinned buffer): every dword is then read over PCIe
+// exactly once, with unit-stride loads through LDS (a per-thread stride of 12 bytes would touch every line three times, and mapped host
+// memory is not cached).  recentre: records = fl32(double(x) - origin) (common.hpp, device frames).  d_box != nullptr: the bounding
+// box of the finite INPUT coordinates is handed to the host as a note (notes.hpp) — how a pinned upload learns its origin.
+__global__ __launch_bounds__(256) void pack_cloud_kernel(const float* __restrict__ xyz, const float* __restrict__ nrm, const float* __restrict__ cov6, size_t n, double ox, double oy, double oz, int recentre, float4* __restrict__ pts,
+                                                         float4* __restrict__ onrm, Cov8* __restrict__ ocov, int* __restrict__ d_box, unsigned long long* __restrict__ note_slot, unsigned long long seq) {
+  __shared__ float sh[256 * 6];
+  const size_t base = blockIdx.x * static_cast<size_t>(256);
+  const size_t i = base + threadIdx.x;
+  const int t = threadIdx.x;
+  {
+    const size_t f0 = base * 3, fend = n * 3;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const size_t f = f0 + k * 256 + t;
+      sh[k * 256 + t] = f < fend ? xyz[f] : 0.f;
+    }
   }
+  __syncthreads();
+  float x = sh[3 * t], y = sh[3 * t + 1], z = sh[3 * t + 2];
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  if (i < n) {
+    if (d_box != nullptr) {  // finite coordinates only (what the origin is chosen from)
+      if (fabsf(x) <= 3.4028234e38f) lo[0] = hi[0] = x;
+      if (fabsf(y) <= 3.4028234e38f) lo[1] = hi[1] = y;
+      if (fabsf(z) <= 3.4028234e38f) lo[2] = hi[2] = z;
+    }
+    if (recentre) {
+      x = static_cast<float>(static_cast<double>(x) - ox);
+      y = static_cast<float>(static_cast<double>(y) - oy);
+      z = static_cast<float>(static_cast<double>(z) - oz);
+    }
+    pts[i] = make_float4(x, y, z, __uint_as_float(static_cast<uint32_t>(i)));
+  }
+  if (nrm != nullptr) {
+    __syncthreads();
+    const size_t f0 = base * 3, fend = n * 3;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const size_t f = f0 + k * 256 + t;
+      sh[k * 256 + t] = f < fend ? nrm[f] : 0.f;
+    }
+    __syncthreads();
+    if (i < n) onrm[i] = make_float4(sh[3 * t], sh[3 * t + 1], sh[3 * t + 2], 0.f);
+  }
+  if (cov6 != nullptr) {
+    __syncthreads();
+    const size_t f0 = base * 6, fend = n * 6;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      const size_t f = f0 + k * 256 + t;
+      sh[k * 256 + t] = f < fend ? cov6[f] : 0.f;
+    }
+    __syncthreads();
+    if (i < n) {
+      Cov8 c;
+      c.xx = sh[6 * t];
+      c.xy = sh[6 * t + 1];
+      c.xz = sh[6 * t + 2];
+      c.yy = sh[6 * t + 3];
+      c.yz = sh[6 * t + 4];
+      c.zz = sh[6 * t + 5];
+      c.pad0 = c.pad1 = 0.f;
+      ocov[i] = c;
+    }
+  }
+  if (d_box != nullptr) box_reduce_publish(lo, hi, d_box, note_slot, seq);
 }
 
 __global__ void unpack_cloud_kernel(const float4* __restrict__ pts, const float4* __restrict__ nrm, const Cov8* __restrict__ cov, size_t n, float* __restrict__ xyz, float* __restrict__ onrm, float* __restrict__ cov6) {
@@ -393,6 +451,8 @@ int sga_device_count(void) {
   return n;
 }
 
+constexpr int kNotesAt = 160;  // h_accum: doubles [0, 129) results + sequence word, [136, 144) scratch ints, [160, 192) notes
+constexpr int kPinnedDoubles = kNotesAt + sga::kNoteSlots * sga::kNoteWords;
 static int context_create_impl(int device, void* stream, bool borrow, sga_context** out) {
   if (!out) return fail(SGA_ERR_INVALID, "null out");
   *out = nullptr;
@@ -423,11 +483,18 @@ static int context_create_impl(int device, void* stream, bool borrow, sga_contex
   int rc = ctx->d_accum.alloc(128);
   if (rc == SGA_OK) rc = ctx->d_ticket.alloc(16);
   if (rc == SGA_OK && hipMemsetAsync(ctx->d_ticket.p, 0, 16 * sizeof(unsigned), ctx->stream) != hipSuccess) rc = fail(SGA_ERR_HIP, "hipMemsetAsync failed");
-  if (rc == SGA_OK && hipHostMalloc(reinterpret_cast<void**>(&ctx->h_accum), 160 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) rc = fail(SGA_ERR_HIP, "hipHostMalloc failed");
+  if (rc == SGA_OK && hipHostMalloc(reinterpret_cast<void**>(&ctx->h_accum), kPinnedDoubles * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) rc = fail(SGA_ERR_HIP, "hipHostMalloc failed");
   if (rc == SGA_OK) {
-    std::memset(ctx->h_accum, 0, 160 * sizeof(double));
+    std::memset(ctx->h_accum, 0, kPinnedDoubles * sizeof(double));
     ctx->h_scratch = reinterpret_cast<int*>(ctx->h_accum + 136);  // doubles [136, 144) of the pinned block
     if (hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->h_accum_dev), ctx->h_accum, 0) != hipSuccess) rc = fail(SGA_ERR_HIP, "hipHostGetDevicePointer failed");
+    ctx->h_notes = reinterpret_cast<unsigned long long*>(ctx->h_accum + kNotesAt);  // words [160, 192): the notes (notes.hpp)
+    ctx->h_notes_dev = reinterpret_cast<unsigned long long*>(ctx->h_accum_dev + kNotesAt);
+  }
+  if (rc == SGA_OK) rc = ctx->d_box.alloc(8);
+  if (rc == SGA_OK) {
+    const int init[8] = {kBoxEncPosInf, kBoxEncPosInf, kBoxEncPosInf, kBoxEncNegInf, kBoxEncNegInf, kBoxEncNegInf, 0, 0};
+    if (hipMemcpyAsync(ctx->d_box.p, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(SGA_ERR_HIP, "box accumulator init failed");
   }
   if (rc == SGA_OK && (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess || hipEventCreate(&ctx->ev2) != hipSuccess || hipEventCreate(&ctx->ev3) != hipSuccess || hipEventCreate(&ctx->ev_mid) != hipSuccess || hipEventCreate(&ctx->ev_comm) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_aux, hipEventDisableTiming) != hipSuccess)) rc = fail(SGA_ERR_HIP, "hipEventCreate failed");
   if (rc != SGA_OK) {
@@ -460,7 +527,10 @@ int sga_context_destroy(sga_context* ctx) {
   if (ctx->ev_comm) (void)hipEventDestroy(ctx->ev_comm);
   if (ctx->ev_aux) (void)hipEventDestroy(ctx->ev_aux);
   if (ctx->h_accum) (void)hipHostFree(ctx->h_accum);
-  if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+  for (auto& slot : ctx->stage) {
+    if (slot.host) (void)hipHostFree(slot.host);
+    if (slot.done) (void)hipEventDestroy(slot.done);
+  }
   const int device = ctx->device;
   const hipStream_t stream = ctx->stream;
   const bool registered = ctx->registered, owns = ctx->owns_stream;
@@ -563,80 +633,242 @@ int sga_context_get_search_ms(sga_context* ctx, double* search_ms, uint64_t* sea
   return SGA_OK;
 }
 
-// the context's pinned staging buffer for host -> device uploads (grow-only; the stream must be idle: uploads synchronise)
-static int ctx_pinned_stage(sga_context* ctx, size_t bytes, void** out) {
-  if (ctx->h_stage_bytes < bytes) {
-    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
-    ctx->h_stage = nullptr;
-    ctx->h_stage_bytes = 0;
+// ---- notes (notes.hpp) -------------------------------------------------------------------------------------------------------
+}  // extern "C"
+namespace sga {
+unsigned long long note_begin(sga_context* ctx, unsigned long long** dev_slot) {
+  const unsigned long long seq = ++ctx->note_seq;
+  *dev_slot = ctx->h_notes_dev + (seq % kNoteSlots) * kNoteWords;
+  return seq;
+}
+int note_wait(sga_context* ctx, unsigned long long seq, unsigned long long payload[kNoteWords - 1]) {
+  const unsigned long long* slot = ctx->h_notes + (seq % kNoteSlots) * kNoteWords;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 0;; spins++) {
+    if (__atomic_load_n(slot, __ATOMIC_ACQUIRE) == seq) break;
+    __builtin_ia32_pause();
+    if (spins > 200000u) std::this_thread::yield();
+    if ((spins & 0xfffu) == 0xfffu) {
+      // the stream has drained without publishing (a fault), or this is taking implausibly long: let the runtime report it
+      const hipError_t q = hipStreamQuery(ctx->stream);
+      if (q != hipErrorNotReady || std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
+        (void)hipGetLastError();
+        SGA_HIP(hipStreamSynchronize(ctx->stream));
+        if (__atomic_load_n(slot, __ATOMIC_ACQUIRE) == seq) break;
+        return fail(SGA_ERR_HIP, "a note was not published by the device");
+      }
+      (void)hipGetLastError();  // hipErrorNotReady is sticky in hipGetLastError
+    }
+  }
+  for (int k = 0; k < kNoteWords - 1; k++) payload[k] = slot[1 + k];
+  return SGA_OK;
+}
+}  // namespace sga
+
+// ---- uploads ------------------------------------------------------------------------------------------------------------------
+// A slot of the context's pinned staging ring with room for `bytes` (grow-only).  A slot handed out before is reused only after the
+// event recorded behind its reader (stage_release) has completed.
+static int stage_acquire(sga_context* ctx, size_t bytes, sga_context::StageSlot** out) {
+  sga_context::StageSlot& slot = ctx->stage[ctx->stage_next++ % sga_context::kStageSlots];
+  if (slot.busy) {
+    SGA_HIP(hipEventSynchronize(slot.done));
+    slot.busy = false;
+  }
+  if (slot.bytes < bytes) {
+    if (slot.host) (void)hipHostFree(slot.host);
+    slot.host = slot.dev = nullptr;
+    slot.bytes = 0;
     size_t want = 1u << 20;
     while (want < bytes) want <<= 1;
-    if (hipHostMalloc(&ctx->h_stage, want, hipHostMallocDefault) != hipSuccess) return fail(SGA_ERR_HIP, "hipHostMalloc(%zu bytes) failed", want);
-    ctx->h_stage_bytes = want;
+    if (hipHostMalloc(&slot.host, want, hipHostMallocMapped) != hipSuccess) return fail(SGA_ERR_HIP, "hipHostMalloc(%zu bytes) failed", want);
+    if (hipHostGetDevicePointer(&slot.dev, slot.host, 0) != hipSuccess) return fail(SGA_ERR_HIP, "hipHostGetDevicePointer failed");
+    slot.bytes = want;
   }
-  *out = ctx->h_stage;
+  *out = &slot;
+  return SGA_OK;
+}
+// behind the launch that reads the slot
+static int stage_release(sga_context* ctx, sga_context::StageSlot* slot) {
+  if (!slot->done) SGA_HIP(hipEventCreateWithFlags(&slot->done, hipEventDisableTiming));
+  SGA_HIP(hipEventRecord(slot->done, ctx->stream));
+  slot->busy = true;
   return SGA_OK;
 }
 
-}  // extern "C"
+// One pass over a pageable xyz array: copy it into the staging slot AND take the bounding box of its finite coordinates (the origin of
+// the device frame is chosen from it).  Twelve running minima / maxima (four points) so that the compiler keeps them in vector registers;
+// a 115k-point scan (1.4 MB) went through a scalar box pass and a memcpy before: two passes, ~0.25 ms.
+#if defined(__x86_64__)
+// 24 floats (8 points) per step: three 8-wide vectors whose lanes keep their coordinate (24 is a multiple of 3)
+__attribute__((target("avx2"))) static void copy_with_box_wide(const float* __restrict__ src, float* __restrict__ dst, size_t count /* floats, a multiple of 24 */, float lo24[24], float hi24[24]) {
+  const __m256 absmask = _mm256_castsi256_ps(_mm256_set1_epi32(0x7fffffff)), fmax = _mm256_set1_ps(3.4028234e38f);
+  __m256 lo0 = _mm256_loadu_ps(lo24), lo1 = _mm256_loadu_ps(lo24 + 8), lo2 = _mm256_loadu_ps(lo24 + 16);
+  __m256 hi0 = _mm256_loadu_ps(hi24), hi1 = _mm256_loadu_ps(hi24 + 8), hi2 = _mm256_loadu_ps(hi24 + 16);
+  for (size_t i = 0; i < count; i += 24) {
+    const __m256 a = _mm256_loadu_ps(src + i), b = _mm256_loadu_ps(src + i + 8), c = _mm256_loadu_ps(src + i + 16);
+    _mm256_storeu_ps(dst + i, a);
+    _mm256_storeu_ps(dst + i + 8, b);
+    _mm256_storeu_ps(dst + i + 16, c);
+    // non-finite values (NaN compares false, inf fails <= FLT_MAX) are replaced by the running bound: they change nothing
+    const __m256 ma = _mm256_cmp_ps(_mm256_and_ps(a, absmask), fmax, _CMP_LE_OQ), mb = _mm256_cmp_ps(_mm256_and_ps(b, absmask), fmax, _CMP_LE_OQ), mc = _mm256_cmp_ps(_mm256_and_ps(c, absmask), fmax, _CMP_LE_OQ);
+    lo0 = _mm256_min_ps(_mm256_blendv_ps(lo0, a, ma), lo0);
+    lo1 = _mm256_min_ps(_mm256_blendv_ps(lo1, b, mb), lo1);
+    lo2 = _mm256_min_ps(_mm256_blendv_ps(lo2, c, mc), lo2);
+    hi0 = _mm256_max_ps(_mm256_blendv_ps(hi0, a, ma), hi0);
+    hi1 = _mm256_max_ps(_mm256_blendv_ps(hi1, b, mb), hi1);
+    hi2 = _mm256_max_ps(_mm256_blendv_ps(hi2, c, mc), hi2);
+  }
+  _mm256_storeu_ps(lo24, lo0), _mm256_storeu_ps(lo24 + 8, lo1), _mm256_storeu_ps(lo24 + 16, lo2);
+  _mm256_storeu_ps(hi24, hi0), _mm256_storeu_ps(hi24 + 8, hi1), _mm256_storeu_ps(hi24 + 16, hi2);
+}
+#endif
+static void copy_with_box_plain(const float* __restrict__ src, float* __restrict__ dst, size_t first, size_t count, float lo24[24], float hi24[24]) {
+  for (size_t f = first; f < count; f++) {
+    const float v = src[f];
+    dst[f] = v;
+    const int j = static_cast<int>(f % 24);  // 24 is a multiple of 3: lane j keeps coordinate j % 3
+    if (__builtin_fabsf(v) <= 3.4028234e38f) {
+      lo24[j] = v < lo24[j] ? v : lo24[j];
+      hi24[j] = v > hi24[j] ? v : hi24[j];
+    }
+  }
+}
+static void copy_with_box(const float* src, float* dst, size_t n, double lo[3], double hi[3]) {
+  float lo24[24], hi24[24];
+  for (int j = 0; j < 24; j++) lo24[j] = INFINITY, hi24[j] = -INFINITY;
+  const size_t count = n * 3;
+  size_t body = 0;
+#if defined(__x86_64__)
+  static const bool avx2 = __builtin_cpu_supports("avx2");
+  if (avx2) {
+    body = count / 24 * 24;
+    copy_with_box_wide(src, dst, body, lo24, hi24);
+  }
+#endif
+  copy_with_box_plain(src, dst, body, count, lo24, hi24);
+  for (int k = 0; k < 3; k++) {
+    lo[k] = INFINITY, hi[k] = -INFINITY;
+    for (int j = k; j < 24; j += 3) {
+      lo[k] = lo24[j] < lo[k] ? lo24[j] : lo[k];
+      hi[k] = hi24[j] > hi[k] ? hi24[j] : hi[k];
+    }
+  }
+}
 
-// The cloud whose fp32 coordinates are given RELATIVE to `origin` (true position = xyz_rel + origin): the records go to the device as they are.
-static int cloud_create_rel(sga_context* ctx, const float* xyz, const float* normals, const float* cov6, size_t n, const double origin[3], const double* recentre_by, sga_cloud** out) {
+// Is [p, p + bytes) pinned host memory a kernel of this device can read (hipHostMalloc / hipHostRegister / sga_host_alloc)?  -> its device address
+static const void* pinned_device_view(const void* p, size_t bytes) {
+  if (p == nullptr) return nullptr;
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();  // an ordinary (pageable) pointer: not an error of ours
+    return nullptr;
+  }
+  if (a.type != hipMemoryTypeHost || a.devicePointer == nullptr) return nullptr;
+  (void)bytes;
+  return a.devicePointer;
+}
+
+// How an upload learns its frame: `origin` given (the records are relative to it, or become so: recentre) or chosen from the bounding box.
+enum class UploadFrame { Given, GivenRecentre, FromBox };
+
+// The cloud of n points from host arrays: xyz (3 floats per point), optional normals (3) and covariances (6).
+//   * pageable arrays are copied once into a slot of the context's pinned staging ring (the box is taken in the same pass) and the pack
+//     kernel reads the slot over PCIe; in stream-ordered mode the call returns with the kernel in flight (the slot is reused only after
+//     the event recorded behind it) — the caller's arrays are free as soon as the call returns either way;
+//   * arrays that already live in pinned host memory (sga_host_alloc, hipHostMalloc) are read by the pack kernel where they are: no CPU
+//     pass at all; the box comes back from the kernel as a note (notes.hpp), so the kernel has finished reading when the call returns.
+static int cloud_upload(sga_context* ctx, const float* xyz, const float* normals, const float* cov6, size_t n, UploadFrame frame, const double origin_in[3], sga_cloud** out) {
   if (!ctx || !out || (n > 0 && !xyz)) return fail(SGA_ERR_INVALID, "null argument");
   if (n >= (1ull << 31)) return fail(SGA_ERR_INVALID, "cloud too large (%zu points; limit 2^31-1)", n);
   *out = nullptr;
   SGA_ENTER(ctx);
-  auto* c = new sga_cloud;
+  std::unique_ptr<sga_cloud> c(new sga_cloud);
   c->device = ctx->device;
   c->n = n;
-  for (int k = 0; k < 3; k++) c->origin[k] = origin ? origin[k] : 0.0;
+  for (int k = 0; k < 3; k++) c->origin[k] = (frame != UploadFrame::FromBox && origin_in) ? origin_in[k] : 0.0;
   c->has_normals = normals != nullptr;
   c->has_covs = cov6 != nullptr;
-  DevBuf<float> sx, sn, sc;
-  int rc = c->pts.alloc(n);
-  if (rc == SGA_OK && normals) rc = c->nrm.alloc(n);
-  if (rc == SGA_OK && cov6) rc = c->cov.alloc(n);
-  if (rc == SGA_OK) rc = sx.alloc(n * 3);
-  if (rc == SGA_OK && normals) rc = sn.alloc(n * 3);
-  if (rc == SGA_OK && cov6) rc = sc.alloc(n * 6);
-  if (rc != SGA_OK) {
-    delete c;
-    return rc;
+  SGA_TRY(c->pts.alloc(n));
+  if (normals) SGA_TRY(c->nrm.alloc(n));
+  if (cov6) SGA_TRY(c->cov.alloc(n));
+  if (n == 0) {
+    *out = c.release();
+    return SGA_OK;
   }
-  if (n > 0) {
-    // The caller's buffers are pageable: copied from there the runtime has to lock their pages first, which costs up to tens of
-    // milliseconds per fresh megabyte-sized buffer on some hosts (measured: 15-28 ms for a 1.4 MB scan).  They are staged through the
-    // context's own pinned buffer instead (a CPU memcpy at memory speed).
-    const size_t fx = n * 3, fn = normals ? n * 3 : 0, fc = cov6 ? n * 6 : 0;
-    float* stage = nullptr;
-    rc = ctx_pinned_stage(ctx, (fx + fn + fc) * sizeof(float), reinterpret_cast<void**>(&stage));
-    if (rc != SGA_OK) {
-      delete c;
-      return rc;
+  const size_t fx = n * 3, fn = normals ? n * 3 : 0, fc = cov6 ? n * 6 : 0;
+  const dim3 grid((n + 255) / 256), block(256);
+  static const bool zero_copy = !(getenv("SGA_UPLOAD_PINNED") && atoi(getenv("SGA_UPLOAD_PINNED")) == 0);
+  const float* dx = zero_copy ? static_cast<const float*>(pinned_device_view(xyz, fx * sizeof(float))) : nullptr;
+  const float* dn = (dx && normals) ? static_cast<const float*>(pinned_device_view(normals, fn * sizeof(float))) : nullptr;
+  const float* dc = (dx && cov6) ? static_cast<const float*>(pinned_device_view(cov6, fc * sizeof(float))) : nullptr;
+  double lo[3], hi[3];
+  if (dx && (!normals || dn) && (!cov6 || dc)) {
+    // ---- the caller's arrays are pinned: the kernel reads them in place
+    if (frame == UploadFrame::FromBox) {
+      unsigned long long* slot = nullptr;
+      const unsigned long long seq = note_begin(ctx, &slot);
+      hipLaunchKernelGGL(pack_cloud_kernel, grid, block, 0, ctx->stream, dx, dn, dc, n, 0.0, 0.0, 0.0, 0, c->pts.p, c->nrm.p, c->cov.p, ctx->d_box.p, slot, seq);
+      SGA_HIP(hipGetLastError());
+      unsigned long long payload[kNoteWords - 1];
+      SGA_TRY(note_wait(ctx, seq, payload));
+      float flo[3], fhi[3];
+      box_note_decode(payload, flo, fhi);
+      for (int k = 0; k < 3; k++) lo[k] = flo[k], hi[k] = fhi[k];
+      choose_origin(lo, hi, c->origin);
+      if (!origin_is_zero(c->origin)) {  // far from the origin (rare): once more, the subtraction in double
+        hipLaunchKernelGGL(pack_cloud_kernel, grid, block, 0, ctx->stream, dx, nullptr, nullptr, n, c->origin[0], c->origin[1], c->origin[2], 1, c->pts.p, static_cast<float4*>(nullptr), static_cast<Cov8*>(nullptr), static_cast<int*>(nullptr),
+                           static_cast<unsigned long long*>(nullptr), 0ull);
+        SGA_HIP(hipGetLastError());
+        SGA_HIP(hipStreamSynchronize(ctx->stream));  // the caller's buffer is being read
+      }
+    } else {
+      hipLaunchKernelGGL(pack_cloud_kernel, grid, block, 0, ctx->stream, dx, dn, dc, n, c->origin[0], c->origin[1], c->origin[2], frame == UploadFrame::GivenRecentre ? 1 : 0, c->pts.p, c->nrm.p, c->cov.p, static_cast<int*>(nullptr),
+                         static_cast<unsigned long long*>(nullptr), 0ull);
+      SGA_HIP(hipGetLastError());
+      SGA_HIP(hipStreamSynchronize(ctx->stream));  // the caller's buffer is being read
+      lo[0] = INFINITY;  // (no box)
     }
-    if (recentre_by == nullptr) {
-      std::memcpy(stage, xyz, fx * sizeof(float));
-    } else {  // absolute fp32 coordinates far from the origin: the subtraction in double, while the points are staged anyway
-      for (size_t i = 0; i < n; i++)
-        for (int k = 0; k < 3; k++) stage[3 * i + k] = static_cast<float>(static_cast<double>(xyz[3 * i + k]) - recentre_by[k]);
-    }
+  } else {
+    // ---- pageable arrays: one CPU pass into the staging ring
+    sga_context::StageSlot* slot = nullptr;
+    SGA_TRY(stage_acquire(ctx, (fx + fn + fc) * sizeof(float), &slot));
+    float* stage = static_cast<float*>(slot->host);
+    const float* dstage = static_cast<const float*>(slot->dev);
+    copy_with_box(xyz, stage, n, lo, hi);
     if (normals) std::memcpy(stage + fx, normals, fn * sizeof(float));
     if (cov6) std::memcpy(stage + fx + fn, cov6, fc * sizeof(float));
-    hipError_t e = hipMemcpyAsync(sx.p, stage, fx * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess && normals) e = hipMemcpyAsync(sn.p, stage + fx, fn * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess && cov6) e = hipMemcpyAsync(sc.p, stage + fx + fn, fc * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) {
-      hipLaunchKernelGGL(pack_cloud_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, sx.p, sn.p, sc.p, n, c->pts.p, c->nrm.p, c->cov.p);
-      e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) {
-      delete c;
-      return fail(SGA_ERR_HIP, "cloud upload failed: %s", hipGetErrorString(e));
+    if (frame == UploadFrame::FromBox) choose_origin(lo, hi, c->origin);
+    const bool recentre = frame == UploadFrame::GivenRecentre || (frame == UploadFrame::FromBox && !origin_is_zero(c->origin));
+    hipLaunchKernelGGL(pack_cloud_kernel, grid, block, 0, ctx->stream, dstage, normals ? dstage + fx : nullptr, cov6 ? dstage + fx + fn : nullptr, n, c->origin[0], c->origin[1], c->origin[2], recentre ? 1 : 0, c->pts.p, c->nrm.p, c->cov.p,
+                       static_cast<int*>(nullptr), static_cast<unsigned long long*>(nullptr), 0ull);
+    SGA_HIP(hipGetLastError());
+    if (ctx->stream_ordered) {
+      SGA_TRY(stage_release(ctx, slot));
+    } else {
+      SGA_HIP(hipStreamSynchronize(ctx->stream));
     }
   }
-  *out = c;
+  if (lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2] && frame != UploadFrame::Given) {
+    // the box of the records (device frame): outward-rounded fp32 of (box - origin)
+    c->has_box = true;
+    for (int k = 0; k < 3; k++) {
+      c->box_lo[k] = std::nextafterf(static_cast<float>(lo[k] - c->origin[k]), -INFINITY);
+      c->box_hi[k] = std::nextafterf(static_cast<float>(hi[k] - c->origin[k]), INFINITY);
+    }
+  } else if (lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2]) {
+    c->has_box = true;  // records relative to a given origin: the box of the inputs IS the box of the records
+    for (int k = 0; k < 3; k++) c->box_lo[k] = static_cast<float>(lo[k]), c->box_hi[k] = static_cast<float>(hi[k]);
+  }
+  SGA_TRY(mark_ready(ctx, c->ready));
+  *out = c.release();
   return SGA_OK;
+}
+
+// The cloud whose fp32 coordinates are given RELATIVE to `origin` (true position = xyz_rel + origin): the records go to the device as they are.
+// recentre_by != nullptr: absolute fp32 coordinates, records = fl32(double(x) - recentre_by).
+static int cloud_create_rel(sga_context* ctx, const float* xyz, const float* normals, const float* cov6, size_t n, const double origin[3], const double* recentre_by, sga_cloud** out) {
+  static const double zero[3] = {0, 0, 0};
+  return cloud_upload(ctx, xyz, normals, cov6, n, recentre_by ? UploadFrame::GivenRecentre : UploadFrame::Given, origin ? origin : zero, out);
 }
 
 // bounding box over the finite coordinates of n points with `stride` values per point
@@ -668,11 +900,27 @@ int sga_cloud_create_f32_origin(sga_context* ctx, const float* xyz_rel, const fl
 }
 
 int sga_cloud_create_f32(sga_context* ctx, const float* xyz, const float* normals, const float* cov6, size_t n, sga_cloud** out) {
-  if (!ctx || !out || (n > 0 && !xyz)) return fail(SGA_ERR_INVALID, "null argument");
-  double lo[3], hi[3], origin[3];
-  host_bbox(xyz, n, 3, lo, hi);
-  choose_origin(lo, hi, origin);
-  return cloud_create_rel(ctx, xyz, normals, cov6, n, origin, origin_is_zero(origin) ? nullptr : origin, out);
+  return cloud_upload(ctx, xyz, normals, cov6, n, UploadFrame::FromBox, nullptr, out);  // the origin: chosen from the box the upload takes in passing
+}
+
+// Pinned host memory for the caller's scans: sga_cloud_create_f32 reads arrays that live in it in place (no staging copy on the CPU).
+int sga_host_alloc(size_t bytes, void** out) {
+  if (!out) return fail(SGA_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (bytes == 0) return SGA_OK;
+  if (hipHostMalloc(out, bytes, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) {
+    (void)hipGetLastError();
+    *out = nullptr;
+    return fail(SGA_ERR_HIP, "hipHostMalloc(%zu bytes) failed", bytes);
+  }
+  return SGA_OK;
+}
+int sga_host_free(void* p) {
+  if (p && hipHostFree(p) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(SGA_ERR_HIP, "hipHostFree failed");
+  }
+  return SGA_OK;
 }
 
 int sga_cloud_create_f64_origin(sga_context* ctx, const double* xyzw, const double* normals4, const double* cov4x4, size_t n, const double origin_in[3], sga_cloud** out) {

@@ -6,6 +6,7 @@
 #include <cmath>
 
 #include "common.hpp"
+#include "notes.hpp"
 
 #include <memory>
 #include <rocprim/rocprim.hpp>
@@ -19,14 +20,9 @@ int build_cell_grid(sga_context* ctx, sga_index* idx);  // cell_grid.hip
 
 // ---- bounding box --------------------------------------------------------------------------------------------------------
 // <= 256 workgroups stream the cloud; wave shuffles + one LDS stage reduce a workgroup to six values, so only six atomics per
-// workgroup reach memory (order-preserving int encoding of the floats).
-__device__ __forceinline__ int bbox_enc(float f) {
-  const int i = __float_as_int(f);
-  return i >= 0 ? i : i ^ 0x7fffffff;
-}
-
-__global__ __launch_bounds__(256) void bbox_kernel(const float4* __restrict__ pts, size_t n, int* __restrict__ out6 /* min xyz (init +inf), max xyz (init -inf), encoded */) {
-  __shared__ float sh[4][6];
+// workgroup reach memory (order-preserving int encoding of the floats); the last workgroup to arrive hands the box to the host as a
+// note (notes.hpp: box_reduce_publish): no copy commands, no stream synchronisation.
+__global__ __launch_bounds__(256) void bbox_note_kernel(const float4* __restrict__ pts, size_t n, int* __restrict__ d_box, unsigned long long* __restrict__ note_slot, unsigned long long seq) {
   float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
   for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n; i += static_cast<size_t>(gridDim.x) * blockDim.x) {
     float4 p = pts[i];
@@ -41,79 +37,33 @@ __global__ __launch_bounds__(256) void bbox_kernel(const float4* __restrict__ pt
     hi[1] = fmaxf(hi[1], p.y);
     hi[2] = fmaxf(hi[2], p.z);
   }
-  for (int k = 0; k < 3; k++) {
-    for (int off = 32; off > 0; off >>= 1) {
-      lo[k] = fminf(lo[k], __shfl_xor(lo[k], off));
-      hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
-    }
-  }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0)
-    for (int k = 0; k < 3; k++) {
-      sh[wave][k] = lo[k];
-      sh[wave][3 + k] = hi[k];
-    }
-  __syncthreads();
-  if (threadIdx.x < 6) {
-    const int k = threadIdx.x;
-    float v = sh[0][k];
-    for (int w = 1; w < 4; w++) v = k < 3 ? fminf(v, sh[w][k]) : fmaxf(v, sh[w][k]);
-    if (k < 3)
-      atomicMin(&out6[k], bbox_enc(v));
-    else
-      atomicMax(&out6[k], bbox_enc(v));
-  }
+  box_reduce_publish(lo, hi, d_box, note_slot, seq);
 }
 
-static inline float dec_ordered(int i) {
-  int j = i >= 0 ? i : i ^ 0x7fffffff;
-  float f;
-  memcpy(&f, &j, 4);
-  return f;
-}
-
-// bounding box of a device cloud: enqueue (the six encoded values land in pinned host memory when the stream gets there) ...
-int cloud_bbox_enqueue(sga_context* ctx, const float4* pts, size_t n, DevBuf<int>& d_bbox, int* h_bbox6_pinned) {
-  SGA_TRY(d_bbox.alloc(6));
-  const int init[6] = {0x7f800000, 0x7f800000, 0x7f800000, static_cast<int>(0xff800000u) ^ 0x7fffffff, static_cast<int>(0xff800000u) ^ 0x7fffffff, static_cast<int>(0xff800000u) ^ 0x7fffffff};
-  for (int k = 0; k < 6; k++) h_bbox6_pinned[k] = init[k];
-  SGA_HIP(hipMemcpyAsync(d_bbox.p, h_bbox6_pinned, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
-  if (n > 0) hipLaunchKernelGGL(bbox_kernel, dim3(std::min<size_t>(256, (n + 255) / 256)), dim3(256), 0, ctx->stream, pts, n, d_bbox.p);
+// bounding box of a device cloud: enqueue (the box lands in the context's note block when the stream gets there) ...
+int cloud_bbox_enqueue(sga_context* ctx, const float4* pts, size_t n, unsigned long long* seq_out) {
+  unsigned long long* slot = nullptr;
+  *seq_out = note_begin(ctx, &slot);
+  hipLaunchKernelGGL(bbox_note_kernel, dim3(std::max<size_t>(1, std::min<size_t>(256, (n + 255) / 256))), dim3(256), 0, ctx->stream, pts, n, ctx->d_box.p, slot, *seq_out);
   SGA_HIP(hipGetLastError());
-  SGA_HIP(hipMemcpyAsync(h_bbox6_pinned, d_bbox.p, sizeof(init), hipMemcpyDeviceToHost, ctx->stream));
   return SGA_OK;
 }
-// ... and decode after the stream has been synchronised
-void cloud_bbox_decode(const int* h_bbox6, size_t n, float lo[3], float hi[3]) {
-  for (int k = 0; k < 3; k++) {
-    lo[k] = n ? dec_ordered(h_bbox6[k]) : 0.f;
-    hi[k] = n ? dec_ordered(h_bbox6[3 + k]) : 0.f;
-  }
+// ... and wait for it (a spin on mapped memory: the work enqueued behind the box kernel keeps running)
+int cloud_bbox_collect(sga_context* ctx, unsigned long long seq, size_t n, float lo[3], float hi[3]) {
+  unsigned long long payload[kNoteWords - 1];
+  SGA_TRY(note_wait(ctx, seq, payload));
+  box_note_decode(payload, lo, hi);
+  if (n == 0)
+    for (int k = 0; k < 3; k++) lo[k] = hi[k] = 0.f;
+  return SGA_OK;
 }
 
-// both steps at once (synchronises the context's stream)
+// both steps at once
 int cloud_bbox(sga_context* ctx, const float4* pts, size_t n, float lo[3], float hi[3]) {
-  DevBuf<int> d_bbox;
-  int* h = ctx->h_scratch;
-  SGA_TRY(cloud_bbox_enqueue(ctx, pts, n, d_bbox, h));
-  SGA_HIP(hipStreamSynchronize(ctx->stream));
-  cloud_bbox_decode(h, n, lo, hi);
-  return SGA_OK;
+  unsigned long long seq = 0;
+  SGA_TRY(cloud_bbox_enqueue(ctx, pts, n, &seq));
+  return cloud_bbox_collect(ctx, seq, n, lo, hi);
 }
-
-__global__ void gather_sorted_kernel(
-  const uint32_t* __restrict__ order, size_t n, const float4* __restrict__ pts, const float4* __restrict__ nrm, const Cov8* __restrict__ cov, float4* __restrict__ opts, float4* __restrict__ onrm, Cov8* __restrict__ ocov) {
-  const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
-  if (i >= n) {
-    if (i < n + kKdLeafMax) opts[i] = make_float4(INFINITY, INFINITY, INFINITY, __uint_as_float(0xffffffffu));  // padding leaf (kd_search.hpp)
-    return;
-  }
-  const uint32_t s = order[i];
-  opts[i] = pts[s];  // w keeps the original index bits
-  if (nrm) onrm[i] = nrm[s];
-  if (cov) ocov[i] = cov[s];
-}
-
 
 // ---- implicit balanced kd-tree (see kd_search.hpp for the layout) ----------------------------------------------------------------
 // Built top-down, one level per pass: per-segment bounding box -> split axis = longest extent -> sort by (segment, coordinate)
@@ -394,7 +344,8 @@ __device__ __forceinline__ uint32_t split_scan_exclusive(uint32_t v, uint32_t* _
 }
 
 template <int THREADS, int kSplitKeys>  // kSplitKeys: keys per thread; the launcher picks the smallest THREADS x kSplitKeys that holds a segment
-__global__ __launch_bounds__(THREADS) void kd_split_level_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ perm_in, uint32_t* __restrict__ perm_out, uint32_t n, int d, float2* __restrict__ nodes) {
+__global__ __launch_bounds__(THREADS) void kd_split_level_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ perm_in /* null: the identity (level 0) */, uint32_t* __restrict__ perm_out, uint32_t n, int d, float2* __restrict__ nodes,
+                                                                 unsigned long long* __restrict__ note_slot /* level 0: the cloud's bounding box goes to the host as a note (notes.hpp), or null */, unsigned long long note_seq) {
   constexpr int kWaves = THREADS / 64, kBinsPerThread = kSplitBins / THREADS;
   __shared__ uint32_t hist[3][kSplitBins];
   __shared__ uint32_t sh_wave[4][kWaves];
@@ -414,7 +365,10 @@ __global__ __launch_bounds__(THREADS) void kd_split_level_kernel(const float4* _
   // costs two dependent memory latencies, and there are up to 32 rows.
   uint32_t src[kSplitKeys];
 #pragma unroll
-  for (int j = 0; j < kSplitKeys; j++) src[j] = perm_in[first + min(static_cast<uint32_t>(j * THREADS) + tid, len - 1u)];
+  for (int j = 0; j < kSplitKeys; j++) {
+    const uint32_t at = first + min(static_cast<uint32_t>(j * THREADS) + tid, len - 1u);
+    src[j] = perm_in != nullptr ? perm_in[at] : at;
+  }
   float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
   constexpr int kChunk = kSplitKeys < 8 ? kSplitKeys : 8;
 #pragma unroll
@@ -424,6 +378,11 @@ __global__ __launch_bounds__(THREADS) void kd_split_level_kernel(const float4* _
     for (int u = 0; u < kChunk; u++) p[u] = pts[src[j0 + u]];
 #pragma unroll
     for (int u = 0; u < kChunk; u++) {  // (a repeated last element changes nothing in a box)
+      if (note_slot != nullptr) {  // the box the host sees must report non-finite coordinates (fminf / fmaxf let a NaN slip through unseen): they count as +inf
+        p[u].x = fabsf(p[u].x) <= 3.4028234e38f ? p[u].x : INFINITY;
+        p[u].y = fabsf(p[u].y) <= 3.4028234e38f ? p[u].y : INFINITY;
+        p[u].z = fabsf(p[u].z) <= 3.4028234e38f ? p[u].z : INFINITY;
+      }
       lo[0] = fminf(lo[0], p[u].x), lo[1] = fminf(lo[1], p[u].y), lo[2] = fminf(lo[2], p[u].z);
       hi[0] = fmaxf(hi[0], p[u].x), hi[1] = fmaxf(hi[1], p[u].y), hi[2] = fmaxf(hi[2], p[u].z);
     }
@@ -447,7 +406,9 @@ __global__ __launch_bounds__(THREADS) void kd_split_level_kernel(const float4* _
       h = fmaxf(h, sh_hi[w][a]);
     }
     ext[a] = h - l;
+    if (note_slot != nullptr && tid == 0) note_slot[1 + a] = static_cast<unsigned long long>(static_cast<unsigned>(box_enc(l))) | (static_cast<unsigned long long>(static_cast<unsigned>(box_enc(h))) << 32);
   }
+  if (note_slot != nullptr && tid == 0) note_publish(note_slot, note_seq);  // (one workgroup at level 0)
   const int axis = ext[0] >= ext[1] ? (ext[0] >= ext[2] ? 0 : 2) : (ext[1] >= ext[2] ? 1 : 2);  // same rule as kd_longest_axis
   uint32_t key[kSplitKeys];  // the coordinate along the split axis (read again, one word: the lines are in the cache), order-preserving encoding
   const float* __restrict__ coord = reinterpret_cast<const float*>(pts) + axis;
@@ -520,24 +481,6 @@ __global__ __launch_bounds__(THREADS) void kd_split_level_kernel(const float4* _
   if (tid == 0) nodes[(1u << d) + seg] = make_float2(float_from_ordered(static_cast<int>(median ^ 0x80000000u)), __int_as_float(axis));
 }
 
-// pair records for the 1-NN walk (kd_search.hpp): node of even depth + its two children in one 16-byte record, stored at the node's
-// heap number; one launch covers every even depth
-__global__ void kd_pairs_kernel(const float2* __restrict__ nodes, int D, uint32_t count, float4* __restrict__ pairs) {
-  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= count || r == 0) return;
-  const uint32_t node = r;  // records are indexed by heap number (kd_search.hpp); only the even depths carry one
-  const int d = 31 - __clz(static_cast<int>(node));
-  if (d & 1) return;
-  const float2 a = nodes[node];
-  float2 l = make_float2(0.f, 0.f), rr = make_float2(0.f, 0.f);
-  if (d + 1 < D) {
-    l = nodes[2 * node];
-    rr = nodes[2 * node + 1];
-  }
-  const uint32_t axes = static_cast<uint32_t>(__float_as_int(a.y)) | (static_cast<uint32_t>(__float_as_int(l.y)) << 2) | (static_cast<uint32_t>(__float_as_int(rr.y)) << 4);
-  pairs[r] = make_float4(a.x, l.x, rr.x, __uint_as_float(axes));
-}
-
 // Tight bounding boxes of all nodes, bottom-up (kd_search.hpp: a pending far side is opened only if its box can hold a closer point).
 // One launch covers up to 8 levels: every workgroup takes 256 adjacent nodes of depth `base` — their boxes come from the points
 // (base = D, leaves) or from the previous launch — and merges them pairwise in LDS up to depth base - 8.
@@ -600,6 +543,117 @@ __global__ __launch_bounds__(256) void kd_boxes_kernel(const float4* __restrict_
   }
 }
 
+// The tail of a build in ONE launch (round 6: a 11.5k-point scan paid six launches for it — gather, leaf boxes, group headers, leaf blocks,
+// pair records, upper boxes).  Thread g of the grid owns leaf g and heap node g:
+//   * the leaf's points are gathered into kd order (with their attributes); 8 points at infinity follow the last leaf (leaf scans read 8
+//     slots unconditionally);
+//   * its LEAF BLOCK (kd_search.hpp: the fast leaf scan): the points as structure of arrays in one 128-byte line — x[8], y[8], z[8],
+//     original index[8] — so that a lane loads the coordinates of two points into adjacent registers (packed fp32 arithmetic); slots a
+//     leaf does not fill lie far away (kKdFar): their distance is huge but finite and never wins;
+//   * its tight box; the boxes are merged pairwise in LDS up to 8 levels (kd_boxes_kernel's loop);
+//   * GROUP HEADERS (kd_search.hpp: kd_visit_group): for every node of depth D - G (G = min(2, D)) the tight boxes of its 2^G leaves as six
+//     float4 {lo.x, lo.y, lo.z, hi.x, hi.y, hi.z} with one lane per leaf, in one 128-byte line; missing leaves get an empty box;
+//   * node g's PAIR RECORD for the 1-NN walk (kd_search.hpp): a node of even depth + its two children in one 16-byte record, stored at
+//     the node's heap number.
+// Trees deeper than 8 levels finish their upper boxes with kd_boxes_kernel(base = D - 8) as before.
+__global__ __launch_bounds__(256) void kd_tail_kernel(const uint32_t* __restrict__ order, uint32_t n, int D, const float4* __restrict__ pts, const float4* __restrict__ nrm, const Cov8* __restrict__ cov, const float2* __restrict__ nodes,
+                                                      float4* __restrict__ opts, float4* __restrict__ onrm, Cov8* __restrict__ ocov, float4* __restrict__ boxes, float4* __restrict__ groups, float* __restrict__ blocks,
+                                                      float4* __restrict__ pairs, uint32_t npairs) {
+  __shared__ float slo[3][256], shi[3][256];
+  const uint32_t t = threadIdx.x, k = blockIdx.x * 256u + t;
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  if (k < (1u << D)) {
+    const uint32_t first = kd_bound(n, D, k), end = kd_bound(n, D, k + 1);
+    float4 p[kKdLeafMax];
+#pragma unroll
+    for (int j = 0; j < kKdLeafMax; j++) {
+      const uint32_t pos = first + j;
+      const bool valid = pos < end;
+      const uint32_t src = order[valid ? pos : first < n ? first : 0u];
+      p[j] = pts[src];  // w keeps the original index bits
+      if (valid) {
+        opts[pos] = p[j];
+        if (nrm) onrm[pos] = nrm[src];
+        if (cov) ocov[pos] = cov[src];
+        lo[0] = fminf(lo[0], p[j].x), lo[1] = fminf(lo[1], p[j].y), lo[2] = fminf(lo[2], p[j].z);
+        hi[0] = fmaxf(hi[0], p[j].x), hi[1] = fmaxf(hi[1], p[j].y), hi[2] = fmaxf(hi[2], p[j].z);
+      } else {
+        p[j] = make_float4(kKdFar, kKdFar, kKdFar, 0.f);
+      }
+    }
+    float* b = blocks + 32ull * k;  // x[8], y[8], z[8], original index[8]: one 128-byte line
+#pragma unroll
+    for (int j = 0; j < kKdLeafMax; j += 4) {
+      *reinterpret_cast<float4*>(b + j) = make_float4(p[j].x, p[j + 1].x, p[j + 2].x, p[j + 3].x);
+      *reinterpret_cast<float4*>(b + 8 + j) = make_float4(p[j].y, p[j + 1].y, p[j + 2].y, p[j + 3].y);
+      *reinterpret_cast<float4*>(b + 16 + j) = make_float4(p[j].z, p[j + 1].z, p[j + 2].z, p[j + 3].z);
+      *reinterpret_cast<float4*>(b + 24 + j) = make_float4(p[j].w, p[j + 1].w, p[j + 2].w, p[j + 3].w);
+    }
+    const uint32_t node = (1u << D) + k;
+    boxes[2 * node] = make_float4(lo[0], lo[1], lo[2], 0.f);
+    boxes[2 * node + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
+    if (k == (1u << D) - 1u) {
+#pragma unroll
+      for (int j = 0; j < kKdLeafMax; j++) opts[n + j] = make_float4(INFINITY, INFINITY, INFINITY, __uint_as_float(0xffffffffu));  // padding leaf (kd_search.hpp)
+    }
+  }
+  if (k >= 1u && k < npairs) {  // pair record of heap node k (even depths carry one)
+    const int d = 31 - __clz(static_cast<int>(k));
+    if ((d & 1) == 0) {
+      const float2 a = nodes[k];
+      float2 l = make_float2(0.f, 0.f), rr = make_float2(0.f, 0.f);
+      if (d + 1 < D) {
+        l = nodes[2 * k];
+        rr = nodes[2 * k + 1];
+      }
+      const uint32_t axes = static_cast<uint32_t>(__float_as_int(a.y)) | (static_cast<uint32_t>(__float_as_int(l.y)) << 2) | (static_cast<uint32_t>(__float_as_int(rr.y)) << 4);
+      pairs[k] = make_float4(a.x, l.x, rr.x, __uint_as_float(axes));
+    }
+  }
+  for (int a = 0; a < 3; a++) {
+    slo[a][t] = lo[a];
+    shi[a][t] = hi[a];
+  }
+  __syncthreads();
+  {  // group headers: the leaves under a node of depth D - G, G = min(2, D)
+    const int G = D < 2 ? D : 2;
+    const uint32_t per = 1u << G;
+    if ((t & (per - 1u)) == 0u && k < (1u << D)) {
+      float4* h = groups + 8ull * (k >> G);
+      for (int a = 0; a < 3; a++) {
+        float l4[4] = {INFINITY, INFINITY, INFINITY, INFINITY}, h4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        for (uint32_t l = 0; l < per; l++) l4[l] = slo[a][t + l], h4[l] = shi[a][t + l];
+        h[a] = make_float4(l4[0], l4[1], l4[2], l4[3]);
+        h[3 + a] = make_float4(h4[0], h4[1], h4[2], h4[3]);
+      }
+      h[6] = h[7] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  for (int l = 1; l <= 8 && l <= D; l++) {
+    const uint32_t width = 256u >> l;  // nodes of depth D - l in this workgroup
+    if (t < width) {
+      for (int a = 0; a < 3; a++) {
+        lo[a] = fminf(slo[a][2 * t], slo[a][2 * t + 1]);
+        hi[a] = fmaxf(shi[a][2 * t], shi[a][2 * t + 1]);
+      }
+    }
+    __syncthreads();
+    if (t < width) {
+      for (int a = 0; a < 3; a++) {
+        slo[a][t] = lo[a];
+        shi[a][t] = hi[a];
+      }
+      const uint32_t kk = (blockIdx.x * 256u >> l) + t;
+      if (kk < (1u << (D - l))) {
+        const uint32_t node = (1u << (D - l)) + kk;
+        boxes[2 * node] = make_float4(lo[0], lo[1], lo[2], 0.f);
+        boxes[2 * node + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 __global__ void iota_kernel(uint32_t* __restrict__ v, size_t n) {
   const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
   if (i < n) v[i] = static_cast<uint32_t>(i);
@@ -611,48 +665,6 @@ __global__ void gather_attr_kernel(const float4* __restrict__ sorted_pts, size_t
   const uint32_t s = __float_as_uint(sorted_pts[i].w);
   if (nrm) onrm[i] = nrm[s];
   if (cov) ocov[i] = cov[s];
-}
-
-// Group headers (kd_search.hpp: kd_visit_group): for every node of depth D - G (G = min(2, D)) the tight boxes of its 2^G leaves,
-// as six float4 {lo.x, lo.y, lo.z, hi.x, hi.y, hi.z} with one lane per leaf, in one 128-byte line.  Missing leaves get an empty box.
-__global__ void kd_groups_kernel(const float4* __restrict__ boxes, int D, int G, float4* __restrict__ groups) {
-  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= (1u << (D - G))) return;
-  const uint32_t gnode = (1u << (D - G)) + g;
-  float lo[3][4], hi[3][4];
-  for (int l = 0; l < 4; l++) {
-    float4 a = make_float4(INFINITY, INFINITY, INFINITY, 0.f), b = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.f);
-    if (l < (1 << G)) {
-      const uint32_t leaf = (gnode << G) + l;
-      a = boxes[2 * leaf];
-      b = boxes[2 * leaf + 1];
-    }
-    lo[0][l] = a.x, lo[1][l] = a.y, lo[2][l] = a.z;
-    hi[0][l] = b.x, hi[1][l] = b.y, hi[2][l] = b.z;
-  }
-  float4* h = groups + 8ull * g;
-  for (int a = 0; a < 3; a++) {
-    h[a] = make_float4(lo[a][0], lo[a][1], lo[a][2], lo[a][3]);
-    h[3 + a] = make_float4(hi[a][0], hi[a][1], hi[a][2], hi[a][3]);
-  }
-  h[6] = h[7] = make_float4(0.f, 0.f, 0.f, 0.f);
-}
-
-// Leaf blocks (kd_search.hpp: the fast leaf scan): the points of every leaf as structure of arrays in one 128-byte line —
-// x[8], y[8], z[8], original index[8] — so that a lane loads the coordinates of two points into adjacent registers (packed fp32
-// arithmetic).  Slots a leaf does not fill lie far away (kKdFar): their distance is huge but finite and never wins.
-__global__ void kd_leaf_blocks_kernel(const float4* __restrict__ pts, uint32_t n, int D, float* __restrict__ blocks) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (8u << D)) return;
-  const uint32_t leaf = i >> 3, slot = i & 7u;
-  const uint32_t pos = kd_bound(n, D, leaf) + slot;
-  const bool valid = pos < kd_bound(n, D, leaf + 1);
-  const float4 p = valid ? pts[pos] : make_float4(kKdFar, kKdFar, kKdFar, 0.f);
-  float* b = blocks + 32ull * leaf;
-  b[slot] = p.x;
-  b[8 + slot] = p.y;
-  b[16 + slot] = p.z;
-  b[24 + slot] = p.w;
 }
 
 // Leaf adjacency (kd_search.hpp: kd_adj_nearest_fast).  One lane per leaf L: its CELL C_L — the box the split planes of its root path cut
@@ -788,7 +800,9 @@ int build_leaf_adjacency(sga_context* ctx, sga_index* idx) {
   return SGA_OK;
 }
 
-static int build_kdtree(sga_context* ctx, const sga_cloud* cloud, sga_index* idx) {
+// box_seq: the note (notes.hpp) that carries the cloud's bounding box to the host — from the first split level when there is one (it takes
+// the box of its segment, the whole cloud, anyway), else from bbox_note_kernel
+static int build_kdtree(sga_context* ctx, const sga_cloud* cloud, sga_index* idx, unsigned long long* box_seq) {
   const size_t n = cloud->n;
   idx->kd_depth = 0;
   if (n == 0) return SGA_OK;
@@ -807,7 +821,6 @@ static int build_kdtree(sga_context* ctx, const sga_cloud* cloud, sga_index* idx
   SGA_TRY(idx->kd_nodes.alloc(1ull << D));
   SGA_TRY(idx->kd_nodes4.alloc(kd_pair_count(D)));
   const dim3 grid((n + 255) / 256), block(256);
-  hipLaunchKernelGGL(iota_kernel, grid, block, 0, ctx->stream, perm.p, n);
   uint32_t* cur = perm.p;
   uint32_t* nxt = perm2.p;
   size_t tb = 0;
@@ -823,12 +836,19 @@ static int build_kdtree(sga_context* ctx, const sga_cloud* cloud, sga_index* idx
   if (!lds_finish || D - dA > 8) dA = D;
   // small clouds: one launch per level (kd_split_level_kernel) down to segments of kSplitFinish points, the rest in LDS
   const bool split_path = lds_finish && n <= kSplitMaxPoints && !(getenv("SGA_KD_SPLIT") && atoi(getenv("SGA_KD_SPLIT")) == 0);
+  bool boxed = false;
   if (split_path) {
     dA = 0;
     while (dA < D && ((n + (1ull << dA) - 1) >> dA) > static_cast<size_t>(kSplitFinish)) dA++;
     for (int d = 0; d < dA; d++) {
       const size_t seg_max = (n + (1ull << d) - 1) >> d;
-#define SGA_SPLIT(THREADS, KEYS) hipLaunchKernelGGL((kd_split_level_kernel<THREADS, KEYS>), dim3(1u << d), dim3(THREADS), 0, ctx->stream, cloud->pts.p, cur, nxt, static_cast<uint32_t>(n), d, idx->kd_nodes.p)
+      unsigned long long* note_slot = nullptr;
+      if (d == 0) {  // the root level reads the identity permutation and hands the cloud's box to the host
+        *box_seq = note_begin(ctx, &note_slot);
+        boxed = true;
+      }
+      const uint32_t* level_in = d == 0 ? nullptr : cur;
+#define SGA_SPLIT(THREADS, KEYS) hipLaunchKernelGGL((kd_split_level_kernel<THREADS, KEYS>), dim3(1u << d), dim3(THREADS), 0, ctx->stream, cloud->pts.p, level_in, nxt, static_cast<uint32_t>(n), d, idx->kd_nodes.p, note_slot, *box_seq)
       if (seg_max <= 256 * 2) SGA_SPLIT(256, 2);
       else if (seg_max <= 256 * 4) SGA_SPLIT(256, 4);
       else if (seg_max <= 256 * 8) SGA_SPLIT(256, 8);
@@ -840,6 +860,8 @@ static int build_kdtree(sga_context* ctx, const sga_cloud* cloud, sga_index* idx
       std::swap(cur, nxt);
     }
   }
+  if (!boxed) SGA_TRY(cloud_bbox_enqueue(ctx, cloud->pts.p, n, box_seq));
+  if (!split_path || dA == 0) hipLaunchKernelGGL(iota_kernel, grid, block, 0, ctx->stream, perm.p, n);
   for (int d = 0; d < dA && !split_path; d++) {
     const uint32_t nseg = 1u << d;
     const dim3 sgrid((nseg + 255) / 256);
@@ -866,27 +888,17 @@ static int build_kdtree(sga_context* ctx, const sga_cloud* cloud, sga_index* idx
       hipLaunchKernelGGL(kd_finish_kernel<kFinishCap / 2>, dim3(1u << dA), dim3(kFinishThreads), 0, ctx->stream, cloud->pts.p, cur, nxt, static_cast<uint32_t>(n), dA, D, idx->kd_nodes.p);
     std::swap(cur, nxt);
   }
-  {
-    const uint32_t npairs = kd_pair_count(D);
-    hipLaunchKernelGGL(kd_pairs_kernel, dim3((npairs + 255) / 256), block, 0, ctx->stream, idx->kd_nodes.p, D, npairs, idx->kd_nodes4.p);
-  }
   SGA_HIP(hipGetLastError());
   SGA_TRY(idx->kd_pts.alloc(n + kKdLeafMax));  // + one leaf of points at infinity: leaf scans read 8 slots unconditionally
   if (cloud->has_normals) SGA_TRY(idx->nrm.alloc(n));
   if (cloud->has_covs) SGA_TRY(idx->cov.alloc(n));
-  hipLaunchKernelGGL(gather_sorted_kernel, dim3((n + kKdLeafMax + 255) / 256), block, 0, ctx->stream, cur, n, cloud->pts.p, cloud->has_normals ? cloud->nrm.p : nullptr, cloud->has_covs ? cloud->cov.p : nullptr, idx->kd_pts.p, idx->nrm.p, idx->cov.p);
   SGA_TRY(idx->kd_boxes.alloc(4ull << D));
-  for (int base = D;; base -= 8) {
-    hipLaunchKernelGGL(kd_boxes_kernel, dim3(((1u << base) + 255) / 256), block, 0, ctx->stream, idx->kd_pts.p, static_cast<uint32_t>(n), D, base, idx->kd_boxes.p);
-    if (base <= 8) break;
-  }
-  {
-    const int G = D < 2 ? D : 2;
-    SGA_TRY(idx->kd_groups.alloc(8ull << (D - G)));
-    hipLaunchKernelGGL(kd_groups_kernel, dim3(((1u << (D - G)) + 255) / 256), block, 0, ctx->stream, idx->kd_boxes.p, D, G, idx->kd_groups.p);
-  }
+  SGA_TRY(idx->kd_groups.alloc(8ull << (D - (D < 2 ? D : 2))));
   SGA_TRY(idx->kd_leaf.alloc(8ull << D));
-  hipLaunchKernelGGL(kd_leaf_blocks_kernel, dim3(((8u << D) + 255) / 256), block, 0, ctx->stream, idx->kd_pts.p, static_cast<uint32_t>(n), D, reinterpret_cast<float*>(idx->kd_leaf.p));
+  // gather into kd order, leaf blocks, leaf boxes + 8 levels of boxes, group headers, pair records: one launch (kd_tail_kernel)
+  hipLaunchKernelGGL(kd_tail_kernel, dim3(((1u << D) + 255) / 256), block, 0, ctx->stream, cur, static_cast<uint32_t>(n), D, cloud->pts.p, cloud->has_normals ? cloud->nrm.p : nullptr, cloud->has_covs ? cloud->cov.p : nullptr, idx->kd_nodes.p,
+                     idx->kd_pts.p, idx->nrm.p, idx->cov.p, idx->kd_boxes.p, idx->kd_groups.p, reinterpret_cast<float*>(idx->kd_leaf.p), idx->kd_nodes4.p, kd_pair_count(D));
+  for (int base = D - 8; base > 0; base -= 8) hipLaunchKernelGGL(kd_boxes_kernel, dim3(((1u << base) + 255) / 256), block, 0, ctx->stream, idx->kd_pts.p, static_cast<uint32_t>(n), D, base, idx->kd_boxes.p);
   SGA_HIP(hipGetLastError());
   SGA_TRY(build_leaf_adjacency(ctx, idx));
   if (!ctx->stream_ordered) SGA_HIP(hipStreamSynchronize(ctx->stream));
@@ -1004,13 +1016,10 @@ int sga_index_build_kdtree(sga_context* ctx, const sga_cloud* target, sga_index*
   idx->has_covs = target->has_covs;
   SGA_TRY(wait_ready(ctx, target->ready));  // attributes estimated on another context in stream-ordered mode
   if (n > 0) {
-    // the bounding box travels to the host behind the build: build_kdtree synchronises the stream once, at its end
-    DevBuf<int> d_bbox;
-    SGA_TRY(cloud_bbox_enqueue(ctx, target->pts.p, n, d_bbox, ctx->h_scratch));
-    if (ctx->stream_ordered) SGA_HIP(hipEventRecord(ctx->ev_aux, ctx->stream));  // the box is on the host once this event has completed
-    SGA_TRY(build_kdtree(ctx, target, idx.get()));
-    if (ctx->stream_ordered) SGA_HIP(hipEventSynchronize(ctx->ev_aux));  // (otherwise build_kdtree has synchronised the stream)
-    cloud_bbox_decode(ctx->h_scratch, n, idx->bbox_lo, idx->bbox_hi);
+    // the bounding box travels to the host as a note (notes.hpp) while the build behind it is being enqueued
+    unsigned long long box_seq = 0;
+    SGA_TRY(build_kdtree(ctx, target, idx.get(), &box_seq));
+    SGA_TRY(cloud_bbox_collect(ctx, box_seq, n, idx->bbox_lo, idx->bbox_hi));
     for (int k = 0; k < 3; k++)
       if (!std::isfinite(idx->bbox_lo[k]) || !std::isfinite(idx->bbox_hi[k])) return fail(SGA_ERR_INVALID, "target cloud contains non-finite coordinates");
     SGA_TRY(build_cell_grid(ctx, idx.get()));  // large targets: the second search structure (cell_grid.hpp)

@@ -1761,6 +1761,7 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
   // to no pose the host knows, so an early return below (allocation, rejector callback, launch error) must not leave them marked
   // valid for T_prev.
   if (!voxel) pb->prev_valid = false;
+  pb->state_fresh = false;
   if (p.n > 0 && !voxel) {
     NNParams<Real> q{};
     q.src_pts = pb->src_pts();

@@ -253,8 +253,11 @@ int sga_align_problem(sga_context* ctx, sga_problem* problem, const double init_
   // every registration starts without search hints: its result must not depend on earlier calls on the same problem
   // (with the canonical tie rule of kd_search.hpp they could not change it anyway; what this guarantees is that no search work is
   // carried over from one registration to the next)
-  if (problem->n > 0) SGA_HIP(hipMemsetAsync(problem->hint.p, 0xff, problem->n * sizeof(int), ctx->stream));
-  if (problem->n > 0 && problem->hint2.n >= problem->n) SGA_HIP(hipMemsetAsync(problem->hint2.p, 0xff, problem->n * sizeof(int), ctx->stream));
+  if (!problem->state_fresh) {  // (a problem nothing has searched yet holds no hints: two fills less for every scan of an odometry stream)
+    SGA_HIP(hipSetDevice(ctx->device));
+    if (problem->n > 0) SGA_HIP(hipMemsetAsync(problem->hint.p, 0xff, problem->n * sizeof(int), ctx->stream));
+    if (problem->n > 0 && problem->hint2.n >= problem->n) SGA_HIP(hipMemsetAsync(problem->hint2.p, 0xff, problem->n * sizeof(int), ctx->stream));
+  }
   problem->prev_valid = false;
   GpuReduction g{ctx, problem, &setting->factor};
   return optimize_impl(*setting, init_T ? init_T : I16, gpu_linearize, gpu_error, &g, out);

@@ -9,59 +9,168 @@
 #include <rocprim/rocprim.hpp>
 
 #include "kd_search.hpp"
+#include "knn_wave.hpp"
+#include "notes.hpp"
 
 namespace sga {
 
 int ensure_temp(sga_context* ctx, size_t bytes);
 
 // ---- voxel grid ----------------------------------------------------------------------------------------------------------------
+// util/downsampling.hpp:23-78: key = x | y << 21 | z << 42 of the voxel coordinates + 2^20, points sorted by key, one centroid per run,
+// output in ascending key order.  Round 6 (the chain of a C5 scan was 240 us of wall time for 120 us of kernels):
+//   * SHORT KEYS.  An uploaded cloud knows the bounding box of its records (sga_cloud::has_box), so the host knows the range of voxel
+//     coordinates per axis and the kernel packs (c - c_min) into just as many bits as the range needs, x lowest, z highest: the same
+//     ORDER as the reference's 63-bit key (same axes, same significance), in 27 bits for a KITTI scan at 0.25 m — a 32-bit radix sort over
+//     28 bits instead of a 64-bit one over 64.  Clouds without a box (made on the device) keep the 63-bit key.
+//   * ONE KERNEL from sorted keys to run starts (ds_segments_kernel: head flags, a single-pass scan with decoupled look-back, the
+//     compacted starts, the number of runs) instead of heads + a three-launch library scan + starts.
+//   * NO copy commands, no stream synchronisation: the number of runs reaches the host as a note (notes.hpp) while the centroid kernel
+//     — launched for the largest possible number of runs, it reads the true one on the device — is already running.
 __device__ __forceinline__ int fast_floor_dd(double x) {
   const int n = static_cast<int>(x);
   return n - (x < static_cast<double>(n));
 }
 
-// (ox, oy, oz): the origin of the cloud's device frame (common.hpp) — the voxel a point falls into is a property of its position in the
-// CALLER's frame, so the origin is added back in double before the floor
-__global__ void downsample_keys_kernel(const float4* __restrict__ pts, size_t n, double inv_leaf, double ox, double oy, double oz, unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals) {
-  const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
+struct VoxelKeyLayout {
+  int cmin[3];   // smallest voxel coordinate (+ 2^20) the keys can hold, per axis
+  int bits[3];   // bits per axis; 21 / 21 / 21 with cmin = 0 is the reference's key
+  int total;     // bits[0] + bits[1] + bits[2]; the key of a dropped point is 1 << total: it sorts behind every voxel
+};
+
+// scratch words of a voxel-grid call (per context, kept between calls): [0] arrival counter of ds_segments_kernel (0 between launches),
+// [1] number of runs, [2] number of points with a valid key
+template <typename Key>
+__global__ void downsample_keys_kernel(const float4* __restrict__ pts, uint32_t n, double inv_leaf, double ox, double oy, double oz, VoxelKeyLayout L, Key* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ scratch) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) scratch[2] = n;  // lowered by the first dropped point ds_segments_kernel meets
   if (i >= n) return;
   const float4 p = pts[i];
-  // downsampling.hpp:36-49: coord = fast_floor(p * inv_leaf) + 2^20, valid iff 0 <= coord <= 2^21-1, key = x | y<<21 | z<<42
+  // downsampling.hpp:36-49: coord = fast_floor(p * inv_leaf) + 2^20, valid iff 0 <= coord <= 2^21-1.  (ox, oy, oz): origin of the cloud's
+  // device frame (common.hpp) — the voxel a point falls into is a property of its position in the CALLER's frame
   const int cx = fast_floor_dd((static_cast<double>(p.x) + ox) * inv_leaf) + (1 << 20);
   const int cy = fast_floor_dd((static_cast<double>(p.y) + oy) * inv_leaf) + (1 << 20);
   const int cz = fast_floor_dd((static_cast<double>(p.z) + oz) * inv_leaf) + (1 << 20);
   const int mask = (1 << 21) - 1;
-  const bool bad = cx < 0 || cy < 0 || cz < 0 || cx > mask || cy > mask || cz > mask;
-  keys[i] = bad ? ~0ull : (static_cast<unsigned long long>(cx) | (static_cast<unsigned long long>(cy) << 21) | (static_cast<unsigned long long>(cz) << 42));
-  vals[i] = static_cast<uint32_t>(i);
+  bool bad = cx < 0 || cy < 0 || cz < 0 || cx > mask || cy > mask || cz > mask;
+  // a non-finite coordinate has no voxel: the reference's fast_floor turns it into INT_MIN on x86 (cvttsd2si), i.e. an invalid coordinate
+  // that is dropped (downsampling.hpp:41-46); the conversion on the device would give 0 for a NaN — a voxel next to the origin
+  bad = bad || !(fabsf(p.x) <= 3.4028234e38f) || !(fabsf(p.y) <= 3.4028234e38f) || !(fabsf(p.z) <= 3.4028234e38f);
+  const unsigned ux = static_cast<unsigned>(cx - L.cmin[0]), uy = static_cast<unsigned>(cy - L.cmin[1]), uz = static_cast<unsigned>(cz - L.cmin[2]);
+  bad = bad || (ux >> L.bits[0]) != 0u || (uy >> L.bits[1]) != 0u || (uz >> L.bits[2]) != 0u;  // (outside the cloud's box: only a non-finite coordinate gets here)
+  const Key key = static_cast<Key>(ux) | (static_cast<Key>(uy) << L.bits[0]) | (static_cast<Key>(uz) << (L.bits[0] + L.bits[1]));
+  keys[i] = bad ? (static_cast<Key>(1) << L.total) : key;
+  vals[i] = i;
 }
 
-__global__ void ds_heads_kernel(const unsigned long long* __restrict__ keys, size_t n, uint32_t* __restrict__ flags) {
-  const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
-  if (i >= n) return;
-  const unsigned long long k = keys[i];
-  flags[i] = (k != ~0ull && (i == 0 || keys[i - 1] != k)) ? 1u : 0u;
-}
-
-__global__ void ds_starts_kernel(const uint32_t* __restrict__ flags, const uint32_t* __restrict__ seg_id, size_t n, uint32_t* __restrict__ seg_start) {
-  const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
-  if (i >= n) return;
-  if (flags[i]) seg_start[seg_id[i]] = static_cast<uint32_t>(i);
+// Sorted keys -> the start of every run (seg_start[r], r in ascending key order), the number of runs (scratch[1]) and of valid points
+// (scratch[2]); the number of runs also goes to the host as a note.  Single pass: a workgroup takes the next tile of 2048 keys (arrival
+// order = tile order, so a workgroup only ever waits for workgroups that are already running), counts its run heads, publishes the count
+// and looks back over its predecessors' published counts / prefixes 64 at a time (decoupled look-back).  status[]: one word per tile,
+// {epoch : 30, state : 2, value : 32}; words of earlier launches carry an older epoch and read as "nothing yet", so nothing is cleared.
+constexpr int kSegThreads = 256, kSegItems = 8, kSegTile = kSegThreads * kSegItems;
+template <typename Key>
+__global__ __launch_bounds__(kSegThreads) void ds_segments_kernel(const Key* __restrict__ keys, uint32_t n, Key bad, unsigned long long* __restrict__ status, unsigned epoch, uint32_t* __restrict__ scratch, uint32_t* __restrict__ seg_start,
+                                                                   unsigned long long* __restrict__ note_slot, unsigned long long seq) {
+  __shared__ uint32_t sh_tile, sh_wave[kSegThreads / 64], sh_excl;
+  if (threadIdx.x == 0) sh_tile = atomicAdd(&scratch[0], 1u);
+  __syncthreads();
+  const uint32_t tile = sh_tile, num_tiles = gridDim.x;
+  const uint32_t first = tile * kSegTile + threadIdx.x * kSegItems;
+  Key k[kSegItems + 1];
+  k[0] = (first > 0 && first - 1 < n) ? keys[first - 1] : bad;
+#pragma unroll
+  for (int j = 0; j < kSegItems; j++) k[j + 1] = first + j < n ? keys[first + j] : bad;
+  unsigned heads = 0;
+#pragma unroll
+  for (int j = 0; j < kSegItems; j++) {
+    const uint32_t i = first + j;
+    if (i < n && k[j + 1] != bad && (i == 0 || k[j] != k[j + 1])) heads |= 1u << j;
+    if (i < n && k[j + 1] == bad && (i == 0 || k[j] != bad)) scratch[2] = i;  // the first dropped point: one writer
+  }
+  const uint32_t mine = __popc(heads);
+  // workgroup scan of the head counts
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t incl = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t v = __shfl_up(incl, off);
+    if (lane >= off) incl += v;
+  }
+  if (lane == 63) sh_wave[wave] = incl;
+  __syncthreads();
+  uint32_t wave_base = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < kSegThreads / 64; w++) {
+    if (w < wave) wave_base += sh_wave[w];
+    total += sh_wave[w];
+  }
+  const unsigned long long tag = static_cast<unsigned long long>(epoch) << 34;
+  constexpr unsigned long long kAgg = 1ull << 32, kPrefix = 2ull << 32;
+  if (wave == 0) {
+    uint32_t excl = 0;
+    if (tile > 0) {
+      if (lane == 0) __hip_atomic_store(&status[tile], tag | kAgg | total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      int look = static_cast<int>(tile) - 1;
+      for (;;) {
+        const int j = look - lane;
+        unsigned long long w;
+        do {
+          w = j >= 0 ? __hip_atomic_load(&status[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) : (tag | kPrefix);
+        } while (__ballot((w >> 34) != (tag >> 34)) != 0ull);  // every predecessor of this window has taken its tile: it publishes without waiting for anybody
+        const unsigned long long prefixes = __ballot((w & kPrefix) != 0ull);
+        const int stop = prefixes != 0ull ? __ffsll(static_cast<long long>(prefixes)) - 1 : 63;  // nearest predecessor holding an inclusive prefix
+        uint32_t v = lane <= stop ? static_cast<uint32_t>(w) : 0u;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        excl += v;
+        if (prefixes != 0ull) break;
+        look -= 64;
+      }
+    }
+    if (lane == 0) {
+      __hip_atomic_store(&status[tile], tag | kPrefix | (excl + total), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      sh_excl = excl;
+    }
+  }
+  __syncthreads();
+  uint32_t r = sh_excl + wave_base + incl - mine;  // rank of this thread's first head
+#pragma unroll
+  for (int j = 0; j < kSegItems; j++)
+    if (heads & (1u << j)) seg_start[r++] = first + j;
+  if (tile == num_tiles - 1 && threadIdx.x == 0) {  // the last tile to be TAKEN: every arrival has happened, its prefix is the number of runs
+    const uint32_t nseg = sh_excl + total;
+    scratch[1] = nseg;
+    __hip_atomic_store(&scratch[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    note_slot[1] = nseg;
+    note_publish(note_slot, seq);
+  }
 }
 
 // Eight lanes per voxel: a LiDAR scan has a few voxels with hundreds of points next to the sensor, and one lane walking such a
 // segment alone was the tail of the whole kernel.  Lane g sums the points g, g+8, ... of the segment in fp64, then the eight partial
 // sums are added in a fixed order (bit-reproducible; the grouping differs from a serial sum by rounding of the last bit at most).
-__global__ void ds_mean_kernel(const uint32_t* __restrict__ seg_start, uint32_t nseg, const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ order, size_t n, const float4* __restrict__ pts, float4* __restrict__ out) {
+// Launched for `capacity` voxels; the number there are (scratch[1]) and the end of the last run (scratch[2]) are read here.
+__global__ void ds_mean_kernel(const uint32_t* __restrict__ seg_start, const uint32_t* __restrict__ scratch, const uint32_t* __restrict__ order, const float4* __restrict__ pts, float4* __restrict__ out) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t v = t >> 3, g = t & 7u;
+  const uint32_t nseg = scratch[1];
+  if ((blockIdx.x * blockDim.x) >> 3 >= nseg) return;  // workgroup-uniform
   const bool valid = v < nseg;
   double sx = 0, sy = 0, sz = 0;
   uint32_t cnt = 0;
   if (valid) {
-    const uint32_t s = seg_start[v];
-    const unsigned long long key = keys[s];
-    for (size_t i = s + g; i < n && keys[i] == key; i += 8) {
+    const uint32_t s = seg_start[v], e = v + 1 < nseg ? seg_start[v + 1] : scratch[2];
+    uint32_t i = s + g;
+    for (; i + 24 < e; i += 32) {  // four points of this lane in flight
+      const float4 p0 = pts[order[i]], p1 = pts[order[i + 8]], p2 = pts[order[i + 16]], p3 = pts[order[i + 24]];
+      sx += p0.x, sy += p0.y, sz += p0.z;
+      sx += p1.x, sy += p1.y, sz += p1.z;
+      sx += p2.x, sy += p2.y, sz += p2.z;
+      sx += p3.x, sy += p3.y, sz += p3.z;
+      cnt += 4;
+    }
+    for (; i < e; i += 8) {
       const float4 p = pts[order[i]];
       sx += p.x;
       sy += p.y;
@@ -197,46 +306,15 @@ __device__ __forceinline__ Eig3 eigen_sym3(const double a[3][3] /* lower triangl
 constexpr int kFeatBlock = 64;
 constexpr int kFeatWindow = 128;
 
-// One lane per point of the kd-ordered index; neighbours come from the same tree.  Results are written both to the index's
-// kd-ordered attribute arrays and, through the original index kept in pts.w, to the caller's cloud.
-template <int K>  // K > 0: k = K neighbours in registers (kd_knn_own_points); K = 0: any k, list in LDS (kd_knn)
-__global__ __launch_bounds__(kFeatBlock) void local_features_kernel(
-  const KdView g, size_t n, int k, int flags, float4* __restrict__ idx_nrm, Cov8* __restrict__ idx_cov, float4* __restrict__ cloud_nrm, Cov8* __restrict__ cloud_cov, double ox, double oy, double oz) {
-  extern __shared__ float sh[];
-  __shared__ float4 window[kFeatWindow];  // the kd positions around the wave's own, scanned before the walk
-  const int kpad = (k + 3) & ~3;  // kd_knn sweeps the list four slots at a time
-  float* sd = sh;
-  int* si = reinterpret_cast<int*>(sh + static_cast<size_t>(kpad) * kFeatBlock);
-  uint32_t* stack = reinterpret_cast<uint32_t*>(sh + 2 * static_cast<size_t>(kpad) * kFeatBlock);
-  const int lane = threadIdx.x;
-  const size_t i = blockIdx.x * static_cast<size_t>(kFeatBlock) + lane;
-  for (int j = 0; j < kpad; j++) {
-    sd[j * kFeatBlock + lane] = INFINITY;
-    si[j * kFeatBlock + lane] = -1;
-  }
-  // candidates scanned before the walk: the wave's own 64 positions and 32 on either side (kFeatWindow = 128), fetched with two coalesced loads
-  const uint32_t base = blockIdx.x * kFeatBlock;
-  const uint32_t pre_first = base > (kFeatWindow - kFeatBlock) / 2 ? base - (kFeatWindow - kFeatBlock) / 2 : 0u;
-  const uint32_t pre_end = static_cast<uint32_t>(min(static_cast<size_t>(pre_first) + kFeatWindow, n));
-  for (uint32_t w = lane; w < pre_end - pre_first; w += kFeatBlock) window[w] = g.pts[pre_first + w];
-  __syncthreads();
-  if (i >= n) return;
-  const float4 p = g.pts[i];
-  if constexpr (K > 0) {
-    KnnRegs<K> L;
-    kd_knn_own_points<K, kFeatBlock>(g, p.x, p.y, p.z, L, window, pre_first, pre_end, min(base, pre_end), min(base + kFeatBlock, pre_end), stack, lane);
-#pragma unroll
-    for (int j = 0; j < K; j++) {  // hand the list to the common code below
-      sd[j * kFeatBlock + lane] = L.d[j];
-      si[j * kFeatBlock + lane] = L.id[j];
-    }
-  } else {
-    kd_knn<kFeatBlock>(g, p.x, p.y, p.z, k, INFINITY, sd, si, stack, lane, false, pre_first, pre_end, window, base, base + kFeatBlock);  // unsorted: the sums below do not depend on the order
-  }
+// mean / covariance of the neighbourhood -> normal, regularised covariance (normal_estimation.hpp:65-92, :13-63), written to the index's
+// kd-ordered arrays and, through the original index in p.w, to the caller's cloud.  id_at(j): kd position of the j-th neighbour, < 0 = no more.
+template <class IdAt>
+__device__ __forceinline__ void features_from_neighbours(const KdView& g, size_t i, const float4 p, IdAt id_at, int k, int flags, float4* __restrict__ idx_nrm, Cov8* __restrict__ idx_cov, float4* __restrict__ cloud_nrm,
+                                                         Cov8* __restrict__ cloud_cov, double ox, double oy, double oz) {
   int found = 0;
   double sp[3] = {0, 0, 0}, sc[6] = {0, 0, 0, 0, 0, 0};
   for (int j = 0; j < k; j++) {
-    const int id = si[j * kFeatBlock + lane];
+    const int id = id_at(j);
     if (id < 0) break;
     const float4 q = g.pts[id];
     const double x = q.x, y = q.y, z = q.z;
@@ -310,6 +388,64 @@ __global__ __launch_bounds__(kFeatBlock) void local_features_kernel(
   }
 }
 
+// One lane per point of the kd-ordered index; neighbours come from the same tree.  Results are written both to the index's
+// kd-ordered attribute arrays and, through the original index kept in pts.w, to the caller's cloud.
+template <int K>  // K > 0: k = K neighbours in registers (kd_knn_own_points); K = 0: any k, list in LDS (kd_knn)
+__global__ __launch_bounds__(kFeatBlock) void local_features_kernel(
+  const KdView g, size_t n, int k, int flags, float4* __restrict__ idx_nrm, Cov8* __restrict__ idx_cov, float4* __restrict__ cloud_nrm, Cov8* __restrict__ cloud_cov, double ox, double oy, double oz) {
+  extern __shared__ float sh[];
+  __shared__ float4 window[kFeatWindow];  // the kd positions around the wave's own, scanned before the walk
+  const int kpad = (k + 3) & ~3;  // kd_knn sweeps the list four slots at a time
+  float* sd = sh;
+  int* si = reinterpret_cast<int*>(sh + static_cast<size_t>(kpad) * kFeatBlock);
+  uint32_t* stack = reinterpret_cast<uint32_t*>(sh + 2 * static_cast<size_t>(kpad) * kFeatBlock);
+  const int lane = threadIdx.x;
+  const size_t i = blockIdx.x * static_cast<size_t>(kFeatBlock) + lane;
+  for (int j = 0; j < kpad; j++) {
+    sd[j * kFeatBlock + lane] = INFINITY;
+    si[j * kFeatBlock + lane] = -1;
+  }
+  // candidates scanned before the walk: the wave's own 64 positions and 32 on either side (kFeatWindow = 128), fetched with two coalesced loads
+  const uint32_t base = blockIdx.x * kFeatBlock;
+  const uint32_t pre_first = base > (kFeatWindow - kFeatBlock) / 2 ? base - (kFeatWindow - kFeatBlock) / 2 : 0u;
+  const uint32_t pre_end = static_cast<uint32_t>(min(static_cast<size_t>(pre_first) + kFeatWindow, n));
+  for (uint32_t w = lane; w < pre_end - pre_first; w += kFeatBlock) window[w] = g.pts[pre_first + w];
+  __syncthreads();
+  if (i >= n) return;
+  const float4 p = g.pts[i];
+  if constexpr (K > 0) {
+    KnnRegs<K> L;
+    kd_knn_own_points<K, kFeatBlock>(g, p.x, p.y, p.z, L, window, pre_first, pre_end, min(base, pre_end), min(base + kFeatBlock, pre_end), stack, lane);
+#pragma unroll
+    for (int j = 0; j < K; j++) {  // hand the list to the common code below
+      sd[j * kFeatBlock + lane] = L.d[j];
+      si[j * kFeatBlock + lane] = L.id[j];
+    }
+  } else {
+    kd_knn<kFeatBlock>(g, p.x, p.y, p.z, k, INFINITY, sd, si, stack, lane, false, pre_first, pre_end, window, base, base + kFeatBlock);  // unsorted: the sums below do not depend on the order
+  }
+  features_from_neighbours(g, i, p, [&](int j) { return si[j * kFeatBlock + lane]; }, k, flags, idx_nrm, idx_cov, cloud_nrm, cloud_cov, ox, oy, oz);
+}
+
+// ---- small clouds: one wave per query (knn_wave.hpp), then one lane per point for the eigen-decompositions ------------------------
+__global__ __launch_bounds__(64) void knn_wave_kernel(const KdView g, uint32_t n, int k, int* __restrict__ nbr /* n x k kd positions, nearest first, -1 = none */) {
+  __shared__ uint32_t stack[2 * kKdMaxDepth + 2];
+  const int lane = threadIdx.x;
+  const uint32_t i = blockIdx.x;
+  float bd;
+  int bid;
+  knn_wave_query(g, i, k, lane, stack, bd, bid);
+  if (lane < k) nbr[static_cast<size_t>(i) * k + lane] = bd < INFINITY ? bid : -1;
+}
+
+__global__ __launch_bounds__(64) void features_from_list_kernel(const KdView g, size_t n, int k, const int* __restrict__ nbr, int flags, float4* __restrict__ idx_nrm, Cov8* __restrict__ idx_cov, float4* __restrict__ cloud_nrm,
+                                                                Cov8* __restrict__ cloud_cov, double ox, double oy, double oz) {
+  const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
+  if (i >= n) return;
+  const int* __restrict__ mine = nbr + i * k;
+  features_from_neighbours(g, i, g.pts[i], [&](int j) { return mine[j]; }, k, flags, idx_nrm, idx_cov, cloud_nrm, cloud_cov, ox, oy, oz);
+}
+
 __global__ void refresh_attributes_kernel(const float4* __restrict__ idx_pts, size_t n, const float4* __restrict__ cloud_nrm, const Cov8* __restrict__ cloud_cov, float4* __restrict__ idx_nrm, Cov8* __restrict__ idx_cov) {
   const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
   if (i >= n) return;
@@ -321,6 +457,84 @@ __global__ void refresh_attributes_kernel(const float4* __restrict__ idx_pts, si
 }  // namespace sga
 
 using namespace sga;
+
+// clouds of at most this many points estimate their normals / covariances with one wave per query (knn_wave.hpp); SGA_KNN_WAVE_MAX, sga_set_knn_wave_max
+static long long g_knn_wave_max = getenv("SGA_KNN_WAVE_MAX") ? atoll(getenv("SGA_KNN_WAVE_MAX")) : 32768;
+
+extern "C" {
+
+void sga_set_knn_wave_max(long long max_points) { g_knn_wave_max = max_points; }
+
+}  // extern "C"
+
+namespace {
+// bits needed for the values 0 .. range - 1
+int bits_for(long long range) {
+  int b = 0;
+  while ((1ll << b) < range) b++;
+  return b;
+}
+
+template <typename Key>
+int voxelgrid_run(sga_context* ctx, const sga_cloud* in, double leaf, const VoxelKeyLayout& L, sga_cloud* res) {
+  const size_t n = in->n;
+  const uint32_t n32 = static_cast<uint32_t>(n);
+  DevBuf<Key> keys, keys_sorted;
+  DevBuf<uint32_t> vals, order, seg_start;
+  SGA_TRY(keys.alloc(n));
+  SGA_TRY(keys_sorted.alloc(n));
+  SGA_TRY(vals.alloc(n));
+  SGA_TRY(order.alloc(n));
+  SGA_TRY(seg_start.alloc(n + 1));
+  const uint32_t tiles = (n32 + kSegTile - 1) / kSegTile;
+  if (ctx->vg_status.n < tiles || ctx->vg_scratch.n < 4 || ctx->vg_epoch >= (1u << 30) - 1u) {  // grow-only; a fresh array reads "nothing yet" for every epoch > 0
+    if (ctx->vg_status.n < tiles) SGA_TRY(ctx->vg_status.alloc(std::max<size_t>(2 * tiles, 1024)));
+    SGA_HIP(hipMemsetAsync(ctx->vg_status.p, 0, ctx->vg_status.n * sizeof(unsigned long long), ctx->stream));
+    if (ctx->vg_scratch.n < 4) {
+      SGA_TRY(ctx->vg_scratch.alloc(4));
+      SGA_HIP(hipMemsetAsync(ctx->vg_scratch.p, 0, 4 * sizeof(uint32_t), ctx->stream));
+    }
+    ctx->vg_epoch = 0;
+  }
+  const unsigned epoch = ++ctx->vg_epoch;
+  const dim3 grid((n + 255) / 256), block(256);
+  hipLaunchKernelGGL((downsample_keys_kernel<Key>), grid, block, 0, ctx->stream, in->pts.p, n32, 1.0 / leaf, in->origin[0], in->origin[1], in->origin[2], L, keys.p, vals.p, ctx->vg_scratch.p);
+  const unsigned end_bit = static_cast<unsigned>(std::min<int>(L.total + 1, 8 * static_cast<int>(sizeof(Key))));
+  size_t tb = 0;
+  // (rocPRIM sorts up to 1M items with a merge sort — block sort + 6 merges + 3 bookkeeping launches for a 115k-point scan — whatever the
+  // key width; its onesweep radix sort, forced by lowering the limit, was measured slower here: 82 us of passes + 33 us of state fills
+  // against 54 us.  The short keys still halve the bytes the merges move.)
+  SGA_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys.p, keys_sorted.p, vals.p, order.p, n, 0, end_bit, ctx->stream));
+  SGA_TRY(ensure_temp(ctx, tb));
+  SGA_HIP(rocprim::radix_sort_pairs(ctx->d_temp.p, tb, keys.p, keys_sorted.p, vals.p, order.p, n, 0, end_bit, ctx->stream));
+  unsigned long long* slot = nullptr;
+  const unsigned long long seq = note_begin(ctx, &slot);
+  hipLaunchKernelGGL((ds_segments_kernel<Key>), dim3(tiles), dim3(kSegThreads), 0, ctx->stream, keys_sorted.p, n32, static_cast<Key>(1) << L.total, ctx->vg_status.p, epoch, ctx->vg_scratch.p, seg_start.p, slot, seq);
+  SGA_HIP(hipGetLastError());
+  // Small clouds (a LiDAR scan): the centroid kernel is launched for n voxels before the host knows how many there are, so the device
+  // never waits for the host; the output then keeps room for n points.  Large clouds wait for the count and allocate what they need.
+  constexpr size_t kSpeculativeMax = 262144;
+  unsigned long long payload[kNoteWords - 1];
+  uint32_t nseg = 0;
+  if (n <= kSpeculativeMax) {
+    SGA_TRY(res->pts.alloc(n));
+    hipLaunchKernelGGL(ds_mean_kernel, dim3((n * 8 + 255) / 256), dim3(256), 0, ctx->stream, seg_start.p, ctx->vg_scratch.p, order.p, in->pts.p, res->pts.p);
+    SGA_HIP(hipGetLastError());
+    SGA_TRY(note_wait(ctx, seq, payload));
+    nseg = static_cast<uint32_t>(payload[0]);
+  } else {
+    SGA_TRY(note_wait(ctx, seq, payload));
+    nseg = static_cast<uint32_t>(payload[0]);
+    if (nseg > 0) {
+      SGA_TRY(res->pts.alloc(nseg));
+      hipLaunchKernelGGL(ds_mean_kernel, dim3((static_cast<size_t>(nseg) * 8 + 255) / 256), dim3(256), 0, ctx->stream, seg_start.p, ctx->vg_scratch.p, order.p, in->pts.p, res->pts.p);
+      SGA_HIP(hipGetLastError());
+    }
+  }
+  res->n = nseg;
+  return SGA_OK;
+}
+}  // namespace
 
 extern "C" {
 
@@ -339,39 +553,31 @@ int sga_voxelgrid_sampling(sga_context* ctx, const sga_cloud* in, double leaf, s
     *out = res.release();
     return SGA_OK;
   }
-  DevBuf<unsigned long long> keys, keys_sorted;
-  DevBuf<uint32_t> vals, order, flags, seg_id, seg_start;
-  SGA_TRY(keys.alloc(n));
-  SGA_TRY(keys_sorted.alloc(n));
-  SGA_TRY(vals.alloc(n));
-  SGA_TRY(order.alloc(n));
-  SGA_TRY(flags.alloc(n));
-  SGA_TRY(seg_id.alloc(n));
-  const dim3 grid((n + 255) / 256), block(256);
-  hipLaunchKernelGGL(downsample_keys_kernel, grid, block, 0, ctx->stream, in->pts.p, n, 1.0 / leaf, in->origin[0], in->origin[1], in->origin[2], keys.p, vals.p);
-  size_t tb = 0;
-  SGA_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys.p, keys_sorted.p, vals.p, order.p, n, 0, 64, ctx->stream));
-  SGA_TRY(ensure_temp(ctx, tb));
-  SGA_HIP(rocprim::radix_sort_pairs(ctx->d_temp.p, tb, keys.p, keys_sorted.p, vals.p, order.p, n, 0, 64, ctx->stream));
-  hipLaunchKernelGGL(ds_heads_kernel, grid, block, 0, ctx->stream, keys_sorted.p, n, flags.p);
-  size_t tb2 = 0;
-  SGA_HIP(rocprim::exclusive_scan(nullptr, tb2, flags.p, seg_id.p, 0u, n, rocprim::plus<uint32_t>(), ctx->stream));
-  SGA_TRY(ensure_temp(ctx, tb2));
-  SGA_HIP(rocprim::exclusive_scan(ctx->d_temp.p, tb2, flags.p, seg_id.p, 0u, n, rocprim::plus<uint32_t>(), ctx->stream));
-  uint32_t last_flag = 0, last_seg = 0;
-  SGA_HIP(hipMemcpyAsync(&last_flag, flags.p + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
-  SGA_HIP(hipMemcpyAsync(&last_seg, seg_id.p + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
-  SGA_HIP(hipStreamSynchronize(ctx->stream));
-  const uint32_t nseg = last_seg + last_flag;
-  res->n = nseg;
-  if (nseg > 0) {
-    SGA_TRY(seg_start.alloc(nseg));
-    SGA_TRY(res->pts.alloc(nseg));
-    hipLaunchKernelGGL(ds_starts_kernel, grid, block, 0, ctx->stream, flags.p, seg_id.p, n, seg_start.p);
-    hipLaunchKernelGGL(ds_mean_kernel, dim3((static_cast<size_t>(nseg) * 8 + 255) / 256), dim3(256), 0, ctx->stream, seg_start.p, nseg, keys_sorted.p, order.p, n, in->pts.p, res->pts.p);
-    SGA_HIP(hipGetLastError());
-    SGA_HIP(hipStreamSynchronize(ctx->stream));
+  // the reference's key layout, or — when the box of the records is known — as many bits per axis as the cloud's voxel range needs
+  VoxelKeyLayout L{{0, 0, 0}, {21, 21, 21}, 63};
+  if (in->has_box) {
+    long long lo[3], hi[3];
+    bool ok = true;
+    for (int k = 0; k < 3; k++) {
+      const double a = std::floor((static_cast<double>(in->box_lo[k]) + in->origin[k]) / leaf), b = std::floor((static_cast<double>(in->box_hi[k]) + in->origin[k]) / leaf);
+      ok = ok && std::isfinite(a) && std::isfinite(b) && std::fabs(a) < 1e15 && std::fabs(b) < 1e15;
+      // one voxel of slack on either side: p * (1 / leaf) in the kernel and p / leaf here may round to different sides of an integer
+      const long long top = (1 << 21) - 1;
+      lo[k] = std::min(std::max<long long>(ok ? static_cast<long long>(a) - 1 + (1 << 20) : 0, 0), top);
+      hi[k] = std::max(std::min<long long>(ok ? static_cast<long long>(b) + 1 + (1 << 20) : top, top), lo[k]);  // (a box outside the grid: its points are dropped by the range test)
+    }
+    if (ok) {
+      L.total = 0;
+      for (int k = 0; k < 3; k++) {
+        L.cmin[k] = static_cast<int>(lo[k]);
+        L.bits[k] = std::max(1, bits_for(hi[k] - lo[k] + 1));
+        L.total += L.bits[k];
+      }
+    }
   }
+  SGA_TRY(L.total <= 31 ? voxelgrid_run<uint32_t>(ctx, in, leaf, L, res.get()) : voxelgrid_run<unsigned long long>(ctx, in, leaf, L, res.get()));
+  if (!ctx->stream_ordered) SGA_HIP(hipStreamSynchronize(ctx->stream));
+  SGA_TRY(mark_ready(ctx, res->ready));
   *out = res.release();
   return SGA_OK;
 }
@@ -430,15 +636,22 @@ int sga_estimate_normals_covariances(sga_context* ctx, sga_cloud* cloud, const s
     const dim3 fgrid((n + kFeatBlock - 1) / kFeatBlock), fblock(kFeatBlock);
     float4* inrm = temp ? nullptr : index->nrm.p;
     Cov8* icov = temp ? nullptr : index->cov.p;
-    // the reference's two neighbourhood sizes (registration_helper.cpp:60-61 k = 10, the benchmarks' k = 20) keep the list in registers
-    if (k == 20)
+    // clouds that do not fill the chip (a LiDAR scan after the voxel grid): one wave per query (knn_wave.hpp), then one lane per point
+    if (n <= static_cast<size_t>(g_knn_wave_max) && k <= 64) {
+      DevBuf<int> nbr;
+      rc = nbr.alloc(n * static_cast<size_t>(k));
+      if (rc == SGA_OK) {
+        hipLaunchKernelGGL(knn_wave_kernel, dim3(static_cast<unsigned>(n)), dim3(64), 0, ctx->stream, kv, static_cast<uint32_t>(n), k, nbr.p);
+        hipLaunchKernelGGL(features_from_list_kernel, fgrid, fblock, 0, ctx->stream, kv, n, k, nbr.p, flags, inrm, icov, cloud->nrm.p, cloud->cov.p, cloud->origin[0], cloud->origin[1], cloud->origin[2]);
+      }
+    } else if (k == 20)
       hipLaunchKernelGGL((local_features_kernel<20>), fgrid, fblock, shmem, ctx->stream, kv, n, k, flags, inrm, icov, cloud->nrm.p, cloud->cov.p, cloud->origin[0], cloud->origin[1], cloud->origin[2]);
     else if (k == 10)
       hipLaunchKernelGGL((local_features_kernel<10>), fgrid, fblock, shmem, ctx->stream, kv, n, k, flags, inrm, icov, cloud->nrm.p, cloud->cov.p, cloud->origin[0], cloud->origin[1], cloud->origin[2]);
     else
       hipLaunchKernelGGL((local_features_kernel<0>), fgrid, fblock, shmem, ctx->stream, kv, n, k, flags, inrm, icov, cloud->nrm.p, cloud->cov.p, cloud->origin[0], cloud->origin[1], cloud->origin[2]);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess && !ctx->stream_ordered) e = hipStreamSynchronize(ctx->stream);
+    hipError_t e = rc == SGA_OK ? hipGetLastError() : hipSuccess;
+    if (rc == SGA_OK && e == hipSuccess && !ctx->stream_ordered) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) rc = fail(SGA_ERR_HIP, "local_features_kernel: %s", hipGetErrorString(e));
   }
   if (rc == SGA_OK) {

@@ -236,6 +236,7 @@ static int problem_alloc_state(sga_context* ctx, sga_problem* pb, size_t n, bool
   // correspondences and certificates start as "none": one launch (four fills cost four launches, which is what a 15k-point scan pays for)
   hipLaunchKernelGGL(problem_state_init_kernel, dim3((n + 255) / 256 + 1), dim3(256), 0, ctx->stream, pb->corr.p, pb->hint.p, pb->hint2.p, pb->walked.p, n);
   SGA_HIP(hipGetLastError());
+  pb->state_fresh = true;
   return SGA_OK;
 }
 
