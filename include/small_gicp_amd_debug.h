@@ -32,6 +32,10 @@ void sga_set_grid_mode(int mode, long long min_points);
  * the form for clouds that do not fill the chip), larger ones with one query per lane.  Both are exact; the tests compare them.
  * Default 32768 (environment: SGA_KNN_WAVE_MAX); 0 = never. */
 void sga_set_knn_wave_max(long long max_points);
+/* GPU time (HIP events) between two points of the context's stream: start() records an event, stop() records another, waits for it and
+ * returns the milliseconds in between — the kernel times of bench.py's per-stage roofline lines (voxel grid, index build, covariances). */
+int sga_debug_timer_start(sga_context* ctx);
+int sga_debug_timer_stop(sga_context* ctx, double* ms);
 /* The host arithmetic of the frame check of sharded registrations (linearize.hip: problem_check_shard_frames), exposed so that it can be
  * tested without a device: pack() turns a source origin into the SGA_FRAME_CHECK_DOUBLES values a rank contributes to the all-reduce,
  * agree() says whether the ranks whose contributions were summed all named the same origin (exact for any origin, up to 1024 ranks). */

@@ -138,6 +138,8 @@ SYMBOLS = [
     ("sga_host_alloc", C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     ("sga_host_free", C.c_int, [C.c_void_p]),
     ("sga_set_knn_wave_max", None, [C.c_longlong]),
+    ("sga_debug_timer_start", C.c_int, [C.c_void_p]),
+    ("sga_debug_timer_stop", C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     ("sga_debug_shard_frame_pack", None, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("sga_debug_shard_frame_agree", C.c_int, [C.POINTER(C.c_double)]),
     ("sga_debug_kd_trips", C.c_int, [C.c_void_p]),

@@ -88,6 +88,14 @@ class Context:
         self.stream_ordered = bool(enabled)
         return prev
 
+    def gpu_time_ms(self, fn):
+        """GPU time (HIP events on the context's stream) of whatever fn() enqueues; returns (milliseconds, fn's result)."""
+        check(load().sga_debug_timer_start(self.h))
+        r = fn()
+        ms = C.c_double()
+        check(load().sga_debug_timer_stop(self.h, C.byref(ms)))
+        return ms.value, r
+
     def set_profiling(self, enabled=True):
         check(load().sga_context_set_profiling(self.h, int(enabled)))
 

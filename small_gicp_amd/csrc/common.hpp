@@ -144,6 +144,7 @@ struct sga_context {
   bool comm_recorded = false;
   double comm_ms = 0.0;
   uint64_t comm_calls = 0;
+  hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;  // sga_debug_timer_*: GPU time between two points of the stream
   hipEvent_t ev_aux = nullptr;   // small read-backs that must not wait for the work enqueued behind them (stream-ordered mode)
   bool stream_ordered = false;   // sga_context_set_stream_ordered: preprocessing entry points return once their work is enqueued
   bool mid_recorded = false;

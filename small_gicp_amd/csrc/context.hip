@@ -526,6 +526,8 @@ int sga_context_destroy(sga_context* ctx) {
   if (ctx->ev_mid) (void)hipEventDestroy(ctx->ev_mid);
   if (ctx->ev_comm) (void)hipEventDestroy(ctx->ev_comm);
   if (ctx->ev_aux) (void)hipEventDestroy(ctx->ev_aux);
+  if (ctx->ev_t0) (void)hipEventDestroy(ctx->ev_t0);
+  if (ctx->ev_t1) (void)hipEventDestroy(ctx->ev_t1);
   if (ctx->h_accum) (void)hipHostFree(ctx->h_accum);
   for (auto& slot : ctx->stage) {
     if (slot.host) (void)hipHostFree(slot.host);
@@ -593,6 +595,25 @@ int sga_context_set_profiling(sga_context* ctx, int enabled) {
   ctx->comm_calls = 0;
   ctx->comm_recorded = false;
   ctx->pending = 0;
+  return SGA_OK;
+}
+
+// GPU time between two points of the context's stream (bench.py: the per-stage roofline lines of the preprocessing kernels)
+int sga_debug_timer_start(sga_context* ctx) {
+  if (!ctx) return fail(SGA_ERR_INVALID, "null context");
+  SGA_HIP(hipSetDevice(ctx->device));
+  if (!ctx->ev_t0) SGA_HIP(hipEventCreate(&ctx->ev_t0));
+  if (!ctx->ev_t1) SGA_HIP(hipEventCreate(&ctx->ev_t1));
+  SGA_HIP(hipEventRecord(ctx->ev_t0, ctx->stream));
+  return SGA_OK;
+}
+int sga_debug_timer_stop(sga_context* ctx, double* ms) {
+  if (!ctx || !ms || !ctx->ev_t0) return fail(SGA_ERR_INVALID, "no timer running");
+  SGA_HIP(hipEventRecord(ctx->ev_t1, ctx->stream));
+  SGA_HIP(hipEventSynchronize(ctx->ev_t1));
+  float f = 0.f;
+  SGA_HIP(hipEventElapsedTime(&f, ctx->ev_t0, ctx->ev_t1));
+  *ms = f;
   return SGA_OK;
 }
 
