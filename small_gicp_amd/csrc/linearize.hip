@@ -1041,12 +1041,46 @@ __device__ __forceinline__ void linearize_group(const LinParams<Real>& p0, int f
 #pragma unroll
       for (int u = 0; u < PTS; u++) m4[u] = jn[u] >= 0 ? p.tgt_pts[jn[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    bool decided64[PTS];
+#pragma unroll
+    for (int u = 0; u < PTS; u++) decided64[u] = false;
+    if constexpr (TARGET == 0 && !CERT && sizeof(Real) == 8) {
+      // fp64 per-pair arithmetic: the reference compares DOUBLE distances (ann/knn_result.hpp:80-100, double queries against the stored
+      // points).  The walk compared fp32 distances of the fp32-rounded query; it also kept its runner-up — the only other point that can
+      // be the nearest in double when the two agree to fp32 rounding.  Both candidates are measured again here, in double, against the
+      // double query: the nearer one is the correspondence (equidistant: the lower kd position, the canonical rule), and the rejector's
+      // test (rejector.hpp:19-28: reject iff sq_dist > max_dist_sq) runs on that double distance.  hint[] / hint2[] / rex[] — the state of
+      // the SEARCH — stay what the walk wrote.
+      if (p.cert_nn2 != nullptr) {
+#pragma unroll
+        for (int u = 0; u < PTS; u++) {
+          const int i = first + u * stride;
+          if (!act[u] || jn[u] < 0) continue;
+          const int j2 = p.cert_nn2[i];
+          const double ax = static_cast<double>(m4[u].x) - Q[u][0], ay = static_cast<double>(m4[u].y) - Q[u][1], az = static_cast<double>(m4[u].z) - Q[u][2];
+          double d1 = ax * ax + ay * ay + az * az;
+          if (j2 >= 0) {
+            const float4 c = p.tgt_pts[j2];
+            const double bx = static_cast<double>(c.x) - Q[u][0], by = static_cast<double>(c.y) - Q[u][1], bz = static_cast<double>(c.z) - Q[u][2];
+            const double d2 = bx * bx + by * by + bz * bz;
+            if (d2 < d1 || (d2 == d1 && j2 < jn[u])) {
+              d1 = d2;
+              jn[u] = j2;
+              m4[u] = c;
+            }
+          }
+          within[u] = d1 <= static_cast<double>(p.max_sq);
+          if (p.reject != nullptr) within[u] = within[u] && p.reject[__float_as_uint(ps4[u].w)] == 0;
+          decided64[u] = true;
+        }
+      }
+    }
     SGA_STAGE_PARAMS(p);
 #pragma unroll
     for (int u = 0; u < PTS; u++) {
       Tg[u][0] = m4[u].x, Tg[u][1] = m4[u].y, Tg[u][2] = m4[u].z;
       if constexpr (TARGET == 0) {
-        if (jn[u] >= 0) {
+        if (jn[u] >= 0 && !decided64[u]) {
           // the search reaches a little beyond the rejector (kSearchMargin) and a certified neighbour may have drifted out of
           // reach: a neighbour counts only inside the reach of a plain search, whichever way it was found
           within[u] = kd_dist2(m4[u].x, m4[u].y, m4[u].z, static_cast<float>(Q[u][0]), static_cast<float>(Q[u][1]), static_cast<float>(Q[u][2])) < p.bound2;
@@ -1712,6 +1746,7 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
   }
   p.corr = pb->corr.p;
   p.hint = pb->hint.p;
+  p.cert_nn2 = (!voxel && sizeof(Real) == 8) ? pb->hint2.p : nullptr;  // fp64 arithmetic: the factor kernel measures the walk's two candidates again, in double
   if constexpr (sizeof(Real) == 4) {
     p.maha = pb->maha.p;
   } else {

@@ -206,7 +206,7 @@ def test_two_ranks_share_one_registration_through_the_callback_transport(tmp_pat
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shards", [2, 3])
+@pytest.mark.parametrize("shards", [2, 3, 8])
 def test_single_process_shards_equal_one_problem(shards):
     """sga_multi (small_gicp_amd.h): the source sharded over G contexts inside ONE process — here G logical shards on device 0 —
     gives the system of the unsharded problem (the loop being partitioned: reduction_omp.hpp:32-58), to summation order in fp32
