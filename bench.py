@@ -68,6 +68,7 @@ def parse():
     ap.add_argument("--no-traffic", action="store_true", help="do not re-run one registration under rocprofv3 for the HBM traffic of K1")
     ap.add_argument("--require-native", action="store_true", help="N > 1: fail if the library's own RCCL communicator cannot be created (default: measure the torch.distributed callback path, flagged \"fallback\": true)")
     ap.add_argument("--allow-fallback", action="store_true", help="(the default since round 5; kept for old command lines)")
+    ap.add_argument("--no-scaled", action="store_true", help="skip the headline on copies of the C3 clouds in other units of length (x0.01, x10)")
     ap.add_argument("--no-preprocess", action="store_true", help="skip the per-stage roofline lines of the preprocessing kernels (voxel grid, index build, covariances)")
     ap.add_argument("--no-fp64", action="store_true", help="skip the fp64-math repetition of the headline")
     ap.add_argument("--sustain-s", type=float, default=3.0, help="extra (reported separately) sustained run of the same steps for this many seconds; 0 = skip")
@@ -463,6 +464,8 @@ def main():
                 # the same VGICP through the reference's Registration<GICPFactor, ParallelReductionHIP, ..., HipAligned<LM>>::align(voxelmap, source, voxelmap):
                 # the target is the reference's own GaussianVoxelMap object, built on the host by the reference's insert()
                 out["policy_c4"] = policy_leg(sga, "VGICP", tgt, src, out["vgicp_c4"]["value"], None)
+        if single and not args.no_scaled:
+            out["scaled_scenes"] = scaled_scenes_leg(sga, ctx, target, source, args, value)
         if single and not args.no_preprocess:
             out["preprocess_rooflines"] = preprocess_rooflines(sga, ctx, target, args)
         if single and args.odom_frames > 1:
@@ -769,6 +772,44 @@ def vgicp_leg(sga, ctx, tgt, src, args):
                 "workload": "C4: VGICP, GaussianVoxelMap(0.5 m) of the 1M-point target, 1M source points"}
     except Exception as ex:  # noqa: BLE001
         return {"error": repr(ex)}
+
+
+def scaled_scenes_leg(sga, ctx, target, source, args, headline):
+    """The headline's steps on copies of the C3 clouds in other units of length (coordinates x0.01 and x10, the rejector's reach with
+    them): the pass routing measures motions in units of the target's own length scale (csrc/linearize.hip: routing_unit), so the rate
+    must not depend on the unit (within 3 % of C3).  LM's damping is not scale invariant (H_rr grows with the square of
+    the coordinates), so the iterates — and with them the passes — differ a little from the metre-scale run's; tests/test_scale_free.py
+    replays identical pose sequences and finds identical passes."""
+    out = {}
+    try:
+        for scale in (0.01, 10.0):
+            tgt = sga.PointCloud((target.astype(np.float64) * scale).astype(np.float32), ctx=ctx)
+            src = sga.PointCloud((source.astype(np.float64) * scale).astype(np.float32), ctx=ctx)
+            sga.estimate_covariances(tgt, None, args.neighbors)
+            sga.estimate_covariances(src, None, args.neighbors)
+            tree = sga.KdTree(tgt)
+            problem = sga.Problem(tree, src, np.eye(4))
+            st = sga.make_setting("GICP", max_correspondence_distance=1.0 * scale, max_iterations=ITERS_PER_ALIGN, rotation_eps=0.0, translation_eps=0.0, math_mode=args.math)
+            for _ in range(2):
+                problem.align(st, np.eye(4))
+            s0 = problem.pass_stats()
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            steps = 0
+            while steps < 200:
+                steps += problem.align(st, np.eye(4)).iterations + 1
+            ctx.synchronize()
+            el = time.perf_counter() - t0
+            s1 = problem.pass_stats()
+            regs = steps / ITERS_PER_ALIGN
+            out["x%g" % scale] = {"iterations_per_s": steps / el, "relative_to_headline": steps / el / headline if headline else None, "target_length_scale": tree.spacing(),
+                                  "passes_per_registration": {"cold": (s1["cold_passes"] - s0["cold_passes"]) / regs, "warm": (s1["warm_passes"] - s0["warm_passes"]) / regs,
+                                                              "walkers": (s1["walked_points"] - s0["walked_points"]) / regs}}
+            del problem, tree, tgt, src
+        return out
+    except Exception as ex:  # noqa: BLE001
+        out["error"] = repr(ex)
+        return out
 
 
 def preprocess_rooflines(sga, ctx, target_c3, args):

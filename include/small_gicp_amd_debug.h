@@ -19,8 +19,7 @@ int sga_problem_get_search_stats(sga_context* ctx, const sga_problem* pb, int* l
 int sga_problem_get_sorted_points(sga_context* ctx, const sga_problem* pb, float* xyzw);
 /* Cell-grid passes (cell_grid.hip) since the problem was created: out[0] = passes searched through the grid, out[1] = queries their
  * first ring left open (finished by the second kernel), out[2] = sum of the rings those queries then scanned, out[3] = cell edge in
- * micrometres (0: the target has no grid); with SGA_ADJ_STATS set: out[4] = queries that went through the leaf adjacency lists, out[5] =
- * those the lists did not settle (they walked the tree), cumulative. */
+ * micrometres (0: the target has no grid); out[4], out[5]: always 0 (counters of experiments removed in round 6). */
 int sga_problem_get_grid_stats(const sga_problem* pb, uint64_t out[6]);
 /* What the cell grid (a second, flat search structure of large kd-tree indices) is used for; results do not depend on it (tests compare
  * the searches): mode 0 nothing (no grid is built); 1 (default) the walkers of warm passes try its first ring before they walk the tree;
@@ -32,6 +31,11 @@ void sga_set_grid_mode(int mode, long long min_points);
  * the form for clouds that do not fill the chip), larger ones with one query per lane.  Both are exact; the tests compare them.
  * Default 32768 (environment: SGA_KNN_WAVE_MAX); 0 = never. */
 void sga_set_knn_wave_max(long long max_points);
+/* The length scale of a kd-tree index: the geometric mean of the diagonals of its leaf boxes (a leaf = a neighbourhood of <= 8 points),
+ * computed by the build.  The pass routing of the linearization measures the source's motion in units of it (csrc/linearize.hip:
+ * routing_unit), so that the choice between the exact search kernels does not depend on the unit of length or the density of the cloud.
+ * 0 while the build's kernels have not run yet (the value arrives as a late note, csrc/notes.hpp) or for other kinds of index. */
+int sga_index_spacing(const sga_index* index, double* spacing);
 /* GPU time (HIP events) between two points of the context's stream: start() records an event, stop() records another, waits for it and
  * returns the milliseconds in between — the kernel times of bench.py's per-stage roofline lines (voxel grid, index build, covariances). */
 int sga_debug_timer_start(sga_context* ctx);

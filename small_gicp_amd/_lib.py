@@ -137,6 +137,7 @@ SYMBOLS = [
     ("sga_set_grid_mode", None, [C.c_int, C.c_longlong]),
     ("sga_host_alloc", C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     ("sga_host_free", C.c_int, [C.c_void_p]),
+    ("sga_index_spacing", C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     ("sga_set_knn_wave_max", None, [C.c_longlong]),
     ("sga_debug_timer_start", C.c_int, [C.c_void_p]),
     ("sga_debug_timer_stop", C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),

@@ -315,6 +315,12 @@ class KdTree:
 
     __len__ = size
 
+    def spacing(self):
+        """The index's own length scale (geometric mean leaf diagonal; sga_index_spacing): what the pass routing measures motions in."""
+        v = C.c_double()
+        check(load().sga_index_spacing(self.h, C.byref(v)))
+        return v.value
+
     def refresh_attributes(self):
         """Pull the cloud's current normals / covariances into the index (needed when they were set after the index was built)."""
         check(load().sga_index_refresh_attributes(self.ctx.h, self.h, self.cloud.h))

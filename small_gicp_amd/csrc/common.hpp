@@ -130,6 +130,7 @@ struct sga_context {
   sga::DevBuf<unsigned long long> vg_status;
   sga::DevBuf<uint32_t> vg_scratch;
   unsigned vg_epoch = 0;
+  sga::DevBuf<unsigned long long> d_spacing;  // kd_tail_kernel: {sum of log2(leaf diagonal) in 2^-20 units, leaves counted, arrival counter, 0}; zero between launches
   sga::DevBuf<int> d_box;         // bounding-box accumulator of box_reduce_publish: identity values + arrival counter between launches
   int* h_scratch = nullptr;       // 16 pinned ints behind h_accum: small asynchronous read-backs (bounding boxes)
   unsigned long long publish_seq = 0;
@@ -240,10 +241,12 @@ struct sga_index {
   sga::DevBuf<float4> kd_boxes;     // tight bounding box of every node: [2 * node] = min corner, [2 * node + 1] = max corner
   sga::DevBuf<float4> kd_groups;    // group headers of the 1-NN walk: the boxes of the (up to) 4 leaves under every node of depth kd_depth - 2
   sga::DevBuf<float4> kd_leaf;      // leaf blocks of the 1-NN walk: per leaf x[8], y[8], z[8], original index[8] (kd_search.hpp: the fast leaf scan)
-  sga::DevBuf<float4> kd_adj;       // leaf adjacency (kd_search.hpp: kd_adj_nearest_fast): per leaf its 32 nearest leaves, two float4 each {box lo, rank | box hi, squared distance to this leaf's cell}
-  sga::DevBuf<float> kd_adj_delta;  // per leaf: squared distance from its cell to the nearest leaf NOT in its list
   int kd_depth = 0;
   float bbox_lo[3] = {0, 0, 0}, bbox_hi[3] = {0, 0, 0};
+  // the target's own length scale (notes.hpp: late notes): geometric mean of the diagonals of the tree's leaf boxes, i.e. the size of a
+  // neighbourhood of 8 points; the pass routing of linearize.hip measures motions in units of it.  0 = not known (yet)
+  mutable double spacing = 0.0;
+  mutable unsigned long long spacing_seq = 0;  // the late note that carries it; 0 = none
   // uniform cell grid over the same points (cell_grid.hpp / cell_grid.hip): the exact search of cold passes near the optimum; grid_h == 0: none
   sga::DevBuf<float4> grid_pts;       // cell order, w = kd position bits
   sga::DevBuf<uint32_t> grid_start;   // cells + 1
@@ -329,6 +332,4 @@ struct sga_problem {
   double model_T[16] = {0};      // its pose
   // reduction scratch
   sga::DevBuf<double> partials;  // partial rows + the stage rows of reduce_rows_kernel
-  sga::DevBuf<uint32_t> row_flags;  // row collectors (linearize.hip): row r of the current pass is complete once row_flags[r] == flag_seq
-  uint32_t flag_seq = 0;
 };

@@ -2,6 +2,7 @@
 #include "common.hpp"
 #include "notes.hpp"
 
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <thread>
@@ -491,6 +492,8 @@ static int context_create_impl(int device, void* stream, bool borrow, sga_contex
     ctx->h_notes = reinterpret_cast<unsigned long long*>(ctx->h_accum + kNotesAt);  // words [160, 192): the notes (notes.hpp)
     ctx->h_notes_dev = reinterpret_cast<unsigned long long*>(ctx->h_accum_dev + kNotesAt);
   }
+  if (rc == SGA_OK) rc = ctx->d_spacing.alloc(4);
+  if (rc == SGA_OK && hipMemsetAsync(ctx->d_spacing.p, 0, 4 * sizeof(unsigned long long), ctx->stream) != hipSuccess) rc = fail(SGA_ERR_HIP, "hipMemsetAsync failed");
   if (rc == SGA_OK) rc = ctx->d_box.alloc(8);
   if (rc == SGA_OK) {
     const int init[8] = {kBoxEncPosInf, kBoxEncPosInf, kBoxEncPosInf, kBoxEncNegInf, kBoxEncNegInf, kBoxEncNegInf, 0, 0};
@@ -683,6 +686,60 @@ int note_wait(sga_context* ctx, unsigned long long seq, unsigned long long paylo
   }
   for (int k = 0; k < kNoteWords - 1; k++) payload[k] = slot[1 + k];
   return SGA_OK;
+}
+}  // namespace sga
+
+namespace sga {
+namespace {
+struct LateRing {
+  std::mutex mu;
+  unsigned long long* host = nullptr;
+  bool failed = false;
+  std::atomic<unsigned long long> seq{0};
+};
+LateRing& late_ring() {
+  static LateRing* r = new LateRing;  // never destroyed: no HIP calls during static destruction
+  return *r;
+}
+}  // namespace
+unsigned long long late_note_begin(int device, unsigned long long** dev_slot) {
+  LateRing& r = late_ring();
+  *dev_slot = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(r.mu);
+    if (r.host == nullptr && !r.failed) {
+      void* p = nullptr;
+      if (hipHostMalloc(&p, sizeof(unsigned long long) * kLateSlots * kLateWords, hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent) != hipSuccess) {
+        (void)hipGetLastError();
+        r.failed = true;
+      } else {
+        std::memset(p, 0, sizeof(unsigned long long) * kLateSlots * kLateWords);
+        r.host = static_cast<unsigned long long*>(p);
+      }
+    }
+    if (r.host == nullptr) return 0;
+  }
+  void* dev = nullptr;
+  (void)device;
+  if (hipHostGetDevicePointer(&dev, r.host, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  const unsigned long long seq = ++r.seq;
+  *dev_slot = static_cast<unsigned long long*>(dev) + (seq % kLateSlots) * kLateWords;
+  return seq;
+}
+int late_note_peek(unsigned long long seq, unsigned long long payload[kLateWords - 1]) {
+  LateRing& r = late_ring();
+  if (seq == 0 || r.host == nullptr) return -1;
+  const unsigned long long* slot = r.host + (seq % kLateSlots) * kLateWords;
+  const unsigned long long have = __atomic_load_n(slot + kLateWords - 1, __ATOMIC_ACQUIRE);
+  if (have == seq) {
+    for (int k = 0; k < kLateWords - 1; k++) payload[k] = slot[k];
+    if (__atomic_load_n(slot + kLateWords - 1, __ATOMIC_ACQUIRE) != seq) return -1;  // overwritten while it was being read
+    return 1;
+  }
+  return have < seq ? 0 : -1;
 }
 }  // namespace sga
 

@@ -558,8 +558,11 @@ __global__ __launch_bounds__(256) void kd_boxes_kernel(const float4* __restrict_
 // Trees deeper than 8 levels finish their upper boxes with kd_boxes_kernel(base = D - 8) as before.
 __global__ __launch_bounds__(256) void kd_tail_kernel(const uint32_t* __restrict__ order, uint32_t n, int D, const float4* __restrict__ pts, const float4* __restrict__ nrm, const Cov8* __restrict__ cov, const float2* __restrict__ nodes,
                                                       float4* __restrict__ opts, float4* __restrict__ onrm, Cov8* __restrict__ ocov, float4* __restrict__ boxes, float4* __restrict__ groups, float* __restrict__ blocks,
-                                                      float4* __restrict__ pairs, uint32_t npairs) {
+                                                      float4* __restrict__ pairs, uint32_t npairs, unsigned long long* __restrict__ d_spacing, unsigned long long* __restrict__ late_slot, unsigned long long late_seq) {
   __shared__ float slo[3][256], shi[3][256];
+  __shared__ long long sh_sum[4];
+  __shared__ unsigned sh_cnt[4];
+  __shared__ bool sh_last;
   const uint32_t t = threadIdx.x, k = blockIdx.x * 256u + t;
   float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
   if (k < (1u << D)) {
@@ -595,6 +598,39 @@ __global__ __launch_bounds__(256) void kd_tail_kernel(const uint32_t* __restrict
     if (k == (1u << D) - 1u) {
 #pragma unroll
       for (int j = 0; j < kKdLeafMax; j++) opts[n + j] = make_float4(INFINITY, INFINITY, INFINITY, __uint_as_float(0xffffffffu));  // padding leaf (kd_search.hpp)
+    }
+  }
+  // The target's own length scale: the geometric mean of the leaf diagonals (a leaf = a neighbourhood of <= 8 points), accumulated as
+  // integers (log2 in 2^-20 units: the sum does not depend on the order of the additions) and handed over as a LATE note (notes.hpp) by
+  // the last workgroup to arrive.  Scaling the cloud by s scales it by s; the pass routing of linearize.hip measures motions in it.
+  if (late_slot != nullptr) {  // grid-uniform
+    const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    const float diag2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+    const bool counted = k < (1u << D) && diag2 > 0.f && diag2 < 3.0e38f;
+    long long q = counted ? static_cast<long long>(rintf(0.5f * log2f(diag2) * 1048576.f)) : 0ll;
+    unsigned c = counted ? 1u : 0u;
+    for (int off = 32; off > 0; off >>= 1) {
+      q += __shfl_xor(q, off);
+      c += __shfl_xor(c, off);
+    }
+    if ((t & 63u) == 0u) sh_sum[t >> 6] = q, sh_cnt[t >> 6] = c;
+    __syncthreads();
+    if (t == 0) {
+      const long long bs = sh_sum[0] + sh_sum[1] + sh_sum[2] + sh_sum[3];
+      const unsigned bc = sh_cnt[0] + sh_cnt[1] + sh_cnt[2] + sh_cnt[3];
+      atomicAdd(&d_spacing[0], static_cast<unsigned long long>(bs));
+      atomicAdd(&d_spacing[1], static_cast<unsigned long long>(bc));
+      __threadfence();
+      sh_last = __hip_atomic_fetch_add(&d_spacing[2], 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+      if (sh_last) {
+        late_slot[0] = __hip_atomic_load(&d_spacing[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        late_slot[1] = __hip_atomic_load(&d_spacing[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        late_slot[2] = 0ull;
+        __hip_atomic_store(&d_spacing[0], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&d_spacing[1], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&d_spacing[2], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        note_publish(late_slot + kLateWords - 1, late_seq);
+      }
     }
   }
   if (k >= 1u && k < npairs) {  // pair record of heap node k (even depths carry one)
@@ -665,139 +701,6 @@ __global__ void gather_attr_kernel(const float4* __restrict__ sorted_pts, size_t
   const uint32_t s = __float_as_uint(sorted_pts[i].w);
   if (nrm) onrm[i] = nrm[s];
   if (cov) ocov[i] = cov[s];
-}
-
-// Leaf adjacency (kd_search.hpp: kd_adj_nearest_fast).  One lane per leaf L: its CELL C_L — the box the split planes of its root path cut
-// out, unbounded where no plane limits it; every query that descends to L lies inside — then a best-first descent over the tree with the
-// tight boxes, keeping the kKdAdj + 1 leaves whose boxes are nearest to the cell (box-to-box distance, rounded down): the first kKdAdj,
-// ascending, are the list, the distance of the next one is delta_L.  For a query q in C_L and a point p of a leaf X outside the list:
-// |p - q| >= dist(box(X), C_L) >= delta_L.  The candidate list lives in LDS as [slot][lane], unsorted while the search runs (a better
-// candidate replaces the worst, found by a sweep), sorted once at the end.
-constexpr int kAdjKeep = kKdAdj + 1;
-__device__ __forceinline__ float box_cell_dist2(const float4 blo, const float4 bhi, const float (&clo)[3], const float (&chi)[3]) {
-  const float dx = fmaxf(fmaxf(blo.x - chi[0], clo[0] - bhi.x), 0.f);
-  const float dy = fmaxf(fmaxf(blo.y - chi[1], clo[1] - bhi.y), 0.f);
-  const float dz = fmaxf(fmaxf(blo.z - chi[2], clo[2] - bhi.z), 0.f);
-  return fmaf(dx, dx, fmaf(dy, dy, dz * dz)) * 0.999999f;  // never above the true distance
-}
-__global__ __launch_bounds__(64) void kd_adjacency_kernel(const KdView t, float4* __restrict__ adj, float* __restrict__ delta) {
-  __shared__ float sd[kAdjKeep][64];
-  __shared__ uint32_t si[kAdjKeep][64];
-  __shared__ uint32_t stack[2 * kKdMaxDepth][64];
-  const int lane = threadIdx.x, D = t.depth;
-  const uint32_t k = blockIdx.x * 64u + lane, leaf0 = 1u << D;
-  if (k >= leaf0) return;
-  const uint32_t self = leaf0 + k;
-  float clo[3] = {-INFINITY, -INFINITY, -INFINITY}, chi[3] = {INFINITY, INFINITY, INFINITY};
-  for (int d = 0; d < D; d++) {
-    const uint32_t a = self >> (D - d);
-    const bool right = ((self >> (D - d - 1)) & 1u) != 0u;
-    const float2 nd = t.nodes[a];
-    const int axis = __float_as_int(nd.y);
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-      if (axis == c) {
-        if (right) clo[c] = fmaxf(clo[c], nd.x);  // the descent sends q >= threshold to the right
-        else chi[c] = fminf(chi[c], nd.x);
-      }
-    }
-  }
-  int count = 0, worst_slot = 0;
-  float worst = INFINITY;  // admission bound: the largest kept distance once kAdjKeep are kept
-  auto offer = [&](float d2, uint32_t rank) {
-    if (!(d2 < worst)) return;
-    if (count < kAdjKeep) {
-      sd[count][lane] = d2;
-      si[count][lane] = rank;
-      count++;
-      if (count < kAdjKeep) return;
-    } else {
-      sd[worst_slot][lane] = d2;
-      si[worst_slot][lane] = rank;
-    }
-    float wd = -1.f;
-    int ws = 0;
-    for (int j = 0; j < kAdjKeep; j++) {
-      const float v = sd[j][lane];
-      if (v > wd) wd = v, ws = j;
-    }
-    worst = wd;
-    worst_slot = ws;
-  };
-  int sp = 0;
-  uint32_t node = 1;
-  for (;;) {
-    int depth = 31 - __clz(static_cast<int>(node));
-    bool alive = true;
-    while (depth < D) {
-      const uint32_t c0 = 2 * node, c1 = c0 + 1;
-      const float d0 = box_cell_dist2(t.boxes[2 * c0], t.boxes[2 * c0 + 1], clo, chi), d1 = box_cell_dist2(t.boxes[2 * c1], t.boxes[2 * c1 + 1], clo, chi);
-      const bool first0 = d0 <= d1;
-      const float dn = first0 ? d0 : d1, df = first0 ? d1 : d0;
-      if (df < worst) stack[sp++][lane] = first0 ? c1 : c0;
-      if (!(dn < worst)) {
-        alive = false;
-        break;
-      }
-      node = first0 ? c0 : c1;
-      depth++;
-    }
-    if (alive && node != self) offer(box_cell_dist2(t.boxes[2 * node], t.boxes[2 * node + 1], clo, chi), node - leaf0);
-    bool found = false;
-    while (sp > 0) {
-      node = stack[--sp][lane];
-      if (box_cell_dist2(t.boxes[2 * node], t.boxes[2 * node + 1], clo, chi) < worst) {
-        found = true;
-        break;
-      }
-    }
-    if (!found) break;
-  }
-  // ascending by (distance, rank): selection sort of the `count` entries
-  for (int a = 0; a + 1 < count; a++) {
-    float bd = sd[a][lane];
-    uint32_t bi = si[a][lane];
-    int bs = a;
-    for (int j = a + 1; j < count; j++) {
-      const float v = sd[j][lane];
-      const uint32_t vi = si[j][lane];
-      if (v < bd || (v == bd && vi < bi)) bd = v, bi = vi, bs = j;
-    }
-    if (bs != a) {
-      sd[bs][lane] = sd[a][lane];
-      si[bs][lane] = si[a][lane];
-      sd[a][lane] = bd;
-      si[a][lane] = bi;
-    }
-  }
-  float4* out = adj + 2ull * kKdAdj * k;  // every entry carries its leaf's tight box: the query tests it without another dependent load
-  for (int j = 0; j < kKdAdj; j++) {
-    if (j < count) {
-      const uint32_t r = si[j][lane];
-      const float4 blo = t.boxes[2 * (leaf0 + r)], bhi = t.boxes[2 * (leaf0 + r) + 1];
-      out[2 * j] = make_float4(blo.x, blo.y, blo.z, __uint_as_float(r));
-      out[2 * j + 1] = make_float4(bhi.x, bhi.y, bhi.z, sd[j][lane]);
-    } else {
-      out[2 * j] = make_float4(INFINITY, INFINITY, INFINITY, __uint_as_float(kKdAdjNone));
-      out[2 * j + 1] = make_float4(-INFINITY, -INFINITY, -INFINITY, INFINITY);
-    }
-  }
-  delta[k] = count > kKdAdj ? sd[kKdAdj][lane] : INFINITY;
-}
-
-int build_leaf_adjacency(sga_context* ctx, sga_index* idx) {
-  static const long long min_points = getenv("SGA_ADJ_MIN_POINTS") ? atoll(getenv("SGA_ADJ_MIN_POINTS")) : 65536;
-  static const int enabled = getenv("SGA_ADJ") ? atoi(getenv("SGA_ADJ")) : 0;  // off: measured on C3 the lists lose to the walk
-  idx->kd_adj.release();
-  idx->kd_adj_delta.release();
-  if (!enabled || static_cast<long long>(idx->n) < min_points || idx->kd_depth < 1) return SGA_OK;
-  const size_t leaves = 1ull << idx->kd_depth;
-  SGA_TRY(idx->kd_adj.alloc(leaves * kKdAdj * 2));
-  SGA_TRY(idx->kd_adj_delta.alloc(leaves));
-  const KdView kv = make_kd_view(idx);
-  hipLaunchKernelGGL(kd_adjacency_kernel, dim3((leaves + 63) / 64), dim3(64), 0, ctx->stream, kv, idx->kd_adj.p, idx->kd_adj_delta.p);
-  SGA_HIP(hipGetLastError());
-  return SGA_OK;
 }
 
 // box_seq: the note (notes.hpp) that carries the cloud's bounding box to the host — from the first split level when there is one (it takes
@@ -895,12 +798,14 @@ static int build_kdtree(sga_context* ctx, const sga_cloud* cloud, sga_index* idx
   SGA_TRY(idx->kd_boxes.alloc(4ull << D));
   SGA_TRY(idx->kd_groups.alloc(8ull << (D - (D < 2 ? D : 2))));
   SGA_TRY(idx->kd_leaf.alloc(8ull << D));
+  unsigned long long* late_slot = nullptr;
+  idx->spacing_seq = late_note_begin(ctx->device, &late_slot);  // the target's length scale arrives whenever the tail kernel has run: nobody waits for it
+  idx->spacing = 0.0;
   // gather into kd order, leaf blocks, leaf boxes + 8 levels of boxes, group headers, pair records: one launch (kd_tail_kernel)
   hipLaunchKernelGGL(kd_tail_kernel, dim3(((1u << D) + 255) / 256), block, 0, ctx->stream, cur, static_cast<uint32_t>(n), D, cloud->pts.p, cloud->has_normals ? cloud->nrm.p : nullptr, cloud->has_covs ? cloud->cov.p : nullptr, idx->kd_nodes.p,
-                     idx->kd_pts.p, idx->nrm.p, idx->cov.p, idx->kd_boxes.p, idx->kd_groups.p, reinterpret_cast<float*>(idx->kd_leaf.p), idx->kd_nodes4.p, kd_pair_count(D));
+                     idx->kd_pts.p, idx->nrm.p, idx->cov.p, idx->kd_boxes.p, idx->kd_groups.p, reinterpret_cast<float*>(idx->kd_leaf.p), idx->kd_nodes4.p, kd_pair_count(D), ctx->d_spacing.p, late_slot, idx->spacing_seq);
   for (int base = D - 8; base > 0; base -= 8) hipLaunchKernelGGL(kd_boxes_kernel, dim3(((1u << base) + 255) / 256), block, 0, ctx->stream, idx->kd_pts.p, static_cast<uint32_t>(n), D, base, idx->kd_boxes.p);
   SGA_HIP(hipGetLastError());
-  SGA_TRY(build_leaf_adjacency(ctx, idx));
   if (!ctx->stream_ordered) SGA_HIP(hipStreamSynchronize(ctx->stream));
   return SGA_OK;
 }
@@ -997,9 +902,29 @@ __global__ void count_valid_keys_kernel(const unsigned long long* __restrict__ k
 
 }  // namespace sga
 
+namespace sga {
+// the target's length scale (sga_index::spacing), once the late note of its build has arrived; 0 while it is not known
+double index_spacing(const sga_index* idx) {
+  if (idx->spacing > 0.0 || idx->spacing_seq == 0) return idx->spacing;
+  unsigned long long payload[kLateWords - 1];
+  const int r = late_note_peek(idx->spacing_seq, payload);
+  if (r == 0) return 0.0;  // the build has not got there yet
+  idx->spacing_seq = 0;    // read, or lost: never asked for again
+  if (r == 1 && payload[1] > 0) idx->spacing = std::exp2(static_cast<double>(static_cast<long long>(payload[0])) / 1048576.0 / static_cast<double>(payload[1]));
+  return idx->spacing;
+}
+}  // namespace sga
+
 using namespace sga;
 
 extern "C" {
+
+// diagnostics: the index's length scale (0: not a kd-tree, or not known yet)
+int sga_index_spacing(const sga_index* index, double* spacing) {
+  if (!index || !spacing) return fail(SGA_ERR_INVALID, "null argument");
+  *spacing = index->kind == SGA_INDEX_KDTREE ? index_spacing(index) : 0.0;
+  return SGA_OK;
+}
 
 int sga_index_build_kdtree(sga_context* ctx, const sga_cloud* target, sga_index** out) {
   if (!ctx || !target || !out) return fail(SGA_ERR_INVALID, "null argument");
@@ -1143,6 +1068,8 @@ int sga_index_clone(sga_context* ctx, const sga_index* src, sga_index** out) {
   idx->has_normals = src->has_normals;
   idx->has_covs = src->has_covs;
   idx->kd_depth = src->kd_depth;
+  idx->spacing = index_spacing(src);
+  idx->spacing_seq = 0;
   idx->grid_h = src->grid_h;
   idx->grid_eps = src->grid_eps;
   idx->leaf = src->leaf;
@@ -1164,8 +1091,6 @@ int sga_index_clone(sga_context* ctx, const sga_index* src, sga_index** out) {
   SGA_TRY(copy_buf(ctx, idx->kd_boxes, src->kd_boxes, sd));
   SGA_TRY(copy_buf(ctx, idx->kd_groups, src->kd_groups, sd));
   SGA_TRY(copy_buf(ctx, idx->kd_leaf, src->kd_leaf, sd));
-  SGA_TRY(copy_buf(ctx, idx->kd_adj, src->kd_adj, sd));
-  SGA_TRY(copy_buf(ctx, idx->kd_adj_delta, src->kd_adj_delta, sd));
   SGA_TRY(copy_buf(ctx, idx->grid_pts, src->grid_pts, sd));
   SGA_TRY(copy_buf(ctx, idx->grid_start, src->grid_start, sd));
   SGA_TRY(copy_buf(ctx, idx->pts, src->pts, sd));

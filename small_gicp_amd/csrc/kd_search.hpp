@@ -32,8 +32,6 @@ struct KdView {
   const float4* __restrict__ boxes;   // tight bounding boxes: [2 * node] = min corner, [2 * node + 1] = max corner
   const float4* __restrict__ groups;  // group headers: 8 float4 per node of depth gdepth — the boxes of its leaves (kd_visit_group)
   const float4* __restrict__ leafblk; // leaf blocks: 8 float4 per leaf = x[8], y[8], z[8], original index[8] (one 128-byte line; unused slots far away)
-  const float4* __restrict__ adj;     // leaf adjacency lists (kd_adj_nearest_fast) or null: kKdAdj entries per leaf, ascending by distance to the leaf's cell, two float4 each: {box lo, bits of the leaf rank}, {box hi, squared distance box - cell}
-  const float* __restrict__ adj_delta;  // per leaf: squared distance from its cell to the nearest leaf NOT in its list (+inf: every leaf is)
   uint32_t n;
   int depth;    // D; leaves are the 2^D ranges at depth D
   int gdepth;   // D - glevels: the 1-NN walk descends to this depth and handles the leaves below it as one group
@@ -48,8 +46,6 @@ inline KdView make_kd_view(const sga_index* idx) {
   k.boxes = idx->kd_boxes.p;
   k.groups = idx->kd_groups.p;
   k.leafblk = idx->kd_leaf.p;
-  k.adj = idx->kd_adj.p;
-  k.adj_delta = idx->kd_adj_delta.p;
   k.n = static_cast<uint32_t>(idx->n);
   k.depth = idx->kd_depth;
   k.glevels = idx->kd_depth < 2 ? idx->kd_depth : 2;
@@ -656,131 +652,6 @@ __device__ __forceinline__ KdBestFast kd_nearest_fast(const KdView& t, float qx,
   return kd_result(t, s, bound2);
 }
 
-// ---- nearest neighbour through the LEAF ADJACENCY lists (round 4) ------------------------------------------------------------------------
-// The walk above pays for its generality with ~65 dependent loop trips per wave at the pace of its slowest lane (descend, scan, pop, box
-// test, descend ...).  For a query NEAR the target — every linearization but a registration's first few — what it finds is always the same
-// kind of thing: the query's own leaf and a handful of leaves around it.  That neighbourhood is precomputed (index_build.hip:
-// kd_adjacency_kernel): every leaf L knows the kKdAdj leaves nearest to its CELL C_L (the box the split planes of its root path cut out:
-// every query that descends to L lies in it), sorted by their tight box's distance to the cell, WITH those boxes, and delta_L = the
-// distance of the nearest leaf it does NOT list.  So for a query in C_L: every target point outside {L} + list(L) is at least delta_L away.
-// Search = plain descent to the leaf (no stack), scan it, then
-//   phase 1: the records of the list, whose addresses follow from the leaf alone (independent loads): every lane tests the boxes against
-//            its query and notes the leaves that can hold a closer point (at most kKdAdjPick, in LDS) — uniform work, all lanes busy;
-//            the pass stops at the first entry farther from the cell than the best so far plus an exploration margin (the list is sorted);
-//   phase 2: every lane scans the leaves it noted, re-testing each against the bound as it shrinks — trips = the most any lane noted (3 - 5),
-//            not the 11 leaf-scan trips a wave of the walk executes.
-// The result is the walk's canonical neighbour with a valid certificate whenever the bound stays below everything never looked at;
-// otherwise (a query far from everything: clutter, a registration's first pass; more leaves to scan than fit) the caller walks the tree.
-// Same KdFast state, same leaf scan, same kd_result as the walk.
-constexpr int kKdAdj = 32;      // list entries per leaf
-constexpr int kKdAdjPick = 8;   // leaves a query may note for scanning (LDS rows [0, 8) ranks, [8, 16) box distances)
-constexpr uint32_t kKdAdjNone = 0xffffffffu;
-constexpr float kKdAdjSlack = 0.02f;  // exploration margin of phase 1 in metres: the certificate then reaches that far beyond the neighbour
-
-// the leaf (heap node of depth D) whose cell contains the query: kd_locate down to the leaves
-__device__ __forceinline__ uint32_t kd_locate_leaf(const KdView& t, float qx, float qy, float qz) {
-  const int D = t.depth;
-  int depth = 0;
-  uint32_t node = 1;
-  const unsigned long long active = __ballot(true);
-  while (depth < D) {  // wave-uniform top through the scalar cache while the lanes agree
-    const uint32_t un = __builtin_amdgcn_readfirstlane(node);
-    const float2 nd = t.nodes[un];
-    const int axis = __builtin_amdgcn_readfirstlane(__float_as_int(nd.y));
-    const float thr = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(nd.x)));
-    const float qa = axis == 0 ? qx : (axis == 1 ? qy : qz);
-    const unsigned long long right = __ballot(!(qa - thr < 0.f));
-    if (right != 0ull && right != active) break;
-    depth++;
-    node = 2 * un + (right != 0ull ? 1u : 0u);
-  }
-  while (depth < D) {
-    const float2 nd = t.nodes[node];
-    const int axis = __float_as_int(nd.y);
-    const float qa = axis == 0 ? qx : (axis == 1 ? qy : qz);
-    node = 2 * node + (qa - nd.x < 0.f ? 0u : 1u);
-    depth++;
-  }
-  return node;
-}
-
-// Returns whether the lists settled the query (then `out` is what kd_nearest_fast would return; out.ambiguous may still ask for the exact
-// repeat).  pick: LDS, 2 * kKdAdjPick rows of STRIDE words, this lane uses pick[row * STRIDE + tid] (the walk's stack area serves).
-template <int STRIDE>
-__device__ __forceinline__ bool kd_adj_nearest_fast(const KdView& t, float qx, float qy, float qz, float bound2, int seed, uint32_t* __restrict__ pick, int tid, KdBestFast& out) {
-  if (t.n == 0) {
-    out = {{bound2, -1, -1, INFINITY, 0}, false};
-    return true;
-  }
-  float prune0 = bound2;
-  if (seed >= 0 && static_cast<uint32_t>(seed) < t.n) {
-    const float4 c = t.pts[seed];
-    const float d2 = kd_dist2(c.x, c.y, c.z, qx, qy, qz);
-    prune0 = d2 < prune0 ? kd_next_up(d2) : prune0;
-  }
-  KdFast s = kd_fast_state(prune0, 0.f);
-  const uint32_t leaf0 = 1u << t.depth;
-  const uint32_t node = kd_locate_leaf(t, qx, qy, qz);
-  const uint32_t k = node - leaf0;
-  const float delta = t.adj_delta[k];
-  const float4* __restrict__ L = t.adj + 2ull * kKdAdj * k;
-  kd_scan_leaf(t, node, qx, qy, qz, s);
-  // ---- phase 1: box tests.  open0 = the bound after the own leaf; reach = how far the list is read: the bound plus the exploration margin
-  const float open0 = s.open;
-  const float reach = kd_open_bound(open0, kKdAdjSlack);
-  float beyond = delta;  // lower bound of everything never looked at
-  int picked = 0;
-  bool more = true, overflow = false;
-  for (int e0 = 0; e0 < kKdAdj && __ballot(more) != 0ull; e0 += 2) {
-    float4 lo[2], hi[2];
-#pragma unroll
-    for (int u = 0; u < 2; u++) {
-      lo[u] = L[2 * (e0 + u)];
-      hi[u] = L[2 * (e0 + u) + 1];
-    }
-#pragma unroll
-    for (int u = 0; u < 2; u++) {
-      const uint32_t rank = __float_as_uint(lo[u].w);
-      const float cd = hi[u].w;  // squared distance of the entry's box to the cell (ascending over the list)
-      if (more && (rank == kKdAdjNone || !(cd <= reach))) {  // nothing behind this entry lies within reach
-        beyond = rank == kKdAdjNone ? beyond : kd_min(beyond, cd);
-        more = false;
-      }
-      if (more) {
-        const float lb = kd_box_dist2_vals(lo[u].x, lo[u].y, lo[u].z, hi[u].x, hi[u].y, hi[u].z, qx, qy, qz);
-        if (lb <= open0) {
-          if (picked < kKdAdjPick) {
-            pick[picked * STRIDE + tid] = rank;
-            pick[(kKdAdjPick + picked) * STRIDE + tid] = __float_as_uint(lb);
-            picked++;
-          } else {
-            overflow = true;
-            beyond = kd_min(beyond, lb);
-          }
-        } else {
-          s.dropped = kd_min(s.dropped, lb);
-        }
-      }
-    }
-  }
-  // ---- phase 2: the noted leaves, each re-tested against the bound as it stands
-  for (int j = 0; __ballot(j < picked) != 0ull; j++) {
-    if (j < picked) {
-      const uint32_t rank = pick[j * STRIDE + tid];
-      const float lb = __uint_as_float(pick[(kKdAdjPick + j) * STRIDE + tid]);
-      if (lb <= s.open)
-        kd_scan_leaf(t, leaf0 + rank, qx, qy, qz, s);
-      else
-        s.dropped = kd_min(s.dropped, lb);
-    }
-  }
-  // whatever was never looked at lies at `beyond` or farther: the search is complete iff the bound it ended with stays strictly below that
-  // (an equidistant point of lower position could hide there otherwise)
-  const bool settled = !overflow && s.open < beyond;
-  s.dropped = kd_min(s.dropped, beyond);
-  out = kd_result(t, s, bound2);
-  return settled;
-}
 
 // ---- k nearest neighbours (traits::knn_search; normal / covariance estimation) -----------------------------------------------------
 // Same walk as kd_nearest with the k-th best distance as the pruning bound.  The k-best list lives in LDS as [k][STRIDE]

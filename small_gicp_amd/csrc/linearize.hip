@@ -37,6 +37,9 @@ template <typename Real>
 int grid_search_pass(sga_context* ctx, const sga_index* idx, const float4* src_pts, int n, const Rigid<Real>& T, float reach2, int* nn, int* nn2, float* rex, uint32_t* stats);
 int grid_rings_for(const sga_index* idx, double reach);
 
+#ifndef SGA_SPACING_REF
+#define SGA_SPACING_REF 0.5486  // length scale (geometric mean leaf diagonal) of the C3 target (scripts/spacing_probe.py), the scene the routing thresholds were tuned on
+#endif
 constexpr int kTile = 256;           // threads per workgroup = source points per tile
 constexpr int kRow = 96;             // doubles per partial row: [0, 29) the system (21 H, 6 b, e, inliers), [32, 95) the quadratic error model
 constexpr int kCols = 128;           // columns the reduction kernels handle (>= kRow)
@@ -106,101 +109,6 @@ __device__ __forceinline__ void fused_tail(const FusedTail& f, const double* __r
   }
 }
 
-// ---- row collectors -------------------------------------------------------------------------------------------------------------
-// producer side: the row has been written with write-through stores (agent-scope relaxed atomic stores) by this wave / workgroup; once they
-// have left the CU the flag follows, one plain write-through store — nobody reads-modifies-writes anything
-__device__ __forceinline__ void publish_row_flag(uint32_t* __restrict__ flags, int row, uint32_t seq) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if ((threadIdx.x & 63u) == 0u) __hip_atomic_store(&flags[row], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// collector side, executed by wave 0 of collector workgroup g of G (the other waves of a wider workgroup leave at once).  Collector g adds
-// rows g, g + G, g + 2G, ... in that order (eight at a time once their flags are up), then the collectors meet at a ticket exactly like the
-// workgroups of reduce_rows_kernel, and the last one adds the G stage rows in order, derives and hands over.  The arithmetic depends on the
-// row indices only, never on who arrived when: bit-reproducible.  sh: >= kCols doubles of LDS.
-// xcd_order: the producers take their rows in the XCD-aware order of search_tile_of_block (slot b -> row (b % 8) * per_xcd + b / 8); the
-// collectors then walk the SLOTS in launch order, which is the order in which the rows become ready (walking the row indices would park a
-// collector behind the last-started tiles of the first XCD share until the kernel is nearly over).  The order of the additions is still a
-// function of the row count alone.
-__device__ __forceinline__ int row_of_slot(int b, int nrows, bool xcd_order) {
-  const int per_xcd = nrows >> 3;
-  return (xcd_order && b < 8 * per_xcd) ? (b & 7) * per_xcd + (b >> 3) : b;
-}
-__device__ __forceinline__ void collect_rows_wave(
-  const double* __restrict__ partials, int nrows, const uint32_t* __restrict__ flags, uint32_t flag_seq, double* __restrict__ stage, int g, int G, const FusedTail& f, double* __restrict__ sh, bool xcd_order) {
-  const int lane = threadIdx.x & 63;
-  constexpr int kBatch = 8;
-  const int c1 = lane + 64;  // second column of this lane (rows have kRow = 96 of them)
-  double a0 = 0.0, a1 = 0.0;
-  const unsigned long long t0 = __builtin_readcyclecounter();
-  bool timed_out = false;
-  for (int r = g; r < nrows && !timed_out; r += G * kBatch) {
-    const int mine = r + lane * G;  // lane k < kBatch watches the flag of the batch's k-th row
-    const bool watch = lane < kBatch && mine < nrows;
-    const int mine_row = row_of_slot(watch ? mine : 0, nrows, xcd_order);
-    for (unsigned spins = 0;; spins++) {
-      const uint32_t fl = watch ? __hip_atomic_load(&flags[mine_row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : flag_seq;
-      if (__ballot(fl != flag_seq) == 0ull) break;
-      __builtin_amdgcn_s_sleep(8);
-      if ((spins & 1023u) == 1023u && __builtin_readcyclecounter() - t0 > 4000000000ull) {  // ~2 s at the shader clock: a producer died; fail loudly on the host
-        timed_out = true;
-        break;
-      }
-    }
-    double v0[kBatch], v1[kBatch];
-#pragma unroll
-    for (int k = 0; k < kBatch; k++) {
-      const bool ok = r + k * G < nrows;
-      const int row = row_of_slot(ok ? r + k * G : 0, nrows, xcd_order);
-      v0[k] = ok ? __hip_atomic_load(&partials[static_cast<size_t>(row) * kRow + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-      v1[k] = (ok && c1 < kRow) ? __hip_atomic_load(&partials[static_cast<size_t>(row) * kRow + c1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-    }
-#pragma unroll
-    for (int k = 0; k < kBatch; k++) a0 += v0[k], a1 += v1[k];
-  }
-  if (lane == 63) a1 = timed_out ? 1.0 : 0.0;  // column 127 (rows end at 96): the collectors' give-up count rides along to the one that hands over
-  __hip_atomic_store(&stage[g * kCols + lane], a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(&stage[g * kCols + c1], a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  unsigned ticket = 0;
-  if (lane == 0) ticket = __hip_atomic_fetch_add(f.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);  // release this collector's stage row, acquire the earlier ones
-  ticket = __shfl(ticket, 0);
-  if (ticket != static_cast<unsigned>(G - 1)) return;  // wave-uniform
-  double t0s = 0.0, t1s = 0.0;
-  for (int k0 = 0; k0 < G; k0 += kBatch) {
-    double v0[kBatch], v1[kBatch];
-#pragma unroll
-    for (int k = 0; k < kBatch; k++) {
-      const bool ok = k0 + k < G;
-      v0[k] = ok ? __hip_atomic_load(&stage[(k0 + k) * kCols + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-      v1[k] = ok ? __hip_atomic_load(&stage[(k0 + k) * kCols + c1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-    }
-#pragma unroll
-    for (int k = 0; k < kBatch; k++) t0s += v0[k], t1s += v1[k];
-  }
-  const bool gave_up = __shfl(t1s, 63) != 0.0;
-  sh[lane] = t0s;
-  sh[c1] = t1s;
-  __builtin_amdgcn_wave_barrier();
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-  for (int h = 0; h < 2; h++) {
-    const int cc = lane + 64 * h;
-    if (cc < f.out_n) {
-      const double t = is_derived_col(cc) ? derived_entry(cc, sh) : sh[cc];  // moment form: H_rr, H_rt, b_r from the totals
-      const double r = cc < kModelCols ? t : 0.0;
-      f.out[cc] = r;
-      if (f.host != nullptr) f.host[cc] = r;
-    }
-  }
-  if (lane == 0) __hip_atomic_store(f.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch on this stream
-  if (f.host != nullptr) {
-    __threadfence_system();
-    // (a timed-out collection publishes a sequence number nobody waits for: the host's wait ends in its own error path)
-    if (lane == 0) __hip_atomic_store(reinterpret_cast<unsigned long long*>(f.host + kSeqWord), gave_up ? ~0ull : f.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-}
-
 template <typename Real>
 struct LinParams {
   const float4* __restrict__ src_pts;
@@ -225,16 +133,6 @@ struct LinParams {
   Real robust_c;
   double* __restrict__ partials;
   FusedTail tail;
-  // Row collectors (round 5): the last `collectors` workgroups of a fused search / certify launch do not produce a row but ADD the rows of
-  // the others while those still run — they poll one flag per row (plain write-through stores by the producers: no atomics, which is what
-  // sank the arrival-counter forms), add the rows in a fixed order, and the last of them derives the system and hands it to the host.
-  // No reduce_rows_kernel, no launch gap behind the slowest wave: the result is on the host ~5 us after the last row instead of ~14.
-  int collectors;                      // 0: none (reduce_rows_kernel follows)
-  int producers;                       // workgroups [0, producers) produce rows, [producers, producers + collectors) collect them
-  int collect_rows;                    // rows to add (one per producer)
-  uint32_t* __restrict__ row_flags;    // row r is complete once row_flags[r] == flag_seq
-  uint32_t flag_seq;
-  double* __restrict__ collect_stage;  // collectors x kCols doubles
   // warm pass with the certificate check inside the factor kernel (certify_linearize_kernel): the certificate of the previous
   // linearization pose T_prev is checked per point on the way through; a point whose certificate fails contributes nothing to the
   // streaming part, is flagged (rex[i] = -(exploration slack) < 0) and walks at the end of its workgroup's step
@@ -250,7 +148,7 @@ struct LinParams {
 // XCD-aware tile schedule: workgroup b runs on XCD b % 8 (observed placement; used for L2 affinity only).  Each XCD
 // gets one contiguous 1/8th of the (spatially sorted) tiles so that neighbouring tiles share an L2.
 __device__ __forceinline__ void tile_schedule(int num_tiles, int& first, int& stride, int& end, int nblocks = 0) {
-  if (nblocks == 0) nblocks = gridDim.x;  // (launches with row collectors pass the number of producer workgroups)
+  if (nblocks == 0) nblocks = gridDim.x;
   if (nblocks % 8 == 0 && num_tiles >= nblocks) {
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd_blocks = nblocks >> 3;
     const int t0 = static_cast<int>((static_cast<long long>(num_tiles) * xcd) >> 3);
@@ -316,8 +214,6 @@ struct NNParams {
   double inv_leaf;   // 2^depth / n (kd_leaf_rank)
   int chunk_tiles;   // queue-fed kernel: tiles of 64 queries per wave
   int fast;          // one-query-per-lane kernels: walk with the fast leaf scan (exact repeat where it cannot decide)
-  int adj;           // one-query-per-lane searches go through the leaf adjacency lists first (kd_search.hpp: kd_adj_nearest_fast)
-  uint32_t* __restrict__ adj_stats;  // [0] queries that went through the lists, [1] those the lists did not settle (they walk); or null
   GridView grid;     // the target's cell grid (cell_grid.hpp), if grid_walk
   int grid_walk;     // the walkers of certify_linearize_kernel try ring 1 of the grid before they walk the tree
 };
@@ -413,34 +309,13 @@ __device__ __forceinline__ int search_lane(const NNParams<Real>& p, int tile, in
       }
     }
   }
-  if (p.adj) {  // wave-uniform: the query's leaf and its precomputed neighbourhood first; the walk only for what that cannot settle
-    KdBestFast f;
-    if (kd_adj_nearest_fast<BLOCK>(p.kd, fx, fy, fz, p.bound2, seed, kd_stack, threadIdx.x, f) && !f.ambiguous) {
-      p.nn[i] = f.best.idx;
-      p.nn2[i] = f.best.idx2;
-      p.rex[i] = rex_from_r2(f.best.r2);
-      if (p.leaves != nullptr) p.leaves[i] = f.best.leaves;
-      if (p.adj_stats != nullptr) {
-        const unsigned long long m = __ballot(true);
-        if (threadIdx.x == __ffsll(static_cast<long long>(m)) - 1) atomicAdd(&p.adj_stats[0], static_cast<uint32_t>(__popcll(m)));
-      }
-      return f.best.idx;
-    }
-    if (p.adj_stats != nullptr) {
-      const unsigned long long m = __ballot(true);
-      if (threadIdx.x == __ffsll(static_cast<long long>(m)) - 1) {
-        atomicAdd(&p.adj_stats[0], static_cast<uint32_t>(__popcll(m)));
-        atomicAdd(&p.adj_stats[1], static_cast<uint32_t>(__popcll(m)));
-      }
-    }
-  }
   return walk_lane<Real, BLOCK>(p, i, fx, fy, fz, seed, CHECK ? slack : 0.f, kd_stack, threadIdx.x);
 }
 
 // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed placement; only speed depends on it), and the source is sorted by
 // target leaf, so giving each XCD one contiguous eighth of the tiles makes its L2 hold one eighth of the target instead of all of it
 __device__ __forceinline__ int search_tile_of_block(int nblk = 0) {
-  if (nblk == 0) nblk = gridDim.x;  // (launches with row collectors pass the number of producer workgroups)
+  if (nblk == 0) nblk = gridDim.x;
   const int per_xcd = nblk >> 3, b = blockIdx.x;
   return b < 8 * per_xcd ? (b & 7) * per_xcd + (b >> 3) : b;
 }
@@ -506,16 +381,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 6))) void
   __shared__ int q_idx[kQueueCap];        // source point
   __shared__ uint32_t q_leaf[kQueueCap];  // start group (heap node of depth gdepth)
   const int lane = threadIdx.x;
-  if constexpr (FACTOR >= 0) {
-    if (lp.collectors > 0 && static_cast<int>(blockIdx.x) >= lp.producers) {  // workgroup-uniform: a row collector (LinParams)
-      collect_rows_wave(lp.partials, lp.collect_rows, lp.row_flags, lp.flag_seq, lp.collect_stage, static_cast<int>(blockIdx.x) - lp.producers, lp.collectors, lp.tail, reinterpret_cast<double*>(kd_stack), true);
-      return;
-    }
-  }
   const int D = p.kd.gdepth;  // the walk's unit is the group (kd_search.hpp)
   const int num_tiles = (p.n + 63) >> 6;
   // XCD-aware chunk order (workgroup b runs on XCD b % 8): each XCD gets one contiguous eighth of the chunks
-  const int nblk = (FACTOR >= 0 && lp.collectors > 0) ? lp.producers : static_cast<int>(gridDim.x), per_xcd = nblk >> 3, b = blockIdx.x;
+  const int nblk = static_cast<int>(gridDim.x), per_xcd = nblk >> 3, b = blockIdx.x;
   const int chunk = b < 8 * per_xcd ? (b & 7) * per_xcd + (b >> 3) : b;
   int tile = chunk * p.chunk_tiles;
   const int tile_end = min(tile + p.chunk_tiles, num_tiles);
@@ -688,12 +557,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 6))) void
     else
       for (int t0 = chunk * p.chunk_tiles; t0 < tile_end; t0 += 4) linearize_group<Real, FACTOR, 0, 4, true>(lp, t0 * 64 + lane, 64, limit, row, lane);
     __syncthreads();
-    if (lp.collectors > 0) {  // wave-uniform
-      for (int c = lane; c < kRow; c += 64) __hip_atomic_store(&lp.partials[static_cast<size_t>(chunk) * kRow + c], row[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      publish_row_flag(lp.row_flags, chunk, lp.flag_seq);
-    } else {
-      for (int c = lane; c < kRow; c += 64) lp.partials[static_cast<size_t>(chunk) * kRow + c] = row[c];
-    }
+    for (int c = lane; c < kRow; c += 64) lp.partials[static_cast<size_t>(chunk) * kRow + c] = row[c];
   }
 #ifdef SGA_KD_TRIPS
   if (lane == 0) {  // [12] staging, [13] walks, [14] factor stage, [15] waves; [11] latest end - earliest start is derived from the wave times
@@ -1162,15 +1026,11 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(4))) void
   __shared__ unsigned long long sh_failed[kTile / 64][PTS];
   __shared__ int sh_list[PTS * kTile];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (p.collectors > 0 && static_cast<int>(blockIdx.x) >= p.producers) {  // workgroup-uniform: a row collector (LinParams); its first wave does the work
-    if (wave == 0) collect_rows_wave(p.partials, p.collect_rows, p.row_flags, p.flag_seq, p.collect_stage, static_cast<int>(blockIdx.x) - p.producers, p.collectors, p.tail, &sh_acc[0][0], false);
-    return;
-  }
   for (int c = lane; c < kRow; c += 64) sh_acc[wave][c] = 0.0;
   double* acc_row = sh_acc[wave];
 
   int tile, stride, tile_end;
-  tile_schedule(p.num_tiles, tile, stride, tile_end, p.collectors > 0 ? p.producers : 0);
+  tile_schedule(p.num_tiles, tile, stride, tile_end);
   for (; tile < tile_end; tile += stride) {
     const int base = tile * PTS * kTile;
     linearize_group<Real, FACTOR, 0, PTS, false, true, true>(p, base + static_cast<int>(threadIdx.x), kTile, p.n, acc_row, lane, sh_failed[wave]);
@@ -1227,12 +1087,6 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(4))) void
             gx = static_cast<float>(t[0]), gy = static_cast<float>(t[1]), gz = static_cast<float>(t[2]);
           }
           g_settled = grid_ring1_group(q.grid, Gw, gl, has, gx, gy, gz, q.bound2, g_nn, g_nn2, g_rex, g_seen);
-#ifdef SGA_WALK_SETTLE_WAVE  // measured (round 4): a lone walker ring 1 leaves open gets the settling ring with its rows over the lanes instead of the seeded kd walk: passes with < 100 walkers -4 ... -9 us, passes with thousands +20 us (a point with nothing in reach scans 225 rows), the code in the kernel -1.3 % on every pass
-          if (Gw == 64 && has && !g_settled && (q.grid_walk & 16)) {  // wave-uniform (one walker per wave)
-            grid_settle_wave(q.grid, lane, gx, gy, gz, g_seen, q.bound2, g_nn, g_nn2, g_rex);
-            g_settled = true;
-          }
-#endif
         }
         if (mine) {
           const float4 ps = p.src_pts[i];
@@ -1251,10 +1105,6 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(4))) void
             q.nn2[i] = g_nn2;
             q.rex[i] = g_rex;
             j = g_nn;
-          }
-          if (q.adj_stats != nullptr && (q.grid_walk & 1)) {  // diagnostics (SGA_ADJ_STATS)
-            atomicAdd(&q.adj_stats[0], 1u);
-            if (!settled) atomicAdd(&q.adj_stats[1], 1u);
           }
           if (!settled) {
             // seed: the nearer candidate (the check put it first); slack: what the check left in rex[] — both written by this workgroup
@@ -1286,15 +1136,10 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(4))) void
     double t = 0.0;
 #pragma unroll
     for (int w = 0; w < kTile / 64; w++) t += sh_acc[w][threadIdx.x];
-    if (p.tail.enabled || p.collectors > 0)
+    if (p.tail.enabled)
       __hip_atomic_store(&p.partials[static_cast<size_t>(blockIdx.x) * kRow + threadIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else
       p.partials[static_cast<size_t>(blockIdx.x) * kRow + threadIdx.x] = t;
-  }
-  if (p.collectors > 0) {  // workgroup-uniform: the row's two waves wait for their stores, then ONE flag store says the row is there
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(&p.row_flags[blockIdx.x], p.flag_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (p.tail.enabled) fused_tail(p.tail, p.partials, gridDim.x, kModelCols, kRow, true);  // small grids: the last workgroup adds the rows and hands the result over
 }
@@ -1323,11 +1168,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CHECK ? SGA_
   const unsigned long long wave_t0 = wall_clock64();
 #endif
   const int lane = threadIdx.x;
-  if (lp.collectors > 0 && static_cast<int>(blockIdx.x) >= lp.producers) {  // workgroup-uniform: this wave adds the rows of the others (LinParams: row collectors)
-    collect_rows_wave(lp.partials, lp.collect_rows, lp.row_flags, lp.flag_seq, lp.collect_stage, static_cast<int>(blockIdx.x) - lp.producers, lp.collectors, lp.tail, reinterpret_cast<double*>(kd_stack), true);
-    return;
-  }
-  const int slot = search_tile_of_block(lp.collectors > 0 ? lp.producers : 0);
+  const int slot = search_tile_of_block();
   const int tile = p.tile_order != nullptr ? static_cast<int>(p.tile_order[slot]) : slot;  // wave-uniform
   const unsigned long long cost_t0 = p.tile_cost != nullptr ? wall_clock64() : 0ull;
   const int i = tile * 64 + lane;
@@ -1367,12 +1208,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CHECK ? SGA_
   __syncthreads();
   if (inliers > 0) accumulate_moments<Real, 1>(P, Mp, G, E, inliers, row, lane);
   __syncthreads();
-  if (lp.collectors > 0) {  // wave-uniform
-    for (int c = lane; c < kRow; c += 64) __hip_atomic_store(&lp.partials[static_cast<size_t>(tile) * kRow + c], row[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    publish_row_flag(lp.row_flags, tile, lp.flag_seq);
-  } else {
-    for (int c = lane; c < kRow; c += 64) lp.partials[static_cast<size_t>(tile) * kRow + c] = row[c];
-  }
+  for (int c = lane; c < kRow; c += 64) lp.partials[static_cast<size_t>(tile) * kRow + c] = row[c];
   if (p.tile_cost != nullptr && lane == 0) p.tile_cost[tile] = static_cast<uint32_t>(wall_clock64() - cost_t0);
 #ifdef SGA_KD_TRIPS
   if (blockIdx.x < 32768 && lane == 0) {
@@ -1598,29 +1434,6 @@ static void launch_reduce(sga_context* ctx, const double* partials, int nrows, i
   hipLaunchKernelGGL(reduce_rows_kernel, dim3(groups), dim3(kReduceSlices * kCols), 0, ctx->stream, partials, nrows, ncols, row_stride, stage, ctx->d_ticket.p, out, out_n, host, seq, derive ? 1 : 0, stats);
 }
 
-// Row collectors (LinParams): how many of them a launch with `rows` producer rows gets; 0 = none (SGA_COLLECT=0: reduce_rows_kernel as before)
-// (SGA_COLLECT, bits: 1 the one-query-per-lane search kernel, 2 the queue-fed kernel, 4 the streaming warm kernel)
-static int g_collect = getenv("SGA_COLLECT") ? atoi(getenv("SGA_COLLECT")) : 0;
-static int collectors_for(int rows, int kind) { return (g_collect & kind) == 0 || rows < 1 ? 0 : std::min(kReduceGroups, std::max(4, rows / 64)); }
-template <typename Real>
-static int arm_collectors(sga_context* ctx, sga_problem* pb, LinParams<Real>& p, int rows, int kind, double* d_out, int out_n, double* host, unsigned long long seq) {
-  p.collectors = collectors_for(rows, kind);
-  if (p.collectors == 0) return SGA_OK;
-  if (pb->row_flags.n < partial_rows(pb->n)) {
-    SGA_TRY(pb->row_flags.alloc(partial_rows(pb->n)));
-    SGA_HIP(hipMemsetAsync(pb->row_flags.p, 0, pb->row_flags.n * sizeof(uint32_t), ctx->stream));
-    pb->flag_seq = 0;
-  }
-  if (++pb->flag_seq == 0u) pb->flag_seq = 1u;  // (0 is what the flags start from)
-  p.producers = rows;
-  p.collect_rows = rows;
-  p.row_flags = pb->row_flags.p;
-  p.flag_seq = pb->flag_seq;
-  p.collect_stage = pb->partials.p + partial_rows(pb->n) * kRow;
-  p.tail = FusedTail{0, ctx->d_ticket.p, d_out, out_n, host, seq};
-  return SGA_OK;
-}
-
 static bool g_lazy_maha = getenv("SGA_LAZY_MAHA") ? atoi(getenv("SGA_LAZY_MAHA")) != 0 : true;
 static int g_fuse_max = getenv("SGA_FUSE_MAX") ? atoi(getenv("SGA_FUSE_MAX")) : kFuseMaxBlocks;
 static int g_lin_pts_min = getenv("SGA_LIN_PTS_MIN") ? atoi(getenv("SGA_LIN_PTS_MIN")) : 131072;
@@ -1677,9 +1490,24 @@ static double max_displacement(const double Ta[16], const double Tb[16], const f
   return std::sqrt(best);
 }
 
+// The lengths the pass routing compares motions with are properties of the TARGET, not constants of nature: a certificate's exclusion
+// radius is a fraction of the distance between neighbouring target points, so "how far may the source have moved before the
+// certificates are gone" scales with the target's spacing.  The thresholds below were tuned in metres on the C3 scene; they are applied
+// multiplied by  unit = (the target's length scale) / kSpacingRef  — index_spacing(): the geometric mean of the tree's leaf diagonals,
+// computed by the build (kd_tail_kernel); kSpacingRef: that number for the C3 target — so a cloud in millimetres, or one ten times sparser,
+// routes its passes exactly as its metre-scale twin does (tests/test_scale_free.py).  unit = 1 while the length scale of a
+// target is not known (only ever before the first result of a problem has come back: the first pass is cold anyway).
+constexpr double kSpacingRef = SGA_SPACING_REF;
+double index_spacing(const sga_index* idx);  // index_build.hip
+static double routing_unit(const sga_index* idx) {
+  static const bool scale_free = !(getenv("SGA_SCALE_FREE") && atoi(getenv("SGA_SCALE_FREE")) == 0);
+  const double s = scale_free ? index_spacing(idx) : 0.0;
+  return s > 0.0 ? s / kSpacingRef : 1.0;
+}
+
 // A pass runs warm (certified neighbours skip the walk) while no source point can have moved farther than this since the previous
 // linearization; beyond it hardly any certificate holds and checking them is wasted work.  Environment override SGA_WARM_DELTA
-// (metres), run-time override sga_set_warm_limit; negative = never.  Results do not depend on it.
+// (metres at the reference spacing, see above), run-time override sga_set_warm_limit; negative = never.  Results do not depend on it.
 static double g_warm_delta = getenv("SGA_WARM_DELTA") ? atof(getenv("SGA_WARM_DELTA")) : 0.1;
 
 // Search kernel selection (results do not depend on it).  SGA_SEARCH_QUEUE: 0 = one query per lane always (nn_search_kernel),
@@ -1770,7 +1598,8 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
   // while no source point can have moved farther than the certificates can possibly cover.
   const int math = sizeof(Real) == 4 ? SGA_MATH_FP32 : SGA_MATH_FP64;
   const double displacement = (!voxel && p.n > 0 && pb->prev_valid && pb->prev_math == math) ? max_displacement(T, pb->T_prev, pb->bbox_lo, pb->bbox_hi) : INFINITY;
-  bool warm = displacement <= g_warm_delta;
+  const double unit = voxel ? 1.0 : routing_unit(idx);  // the target's own length scale relative to the scene the thresholds were tuned on
+  bool warm = displacement <= g_warm_delta * unit;
   // The cell grid (cell_grid.hpp).  SGA_GRID: 0 no grid at all; 1 (default) the WALKERS of warm passes try ring 1 of the grid before they
   // walk the tree (certify_linearize_kernel) and every full search stays with the kd walk — measured on C3 whole grid passes do not beat
   // it; 2 = also the cold passes of a registration but its first (whose queries lie as far from the target as the
@@ -1804,7 +1633,7 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
     q.kd = p.kd;
     q.T = p.T;
     q.within2 = p.bound2;
-    q.slack_min = g_slack_min, q.slack_max = g_slack_max;
+    q.slack_min = static_cast<float>(g_slack_min * unit), q.slack_max = static_cast<float>(g_slack_max * unit);
     q.cert_pad = std::max(g_cert_pad, 0.f);
     q.bound2 = p.bound2 * (1.f + kSearchMargin) * (1.f + kSearchMargin);
     q.nn = pb->hint.p;
@@ -1812,33 +1641,20 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
     q.rex = pb->rex.p;
     q.check = warm ? 1 : 0;
     q.fast = g_fast_scan;
-    // leaf adjacency lists (experiment, needs SGA_ADJ=1 at index build; SGA_ADJ_PASS: 0 never, 1 every one-query-per-lane pass but a
-    // registration's first, 2 every such pass)
-    static const int adj_pass = getenv("SGA_ADJ_PASS") ? atoi(getenv("SGA_ADJ_PASS")) : 1;
-    q.adj = (p.kd.adj != nullptr && g_fast_scan && (adj_pass >= 2 || (adj_pass == 1 && !first_pass))) ? 1 : 0;
-    static const bool adj_count = getenv("SGA_ADJ_STATS") != nullptr;  // diagnostics: two atomics per wave
-    if (adj_count && (q.adj || warm)) {  // (warm passes: the walkers of certify_linearize_kernel count how many of them ring 1 of the grid did not settle)
-      if (pb->grid_stats.n < 4) {
-        SGA_TRY(pb->grid_stats.alloc(4));
-        SGA_HIP(hipMemsetAsync(pb->grid_stats.p, 0, 4 * sizeof(uint32_t), ctx->stream));
-      }
-      q.adj_stats = pb->grid_stats.p + 2;
-    }
     if (warm) q.T_prev = rigid_from_colmajor<Real>(pb->T_prev);
     q.walked = pb->walked.p;
     q.leaves = pb->dbg_leaves.n >= pb->n ? pb->dbg_leaves.p : nullptr;
     if (q.leaves != nullptr) SGA_HIP(hipMemsetAsync(q.leaves, 0, pb->n * sizeof(int), ctx->stream));
-    const size_t words = static_cast<size_t>(std::max(p.kd.depth, 2 * kKdAdjPick));  // traversal stack rows; the adjacency search notes its leaves in 16 of them
+    const size_t words = static_cast<size_t>(p.kd.depth);  // traversal stack rows
     const dim3 sgrid((p.n + kSearchBlock - 1) / kSearchBlock), sblock(kSearchBlock);
     if (grid_mode != 0 && idx->grid_h > 0.f && q.bound2 < 3.0e38f && !host_rejector && q.leaves == nullptr) {
       const int rings = grid_rings_for(idx, std::sqrt(static_cast<double>(q.bound2)));
-      const bool small_warm = warm && displacement <= g_queue_delta;
+      const bool small_warm = warm && displacement <= g_queue_delta * unit;
       use_grid = grid_mode >= 2 && rings > 0 && rings <= grid_max_rings &&
                  (grid_mode >= 4 || (!small_warm && (grid_mode == 3 || (!first_pass && pb->grid_open_frac <= grid_max_open))));
       // which walkers try ring 1 of the grid first (SGA_GRID_WALK, bits): 1 those of certify_linearize_kernel, 2 those of the
       // one-query-per-lane warm pass (search_linearize_kernel<CHECK>), 4 those of the queue-fed kernel, 8 certify_linearize_kernel scans ring 1
-      // with a group of lanes per walker when a workgroup has few of them (grid_ring1_group), 16 a walker that has a wave to itself and is
-      // not settled by ring 1 gets the ring that settles it, rows over the lanes (grid_settle_wave), instead of a kd walk
+      // with a group of lanes per walker when a workgroup has few of them (grid_ring1_group)
       static const int grid_walk_bits = getenv("SGA_GRID_WALK") ? atoi(getenv("SGA_GRID_WALK")) : 15;
       q.grid_walk = grid_walk_bits;
       q.grid = make_grid_view(idx);
@@ -1855,7 +1671,7 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
       pb->order_tiles = 0;
       pb->grid_passes++;
     }
-    const bool queue = !use_grid && (g_search_queue == 1 || (g_search_queue == 2 && warm && displacement <= g_queue_delta));
+    const bool queue = !use_grid && (g_search_queue == 1 || (g_search_queue == 2 && warm && displacement <= g_queue_delta * unit));
     // Warm pass of a large cloud after a small motion: the certificates are checked inside the streaming factor kernel
     // (certify_linearize_kernel), whose workgroups walk their few failed points themselves.  SGA_WARM_SPLIT=0: the older form
     // (certificate check, queue-fed walks and factors per chunk in nn_search_queue_kernel).
@@ -1870,7 +1686,7 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
     // at those sizes a pass is a chain of launch, a few dependent loads and the hand-off, whichever kernel runs it.
     static const size_t split_min_points = getenv("SGA_SPLIT_MIN_POINTS") ? static_cast<size_t>(atoll(getenv("SGA_SPLIT_MIN_POINTS"))) : 131072;
     static const int split_pts_env = getenv("SGA_SPLIT_PTS") ? atoi(getenv("SGA_SPLIT_PTS")) : 0;
-    const bool split = warm_split && queue && warm && displacement <= split_delta && g_search_queue == 2 && g_fuse_search && !host_rejector && sizeof(Real) == 4 && pb->n >= split_min_points && q.leaves == nullptr;
+    const bool split = warm_split && queue && warm && displacement <= split_delta * unit && g_search_queue == 2 && g_fuse_search && !host_rejector && sizeof(Real) == 4 && pb->n >= split_min_points && q.leaves == nullptr;
     fused_search = !use_grid && g_fuse_search && !host_rejector && !queue && sizeof(Real) == 4;  // fp64 math: the fused kernel would spill
     const unsigned order_tiles_before = pb->order_tiles;
     pb->order_tiles = 0;  // (set again below when this pass records its tiles' durations)
@@ -1884,7 +1700,6 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
       const bool cfuse = cblocks <= g_fuse_max;
       pc.tail = FusedTail{cfuse ? 1 : 0, ctx->d_ticket.p, d_out30, out_n, host, seq};
       split_fused_tail = cfuse;
-      if (!cfuse) SGA_TRY(arm_collectors(ctx, pb, p, cblocks, 4, d_out30, out_n, host, seq));
       p.cert_nn = pb->hint.p;
       p.cert_nn2 = pb->hint2.p;
       p.cert_rex = pb->rex.p;
@@ -1897,9 +1712,9 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
 #define SGA_CERTIFY(F)                                                                                                                      \
   do {                                                                                                                                      \
     if (spts == kLinPts)                                                                                                                    \
-      hipLaunchKernelGGL((certify_linearize_kernel<Real, F, kLinPts>), dim3(cblocks + p.collectors), dim3(kTile), lds, ctx->stream, p, q);  \
+      hipLaunchKernelGGL((certify_linearize_kernel<Real, F, kLinPts>), dim3(cblocks), dim3(kTile), lds, ctx->stream, p, q);  \
     else                                                                                                                                    \
-      hipLaunchKernelGGL((certify_linearize_kernel<Real, F, 1>), dim3(cblocks + p.collectors), dim3(kTile), lds, ctx->stream, p, q);        \
+      hipLaunchKernelGGL((certify_linearize_kernel<Real, F, 1>), dim3(cblocks), dim3(kTile), lds, ctx->stream, p, q);        \
   } while (0)
       switch (fp->factor_kind) {
         case SGA_GICP: SGA_CERTIFY(SGA_GICP); break;
@@ -1913,10 +1728,7 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
       // every search wave evaluates the factors of its own tile: one partial row per tile of 64 points, summed by reduce_rows_kernel
       p.tail.enabled = 0;
       fused_rows = static_cast<int>(sgrid.x);
-      // (not when this pass starts its tiles in the order the previous one recorded: the collectors walk the launch slots, and the sum must not depend on timings)
-      const bool ordered = g_lpt != 0 && sgrid.x >= 8192 && order_tiles_before == sgrid.x && pb->order_stream == ctx->stream && (g_lpt == 2 || warm);
-      SGA_TRY(arm_collectors(ctx, pb, p, ordered ? 0 : fused_rows, 1, d_out30, out_n, host, seq));
-      const dim3 cgrid(sgrid.x + p.collectors);
+      const dim3 cgrid(sgrid.x);
       if (g_lpt != 0 && sgrid.x >= 8192) {  // fewer tiles than wave slots: all waves start at once, the order means nothing
         SGA_TRY(pb->tile_cost.reserve(sgrid.x));
         SGA_TRY(pb->tile_order.reserve(sgrid.x));
@@ -1953,8 +1765,7 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
       if (fused_search) {  // the chunk's wave evaluates the factors as well: one partial row per chunk
         p.tail.enabled = 0;
         fused_rows = static_cast<int>(qgrid.x);
-        SGA_TRY(arm_collectors(ctx, pb, p, fused_rows, 2, d_out30, out_n, host, seq));
-        const dim3 cgrid(qgrid.x + p.collectors);
+        const dim3 cgrid(qgrid.x);
         switch (fp->factor_kind) {
           case SGA_GICP: hipLaunchKernelGGL((nn_search_queue_kernel<Real, true, SGA_GICP>), cgrid, sblock, lds, ctx->stream, q, p); break;
           case SGA_PLANE_ICP: hipLaunchKernelGGL((nn_search_queue_kernel<Real, true, SGA_PLANE_ICP>), cgrid, sblock, lds, ctx->stream, q, p); break;
@@ -2017,8 +1828,8 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
       }
     }
   }
-  if (fused_search && (split_fused_tail || p.collectors > 0)) {
-    // (done inside the kernel: fused tail of a small grid, or the launch's row collectors)
+  if (fused_search && split_fused_tail) {
+    // (done inside the kernel: fused tail of a small grid)
   } else if (fused_search) {
     launch_reduce(ctx, pb->partials.p, fused_rows, ncols, kRow, pb->partials.p + partial_rows(pb->n) * kRow, d_out30, out_n, host, seq, true);
   }

@@ -19,6 +19,17 @@ constexpr int kNoteWords = 8;  // per slot: word 0 = the sequence number, words 
 unsigned long long note_begin(sga_context* ctx, unsigned long long** dev_slot);             // next sequence number + the device address of its slot
 int note_wait(sga_context* ctx, unsigned long long seq, unsigned long long payload[kNoteWords - 1]);  // spin (bounded; then the runtime reports what happened)
 
+// LATE notes: results nobody waits for.  A process-wide ring of kLateSlots slots in pinned, device-mapped, portable host memory; the
+// producer remembers the sequence number it was given, the kernel writes {payload..., seq} into slot seq % kLateSlots when it gets there,
+// and whoever wants the value later looks: the slot shows the number -> the payload is valid; an older number -> not there yet; a newer
+// one -> overwritten (kLateSlots later producers have passed), the value is lost — acceptable for what travels this way: heuristics
+// (the target's length scale, which only steers the choice between exact kernels).
+constexpr int kLateSlots = 1024;
+constexpr int kLateWords = 4;  // words 0..2 payload, word 3 = the sequence number
+unsigned long long late_note_begin(int device, unsigned long long** dev_slot);  // null slot: no ring (allocation failed): the value stays unknown
+// 1 = payload read, 0 = not there yet, -1 = lost
+int late_note_peek(unsigned long long seq, unsigned long long payload[kLateWords - 1]);
+
 // order-preserving int encoding of floats (atomicMin / atomicMax on ints)
 __host__ __device__ inline int box_enc(float f) {
   int i;

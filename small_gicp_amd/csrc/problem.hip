@@ -360,15 +360,7 @@ int sga_problem_get_grid_stats(const sga_problem* pb, uint64_t out[6]) {
   out[1] = pb->grid_open_total;
   out[2] = pb->grid_ring_total;
   out[3] = pb->target ? static_cast<uint64_t>(static_cast<double>(pb->target->grid_h) * 1e6) : 0;
-  out[4] = out[5] = 0;
-  if (pb->grid_stats.n >= 4) {  // SGA_ADJ_STATS: queries through the leaf adjacency lists, and those the lists did not settle (cumulative)
-    uint32_t h[2] = {0, 0};
-    (void)hipSetDevice(pb->device);
-    if (hipMemcpy(h, pb->grid_stats.p + 2, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
-      out[4] = h[0];
-      out[5] = h[1];
-    }
-  }
+  out[4] = out[5] = 0;  // (round 4 / 5 diagnostics of experiments that left the product kernels in round 6)
   return SGA_OK;
 }
 
