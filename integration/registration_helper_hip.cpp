@@ -124,15 +124,32 @@ void remember(const PointCloud::Ptr& host, const std::shared_ptr<DeviceCloud>& d
   for (auto it = g_resident.begin(); it != g_resident.end();) it = it->second.host.expired() ? g_resident.erase(it) : std::next(it);  // clouds that are gone take their device twins along
   g_resident[host.get()] = Resident{host, device, hip_detail::fingerprint(*host)};
 }
+// The device twin of a cloud preprocess_points returned, if it is still what the caller holds.  (twins of clouds that are gone
+// are dropped here as well, not only by the next preprocess_points; the content hash of the cloud — a pass over its points — runs OUTSIDE
+// the table's lock, so concurrent align() calls do not serialise on it.)  A twin is created on the preprocessing thread's context and may
+// be consumed by any thread's: every entry point that takes a cloud or an index waits for the producer's event first (common.hpp: Ready),
+// and the objects live on the device, not in a context.
 std::shared_ptr<DeviceCloud> resident(const PointCloud& cloud) {
   std::shared_ptr<DeviceCloud> dev;
+  std::uint64_t want = 0;
+  std::vector<std::shared_ptr<DeviceCloud>> gone;  // released after the lock (freeing device memory is not a thing to do under it)
   {
     std::lock_guard<std::mutex> lock(g_resident_mutex);
+    for (auto it = g_resident.begin(); it != g_resident.end();) {
+      if (it->second.host.expired()) {
+        gone.push_back(std::move(it->second.device));
+        it = g_resident.erase(it);
+      } else {
+        ++it;
+      }
+    }
     const auto it = g_resident.find(&cloud);
-    if (it == g_resident.end() || it->second.host.expired() || it->second.device->n != cloud.size()) return nullptr;
+    if (it == g_resident.end() || it->second.device->n != cloud.size()) return nullptr;
     dev = it->second.device;
-    if (it->second.fingerprint != hip_detail::fingerprint(cloud)) return nullptr;  // edited since: the general path uploads what the caller holds now
+    want = it->second.fingerprint;
   }
+  gone.clear();
+  if (want != hip_detail::fingerprint(cloud)) return nullptr;  // edited since: the general path uploads what the caller holds now
   return dev;
 }
 

@@ -2227,7 +2227,9 @@ int sga_linearize_async(sga_context* ctx, sga_problem* pb, const sga_factor_para
   double Tdev[16];
   const double* Td = problem_pose(pb, T, Tdev);
   pb->caller_T = T;
-  SGA_TRY(fp->math_mode == SGA_MATH_FP64 ? linearize_dispatch<double>(ctx, pb, fp, Td, d_out30, nullptr, 0) : linearize_dispatch<float>(ctx, pb, fp, Td, d_out30, nullptr, 0));
+  const int rc_dispatch = fp->math_mode == SGA_MATH_FP64 ? linearize_dispatch<double>(ctx, pb, fp, Td, d_out30, nullptr, 0) : linearize_dispatch<float>(ctx, pb, fp, Td, d_out30, nullptr, 0);
+  pb->caller_T = nullptr;  // (valid for this dispatch only)
+  SGA_TRY(rc_dispatch);
   if (!origin_is_zero(pb->src_origin)) {  // the caller reads H / b in its own twist convention (common.hpp: device frames)
     hipLaunchKernelGGL(frame_accumulator_kernel, dim3(1), dim3(64), 0, ctx->stream, d_out30, pb->src_origin[0], pb->src_origin[1], pb->src_origin[2]);
     SGA_HIP(hipGetLastError());
@@ -2247,13 +2249,22 @@ int sga_error_async(sga_context* ctx, sga_problem* pb, const sga_factor_params* 
 }  // extern "C"
 
 namespace sga {
+// pb->caller_T points at the caller's (often stack) pose for the duration of ONE dispatch (a host rejector is shown the caller's pose):
+// cleared when the entry point returns, whichever way (it used to dangle)
+struct CallerPoseScope {
+  sga_problem* pb;
+  CallerPoseScope(sga_problem* p, const double* T) : pb(p) { pb->caller_T = T; }
+  ~CallerPoseScope() { pb->caller_T = nullptr; }
+  CallerPoseScope(const CallerPoseScope&) = delete;
+  CallerPoseScope& operator=(const CallerPoseScope&) = delete;
+};
 // sga_linearize in two halves, so that one host thread can keep several devices busy (multi.hip): enqueue = the kernels of the pass, the
 // sum over ranks if the context has a communicator, and the hand-off of the result to the host; collect = wait for it (ctx->h_accum
 // then holds `count` doubles: the system, or the system and the error model).
 int linearize_enqueue(sga_context* ctx, sga_problem* pb, const sga_factor_params* fp, const double T_caller[16], unsigned long long* seq_out, int* count_out) {
   double Tdev[16];
   const double* T = problem_pose(pb, T_caller, Tdev);  // the kernels work between the two device frames (common.hpp)
-  pb->caller_T = T_caller;
+  CallerPoseScope caller_pose(pb, T_caller);
   SGA_TRY(problem_check_shard_frames(ctx, pb));
   const unsigned long long seq = ++ctx->publish_seq;
   const bool direct = !ctx->sharded();

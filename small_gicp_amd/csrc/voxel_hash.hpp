@@ -56,7 +56,11 @@ __device__ __forceinline__ int voxel_lookup(const VoxelView& v, float qx, float 
 
 // Gaussian maps searched over 7 / 27 voxels (incremental_voxelmap.hpp:99-119: every voxel at the search offsets offers its mean,
 // gaussian_voxelmap.hpp:83-86; KnnResult<1>::push keeps the FIRST of equal distances; offsets in the reference's order: centre, +x +y +z
-// -x -y -z (7), or centre and then the 3 x 3 x 3 cube in i, j, k order (27: its second visit of the centre cannot change the result)).
+// -x -y -z (7), or centre and then the 3 x 3 x 3 cube in i, j, k order (27).  Why the centre comes FIRST for 27 as well (ADVICE r5 read the
+// reference's case 27 as the plain cube): incremental_voxelmap.hpp:176-183 APPENDS the 27 cube offsets to whatever list the map held
+// (emplace_back without a clear), and every list the map can hold starts with the centre (the default {0}, :163-164, or the 7 pattern,
+// :166-174) — so after set_search_offsets(27) the search visits the centre, then the cube; the cube's own centre entry is a second visit
+// of the same voxel and, with KnnResult<1>::push keeping the first of equal distances, cannot change the result: it is skipped here).
 // Returns the voxel id or -1.  Distances between the fp32 records the device holds, evaluated in Real.
 template <typename Real>
 __device__ __forceinline__ int voxel_nearest(const VoxelView& v, const float4* __restrict__ means, Real qx, Real qy, Real qz) {

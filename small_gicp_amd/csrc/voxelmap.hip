@@ -518,9 +518,12 @@ int sga_voxelmap_insert(sga_context* ctx, sga_index* idx, const sga_cloud* cloud
   for (int r = 0; r < 3; r++) T.t[r] += T.r[3 * r] * cloud->origin[0] + T.r[3 * r + 1] * cloud->origin[1] + T.r[3 * r + 2] * cloud->origin[2];
   // The fp32 records the factor kernels read are re-exported after every insert anyway: their device frame follows the inserted scan (the
   // moved origin of the cloud's frame, quantised), so a map that walks kilometres (scan-to-model odometry) keeps sub-millimetre records.
+  // (the new origin is committed only where the records are exported below — an insert that fails on the way leaves the map's
+  // fp32 records AND the origin they are relative to as they were)
+  double new_origin[3] = {idx->origin[0], idx->origin[1], idx->origin[2]};
   if (cloud->n > 0) {
     const double lo[3] = {T.t[0], T.t[1], T.t[2]};
-    choose_origin(lo, lo, idx->origin);
+    choose_origin(lo, lo, new_origin);
   }
   const size_t n = cloud->n;
   const uint32_t n_old = static_cast<uint32_t>(idx->n);
@@ -653,6 +656,7 @@ int sga_voxelmap_insert(sga_context* ctx, sga_index* idx, const sga_cloud* cloud
       SGA_TRY(rebuild_hash(ctx, idx, kept));
     }
   }
+  for (int k = 0; k < 3; k++) idx->origin[k] = new_origin[k];  // every fallible step is behind us: the records exported now are relative to it
   if (idx->n > 0) {
     if (idx->kind == SGA_INDEX_FLATMAP)
       hipLaunchKernelGGL(fvm_export_kernel, dim3((idx->n * kFlatCap + 255) / 256), dim3(256), 0, ctx->stream, static_cast<uint32_t>(idx->n), idx->vcounts.p, idx->fpts64.p, idx->fcov64.p, idx->origin[0], idx->origin[1], idx->origin[2], idx->pts.p, idx->cov.p);
