@@ -827,8 +827,8 @@ __device__ __forceinline__ void knn_regs_insert(KnnRegs<K>& L, float v, int vid)
 }
 
 template <int K, int STRIDE>
-__device__ __forceinline__ void kd_knn_own_points(const KdView& t, float qx, float qy, float qz, KnnRegs<K>& L, const float4* __restrict__ window, uint32_t pre_first, uint32_t pre_end, uint32_t own_first, uint32_t own_end,
-                                                  uint32_t* __restrict__ stack, int tid) {
+__device__ __forceinline__ void kd_knn_own_points_exact(const KdView& t, float qx, float qy, float qz, KnnRegs<K>& L, const float4* __restrict__ window, uint32_t pre_first, uint32_t pre_end, uint32_t own_first, uint32_t own_end,
+                                                        uint32_t* __restrict__ stack, int tid) {
 #pragma unroll
   for (int j = 0; j < K; j++) {
     L.d[j] = INFINITY;
@@ -902,6 +902,118 @@ __device__ __forceinline__ void kd_knn_own_points(const KdView& t, float qx, flo
       }
     }
     if (!found) break;
+  }
+}
+
+// The same search with the window phase on PACKED KEYS (round 6).  What made the function above slow is its insertion
+// network: 7 VALU operations per list slot, run by the whole wave for every window candidate ANY lane wants — 128 candidates x 140
+// operations, four fifths of the kernel.  A candidate of the window is known by its slot (7 bits); put into the low bits of the bits of
+// its squared distance it makes a 32-bit key whose unsigned order is the order of the distances (>= 0) truncated to a multiple of 128
+// ulps, and inserting a key into a sorted list is ONE v_med3_u32 per slot (new[j] = med3(old[j-1], old[j], x)) — unconditional, no
+// ballot, no branch.  The list holds K + 1 keys: the K nearest and the best loser.
+// Truncation can misorder two candidates only if their distances agree in the remaining 17 mantissa bits (relative difference < 1.6e-5);
+// for the SET of the K nearest that matters only at the boundary, and it is detected there: the search ends AMBIGUOUS when the K-th
+// entry and the best loser share their truncated distance — a few queries per ten thousand — and such a query runs the exact function
+// above.  The walk behind the window continues on the truncated distances (new candidates are truncated the same way; the list stays
+// sorted by them) and prunes with the UPPER end of the K-th entry's interval, so nothing that could belong to the set is skipped.
+constexpr uint32_t kKnnSlotBits = 7, kKnnSlotMask = (1u << kKnnSlotBits) - 1u;  // kFeatWindow = 128 candidates
+
+template <int K, int STRIDE>
+__device__ __forceinline__ void kd_knn_own_points(const KdView& t, float qx, float qy, float qz, KnnRegs<K>& L, const float4* __restrict__ window, uint32_t pre_first, uint32_t pre_end, uint32_t own_first, uint32_t own_end,
+                                                  uint32_t* __restrict__ stack, int tid) {
+  if (t.n == 0) {
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+      L.d[j] = INFINITY;
+      L.id[j] = -1;
+    }
+    return;
+  }
+  // ---- the window, packed keys
+  uint32_t kk[K + 1];
+#pragma unroll
+  for (int j = 0; j <= K; j++) kk[j] = 0xffffffffu;
+  for (uint32_t w = 0; w < pre_end - pre_first; w++) {  // (wave-uniform trip count: the candidate is a broadcast read)
+    const float4 c = window[w];
+    const float d2 = kd_dist2(c.x, c.y, c.z, qx, qy, qz);
+    const uint32_t x = (__float_as_uint(d2) & ~kKnnSlotMask) | w;
+#pragma unroll
+    for (int j = K; j >= 1; j--) kk[j] = kd_umed3(kk[j - 1], kk[j], x);  // (the compiler folds the pattern into v_med3_u32)
+    kk[0] = min(kk[0], x);
+  }
+  // ---- unpack: truncated distances (lower ends of their intervals) and kd positions; K + 1 entries
+  KnnRegs<K + 1> M;
+#pragma unroll
+  for (int j = 0; j <= K; j++) {
+    const bool some = (kk[j] & ~kKnnSlotMask) < 0x7f800000u;  // a finite distance: a real candidate
+    M.d[j] = some ? __uint_as_float(kk[j] & ~kKnnSlotMask) : INFINITY;
+    M.id[j] = some ? static_cast<int>(pre_first + (kk[j] & kKnnSlotMask)) : -1;
+  }
+  auto upper = [](float dt) { return dt < INFINITY ? __uint_as_float(__float_as_uint(dt) | kKnnSlotMask) : INFINITY; };  // the largest distance that truncates to dt
+  // ---- the walk: kd_knn's, with the register list of truncated distances
+  const int D = t.depth;
+  int sp = 0, depth = 0;
+  uint32_t node = 1;
+  for (;;) {
+    float bound = upper(M.d[K - 1]);
+    while (depth < D) {
+      const float2 nd = t.nodes[node];
+      const int axis = __float_as_int(nd.y);
+      const float qa = axis == 0 ? qx : (axis == 1 ? qy : qz);
+      const float diff = qa - nd.x;
+      const float cut = diff * diff;
+      depth++;
+      if (cut <= bound) {
+        stack[sp * STRIDE + tid] = kd_pack(cut, depth);
+        sp++;
+      }
+      node = 2 * node + (diff < 0.f ? 0u : 1u);
+    }
+    {
+      const uint32_t kkk = node - (1u << D);
+      const uint32_t first = kd_bound(t.n, D, kkk), end = kd_bound(t.n, D, kkk + 1);
+      if (!(first >= pre_first && end <= pre_end)) {  // not covered by the window
+        float4 p[kKdLeafMax];
+#pragma unroll
+        for (int i = 0; i < kKdLeafMax; i++) p[i] = t.pts[first + i];  // 8 slots are always readable (padding behind the last leaf)
+#pragma unroll
+        for (int i = 0; i < kKdLeafMax; i++) {
+          const uint32_t pos = first + i;
+          const bool valid = pos < end && !(pos >= pre_first && pos < pre_end);
+          const float d2 = kd_dist2(p[i].x, p[i].y, p[i].z, qx, qy, qz);
+          const float dt = __uint_as_float(__float_as_uint(d2) & ~kKnnSlotMask);
+          if (valid && dt < M.d[K]) knn_regs_insert<K + 1>(M, dt, static_cast<int>(pos));  // (it beats the best loser at least) rare once the window has been scanned
+        }
+      }
+    }
+    bound = upper(M.d[K - 1]);
+    bool found = false;
+    while (sp > 0) {
+      sp--;
+      const uint32_t e = stack[sp * STRIDE + tid];
+      if (kd_cut(e) <= bound) {
+        const int dd = static_cast<int>(e & 31u);
+        const uint32_t far_node = (node >> (D - dd)) ^ 1u;
+        if (kd_box_dist2(t, far_node, qx, qy, qz) <= bound) {
+          depth = dd;
+          node = far_node;
+          found = true;
+          break;
+        }
+      }
+    }
+    if (!found) break;
+  }
+  // ---- the K-th entry and the best loser cannot be told apart: the exact search decides (a few queries per ten thousand)
+  const bool ambiguous = M.id[K] >= 0 && M.d[K] == M.d[K - 1];
+  if (ambiguous) {
+    kd_knn_own_points_exact<K, STRIDE>(t, qx, qy, qz, L, window, pre_first, pre_end, own_first, own_end, stack, tid);
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < K; j++) {
+    L.d[j] = M.d[j];
+    L.id[j] = M.id[j];
   }
 }
 

@@ -308,14 +308,12 @@ constexpr int kFeatWindow = 128;
 
 // mean / covariance of the neighbourhood -> normal, regularised covariance (normal_estimation.hpp:65-92, :13-63), written to the index's
 // kd-ordered arrays and, through the original index in p.w, to the caller's cloud.  id_at(j): kd position of the j-th neighbour, < 0 = no more.
-template <class IdAt>
+template <int KS = 0, class IdAt>  // KS > 0: exactly KS neighbours, the loop unrolled (id_at may then index a register array)
 __device__ __forceinline__ void features_from_neighbours(const KdView& g, size_t i, const float4 p, IdAt id_at, int k, int flags, float4* __restrict__ idx_nrm, Cov8* __restrict__ idx_cov, float4* __restrict__ cloud_nrm,
                                                          Cov8* __restrict__ cloud_cov, double ox, double oy, double oz) {
   int found = 0;
   double sp[3] = {0, 0, 0}, sc[6] = {0, 0, 0, 0, 0, 0};
-  for (int j = 0; j < k; j++) {
-    const int id = id_at(j);
-    if (id < 0) break;
+  auto add = [&](int id) {
     const float4 q = g.pts[id];
     const double x = q.x, y = q.y, z = q.z;
     sp[0] += x;
@@ -328,6 +326,19 @@ __device__ __forceinline__ void features_from_neighbours(const KdView& g, size_t
     sc[4] += y * z;
     sc[5] += z * z;
     found++;
+  };
+  if constexpr (KS > 0) {
+#pragma unroll
+    for (int j = 0; j < KS; j++) {
+      const int id = id_at(j);
+      if (id >= 0) add(id);  // (the list is filled from the front: the entries behind the last neighbour are -1)
+    }
+  } else {
+    for (int j = 0; j < k; j++) {
+      const int id = id_at(j);
+      if (id < 0) break;
+      add(id);
+    }
   }
   const uint32_t orig = __float_as_uint(p.w);
   float4 nrm = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -390,12 +401,17 @@ __device__ __forceinline__ void features_from_neighbours(const KdView& g, size_t
 
 // One lane per point of the kd-ordered index; neighbours come from the same tree.  Results are written both to the index's
 // kd-ordered attribute arrays and, through the original index kept in pts.w, to the caller's cloud.
+#ifndef SGA_FEAT_WAVES
+#define SGA_FEAT_WAVES 4
+#endif
 template <int K>  // K > 0: k = K neighbours in registers (kd_knn_own_points); K = 0: any k, list in LDS (kd_knn)
-__global__ __launch_bounds__(kFeatBlock) void local_features_kernel(
+__global__ __launch_bounds__(kFeatBlock) __attribute__((amdgpu_waves_per_eu(SGA_FEAT_WAVES, SGA_FEAT_WAVES))) void local_features_kernel(
   const KdView g, size_t n, int k, int flags, float4* __restrict__ idx_nrm, Cov8* __restrict__ idx_cov, float4* __restrict__ cloud_nrm, Cov8* __restrict__ cloud_cov, double ox, double oy, double oz) {
   extern __shared__ float sh[];
   __shared__ float4 window[kFeatWindow];  // the kd positions around the wave's own, scanned before the walk
-  const int kpad = (k + 3) & ~3;  // kd_knn sweeps the list four slots at a time
+  // K > 0: the list lives in registers from the search to the sums; the dynamic LDS is the traversal stack alone (6 KB per wave instead
+  // of 16: the k-best arrays were the kernel's occupancy limit)
+  const int kpad = K > 0 ? 0 : (k + 3) & ~3;  // kd_knn sweeps the list four slots at a time
   float* sd = sh;
   int* si = reinterpret_cast<int*>(sh + static_cast<size_t>(kpad) * kFeatBlock);
   uint32_t* stack = reinterpret_cast<uint32_t*>(sh + 2 * static_cast<size_t>(kpad) * kFeatBlock);
@@ -416,15 +432,11 @@ __global__ __launch_bounds__(kFeatBlock) void local_features_kernel(
   if constexpr (K > 0) {
     KnnRegs<K> L;
     kd_knn_own_points<K, kFeatBlock>(g, p.x, p.y, p.z, L, window, pre_first, pre_end, min(base, pre_end), min(base + kFeatBlock, pre_end), stack, lane);
-#pragma unroll
-    for (int j = 0; j < K; j++) {  // hand the list to the common code below
-      sd[j * kFeatBlock + lane] = L.d[j];
-      si[j * kFeatBlock + lane] = L.id[j];
-    }
+    features_from_neighbours<K>(g, i, p, [&](int j) { return L.id[j]; }, K, flags, idx_nrm, idx_cov, cloud_nrm, cloud_cov, ox, oy, oz);
   } else {
     kd_knn<kFeatBlock>(g, p.x, p.y, p.z, k, INFINITY, sd, si, stack, lane, false, pre_first, pre_end, window, base, base + kFeatBlock);  // unsorted: the sums below do not depend on the order
+    features_from_neighbours(g, i, p, [&](int j) { return si[j * kFeatBlock + lane]; }, k, flags, idx_nrm, idx_cov, cloud_nrm, cloud_cov, ox, oy, oz);
   }
-  features_from_neighbours(g, i, p, [&](int j) { return si[j * kFeatBlock + lane]; }, k, flags, idx_nrm, idx_cov, cloud_nrm, cloud_cov, ox, oy, oz);
 }
 
 // ---- small clouds: one wave per query (knn_wave.hpp), then one lane per point for the eigen-decompositions ------------------------
@@ -629,7 +641,7 @@ int sga_estimate_normals_covariances(sga_context* ctx, sga_cloud* cloud, const s
   if ((flags & 1) && cloud->nrm.n < n) rc = cloud->nrm.alloc(n);
   if (rc == SGA_OK && (flags & 2) && cloud->cov.n < n) rc = cloud->cov.alloc(n);
   if (rc == SGA_OK && n > 0) {
-    const size_t shmem = (static_cast<size_t>((k + 3) & ~3) * 8 + kKdMaxDepth * 4) * kFeatBlock;
+    const size_t shmem = (static_cast<size_t>((k == 20 || k == 10) ? 0 : ((k + 3) & ~3)) * 8 + kKdMaxDepth * 4) * kFeatBlock;  // (k = 10 / 20: the list lives in registers)
     if ((flags & 1) && !temp && index->nrm.n < n) rc = index->nrm.alloc(n);
     if (rc == SGA_OK && (flags & 2) && !temp && index->cov.n < n) rc = index->cov.alloc(n);
     KdView kv = make_kd_view(index);
