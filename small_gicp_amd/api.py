@@ -868,8 +868,8 @@ def preprocess_points(points, downsampling_resolution=0.25, num_neighbors=10, nu
     """registration_helper.cpp:22-34: downsample -> index -> normals + covariances.  Returns (PointCloud, KdTree)."""
     cloud = points if isinstance(points, PointCloud) else PointCloud(points)
     down = voxelgrid_sampling(cloud, downsampling_resolution)
-    estimate_normals_covariances(down, None, num_neighbors)
-    tree = KdTree(down)
+    tree = KdTree(down)  # (built first: the estimation searches it and fills its kd-ordered attribute copies — one build, not two)
+    estimate_normals_covariances(down, tree, num_neighbors)
     return down, tree
 
 

@@ -12,6 +12,7 @@
 #include "cell_grid.hpp"
 #include "device_math.hpp"
 #include "kd_search.hpp"
+#include "sort_util.hpp"
 
 namespace sga {
 
@@ -136,7 +137,7 @@ int build_cell_grid(sga_context* ctx, sga_index* idx) {
   SGA_TRY(idx->grid_start.alloc(cells + 1));
   SGA_TRY(idx->grid_pts.alloc(n));
   hipLaunchKernelGGL(grid_keys_kernel, grid, block, 0, ctx->stream, idx->kd_pts.p, un, g0, keys.p, vals.p);
-  SGA_HIP(rocprim::radix_sort_pairs(ctx->d_temp.p, tb, keys.p, keys2.p, vals.p, vals2.p, n, 0, 32, ctx->stream));  // stable: kd order inside a cell
+  SGA_TRY(sort_pairs(ctx, keys.p, keys2.p, vals.p, vals2.p, n, 0, 32));  // stable: kd order inside a cell
   hipLaunchKernelGGL(grid_gather_kernel, grid, block, 0, ctx->stream, idx->kd_pts.p, vals2.p, un, idx->grid_pts.p);
   SGA_HIP(hipMemsetAsync(idx->grid_start.p, 0, (cells + 1) * sizeof(uint32_t), ctx->stream));
   hipLaunchKernelGGL(grid_histogram_kernel, grid, block, 0, ctx->stream, keys2.p, un, idx->grid_start.p);

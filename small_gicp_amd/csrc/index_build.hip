@@ -7,6 +7,7 @@
 
 #include "common.hpp"
 #include "notes.hpp"
+#include "sort_util.hpp"
 
 #include <memory>
 #include <rocprim/rocprim.hpp>
@@ -726,9 +727,6 @@ static int build_kdtree(sga_context* ctx, const sga_cloud* cloud, sga_index* idx
   const dim3 grid((n + 255) / 256), block(256);
   uint32_t* cur = perm.p;
   uint32_t* nxt = perm2.p;
-  size_t tb = 0;
-  SGA_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys.p, keys2.p, cur, nxt, n, 0, 64, ctx->stream));
-  SGA_TRY(ensure_temp(ctx, tb));
   DevBuf<int> axis_of_seg;
   SGA_TRY(axis_of_seg.alloc(1ull << (D > 0 ? D - 1 : 0)));
   // top levels in global memory until a segment fits one workgroup, the rest of the sub-tree in LDS (kd_finish_kernel)
@@ -777,7 +775,7 @@ static int build_kdtree(sga_context* ctx, const sga_cloud* cloud, sga_index* idx
       hipLaunchKernelGGL(kd_segment_box_kernel, dim3((n + bs - 1) / bs), dim3(bs), 0, ctx->stream, cloud->pts.p, cur, static_cast<uint32_t>(n), d, seg_box.p);
     }
     hipLaunchKernelGGL(kd_keys_kernel, grid, block, 0, ctx->stream, cloud->pts.p, cur, static_cast<uint32_t>(n), d, seg_box.p, axis_of_seg.p, keys.p);
-    SGA_HIP(rocprim::radix_sort_pairs(ctx->d_temp.p, tb, keys.p, keys2.p, cur, nxt, n, 0, end_bit, ctx->stream));
+    SGA_TRY(sort_pairs(ctx, keys.p, keys2.p, cur, nxt, n, 0, end_bit));
     std::swap(cur, nxt);
     hipLaunchKernelGGL(kd_nodes_kernel, sgrid, block, 0, ctx->stream, cloud->pts.p, cur, static_cast<uint32_t>(n), d, axis_of_seg.p, idx->kd_nodes.p, d + 1 < dA ? seg_box.p : static_cast<int*>(nullptr));
   }
@@ -984,10 +982,7 @@ int sga_index_build_gaussian_voxelmap(sga_context* ctx, const sga_cloud* cloud, 
     SGA_TRY(seg_id.alloc(n));
     SGA_TRY(d_count.alloc(1));
     hipLaunchKernelGGL(voxel_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, cloud->pts.p, n, 1.0 / leaf, cloud->origin[0], cloud->origin[1], cloud->origin[2], keys.p, vals.p);
-    size_t tb = 0;
-    SGA_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys.p, keys_sorted.p, vals.p, order.p, n, 0, 64, ctx->stream));
-    SGA_TRY(ensure_temp(ctx, tb));
-    SGA_HIP(rocprim::radix_sort_pairs(ctx->d_temp.p, tb, keys.p, keys_sorted.p, vals.p, order.p, n, 0, 64, ctx->stream));
+    SGA_TRY(sort_pairs(ctx, keys.p, keys_sorted.p, vals.p, order.p, n, 0, 64));
     hipLaunchKernelGGL(segment_heads_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, keys_sorted.p, n, flags.p);
     size_t tb2 = 0;
     SGA_HIP(rocprim::exclusive_scan(nullptr, tb2, flags.p, seg_id.p, 0u, n, rocprim::plus<uint32_t>(), ctx->stream));

@@ -11,6 +11,7 @@
 #include "kd_search.hpp"
 #include "knn_wave.hpp"
 #include "notes.hpp"
+#include "sort_util.hpp"
 
 namespace sga {
 
@@ -512,13 +513,9 @@ int voxelgrid_run(sga_context* ctx, const sga_cloud* in, double leaf, const Voxe
   const dim3 grid((n + 255) / 256), block(256);
   hipLaunchKernelGGL((downsample_keys_kernel<Key>), grid, block, 0, ctx->stream, in->pts.p, n32, 1.0 / leaf, in->origin[0], in->origin[1], in->origin[2], L, keys.p, vals.p, ctx->vg_scratch.p);
   const unsigned end_bit = static_cast<unsigned>(std::min<int>(L.total + 1, 8 * static_cast<int>(sizeof(Key))));
-  size_t tb = 0;
-  // (rocPRIM sorts up to 1M items with a merge sort — block sort + 6 merges + 3 bookkeeping launches for a 115k-point scan — whatever the
-  // key width; its onesweep radix sort, forced by lowering the limit, was measured slower here: 82 us of passes + 33 us of state fills
-  // against 54 us.  The short keys still halve the bytes the merges move.)
-  SGA_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys.p, keys_sorted.p, vals.p, order.p, n, 0, end_bit, ctx->stream));
-  SGA_TRY(ensure_temp(ctx, tb));
-  SGA_HIP(rocprim::radix_sort_pairs(ctx->d_temp.p, tb, keys.p, keys_sorted.p, vals.p, order.p, n, 0, end_bit, ctx->stream));
+  // (sort_util.hpp: a merge sort for a scan's 115k keys — rocPRIM's onesweep radix sort was measured slower there: 82 us of passes + 33 us
+  // of state fills against 54 us — and the radix sort from 262144 keys on.  The short keys halve the bytes either of them moves.)
+  SGA_TRY(sort_pairs(ctx, keys.p, keys_sorted.p, vals.p, order.p, n, 0, end_bit));
   unsigned long long* slot = nullptr;
   const unsigned long long seq = note_begin(ctx, &slot);
   hipLaunchKernelGGL((ds_segments_kernel<Key>), dim3(tiles), dim3(kSegThreads), 0, ctx->stream, keys_sorted.p, n32, static_cast<Key>(1) << L.total, ctx->vg_status.p, epoch, ctx->vg_scratch.p, seg_start.p, slot, seq);

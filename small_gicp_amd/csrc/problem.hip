@@ -9,6 +9,7 @@
 #include <rocprim/rocprim.hpp>
 #include "device_math.hpp"
 #include "kd_search.hpp"
+#include "sort_util.hpp"
 #include "voxel_hash.hpp"
 
 namespace sga {
@@ -316,10 +317,7 @@ int sga_problem_create(sga_context* ctx, const sga_index* target, const sga_clou
       hipLaunchKernelGGL(source_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, source->pts.p, n, rigid_from_colmajor<float>(T), ox, oy, oz, inv, keys.p, vals.p);
     }
     SGA_HIP(hipGetLastError());
-    size_t tb = 0;
-    SGA_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys.p, keys_sorted.p, vals.p, order.p, n, 0, 63, ctx->stream));
-    SGA_TRY(ensure_temp(ctx, tb));
-    SGA_HIP(rocprim::radix_sort_pairs(ctx->d_temp.p, tb, keys.p, keys_sorted.p, vals.p, order.p, n, 0, 63, ctx->stream));
+    SGA_TRY(sort_pairs(ctx, keys.p, keys_sorted.p, vals.p, order.p, n, 0, 63));
     hipLaunchKernelGGL(gather_source_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, order.p, n, source->pts.p, source->cov.p, pb->pts.p, pb->cov.p);
     SGA_HIP(hipGetLastError());
     SGA_TRY(cloud_bbox(ctx, source->pts.p, n, pb->bbox_lo, pb->bbox_hi));  // synchronises the stream
