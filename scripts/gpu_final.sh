@@ -15,4 +15,4 @@ for f in ('bench_default', 'bench_driver_args'):
     print(' cpu', {k:v for k,v in j['cpu_baseline'].items() if k in ('value','cores')}, 'policy_c3', (j.get('policy_c3') or {}).get('inside_the_optimizer_iterations_per_s'), (j.get('policy_c3') or {}).get('policy_calls_iterations_per_s'))
     print(' c2', j['plane_icp_c2'].get('value'), 'c4', j['vgicp_c4'].get('value'), 'odom', {k:v for k,v in j['kitti_odom'].items() if 'ms_per_scan' in k}, 'conv', j['to_convergence'])
 PY
-echo "=== profile"; COMMIT=$(cat gpurun_out/.commit 2>/dev/null) bash scripts/profile_gpu.sh r05 2>&1 | tail -30
+echo "=== profile"; COMMIT=$(cat gpurun_out/.commit 2>/dev/null) bash scripts/profile_gpu.sh ${TAG:-r06} 2>&1 | tail -30

@@ -47,6 +47,7 @@ struct StreamScope {  // the calling thread's current stream for dev_alloc / dev
   StreamScope(const StreamScope&) = delete;
   StreamScope& operator=(const StreamScope&) = delete;
   hipStream_t prev;
+  unsigned long long prev_epoch;
 };
 #define SGA_ENTER(ctx)                        \
   SGA_HIP(hipSetDevice((ctx)->device));       \

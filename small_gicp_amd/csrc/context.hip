@@ -52,6 +52,13 @@ int fail(int code, const char* fmt, ...) {
 // ---- caching device allocator, stream ordered (see common.hpp) -------------------------------------------------------------------
 namespace {
 thread_local hipStream_t g_cur_stream = nullptr;  // set by SGA_ENTER for the duration of an entry point
+// Every entry-point invocation has a process-wide unique number.  A block that is freed by the invocation that allocated it (a temporary:
+// sort keys, scan flags, staging arrays) was never visible to anybody else — no other stream can hold work that touches it — so it goes
+// straight back to its stream's list.  (Round 6: the general path asks every other stream of the device whether it is busy and records an
+// event on each that is: ~25 us per free with four streams in flight, under the allocator's lock — the pipelined odometry driver spent
+// more time there than its kernels took.)
+thread_local unsigned long long g_cur_epoch = 0;
+std::atomic<unsigned long long> g_epoch_counter{0};
 
 struct FreeKey {
   int device;
@@ -67,13 +74,29 @@ struct PendingBlock {
   void* p;
   int device;
   size_t bucket;
-  std::vector<hipEvent_t> events;  // one per stream that was busy when the block was freed
+};
+// Blocks freed where another stream may still use them wait for events — recorded LAZILY and shared: a free only parks the block
+// (`unbatched`); the next allocation that misses the free lists records ONE event on every busy stream of the device for all the blocks
+// parked since (an event recorded after the free covers everything that was in flight at the free, and more: conservative), and a
+// batch's blocks join the shared pool when its events have completed.  (Round 6: an event per block and stream, recorded at the free,
+// cost ~25 us per free with four streams in flight.)
+struct PendingBatch {
+  int device;
+  std::vector<hipEvent_t> events;
+  std::vector<PendingBlock> blocks;
 };
 struct DevCache {
   std::mutex mu;
-  std::unordered_map<void*, std::pair<int, size_t>> live;  // every block handed out: device, bucket size
+  struct Live {
+    int device;
+    size_t bucket;
+    unsigned long long epoch;  // the entry-point invocation that allocated it (0: outside any)
+    hipStream_t stream;        // ... and its stream
+  };
+  std::unordered_map<void*, Live> live;  // every block handed out
   std::map<FreeKey, std::vector<void*>> free_blocks;
-  std::vector<PendingBlock> pending;                       // freed outside an entry point: reusable once their events have completed
+  std::vector<PendingBlock> unbatched;                     // freed where other streams may be using them; no event recorded yet
+  std::vector<PendingBatch> pending;                       // ... with their events: reusable once those have completed
   std::vector<std::pair<int, hipStream_t>> streams;        // the streams of the live contexts
   std::vector<hipEvent_t> event_pool;
   size_t cached_bytes = 0;
@@ -100,11 +123,12 @@ void recycle_events(DevCache& c, std::vector<hipEvent_t>& evs) {
   evs.clear();
 }
 
-// move the pending blocks whose events have all completed into the shared pool
+// batches whose events have all completed -> the shared pool; the blocks parked since the last call get their batch (one event per busy
+// stream of their device; no busy stream: straight to the pool)
 void collect_pending_locked(DevCache& c) {
   size_t w = 0;
   for (size_t i = 0; i < c.pending.size(); i++) {
-    PendingBlock& b = c.pending[i];
+    PendingBatch& b = c.pending[i];
     bool done = true;
     for (hipEvent_t e : b.events)
       if (hipEventQuery(e) == hipErrorNotReady) {
@@ -113,23 +137,72 @@ void collect_pending_locked(DevCache& c) {
       }
     if (done) {
       recycle_events(c, b.events);
-      c.free_blocks[{b.device, nullptr, b.bucket}].push_back(b.p);
+      for (const PendingBlock& k : b.blocks) c.free_blocks[{k.device, nullptr, k.bucket}].push_back(k.p);
     } else {
       if (w != i) c.pending[w] = std::move(b);
       w++;
     }
   }
   c.pending.resize(w);
-  (void)hipGetLastError();  // hipEventQuery's hipErrorNotReady is sticky in hipGetLastError
+  if (!c.unbatched.empty()) {
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    const int restore = cur;
+    std::vector<PendingBatch> fresh;
+    for (PendingBlock& k : c.unbatched) {
+      PendingBatch* batch = nullptr;
+      for (PendingBatch& f : fresh)
+        if (f.device == k.device) batch = &f;
+      if (batch == nullptr) {
+        fresh.push_back(PendingBatch{k.device, {}, {}});
+        batch = &fresh.back();
+        for (const auto& ds : c.streams) {
+          if (ds.first != k.device) continue;
+          if (hipStreamQuery(ds.second) != hipErrorNotReady) continue;  // idle: nothing of it can touch the blocks
+          if (cur != k.device) {
+            (void)hipSetDevice(k.device);
+            cur = k.device;
+          }
+          hipEvent_t e = nullptr;
+          if (!c.event_pool.empty()) {
+            e = c.event_pool.back();
+            c.event_pool.pop_back();
+          } else if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+            e = nullptr;
+          }
+          if (e == nullptr || hipEventRecord(e, ds.second) != hipSuccess) {
+            (void)hipStreamSynchronize(ds.second);  // cannot track it: wait for it instead
+            if (e) c.event_pool.push_back(e);
+            continue;
+          }
+          batch->events.push_back(e);
+        }
+      }
+      batch->blocks.push_back(k);
+    }
+    c.unbatched.clear();
+    if (cur != restore && restore >= 0) (void)hipSetDevice(restore);
+    for (PendingBatch& f : fresh) {
+      if (f.events.empty()) {
+        for (const PendingBlock& k : f.blocks) c.free_blocks[{k.device, nullptr, k.bucket}].push_back(k.p);
+      } else {
+        c.n_deferred += f.blocks.size();
+        c.pending.push_back(std::move(f));
+      }
+    }
+  }
+  (void)hipGetLastError();  // hipEventQuery's / hipStreamQuery's hipErrorNotReady is sticky in hipGetLastError
 }
 
 void release_cached_locked(DevCache& c) {
-  for (PendingBlock& b : c.pending) {
+  for (PendingBatch& b : c.pending) {
     for (hipEvent_t e : b.events) (void)hipEventSynchronize(e);
     recycle_events(c, b.events);
-    (void)hipFree(b.p);
+    for (const PendingBlock& k : b.blocks) (void)hipFree(k.p);
   }
   c.pending.clear();
+  for (const PendingBlock& k : c.unbatched) (void)hipFree(k.p);  // (hipFree synchronises the device: safe whatever is in flight)
+  c.unbatched.clear();
   for (auto& kv : c.free_blocks)
     for (void* q : kv.second) (void)hipFree(q);
   c.free_blocks.clear();
@@ -145,8 +218,14 @@ void* take_locked(DevCache& c, const FreeKey& key) {
 }
 }  // namespace
 
-StreamScope::StreamScope(hipStream_t s) : prev(g_cur_stream) { g_cur_stream = s; }
-StreamScope::~StreamScope() { g_cur_stream = prev; }
+StreamScope::StreamScope(hipStream_t s) : prev(g_cur_stream), prev_epoch(g_cur_epoch) {
+  g_cur_stream = s;
+  g_cur_epoch = s != nullptr ? ++g_epoch_counter : 0ull;
+}
+StreamScope::~StreamScope() {
+  g_cur_stream = prev;
+  g_cur_epoch = prev_epoch;
+}
 
 int dev_alloc(void** p, size_t bytes) {
   *p = nullptr;
@@ -159,7 +238,7 @@ int dev_alloc(void** p, size_t bytes) {
   // same stream first (stream order makes the reuse safe), then blocks nobody uses, then blocks whose last users have finished
   if (g_cur_stream != nullptr && (*p = take_locked(c, {device, g_cur_stream, bucket})) != nullptr) c.n_stream_hit++;
   if (!*p && (*p = take_locked(c, {device, nullptr, bucket})) != nullptr) c.n_pool_hit++;
-  if (!*p && !c.pending.empty()) {
+  if (!*p && (!c.pending.empty() || !c.unbatched.empty())) {
     collect_pending_locked(c);
     if ((*p = take_locked(c, {device, nullptr, bucket})) != nullptr) c.n_pending_hit++;
   }
@@ -178,7 +257,7 @@ int dev_alloc(void** p, size_t bytes) {
       return fail(SGA_ERR_HIP, "hipMalloc(%zu bytes) -> %s", bucket, hipGetErrorString(e));
     }
   }
-  c.live[*p] = {device, bucket};
+  c.live[*p] = DevCache::Live{device, bucket, g_cur_epoch, g_cur_stream};
   return SGA_OK;
 }
 
@@ -191,60 +270,23 @@ void dev_free(void* p) {
     (void)hipFree(p);
     return;
   }
-  const int device = it->second.first;
-  const size_t bucket = it->second.second;
+  const int device = it->second.device;
+  const size_t bucket = it->second.bucket;
+  const bool temporary = g_cur_stream != nullptr && it->second.epoch == g_cur_epoch && it->second.epoch != 0ull && it->second.stream == g_cur_stream;
   c.live.erase(it);
   if (c.contexts == 0 || c.cached_bytes + bucket > kCacheLimitBytes) {
     (void)hipFree(p);  // synchronises the device: safe whatever is in flight
     return;
   }
   c.cached_bytes += bucket;
-  if (g_cur_stream != nullptr) {
-    // Inside an entry point: later work on the same stream may get this block at once — provided no OTHER stream of the device has
-    // work in flight.  Buffers of long-lived shared objects (an index's attributes, a problem's mahalanobis cache, the rejector
-    // flags) may be read by kernels another context has enqueued on its own stream (sga_linearize_async on context B while
-    // context A refreshes the index): with such a stream busy the block takes the event-deferred path below.
-    bool others_busy = false;
-    for (const auto& ds : c.streams)
-      if (ds.first == device && ds.second != g_cur_stream && hipStreamQuery(ds.second) == hipErrorNotReady) others_busy = true;
-    (void)hipGetLastError();
-    if (!others_busy) {
-      c.free_blocks[{device, g_cur_stream, bucket}].push_back(p);
-      return;
-    }
+  if (temporary) {  // allocated by this very invocation: nobody else has seen it
+    c.free_blocks[{device, g_cur_stream, bucket}].push_back(p);
+    return;
   }
-  // outside an entry point (destroy functions): kernels on any stream of the device may still use the block
-  PendingBlock b{p, device, bucket, {}};
-  int cur = -1;
-  (void)hipGetDevice(&cur);
-  for (const auto& ds : c.streams) {
-    if (ds.first != device) continue;
-    if (hipStreamQuery(ds.second) != hipErrorNotReady) continue;  // idle: nothing of it can touch the block
-    if (cur != device) {
-      (void)hipSetDevice(device);
-      cur = device;
-    }
-    hipEvent_t e = nullptr;
-    if (!c.event_pool.empty()) {
-      e = c.event_pool.back();
-      c.event_pool.pop_back();
-    } else if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
-      e = nullptr;
-    }
-    if (e == nullptr || hipEventRecord(e, ds.second) != hipSuccess) {
-      (void)hipStreamSynchronize(ds.second);  // cannot track it: wait for it instead
-      if (e) c.event_pool.push_back(e);
-      continue;
-    }
-    b.events.push_back(e);
-  }
-  (void)hipGetLastError();
-  if (b.events.empty()) {
-    c.free_blocks[{device, nullptr, bucket}].push_back(p);
-  } else {
-    c.n_deferred++;
-    c.pending.push_back(std::move(b));
-  }
+  // Anything else — a buffer of a long-lived object (an index's attributes, a problem's mahalanobis cache, the rejector flags: kernels
+  // another context has enqueued on its own stream may be reading it) or a block freed outside any entry point (destroy
+  // functions) — may still be in use on any stream of the device: parked until the streams have passed this point (collect_pending_locked)
+  c.unbatched.push_back(PendingBlock{p, device, bucket});
 }
 
 static void dev_cache_context_created(int device, hipStream_t stream) {

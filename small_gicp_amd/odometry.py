@@ -198,6 +198,14 @@ class PipelinedOdometry:
                     state["error"] = ex
                     cv.notify_all()
 
+        # The threads spend their time inside ctypes calls (GIL released) and need the GIL for microseconds in between; with CPython's default
+        # switch interval (5 ms) a thread coming back from a call can wait that long for one that is running bytecode.  SGA_PIPE_SWITCH_S
+        # (default 2e-5 s) for the duration of the run.
+        import os
+        import sys
+
+        old_switch = sys.getswitchinterval()
+        sys.setswitchinterval(float(os.environ.get("SGA_PIPE_SWITCH_S", "2e-5")))
         t0 = time.perf_counter()
         threads = [threading.Thread(target=producer, args=(w,), daemon=True) for w in range(len(self.ctx_pre))]
         for th in threads:
@@ -225,7 +233,9 @@ class PipelinedOdometry:
         for th in threads:
             th.join()
         self.ctx_reg.synchronize()
-        return poses, time.perf_counter() - t0, iters
+        wall = time.perf_counter() - t0
+        sys.setswitchinterval(old_switch)
+        return poses, wall, iters
 
 
 def run_synthetic(num_frames=20, pinned=False, **kw):
