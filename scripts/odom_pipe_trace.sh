@@ -9,7 +9,12 @@ import sys; sys.path.insert(0, "$ROOT")
 from small_gicp_amd import odometry, synthetic
 import time
 scans = [synthetic.kitti_like_scan(f)[0] for f in range(40)]
-od = odometry.PipelinedOdometry(workers=${WORKERS:-2})
+od = odometry.PipelinedOdometry(workers=${WORKERS:-2}) if ${WORKERS:-2} > 0 else None
+class Seq:
+    def run(self, scans):
+        import time as _t
+        o = odometry.OnlineOdometry(); t0 = _t.perf_counter(); poses = [o.estimate(s) for s in scans]; return poses, _t.perf_counter() - t0, []
+od = od or Seq()
 od.run(scans[:3])
 t0 = time.clock_gettime_ns(time.CLOCK_MONOTONIC)
 poses, wall, iters = od.run(scans)

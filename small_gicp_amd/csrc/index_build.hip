@@ -729,41 +729,31 @@ static int build_kdtree(sga_context* ctx, const sga_cloud* cloud, sga_index* idx
   uint32_t* nxt = perm2.p;
   DevBuf<int> axis_of_seg;
   SGA_TRY(axis_of_seg.alloc(1ull << (D > 0 ? D - 1 : 0)));
-  // top levels in global memory until a segment fits one workgroup, the rest of the sub-tree in LDS (kd_finish_kernel)
+  // Three regimes, top down (round 6: large clouds now leave the sort-based levels as soon as a segment fits one workgroup of the split
+  // kernel — five levels instead of nine at 1M — and finish through the same per-level partition and small LDS finish as a scan):
+  //   [0, dS)   segments of more than kSplitMaxPoints points: per level a box pass, a key pass, a key-value sort and a node pass;
+  //   [dS, dA)  one launch per level (kd_split_level_kernel: radix select + partition, one workgroup per segment);
+  //   [dA, D)   the rest of every sub-tree in LDS (kd_finish_kernel<kSplitFinish>).
+  // SGA_KD_SPLIT=0: no split levels (sort-based down to kFinishCap, then the large LDS finish); SGA_KD_FINISH=0: sort-based throughout.
+  const bool lds_finish = !(getenv("SGA_KD_FINISH") && atoi(getenv("SGA_KD_FINISH")) == 0);  // read per build: the tests compare the paths
+  const bool split_levels = lds_finish && !(getenv("SGA_KD_SPLIT") && atoi(getenv("SGA_KD_SPLIT")) == 0);
+  auto seg_max_at = [&](int d) { return (n + (1ull << d) - 1) >> d; };
   const int cap = n >= 400000 ? kFinishCap : kFinishCap / 2;
-  int dA = 0;
-  while (dA < D && ((n + (1ull << dA) - 1) >> dA) > static_cast<size_t>(cap)) dA++;
-  const bool lds_finish = !(getenv("SGA_KD_FINISH") && atoi(getenv("SGA_KD_FINISH")) == 0);  // read per build: the tests compare both paths
-  if (!lds_finish || D - dA > 8) dA = D;
-  // small clouds: one launch per level (kd_split_level_kernel) down to segments of kSplitFinish points, the rest in LDS
-  const bool split_path = lds_finish && n <= kSplitMaxPoints && !(getenv("SGA_KD_SPLIT") && atoi(getenv("SGA_KD_SPLIT")) == 0);
-  bool boxed = false;
-  if (split_path) {
-    dA = 0;
-    while (dA < D && ((n + (1ull << dA) - 1) >> dA) > static_cast<size_t>(kSplitFinish)) dA++;
-    for (int d = 0; d < dA; d++) {
-      const size_t seg_max = (n + (1ull << d) - 1) >> d;
-      unsigned long long* note_slot = nullptr;
-      if (d == 0) {  // the root level reads the identity permutation and hands the cloud's box to the host
-        *box_seq = note_begin(ctx, &note_slot);
-        boxed = true;
-      }
-      const uint32_t* level_in = d == 0 ? nullptr : cur;
-#define SGA_SPLIT(THREADS, KEYS) hipLaunchKernelGGL((kd_split_level_kernel<THREADS, KEYS>), dim3(1u << d), dim3(THREADS), 0, ctx->stream, cloud->pts.p, level_in, nxt, static_cast<uint32_t>(n), d, idx->kd_nodes.p, note_slot, *box_seq)
-      if (seg_max <= 256 * 2) SGA_SPLIT(256, 2);
-      else if (seg_max <= 256 * 4) SGA_SPLIT(256, 4);
-      else if (seg_max <= 256 * 8) SGA_SPLIT(256, 8);
-      else if (seg_max <= 1024 * 4) SGA_SPLIT(1024, 4);
-      else if (seg_max <= 1024 * 8) SGA_SPLIT(1024, 8);
-      else if (seg_max <= 1024 * 16) SGA_SPLIT(1024, 16);
-      else SGA_SPLIT(1024, 32);
-#undef SGA_SPLIT
-      std::swap(cur, nxt);
-    }
+  int dS = 0, dA = 0;
+  if (split_levels) {
+    while (dS < D && seg_max_at(dS) > static_cast<size_t>(kSplitMaxPoints)) dS++;
+    dA = dS;
+    while (dA < D && seg_max_at(dA) > static_cast<size_t>(kSplitFinish)) dA++;
+  } else {
+    while (dS < D && seg_max_at(dS) > static_cast<size_t>(cap)) dS++;
+    if (!lds_finish || D - dS > 8) dS = D;
+    dA = dS;
   }
-  if (!boxed) SGA_TRY(cloud_bbox_enqueue(ctx, cloud->pts.p, n, box_seq));
-  if (!split_path || dA == 0) hipLaunchKernelGGL(iota_kernel, grid, block, 0, ctx->stream, perm.p, n);
-  for (int d = 0; d < dA && !split_path; d++) {
+  if (dS > 0 || dA == 0) {  // (otherwise the root split level below hands over the box and reads the identity permutation)
+    SGA_TRY(cloud_bbox_enqueue(ctx, cloud->pts.p, n, box_seq));
+    hipLaunchKernelGGL(iota_kernel, grid, block, 0, ctx->stream, perm.p, n);
+  }
+  for (int d = 0; d < dS; d++) {
     const uint32_t nseg = 1u << d;
     const dim3 sgrid((nseg + 255) / 256);
     const unsigned end_bit = 32 + (d > 0 ? d : 1);
@@ -777,9 +767,27 @@ static int build_kdtree(sga_context* ctx, const sga_cloud* cloud, sga_index* idx
     hipLaunchKernelGGL(kd_keys_kernel, grid, block, 0, ctx->stream, cloud->pts.p, cur, static_cast<uint32_t>(n), d, seg_box.p, axis_of_seg.p, keys.p);
     SGA_TRY(sort_pairs(ctx, keys.p, keys2.p, cur, nxt, n, 0, end_bit));
     std::swap(cur, nxt);
-    hipLaunchKernelGGL(kd_nodes_kernel, sgrid, block, 0, ctx->stream, cloud->pts.p, cur, static_cast<uint32_t>(n), d, axis_of_seg.p, idx->kd_nodes.p, d + 1 < dA ? seg_box.p : static_cast<int*>(nullptr));
+    hipLaunchKernelGGL(kd_nodes_kernel, sgrid, block, 0, ctx->stream, cloud->pts.p, cur, static_cast<uint32_t>(n), d, axis_of_seg.p, idx->kd_nodes.p, d + 1 < dS ? seg_box.p : static_cast<int*>(nullptr));
   }
-  if (dA < D && split_path) {
+  for (int d = dS; d < dA; d++) {
+    const size_t seg_max = seg_max_at(d);
+    unsigned long long* note_slot = nullptr;
+    if (d == 0) {  // the root level reads the identity permutation and hands the cloud's box to the host
+      *box_seq = note_begin(ctx, &note_slot);
+    }
+    const uint32_t* level_in = d == 0 ? nullptr : cur;
+#define SGA_SPLIT(THREADS, KEYS) hipLaunchKernelGGL((kd_split_level_kernel<THREADS, KEYS>), dim3(1u << d), dim3(THREADS), 0, ctx->stream, cloud->pts.p, level_in, nxt, static_cast<uint32_t>(n), d, idx->kd_nodes.p, note_slot, *box_seq)
+    if (seg_max <= 256 * 2) SGA_SPLIT(256, 2);
+    else if (seg_max <= 256 * 4) SGA_SPLIT(256, 4);
+    else if (seg_max <= 256 * 8) SGA_SPLIT(256, 8);
+    else if (seg_max <= 1024 * 4) SGA_SPLIT(1024, 4);
+    else if (seg_max <= 1024 * 8) SGA_SPLIT(1024, 8);
+    else if (seg_max <= 1024 * 16) SGA_SPLIT(1024, 16);
+    else SGA_SPLIT(1024, 32);
+#undef SGA_SPLIT
+    std::swap(cur, nxt);
+  }
+  if (dA < D && split_levels) {
     hipLaunchKernelGGL(kd_finish_kernel<kSplitFinish>, dim3(1u << dA), dim3(kFinishThreads), 0, ctx->stream, cloud->pts.p, cur, nxt, static_cast<uint32_t>(n), dA, D, idx->kd_nodes.p);
     std::swap(cur, nxt);
   } else if (dA < D) {
