@@ -23,7 +23,7 @@ sga.set_search_mode(0)
 pb = sga.Problem(tree, src)
 lib = _lib.load()
 lib.sga_debug_kd_trips.restype = C.c_int
-names = ["uniform level", "pair step", "group header", "leaf scan", "pop iteration", "outer iteration"]
+names = ["uniform level", "pair step", "group header", "leaf scan", "pop iteration", "outer iteration", "leaf scan of the first group (SGA_KD_STALE builds)"]
 k = [0]
 buf = (C.c_ulonglong * 16)()
 lib.sga_debug_kd_trips(buf)
@@ -33,7 +33,7 @@ def lin(T):
     r = pb.linearize(st.factor, T)
     lib.sga_debug_kd_trips(buf)
     waves = (n + 63) // 64
-    print("pass %d: " % k[0] + "; ".join("%s %.1f/wave (%.0f%% lanes)" % (names[b], buf[8 + b] / waves, 100.0 * buf[b] / max(1, 64 * buf[8 + b])) for b in range(6)), flush=True)
+    print("pass %d: " % k[0] + "; ".join("%s %.1f/wave (%.0f%% lanes)" % (names[b], buf[8 + b] / waves, 100.0 * buf[b] / max(1, 64 * buf[8 + b])) for b in range(len(names)) if buf[8 + b]) + "; leaves per query %.2f" % (buf[3] / n), flush=True)
     wt = (C.c_ulonglong * (2 * min(waves, 32768)))()
     lib.sga_debug_kd_wave_times(wt, min(waves, 32768))
     w = np.array(wt, dtype=np.float64).reshape(-1, 2) * 0.01  # us (100 MHz)

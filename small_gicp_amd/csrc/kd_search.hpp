@@ -129,8 +129,11 @@ struct KdState {
   float open;                 // sub-trees with a lower bound <= open are explored: prune, or (sqrt(prune) + slack)^2 (see kd_nearest)
   float slack;                // exploration margin in metres (0 = the minimal search)
   int leaves;                 // leaves scanned so far
+#ifdef SGA_KD_STALE
+  int groups;                 // pricing build (docs/experiments.md, deferred leaf scans): group visits completed
+#endif
 #ifdef SGA_KD_TRIPS
-  int own[6], wav[6];         // diagnostics build: loop-body executions of this lane / of the wave (counted by its first active lane)
+  int own[8], wav[8];         // diagnostics build: loop-body executions of this lane / of the wave (counted by its first active lane)
 #endif
 };
 #ifdef SGA_KD_TRIPS
@@ -196,9 +199,15 @@ __device__ __forceinline__ void kd_scan_leaf(const KdView& t, uint32_t leaf_node
     s.win = before_win ? key : s.win;
   }
   s.prune = fminf(s.prune0, kd_key_dist(s.win));
+#ifdef SGA_KD_STALE
+  if (s.groups < SGA_KD_STALE)
+#endif
   s.open = kd_open_bound(s.prune, s.slack);
   s.leaves++;
   KD_TRIP(s, 3);
+#ifdef SGA_KD_STALE
+  if (s.groups == 0) KD_TRIP(s, 6);  // leaf scans of the first group visit
+#endif
 }
 
 // ---- the fast leaf scan ----------------------------------------------------------------------------------------------------------
@@ -222,8 +231,11 @@ struct KdFast {
   float open;           // sub-trees with a lower bound <= open are explored
   float slack;
   int leaves;
+#ifdef SGA_KD_STALE
+  int groups;
+#endif
 #ifdef SGA_KD_TRIPS
-  int own[6], wav[6];
+  int own[8], wav[8];
 #endif
 };
 __device__ __forceinline__ KdFast kd_fast_state(float prune0, float slack = 0.f) {
@@ -264,9 +276,15 @@ __device__ __forceinline__ void kd_scan_leaf(const KdView& t, uint32_t leaf_node
   // whose leaf: a key that changed came from this leaf, except a runner-up that is the old winner moved down
   s.l2 = s.w2 != o2 ? (s.w2 == o1 ? s.l1 : k) : s.l2;
   s.l1 = s.w1 != o1 ? k : s.l1;
+#ifdef SGA_KD_STALE
+  if (s.groups < SGA_KD_STALE)  // pricing build: the bound stops tightening after that many group visits (what a walk with deferred leaf scans would see)
+#endif
   s.open = kd_open_bound(fminf(s.prune0, kd_key_hi(s.w1)), s.slack);
   s.leaves++;
   KD_TRIP(s, 3);
+#ifdef SGA_KD_STALE
+  if (s.groups == 0) KD_TRIP(s, 6);  // leaf scans of the first group visit
+#endif
 }
 
 // The bottom of the walk.  The leaves under a node of depth D - 2 (a GROUP: up to 4 leaves, 32 points) are not reached through two
@@ -306,6 +324,9 @@ __device__ __forceinline__ void kd_visit_group(const KdView& t, uint32_t gnode, 
     lb3 = l == 3 ? INFINITY : lb3;
   }
   s.dropped = kd_min(s.dropped, fminf(fminf(lb0, lb1), fminf(lb2, lb3)));  // the leaves not scanned: nothing in there is closer than their box
+#ifdef SGA_KD_STALE
+  s.groups++;
+#endif
 }
 
 // The reference's recursion (descend to the near side; visit the far side iff it can hold a closer point, kdtree.hpp:207-230)
@@ -578,7 +599,7 @@ __device__ __forceinline__ KdBest kd_nearest(const KdView& t, float qx, float qy
   }
   kd_walk<STRIDE>(t, qx, qy, qz, s, node, depth, sp, stack, tid);
 #if defined(SGA_KD_TRIPS) && !defined(SGA_KD_NO_COUNT)
-  for (int k = 0; k < 6; k++) {
+  for (int k = 0; k < 8; k++) {
     atomicAdd(&g_kd_trips[k], static_cast<unsigned long long>(s.own[k]));
     atomicAdd(&g_kd_trips[8 + k], static_cast<unsigned long long>(s.wav[k]));
   }
@@ -644,7 +665,7 @@ __device__ __forceinline__ KdBestFast kd_nearest_fast(const KdView& t, float qx,
   }
   kd_walk<STRIDE>(t, qx, qy, qz, s, node, depth, sp, stack, tid);
 #if defined(SGA_KD_TRIPS) && !defined(SGA_KD_NO_COUNT)
-  for (int k = 0; k < 6; k++) {
+  for (int k = 0; k < 8; k++) {
     atomicAdd(&g_kd_trips[k], static_cast<unsigned long long>(s.own[k]));
     atomicAdd(&g_kd_trips[8 + k], static_cast<unsigned long long>(s.wav[k]));
   }

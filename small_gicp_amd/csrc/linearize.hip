@@ -213,7 +213,6 @@ struct NNParams {
   int* __restrict__ leaves;  // diagnostics (sga_problem_set_search_stats): leaves scanned per source point in this pass, or null
   double inv_leaf;   // 2^depth / n (kd_leaf_rank)
   int chunk_tiles;   // queue-fed kernel: tiles of 64 queries per wave
-  int tile_shift;    // search_linearize_kernel: 6 = a wave searches 64 queries; 5 = 32 (half-empty waves for grids that do not fill the chip: twice the waves, and a wave lasts as long as the longest of 32 walks instead of 64)
   int fast;          // one-query-per-lane kernels: walk with the fast leaf scan (exact repeat where it cannot decide)
   GridView grid;     // the target's cell grid (cell_grid.hpp), if grid_walk
   int grid_walk;     // the walkers of certify_linearize_kernel try ring 1 of the grid before they walk the tree
@@ -295,7 +294,7 @@ __device__ __forceinline__ int search_lane(const NNParams<Real>& p, int tile, in
     // so that the certificate survives the following (smaller) steps
     slack = fminf(fmaxf(moved, p.slack_min), p.slack_max);
     const unsigned long long walking = __ballot(true);
-    if (threadIdx.x == __ffsll(static_cast<long long>(walking)) - 1) atomicAdd(&p.walked[i >> 6], static_cast<uint32_t>(__popcll(walking)));  // statistics (with half tiles two waves share a counter)
+    if (threadIdx.x == __ffsll(static_cast<long long>(walking)) - 1) p.walked[tile] += static_cast<uint32_t>(__popcll(walking));  // the tile belongs to this wave: no atomic
     // A point whose certificate failed sits next to a surface (isolated points carry wide certificates and rarely fail): ring 1 of the
     // cell grid (cell_grid.hpp) settles it exactly with two dependent loads and gives the new certificate the tightest radius there is
     // (the third-nearest distance); the walk — with its exploration margin — only for what the ring does not settle.
@@ -1172,8 +1171,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CHECK ? SGA_
   const int slot = search_tile_of_block();
   const int tile = p.tile_order != nullptr ? static_cast<int>(p.tile_order[slot]) : slot;  // wave-uniform
   const unsigned long long cost_t0 = p.tile_cost != nullptr ? wall_clock64() : 0ull;
-  const int i = (tile << p.tile_shift) + lane;
-  const bool active = lane < (1 << p.tile_shift) && i < p.n;
+  const int i = tile * 64 + lane;
+  const bool active = i < p.n;
   const float4 ps = active ? p.src_pts[i] : make_float4(0.f, 0.f, 0.f, 0.f);
   Real q[3] = {Real(0), Real(0), Real(0)};
   int j = -1;
@@ -1428,10 +1427,7 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __rest
 
 // partial rows (one per workgroup of linearize_kernel / error_kernel, or one per 64 source points when the search kernel does the factor algebra itself);
 // the stage-1 rows of the reduction follow them
-// Half tiles (NNParams::tile_shift = 5): source clouds below this size search 32 queries per wave in the one-query-per-lane kernel
-// (SGA_HALF_TILE_MAX; 0 = never).  Results do not depend on it (a row per tile either way; the rows are added in tile order).
-static const size_t g_half_tile_max = getenv("SGA_HALF_TILE_MAX") ? static_cast<size_t>(atoll(getenv("SGA_HALF_TILE_MAX"))) : 0;
-static size_t partial_rows(size_t n) { return std::max<size_t>(kMaxBlocks, n < g_half_tile_max ? (n + 31) / 32 : (n + 63) / 64); }
+static size_t partial_rows(size_t n) { return std::max<size_t>(kMaxBlocks, (n + 63) / 64); }
 
 static void launch_reduce(sga_context* ctx, const double* partials, int nrows, int ncols, int row_stride, double* stage, double* out, int out_n, double* host, unsigned long long seq, bool derive = false, const uint32_t* stats = nullptr) {
   const int groups = nrows > 256 ? std::min(kReduceGroups, std::max(8, nrows / 128)) : 1;  // <= 256 rows: one workgroup, no hand-off between workgroups
@@ -1650,9 +1646,7 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
     q.leaves = pb->dbg_leaves.n >= pb->n ? pb->dbg_leaves.p : nullptr;
     if (q.leaves != nullptr) SGA_HIP(hipMemsetAsync(q.leaves, 0, pb->n * sizeof(int), ctx->stream));
     const size_t words = static_cast<size_t>(p.kd.depth);  // traversal stack rows
-    q.tile_shift = 6;
-    dim3 sgrid((p.n + kSearchBlock - 1) / kSearchBlock);
-    const dim3 sblock(kSearchBlock);
+    const dim3 sgrid((p.n + kSearchBlock - 1) / kSearchBlock), sblock(kSearchBlock);
     if (grid_mode != 0 && idx->grid_h > 0.f && q.bound2 < 3.0e38f && !host_rejector && q.leaves == nullptr) {
       const int rings = grid_rings_for(idx, std::sqrt(static_cast<double>(q.bound2)));
       const bool small_warm = warm && displacement <= g_queue_delta * unit;
@@ -1733,10 +1727,6 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
     } else if (fused_search) {
       // every search wave evaluates the factors of its own tile: one partial row per tile of 64 points, summed by reduce_rows_kernel
       p.tail.enabled = 0;
-      if (pb->n < g_half_tile_max) {  // a grid that does not fill the chip: 32 queries per wave
-        q.tile_shift = 5;
-        sgrid = dim3((p.n + 31) / 32);
-      }
       fused_rows = static_cast<int>(sgrid.x);
       const dim3 cgrid(sgrid.x);
       if (g_lpt != 0 && sgrid.x >= 8192) {  // fewer tiles than wave slots: all waves start at once, the order means nothing
