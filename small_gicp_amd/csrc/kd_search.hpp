@@ -106,6 +106,13 @@ __device__ __forceinline__ float kd_box_dist2(const KdView& t, uint32_t node, fl
   return fmaf(dx, dx, fmaf(dy, dy, dz * dz));
 }
 
+#ifdef SGA_KD_PREFETCH
+// Experiment build (docs/experiments.md, round 6): a load nobody waits for, to pull a line the walk will want a few steps later into the
+// L2 / L1 of this CU (bit 1: the box of a far side when it is pushed; bit 2: the four leaf blocks of a group with its header).  The
+// destination register is threaded through the walk's state so that nothing else is allocated to it while loads are in flight.
+__device__ __forceinline__ void kd_prefetch(const void* addr, uint32_t& pf) { asm volatile("global_load_dword %0, %1, off" : "+v"(pf) : "v"(addr) : "memory"); }
+#endif
+
 // ---- exact nearest neighbour ---------------------------------------------------------------------------------------------------
 // The target point minimising (kd_dist2, kd position) lexicographically among the points with kd_dist2 < bound2 — a canonical
 // rule (equidistant points: the lowest kd position wins), so the result depends on the tree and the query only, never on the
@@ -131,6 +138,9 @@ struct KdState {
   int leaves;                 // leaves scanned so far
 #ifdef SGA_KD_STALE
   int groups;                 // pricing build (docs/experiments.md, deferred leaf scans): group visits completed
+#endif
+#ifdef SGA_KD_PREFETCH
+  uint32_t pf;                // experiment build: destination of the walk's cache prefetches (never read)
 #endif
 #ifdef SGA_KD_TRIPS
   int own[8], wav[8];         // diagnostics build: loop-body executions of this lane / of the wave (counted by its first active lane)
@@ -234,6 +244,9 @@ struct KdFast {
 #ifdef SGA_KD_STALE
   int groups;
 #endif
+#ifdef SGA_KD_PREFETCH
+  uint32_t pf;
+#endif
 #ifdef SGA_KD_TRIPS
   int own[8], wav[8];
 #endif
@@ -303,6 +316,15 @@ __device__ __forceinline__ float kd_box_dist2_vals(float lox, float loy, float l
 template <class S>
 __device__ __forceinline__ void kd_visit_group(const KdView& t, uint32_t gnode, float qx, float qy, float qz, S& s) {
   const float4* __restrict__ h = t.groups + 8ull * (gnode - (1u << t.gdepth));
+#ifdef SGA_KD_PREFETCH
+  if (SGA_KD_PREFETCH & 2) {
+    const float4* __restrict__ lb = t.leafblk + 8ull * ((gnode << t.glevels) - (1u << t.depth));
+    for (int l = 0; l < (1 << t.glevels); l++) {
+      kd_prefetch(lb + 8 * l, s.pf);
+      kd_prefetch(lb + 8 * l + 4, s.pf);
+    }
+  }
+#endif
   const float4 lox = h[0], loy = h[1], loz = h[2], hix = h[3], hiy = h[4], hiz = h[5];
   float lb0 = kd_box_dist2_vals(lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, qx, qy, qz);
   float lb1 = kd_box_dist2_vals(lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, qx, qy, qz);
@@ -360,6 +382,9 @@ __device__ __forceinline__ void kd_walk(const KdView& t, float qx, float qy, flo
         sp += keep ? 1 : 0;
         s.dropped = kd_min(s.dropped, keep ? INFINITY : cut);
         node = 2 * node + (diff < 0.f ? 0u : 1u);
+#ifdef SGA_KD_PREFETCH
+        if ((SGA_KD_PREFETCH & 1) && keep) kd_prefetch(t.boxes + 2 * (node ^ 1u), s.pf);
+#endif
       }
       if (depth < D) {
         const uint32_t right = node & 1u;
@@ -374,6 +399,9 @@ __device__ __forceinline__ void kd_walk(const KdView& t, float qx, float qy, flo
         sp += keep ? 1 : 0;
         s.dropped = kd_min(s.dropped, keep ? INFINITY : cut);
         node = 2 * node + (diff < 0.f ? 0u : 1u);
+#ifdef SGA_KD_PREFETCH
+        if ((SGA_KD_PREFETCH & 1) && keep) kd_prefetch(t.boxes + 2 * (node ^ 1u), s.pf);
+#endif
       }
     }
     kd_visit_group(t, node, qx, qy, qz, s);
@@ -395,6 +423,9 @@ __device__ __forceinline__ void kd_walk(const KdView& t, float qx, float qy, flo
     depth = static_cast<int>(e & 31u);
     node = (node >> (D - depth)) ^ 1u;  // sibling of the current group's ancestor at that depth
   }
+#ifdef SGA_KD_PREFETCH
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(s.pf) : : "memory");
+#endif
 }
 
 // ---- the walk in pieces, for the queue-fed search kernel (linearize.hip: nn_search_kernel) --------------------------------------
