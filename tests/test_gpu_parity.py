@@ -20,6 +20,7 @@ pytestmark = pytest.mark.gpu
 
 POSE_TOL_T, POSE_TOL_R = 1e-4, 1e-4
 FP32_REL, FP64_REL = 2e-5, 1e-10
+C1_DIFFERING_FP32, C1_INLIER_DELTA_FP32 = 1, 1  # C1 at a fixed pose, fp32 arithmetic: correspondences (of 6 167) / inliers that may differ from the oracle's; observed on the MI355X: 0 / 0 for every factor and pose (gpurun_out/c1_observed.txt, round 6) — the 1 is for a tie within fp32 resolution
 
 
 def rot(axis, ang):
@@ -62,7 +63,7 @@ def test_linearize_and_error_match_oracle(orc, c1_f32, gpu_c1, name, kind, robus
     for T in POSES:
         H, b, e, n = pb.linearize(st.factor, T)
         Ho, bo, eo, no = orc.linearize(otc, osc, os_, T, f)
-        assert abs(int(n) - int(no)) <= (2 if mode == "fp32" else 0)
+        assert abs(int(n) - int(no)) <= (C1_INLIER_DELTA_FP32 if mode == "fp32" else 0)
         scale = np.abs(Ho).max()
         assert np.abs(H - Ho).max() <= rel * scale, (name, mode, np.abs(H - Ho).max() / scale)
         assert np.abs(H - H.T).max() == 0.0
@@ -76,8 +77,9 @@ def test_linearize_and_error_match_oracle(orc, c1_f32, gpu_c1, name, kind, robus
             assert abs(pb.error(st.factor, Tq) - orc.error(otc, osc, os_, Tq, f)) <= rel * abs(eo)
         ti, m6 = pb.factors()
         oti, om = f.get()
-        agree = (ti == oti).mean()
-        assert agree >= (0.999 if mode == "fp32" else 1.0), agree
+        differing = int((ti != oti).sum())
+        print("C1 %s %s%s pose %d: inlier delta %d, correspondences differing %d of %d" % (name, mode, "/" + robust if robust else "", [np.array_equal(T, P) for P in POSES].index(True), int(n) - int(no), differing, len(ti)))
+        assert differing <= (C1_DIFFERING_FP32 if mode == "fp32" else 0), differing
         if name == "GICP" and mode == "fp32":
             same = ti == oti
             om6 = np.stack([om[:, 0, 0], om[:, 0, 1], om[:, 0, 2], om[:, 1, 1], om[:, 1, 2], om[:, 2, 2]], axis=1)
