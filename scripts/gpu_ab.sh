@@ -7,7 +7,7 @@ if [ "${SKIP_TESTS:-0}" != "1" ]; then timeout -s KILL 900 python -m pytest test
 i=0
 for cfg in "$@"; do
   i=$((i+1))
-  env $cfg timeout -s KILL 300 python bench.py --steps ${STEPS:-200} --warmup 20 --no-cpu-baseline --sustain-s 0 --no-fp64 --no-vgicp --odom-frames 0 > gpurun_out/ab_$i.json 2> gpurun_out/ab_$i.err
+  env $cfg timeout -s KILL 300 python bench.py --steps ${STEPS:-200} --warmup 20 --no-cpu-baseline --sustain-s 0 --no-fp64 --no-concurrent --no-vgicp --odom-frames 0 > gpurun_out/ab_$i.json 2> gpurun_out/ab_$i.err
   tail -c 300 gpurun_out/ab_$i.err
   python - "$cfg" gpurun_out/ab_$i.json <<'PY'
 import json, sys

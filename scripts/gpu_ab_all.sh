@@ -4,7 +4,7 @@ mkdir -p gpurun_out
 i=0
 for cfg in "$@"; do
   i=$((i+1))
-  env $cfg timeout -s KILL 400 python bench.py --steps ${STEPS:-200} --warmup 20 --no-cpu-baseline --sustain-s 0 --no-fp64 --no-vgicp --no-policy --no-traffic --no-preprocess --no-scaled --odom-frames ${ODOM:-40} > gpurun_out/aba_$i.json 2> gpurun_out/aba_$i.err
+  env $cfg timeout -s KILL 400 python bench.py --steps ${STEPS:-200} --warmup 20 --no-cpu-baseline --sustain-s 0 --no-fp64 --no-concurrent --no-vgicp --no-policy --no-traffic --no-preprocess --no-scaled --odom-frames ${ODOM:-40} > gpurun_out/aba_$i.json 2> gpurun_out/aba_$i.err
   tail -c 300 gpurun_out/aba_$i.err
   python - "$cfg" gpurun_out/aba_$i.json <<'PY'
 import json, sys

@@ -12,9 +12,9 @@ ROOT=$PWD
 OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps $STEPS --warmup 10 --no-cpu-baseline --odom-frames 0 --no-vgicp --no-plane --no-traffic --no-fp64 --sustain-s 0"
+BENCH="python $ROOT/bench.py --steps $STEPS --warmup 10 --no-cpu-baseline --odom-frames 0 --no-vgicp --no-plane --no-traffic --no-fp64 --no-concurrent --sustain-s 0"
 # the C4 (VGICP) and C2 (point-to-plane) legs of the bench on their own trace: their kernels' stats go to <tag>_c4_c2_kernel_stats.csv
-BENCH_C4C2="python $ROOT/bench.py --steps 20 --warmup 10 --no-cpu-baseline --odom-frames 0 --no-traffic --no-fp64 --sustain-s 0"
+BENCH_C4C2="python $ROOT/bench.py --steps 20 --warmup 10 --no-cpu-baseline --odom-frames 0 --no-traffic --no-fp64 --no-concurrent --sustain-s 0"
 timeout -s KILL 150 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- $BENCH > "$OUT/bench_trace.log" 2>&1
 timeout -s KILL 150 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o pmc -- $BENCH > "$OUT/bench_pmc_fetch.log" 2>&1
 timeout -s KILL 150 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o pmc -- $BENCH > "$OUT/bench_pmc_write.log" 2>&1
