@@ -187,6 +187,9 @@ def load():
     # loaded first so that exactly one HIP runtime is mapped.
     if "torch" in sys.modules or os.environ.get("SGA_WITH_TORCH", "0") == "1":
         import torch  # noqa: F401
+    # contexts are streams, and streams that share a hardware queue serialise (csrc/context.hip: 4 queues per device unless asked otherwise;
+    # read once, when the HIP runtime initialises — so before anything of it runs)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     for name, restype, argtypes in SYMBOLS:
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol

@@ -3,6 +3,7 @@
 #include "notes.hpp"
 
 #include <atomic>
+#include <cstdlib>
 #include <chrono>
 #include <cmath>
 #include <thread>
@@ -12,6 +13,17 @@
 
 #include <map>
 #include <mutex>
+
+// HIP streams share a small pool of hardware queues (4 per device by default), and two streams that land on one queue run their
+// kernels one after the other.  The library's unit of concurrency is a context = a stream (pipelined preprocessing, several registrations
+// side by side, one context per policy thread): measured in round 6, two side-by-side C3 registrations gave 10 800 iterations/s on
+// distinct queues and 8 600 (nothing) when the runtime had put their streams on one — which depended on how many streams the process had
+// created before.  Unless the user has set it, ask for 8 queues before the HIP runtime initialises (it reads the variable once).
+namespace {
+struct HwQueuesDefault {
+  HwQueuesDefault() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+} g_hw_queues_default;
+}  // namespace
 
 namespace sga {
 void preload_hot_kernels();  // linearize.hip
