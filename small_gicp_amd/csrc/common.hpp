@@ -131,12 +131,6 @@ struct sga_context {
   sga::DevBuf<unsigned long long> vg_status;
   sga::DevBuf<uint32_t> vg_scratch;
   unsigned vg_epoch = 0;
-  // voxel grid of a scan without sorting its points (preprocess.hip: voxelgrid_run_hash): the voxel table (keys, fixed-point sums), the
-  // work arrays of the voxel ranking; every call leaves them as it found them (empty table, zero counters)
-  sga::DevBuf<uint32_t> vh_keys;               // open addressing, EMPTY = ~0u
-  sga::DevBuf<unsigned long long> vh_sums;     // 4 per slot: sum x, y, z (fixed point, relative to the voxel's corner), points
-  sga::DevBuf<uint32_t> vh_work;               // {count, -, -, -} | hist[B] | offs[B + 1] | cursor[B] | list[cap] | bkeys[cap] | slots[cap]
-  size_t vh_cap = 0;
   sga::DevBuf<unsigned long long> d_spacing;  // kd_tail_kernel: {sum of log2(leaf diagonal) in 2^-20 units, leaves counted, arrival counter, 0}; zero between launches
   sga::DevBuf<int> d_box;         // bounding-box accumulator of box_reduce_publish: identity values + arrival counter between launches
   int* h_scratch = nullptr;       // 16 pinned ints behind h_accum: small asynchronous read-backs (bounding boxes)

@@ -482,252 +482,6 @@ void sga_set_knn_wave_max(long long max_points) { g_knn_wave_max = max_points; }
 
 namespace {
 // bits needed for the values 0 .. range - 1
-// ---- voxel grid of a scan WITHOUT sorting its points (round 6) ------------------------------------------------------------------------
-// The sort of a LiDAR scan's 115k (key, index) pairs is 50 us in ten launches of the library's merge sort whatever its configuration
-// (scripts/ubench/sort_small.hip) — more than half of the voxel-grid stage — and what the stage needs is less than a sorted cloud: the
-// occupied voxels in ascending key order and the mean of each one's points.
-//   * vg_insert_kernel: a workgroup takes 512 consecutive points.  Consecutive points of a scan are neighbours (a ring of the sensor):
-//     512 of them fall into ~90 voxels, so they are first combined in an LDS table (LDS atomics), and every distinct voxel of the
-//     workgroup then goes into the context's global table with one compare-and-swap and four 64-bit adds.  SUMS ARE INTEGERS: a point
-//     contributes llrint((p - anchor of its voxel) * 2^k) per axis (anchor = the voxel's corner rounded down to a multiple of 2^-10 m, so
-//     that the difference is exact; k: the sum of 2^18 such terms stays below 2^62), so the total does not depend on the order of the
-//     additions — bit-reproducible whatever the atomics do — and exact for every coordinate of magnitude >= 2^-20 m.  The first workgroup
-//     to meet a voxel appends (key, table slot) to a list and counts the voxel in a histogram of the key's top 13 bits.
-//   * vg_scan_kernel (one workgroup): prefix sums of the histogram = where each bucket's voxels start in ascending key order; the number
-//     of voxels goes to the host as a note.
-//   * vg_scatter_kernel: (key, slot) pairs into their buckets (atomic cursors: arbitrary order inside a bucket).
-//   * vg_finalize_kernel: a voxel's rank = start of its bucket + the number of smaller keys in the bucket (a bucket is a few rows of the
-//     grid); mean = anchor + sum / (2^k * points), written at the rank — ascending key order like downsampling.hpp:52-75 — and the table
-//     slot is emptied for the next call.
-// Four launches instead of thirteen.  Used for clouds with a known box whose keys fit 31 bits and with at most kVgHashMaxPoints points
-// (SGA_VG_HASH=0: the sort-based path always).  Against the sort-based path the centroids agree to the last bit except where the exact
-// mean is a rounding tie of the fp32 record and one of the few inexact steps left (the division by a count that is no power of two)
-// falls the other way: one fp32 ulp, a handful of voxels per scan.
-constexpr uint32_t kVgEmpty = 0xffffffffu;
-constexpr int kVgBucketBits = 13;
-constexpr size_t kVgHashMaxPoints = 262144;
-constexpr int kVgTile = 512, kVgThreads = 256, kVgLocal = 1024;
-
-struct VgFrame {
-  VoxelKeyLayout L;
-  double inv_leaf, leaf, ox, oy, oz, scale, inv_scale;  // scale = 2^k of the fixed-point sums
-  uint32_t mask;   // global table slots - 1
-  int shift;       // bucket = key >> shift
-};
-
-__device__ __forceinline__ uint32_t vg_hash(uint32_t key) { return (key * 2654435761u) ^ (key >> 15); }
-// the corner of voxel coordinate c (without the 2^20 offset) rounded down to a multiple of 2^-10: p - anchor is then exact in double
-__device__ __forceinline__ double vg_anchor(int c, double leaf) { return floor(static_cast<double>(c) * leaf * 1024.0) * (1.0 / 1024.0); }
-
-// the voxel key of a point exactly as downsample_keys_kernel forms it (kVgEmpty: the point is dropped) + the voxel coordinates (+ 2^20)
-__device__ __forceinline__ uint32_t vg_point_key(const float4 p, const VgFrame& f, int& cx, int& cy, int& cz) {
-  cx = fast_floor_dd((static_cast<double>(p.x) + f.ox) * f.inv_leaf) + (1 << 20);
-  cy = fast_floor_dd((static_cast<double>(p.y) + f.oy) * f.inv_leaf) + (1 << 20);
-  cz = fast_floor_dd((static_cast<double>(p.z) + f.oz) * f.inv_leaf) + (1 << 20);
-  const int mask = (1 << 21) - 1;
-  bool bad = cx < 0 || cy < 0 || cz < 0 || cx > mask || cy > mask || cz > mask;
-  bad = bad || !(fabsf(p.x) <= 3.4028234e38f) || !(fabsf(p.y) <= 3.4028234e38f) || !(fabsf(p.z) <= 3.4028234e38f);
-  const unsigned ux = static_cast<unsigned>(cx - f.L.cmin[0]), uy = static_cast<unsigned>(cy - f.L.cmin[1]), uz = static_cast<unsigned>(cz - f.L.cmin[2]);
-  bad = bad || (ux >> f.L.bits[0]) != 0u || (uy >> f.L.bits[1]) != 0u || (uz >> f.L.bits[2]) != 0u;
-  return bad ? kVgEmpty : (ux | (uy << f.L.bits[0]) | (uz << (f.L.bits[0] + f.L.bits[1])));
-}
-
-__global__ __launch_bounds__(kVgThreads) void vg_insert_kernel(const float4* __restrict__ pts, uint32_t n, VgFrame f, uint32_t* __restrict__ tkeys, unsigned long long* __restrict__ tsums, uint32_t* __restrict__ count,
-                                                               uint32_t* __restrict__ hist, uint32_t* __restrict__ list, uint32_t* __restrict__ lslot) {
-  __shared__ uint32_t lkeys[kVgLocal];
-  __shared__ unsigned long long lsums[kVgLocal][4];
-  for (int s = threadIdx.x; s < kVgLocal; s += kVgThreads) {
-    lkeys[s] = kVgEmpty;
-    lsums[s][0] = lsums[s][1] = lsums[s][2] = lsums[s][3] = 0ull;
-  }
-  __syncthreads();
-  const uint32_t base = blockIdx.x * static_cast<uint32_t>(kVgTile);
-#pragma unroll
-  for (int j = 0; j < kVgTile / kVgThreads; j++) {
-    const uint32_t i = base + j * kVgThreads + threadIdx.x;
-    if (i < n) {
-      const float4 p = pts[i];
-      int cx, cy, cz;
-      const uint32_t key = vg_point_key(p, f, cx, cy, cz);
-      if (key != kVgEmpty) {
-        // the point relative to the anchor of its voxel, in the caller's frame, as integers
-        const double rx = (static_cast<double>(p.x) + f.ox) - vg_anchor(cx - (1 << 20), f.leaf);
-        const double ry = (static_cast<double>(p.y) + f.oy) - vg_anchor(cy - (1 << 20), f.leaf);
-        const double rz = (static_cast<double>(p.z) + f.oz) - vg_anchor(cz - (1 << 20), f.leaf);
-        const long long qx = __double2ll_rn(rx * f.scale), qy = __double2ll_rn(ry * f.scale), qz = __double2ll_rn(rz * f.scale);
-        uint32_t s = vg_hash(key) & (kVgLocal - 1);
-        for (;;) {  // at most 512 keys in 1024 slots: always ends
-          const uint32_t old = atomicCAS(&lkeys[s], kVgEmpty, key);
-          if (old == kVgEmpty || old == key) break;
-          s = (s + 1) & (kVgLocal - 1);
-        }
-        atomicAdd(&lsums[s][0], static_cast<unsigned long long>(qx));
-        atomicAdd(&lsums[s][1], static_cast<unsigned long long>(qy));
-        atomicAdd(&lsums[s][2], static_cast<unsigned long long>(qz));
-        atomicAdd(&lsums[s][3], 1ull);
-      }
-    }
-  }
-  __syncthreads();
-  for (int s = threadIdx.x; s < kVgLocal; s += kVgThreads) {
-    const uint32_t key = lkeys[s];
-    if (key == kVgEmpty) continue;
-    uint32_t g = vg_hash(key) & f.mask;
-    for (;;) {  // the table has at least twice as many slots as the cloud has points
-      const uint32_t old = atomicCAS(&tkeys[g], kVgEmpty, key);
-      if (old == kVgEmpty) {  // this workgroup met the voxel first
-        const uint32_t at = atomicAdd(count, 1u);
-        list[at] = key;
-        lslot[at] = g;
-        atomicAdd(&hist[key >> f.shift], 1u);
-        break;
-      }
-      if (old == key) break;
-      g = (g + 1) & f.mask;
-    }
-    atomicAdd(&tsums[4ull * g + 0], lsums[s][0]);
-    atomicAdd(&tsums[4ull * g + 1], lsums[s][1]);
-    atomicAdd(&tsums[4ull * g + 2], lsums[s][2]);
-    atomicAdd(&tsums[4ull * g + 3], lsums[s][3]);
-  }
-}
-
-// offs[b] = number of voxels in buckets < b (offs[B] = all of them), cursor = offs, hist back to zero; the count goes to the host
-__global__ __launch_bounds__(1024) void vg_scan_kernel(uint32_t* __restrict__ hist, uint32_t* __restrict__ offs, uint32_t* __restrict__ cursor, const uint32_t* __restrict__ count, unsigned long long* __restrict__ note_slot,
-                                                       unsigned long long seq) {
-  constexpr int B = 1 << kVgBucketBits, PER = B / 1024;
-  static_assert(PER == 8, "two uint4 per thread");
-  __shared__ uint32_t sh_wave[16];
-  uint4* h4 = reinterpret_cast<uint4*>(hist) + 2 * threadIdx.x;
-  const uint4 a = h4[0], c = h4[1];
-  const uint32_t v[PER] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
-  uint32_t sum = 0;
-#pragma unroll
-  for (int k = 0; k < PER; k++) sum += v[k];
-  // exclusive prefix of the per-thread sums over the workgroup: wave scan, wave totals through LDS
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t inc = sum;
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t t = __shfl_up(inc, off);
-    if (lane >= off) inc += t;
-  }
-  if (lane == 63) sh_wave[wave] = inc;
-  __syncthreads();
-  uint32_t run = inc - sum;
-  for (int w = 0; w < 16; w++) run += w < wave ? sh_wave[w] : 0u;
-  uint32_t o[PER];
-#pragma unroll
-  for (int k = 0; k < PER; k++) {
-    o[k] = run;
-    run += v[k];
-  }
-  uint4* o4 = reinterpret_cast<uint4*>(offs) + 2 * threadIdx.x;
-  uint4* c4 = reinterpret_cast<uint4*>(cursor) + 2 * threadIdx.x;
-  o4[0] = c4[0] = make_uint4(o[0], o[1], o[2], o[3]);
-  o4[1] = c4[1] = make_uint4(o[4], o[5], o[6], o[7]);
-  h4[0] = h4[1] = make_uint4(0u, 0u, 0u, 0u);
-  if (threadIdx.x == 1023) offs[B] = run;
-  if (threadIdx.x == 0) {
-    note_slot[1] = *count;
-    note_publish(note_slot, seq);
-  }
-}
-
-__global__ void vg_scatter_kernel(const uint32_t* __restrict__ list, const uint32_t* __restrict__ lslot, const uint32_t* __restrict__ count, int shift, uint32_t* __restrict__ cursor, uint32_t* __restrict__ bkeys,
-                                  uint32_t* __restrict__ bslot) {
-  const uint32_t c = *count;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < c; i += gridDim.x * blockDim.x) {
-    const uint32_t key = list[i];
-    const uint32_t at = atomicAdd(&cursor[key >> shift], 1u);
-    bkeys[at] = key;
-    bslot[at] = lslot[i];
-  }
-}
-
-__global__ void vg_finalize_kernel(const uint32_t* __restrict__ bkeys, const uint32_t* __restrict__ bslot, uint32_t* __restrict__ count, const uint32_t* __restrict__ offs, VgFrame f, uint32_t* __restrict__ tkeys,
-                                   unsigned long long* __restrict__ tsums, float4* __restrict__ out) {
-  const uint32_t c = *count;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < c; i += gridDim.x * blockDim.x) {
-    const uint32_t key = bkeys[i];
-    const uint32_t b = key >> f.shift;
-    uint32_t rank = offs[b];
-    for (uint32_t j = offs[b], e = offs[b + 1]; j < e; j++) rank += bkeys[j] < key ? 1u : 0u;
-    const uint32_t g = bslot[i];
-    const long long sx = static_cast<long long>(tsums[4ull * g + 0]), sy = static_cast<long long>(tsums[4ull * g + 1]), sz = static_cast<long long>(tsums[4ull * g + 2]);
-    const double cnt = static_cast<double>(tsums[4ull * g + 3]);
-    tkeys[g] = kVgEmpty;  // (nobody probes the table any more: the slot travelled with the key)
-    tsums[4ull * g + 0] = tsums[4ull * g + 1] = tsums[4ull * g + 2] = tsums[4ull * g + 3] = 0ull;
-    const uint32_t ux = key & ((1u << f.L.bits[0]) - 1u), uy = (key >> f.L.bits[0]) & ((1u << f.L.bits[1]) - 1u), uz = key >> (f.L.bits[0] + f.L.bits[1]);
-    const double ax = vg_anchor(static_cast<int>(ux) + f.L.cmin[0] - (1 << 20), f.leaf), ay = vg_anchor(static_cast<int>(uy) + f.L.cmin[1] - (1 << 20), f.leaf),
-                 az = vg_anchor(static_cast<int>(uz) + f.L.cmin[2] - (1 << 20), f.leaf);
-    // mean in the caller's frame = anchor + sum / (2^k * points); the record is relative to the device frame's origin
-    out[rank] = make_float4(static_cast<float>((ax + static_cast<double>(sx) * f.inv_scale / cnt) - f.ox), static_cast<float>((ay + static_cast<double>(sy) * f.inv_scale / cnt) - f.oy),
-                            static_cast<float>((az + static_cast<double>(sz) * f.inv_scale / cnt) - f.oz), __uint_as_float(rank));
-  }
-  // the voxel counter goes back to zero, by the last workgroup to arrive (count[1] counts arrivals): every thread of a workgroup has read
-  // `c` before its thread 0 passes the barrier and reports the workgroup's arrival
-  __shared__ bool last;
-  __syncthreads();
-  if (threadIdx.x == 0) last = atomicAdd(count + 1, 1u) == gridDim.x - 1;
-  __syncthreads();
-  if (last && threadIdx.x == 0) {
-    count[0] = 0u;
-    count[1] = 0u;
-  }
-}
-
-int voxelgrid_run_hash(sga_context* ctx, const sga_cloud* in, double leaf, const VoxelKeyLayout& L, sga_cloud* res) {
-  const size_t n = in->n;
-  const uint32_t n32 = static_cast<uint32_t>(n);
-  constexpr size_t B = 1u << kVgBucketBits;
-  size_t slots_needed = 1u << 16;
-  while (slots_needed < 2 * n) slots_needed <<= 1;
-  if (ctx->vh_keys.n < slots_needed) {  // grow-only; a fresh table is empty
-    SGA_TRY(ctx->vh_keys.alloc(slots_needed));
-    SGA_TRY(ctx->vh_sums.alloc(4 * slots_needed));
-    SGA_HIP(hipMemsetAsync(ctx->vh_keys.p, 0xff, slots_needed * sizeof(uint32_t), ctx->stream));
-    SGA_HIP(hipMemsetAsync(ctx->vh_sums.p, 0, 4 * slots_needed * sizeof(unsigned long long), ctx->stream));
-  }
-  if (ctx->vh_cap < n || ctx->vh_work.n == 0) {
-    const size_t cap = std::max<size_t>(n + n / 4, 65536);
-    SGA_TRY(ctx->vh_work.alloc(4 + B + (B + 4) + B + 4 * cap));
-    SGA_HIP(hipMemsetAsync(ctx->vh_work.p, 0, (4 + B) * sizeof(uint32_t), ctx->stream));  // the counters and the histogram; the rest is written before it is read
-    ctx->vh_cap = cap;
-  }
-  uint32_t* count = ctx->vh_work.p;
-  uint32_t* hist = count + 4;
-  uint32_t* offs = hist + B;
-  uint32_t* cursor = offs + B + 4;
-  uint32_t* list = cursor + B;
-  uint32_t* lslot = list + ctx->vh_cap;
-  uint32_t* bkeys = lslot + ctx->vh_cap;
-  uint32_t* bslot = bkeys + ctx->vh_cap;
-  VgFrame f;
-  f.L = L;
-  f.leaf = leaf;
-  f.inv_leaf = 1.0 / leaf;
-  f.ox = in->origin[0], f.oy = in->origin[1], f.oz = in->origin[2];
-  int e = -40;
-  while (std::ldexp(1.0, e) < leaf * 1.001 + 1.0 / 512.0) e++;  // 2^e > |p - anchor| (the anchor lies up to 2^-10 below the corner; the floor of p / leaf may be off by a rounding)
-  f.scale = std::ldexp(1.0, 43 - e);                            // |term| < 2^43: 2^18 terms stay below 2^62
-  f.inv_scale = 1.0 / f.scale;
-  f.mask = static_cast<uint32_t>(ctx->vh_keys.n - 1);  // (the whole table: it is empty between calls whatever size earlier calls used)
-  f.shift = L.total > kVgBucketBits ? L.total - kVgBucketBits : 0;
-  SGA_TRY(res->pts.alloc(n));
-  unsigned long long* slot = nullptr;
-  const unsigned long long seq = note_begin(ctx, &slot);
-  const dim3 few(static_cast<unsigned>(std::min<size_t>((n + 255) / 256, 96))), block(256);
-  hipLaunchKernelGGL(vg_insert_kernel, dim3((n + kVgTile - 1) / kVgTile), dim3(kVgThreads), 0, ctx->stream, in->pts.p, n32, f, ctx->vh_keys.p, ctx->vh_sums.p, count, hist, list, lslot);
-  hipLaunchKernelGGL(vg_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, hist, offs, cursor, count, slot, seq);
-  hipLaunchKernelGGL(vg_scatter_kernel, few, block, 0, ctx->stream, list, lslot, count, f.shift, cursor, bkeys, bslot);
-  hipLaunchKernelGGL(vg_finalize_kernel, few, block, 0, ctx->stream, bkeys, bslot, count, offs, f, ctx->vh_keys.p, ctx->vh_sums.p, res->pts.p);
-  SGA_HIP(hipGetLastError());
-  unsigned long long payload[kNoteWords - 1];
-  SGA_TRY(note_wait(ctx, seq, payload));
-  res->n = static_cast<size_t>(payload[0]);
-  return SGA_OK;
-}
-
 int bits_for(long long range) {
   int b = 0;
   while ((1ll << b) < range) b++;
@@ -830,11 +584,7 @@ int sga_voxelgrid_sampling(sga_context* ctx, const sga_cloud* in, double leaf, s
       }
     }
   }
-  static const bool vg_hash = !(getenv("SGA_VG_HASH") && atoi(getenv("SGA_VG_HASH")) == 0);
-  if (vg_hash && in->has_box && L.total <= 31 && n <= kVgHashMaxPoints && n >= 4096)
-    SGA_TRY(voxelgrid_run_hash(ctx, in, leaf, L, res.get()));
-  else
-    SGA_TRY(L.total <= 31 ? voxelgrid_run<uint32_t>(ctx, in, leaf, L, res.get()) : voxelgrid_run<unsigned long long>(ctx, in, leaf, L, res.get()));
+  SGA_TRY(L.total <= 31 ? voxelgrid_run<uint32_t>(ctx, in, leaf, L, res.get()) : voxelgrid_run<unsigned long long>(ctx, in, leaf, L, res.get()));
   if (!ctx->stream_ordered) SGA_HIP(hipStreamSynchronize(ctx->stream));
   SGA_TRY(mark_ready(ctx, res->ready));
   *out = res.release();
