@@ -951,20 +951,44 @@ def odometry_leg(sga, args, shard):
             out["scans_in_pinned_host_memory"] = {"error": repr(ex)}
         try:
             best = None
-            for workers in (1, 2):  # preprocessing streams beside the registration stream; each run on contexts of its own, released before the next
+            # the stages of the reference's flow graph (odometry_benchmark_small_gicp_tbb_flow.cpp:55-141) on HIP streams: preprocessing workers
+            # beside registration workers (pairs are registered from the identity: independent); each run on contexts of its own, released before the next
+            for workers, reg_workers in ((1, 1), (2, 1), (2, 2)):
                 gc.collect()
-                pr = odometry.run_synthetic_pipelined(max(args.odom_frames, 36), workers=workers)
+                pr = odometry.run_synthetic_pipelined(max(args.odom_frames, 36), workers=workers, reg_workers=reg_workers)
                 same = all(np.array_equal(a, b) for a, b in zip(pr["estimated"], r["estimated"]))
-                out.setdefault("pipelined_by_workers", {})[str(workers)] = {"ms_per_scan": pr["ms_per_scan"], "poses_identical": bool(same)}
+                out.setdefault("pipelined_by_workers", {})["%dx%d" % (workers, reg_workers)] = {"ms_per_scan": pr["ms_per_scan"], "poses_identical": bool(same)}
                 if best is None or pr["ms_per_scan"] < best[0]:
-                    best = (pr["ms_per_scan"], same, workers)
+                    best = (pr["ms_per_scan"], same, "%d preprocessing x %d registration (Python threads)" % (workers, reg_workers))
                 del pr
-            out["pipelined_total_ms_per_scan"] = best[0]  # throughput with the frames' preprocessing chains running beside the registrations (HIP streams)
+            out["pipelined_total_ms_per_scan"] = best[0]  # throughput with the frames' chains running side by side (HIP streams)
             out["pipelined_poses_identical"] = bool(best[1])
             out["pipelined_workers"] = best[2]
         except Exception as ex:  # noqa: BLE001
             out["pipelined_error"] = repr(ex)
         gc.collect()
+        try:  # the same flow as a C++ program (examples/odometry_benchmark_flow.cpp: std::thread workers, no interpreter between the calls)
+            import tempfile, shutil
+
+            work = tempfile.mkdtemp(prefix="sga_flow_")
+            try:
+                fl = {}
+                for pw, rw in ((2, 1), (2, 2)):
+                    fr = odometry.run_synthetic_cpp_flow(max(args.odom_frames, 36), workdir=work, preprocess_workers=pw, registration_workers=rw, repeat=4)
+                    nf = min(len(fr["estimated"]), len(r["estimated"]))
+                    fl["%dx%d" % (pw, rw)] = {"ms_per_scan": fr["ms_per_scan"], "runs_ms_per_scan": fr["runs_ms_per_scan"], "frame_latency_ms": fr["frame_latency_ms"], "mean_iterations": fr["mean_iterations"],
+                                              "max_abs_pose_difference_vs_python_driver": float(max(np.abs(a - b).max() for a, b in zip(fr["estimated"][:nf], r["estimated"][:nf])))}
+                bestk = min(fl, key=lambda k: fl[k]["ms_per_scan"])
+                out["flow_cpp_driver"] = {"total_ms_per_scan": fl[bestk]["ms_per_scan"], "workers": bestk + " (preprocessing x registration)", "by_workers": fl, "driver": fr["driver"],
+                                          "protocol": "src/benchmark/odometry_benchmark_small_gicp_tbb_flow.cpp:50-141 (total throughput = elapsed / frames, :113-114); trajectory written with 6 decimals"}
+                if "pipelined_total_ms_per_scan" not in out or fl[bestk]["ms_per_scan"] < out["pipelined_total_ms_per_scan"]:
+                    out["pipelined_total_ms_per_scan"] = fl[bestk]["ms_per_scan"]
+                    out["pipelined_workers"] = bestk + " (C++ flow driver)"
+                    out["pipelined_poses_identical"] = bool(fl[bestk]["max_abs_pose_difference_vs_python_driver"] < 1e-6)  # the text trajectory carries 6 decimals
+            finally:
+                shutil.rmtree(work, ignore_errors=True)
+        except Exception as ex:  # noqa: BLE001
+            out["flow_cpp_driver"] = {"error": repr(ex)}
         out["protocol"] = "src/benchmark/odometry_benchmark_small_gicp_omp.cpp:16-49: registration = index build + covariances + align; total adds the 0.25 m voxel grid"
         try:  # the same scans through the C++ driver (examples/odometry_benchmark.cpp): the reference's benchmark is a C++ program too
             cr = odometry.run_synthetic_cpp(args.odom_frames)

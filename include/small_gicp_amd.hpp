@@ -111,6 +111,10 @@ struct PointCloud {
   /// xyz n*3 floats [+ normals n*3] [+ cov6 n*6 (xx,xy,xz,yy,yz,zz)]
   PointCloud(const float* xyz, const float* normals, const float* cov6, size_t n, int device = 0) : ctx(default_context(device)) { check(sga_cloud_create_f32(ctx, xyz, normals, cov6, n, &h), "sga_cloud_create_f32"); }
   explicit PointCloud(sga_cloud* handle, int device = 0) : ctx(default_context(device)), h(handle) {}
+  /// On a context of the caller's (sga_context_create: its own HIP stream) instead of the device's default one — the stages of a
+  /// pipeline that run side by side take one each (examples/odometry_benchmark_flow.cpp).
+  PointCloud(const float* xyz, const float* normals, const float* cov6, size_t n, sga_context* context) : ctx(context) { check(sga_cloud_create_f32(ctx, xyz, normals, cov6, n, &h), "sga_cloud_create_f32"); }
+  PointCloud(sga_cloud* handle, sga_context* context) : ctx(context), h(handle) {}
   PointCloud(const PointCloud&) = delete;
   PointCloud& operator=(const PointCloud&) = delete;
   ~PointCloud() { sga_cloud_destroy(h); }
@@ -297,7 +301,7 @@ struct IncrementalVoxelMap<FlatContainerCov> {
 inline PointCloud::Ptr voxelgrid_sampling(const PointCloud& points, double leaf_size) {
   sga_cloud* out = nullptr;
   check(sga_voxelgrid_sampling(points.ctx, points.h, leaf_size, &out), "sga_voxelgrid_sampling");
-  return std::make_shared<PointCloud>(out);
+  return std::make_shared<PointCloud>(out, points.ctx);
 }
 inline void estimate_normals(PointCloud& cloud, int num_neighbors = 20) {
   check(sga_estimate_normals_covariances(cloud.ctx, cloud.h, nullptr, num_neighbors, 1), "estimate_normals");
@@ -425,6 +429,7 @@ struct GaussNewtonOptimizer {
 struct ParallelReductionHIP {
   int device = 0;
   int math_mode = SGA_MATH_FP32;
+  sga_context* context = nullptr;  // the context (HIP stream) the passes run on; null: the source's.  Registrations on different contexts run side by side
 };
 
 /// registration/registration_result.hpp:11-30
@@ -483,7 +488,7 @@ struct Registration {
   RegistrationResult align(const PointCloud& target, const KdTree& source_tree, const KdTree& target_tree, const Isometry3d& init_T = Isometry3d::Identity()) const {
     (void)target;
     static_assert(std::is_same<Reduction, ParallelReductionHIP>::value, "this library provides the ParallelReductionHIP reduction only");
-    sga_context* ctx = source_tree.points->ctx;
+    sga_context* ctx = reduction.context ? reduction.context : source_tree.points->ctx;
     const sga_registration_setting s = make_setting();
     sga_problem* pb = nullptr;
     check(sga_problem_create_from_index(ctx, target_tree.h, source_tree.h, init_T.data(), &pb), "sga_problem_create_from_index");
@@ -517,7 +522,7 @@ private:
     static_assert(std::is_same<Reduction, ParallelReductionHIP>::value, "this library provides the ParallelReductionHIP reduction only");
     const sga_registration_setting s = make_setting();
     sga_result r;
-    check(sga_align(source.ctx, index, source.h, init_T.data(), &s, &r), "sga_align");
+    check(sga_align(reduction.context ? reduction.context : source.ctx, index, source.h, init_T.data(), &s, &r), "sga_align");
     return to_result(r);
   }
 };

@@ -8,6 +8,7 @@
 
 Everything runs on the GPU through the C-ABI; only the raw scan crosses PCIe.
 """
+import os
 import time
 
 import numpy as np
@@ -148,22 +149,27 @@ def run_synthetic_model(num_frames=20, **kw):
 
 
 class PipelinedOdometry:
-    """The same scan-to-scan odometry with the stages of a frame spread over HIP streams (one context each): `workers` threads
-    preprocess the frames i, i + workers, ... (upload, voxel grid, index build, covariances) while the caller's thread registers
-    frame i against frame i-1 in order — the HIP-stream analogue of the reference's TBB flow graph
-    (src/benchmark/odometry_benchmark_small_gicp_tbb_flow.cpp:55-141).  A frame is a chain of ~100 dependent launches that leaves
-    the GPU mostly idle, so several chains interleave almost for free.  Poses are identical to OnlineOdometry's (same kernels,
-    same order of operations per frame)."""
+    """The same scan-to-scan odometry as a flow of stages over HIP streams (one context each) — the HIP-stream analogue of the reference's
+    TBB flow graph (src/benchmark/odometry_benchmark_small_gicp_tbb_flow.cpp:55-141):
 
-    def __init__(self, downsampling_resolution=0.25, num_neighbors=20, max_correspondence_distance=1.0, device=0, workers=3, depth=6):
+      preprocess_node   (`workers` threads, frames i, i + workers, ...: upload, voxel grid, index build, covariances; :61-67)
+      pairing_node      (frame i-1 is the target of frame i; :73-78)
+      registration_node (`reg_workers` threads: pair i is registered from the identity whatever pair i-1 gave, so the pairs are independent
+                         and the reference runs this node with unlimited concurrency too; :81-97)
+      output_node       (the relative poses multiplied up in frame order; :103-110)
+
+    A frame is a chain of ~30 dependent launches that leaves the GPU mostly idle, so several chains interleave almost for free.  Poses
+    are identical to OnlineOdometry's (same kernels, same order of operations per frame and per pair; the products in frame order)."""
+
+    def __init__(self, downsampling_resolution=0.25, num_neighbors=20, max_correspondence_distance=1.0, device=0, workers=3, depth=None, reg_workers=1):
         self.res = downsampling_resolution
         self.k = num_neighbors
         self.setting = api.make_setting("GICP", max_correspondence_distance=max_correspondence_distance)
         self.ctx_pre = [api.Context(device) for _ in range(max(1, workers))]
         for c in self.ctx_pre:  # a frame's chain is enqueued without host waits; whoever consumes its cloud / index waits for their events (common.hpp: Ready)
             c.set_stream_ordered(True)
-        self.ctx_reg = api.Context(device)
-        self.depth = max(depth, len(self.ctx_pre))
+        self.ctx_reg = [api.Context(device) for _ in range(max(1, reg_workers))]
+        self.depth = max(depth or 6, len(self.ctx_pre) + len(self.ctx_reg) + 1)
 
     def _preprocess(self, points, ctx):
         raw = api.PointCloud(points, ctx=ctx)
@@ -178,15 +184,23 @@ class PipelinedOdometry:
 
         scans = list(scans)
         n = len(scans)
-        ready = {}
+        P, R = len(self.ctx_pre), len(self.ctx_reg)
+        ready = {}  # frame -> (cloud, tree), until both of its pairs are registered
+        rel = {}    # frame -> (T_(frame-1) frame, iterations)
         cv = threading.Condition()
-        state = {"consumed": 0, "error": None}
+        state = {"next_pair": 1, "error": None}  # every pair below next_pair is registered (the producers run at most `depth` frames ahead of it)
+
+        def fail(ex):
+            with cv:
+                if state["error"] is None:
+                    state["error"] = ex
+                cv.notify_all()
 
         def producer(w):
             try:
-                for i in range(w, n, len(self.ctx_pre)):
+                for i in range(w, n, P):
                     with cv:
-                        cv.wait_for(lambda: i < state["consumed"] + self.depth or state["error"] is not None)
+                        cv.wait_for(lambda: i < state["next_pair"] + self.depth or state["error"] is not None)
                         if state["error"] is not None:
                             return
                     item = self._preprocess(scans[i], self.ctx_pre[w])
@@ -194,9 +208,30 @@ class PipelinedOdometry:
                         ready[i] = item
                         cv.notify_all()
             except BaseException as ex:  # noqa: BLE001
-                with cv:
-                    state["error"] = ex
-                    cv.notify_all()
+                fail(ex)
+
+        def registrar(r):
+            try:
+                ctx = self.ctx_reg[r]
+                for i in range(1 + r, n, R):
+                    with cv:
+                        cv.wait_for(lambda: (i in ready and i - 1 in ready) or state["error"] is not None)
+                        if state["error"] is not None:
+                            return
+                        tgt, src = ready[i - 1], ready[i]
+                    # the registration runs on its own context / stream, which waits for the events behind the producers' work
+                    res = api.Problem(tgt[1], src[1], np.eye(4), ctx=ctx).align(self.setting, np.eye(4))
+                    del tgt, src
+                    with cv:
+                        rel[i] = (res.T_target_source, res.iterations + 1)
+                        while state["next_pair"] in rel:  # pairs up to here are done: their frames below the last one have served as source and target
+                            ready.pop(state["next_pair"] - 1, None)
+                            state["next_pair"] += 1
+                        if state["next_pair"] == n:
+                            ready.pop(n - 1, None)
+                        cv.notify_all()
+            except BaseException as ex:  # noqa: BLE001
+                fail(ex)
 
         # The threads spend their time inside ctypes calls (GIL released) and need the GIL for microseconds in between; with CPython's default
         # switch interval (5 ms) a thread coming back from a call can wait that long for one that is running bytecode.  SGA_PIPE_SWITCH_S
@@ -207,34 +242,26 @@ class PipelinedOdometry:
         old_switch = sys.getswitchinterval()
         sys.setswitchinterval(float(os.environ.get("SGA_PIPE_SWITCH_S", "2e-5")))
         t0 = time.perf_counter()
-        threads = [threading.Thread(target=producer, args=(w,), daemon=True) for w in range(len(self.ctx_pre))]
+        threads = [threading.Thread(target=producer, args=(w,), daemon=True) for w in range(P)]
+        threads += [threading.Thread(target=registrar, args=(r,), daemon=True) for r in range(R)]
         for th in threads:
             th.start()
-        poses, iters = [], []
-        T_world = np.eye(4)
-        prev = None
-        for i in range(n):
-            with cv:
-                cv.wait_for(lambda: i in ready or state["error"] is not None)
-                if state["error"] is not None:
-                    raise state["error"]
-                cloud, tree = ready.pop(i)
-            if prev is not None:
-                # the registration runs on its own context / stream, which waits for the events behind the producers' work
-                pb = api.Problem(prev[1], tree, np.eye(4), ctx=self.ctx_reg)
-                res = pb.align(self.setting, np.eye(4))
-                T_world = T_world @ res.T_target_source
-                iters.append(res.iterations + 1)
-            poses.append(T_world.copy())
-            prev = (cloud, tree)
-            with cv:
-                state["consumed"] = i + 1
-                cv.notify_all()
         for th in threads:
             th.join()
-        self.ctx_reg.synchronize()
-        wall = time.perf_counter() - t0
         sys.setswitchinterval(old_switch)
+        if state["error"] is not None:
+            raise state["error"]
+        for c in self.ctx_reg:
+            c.synchronize()
+        # output node: the relative poses multiplied up in frame order (the same products as OnlineOdometry's)
+        poses, iters = [], []
+        T_world = np.eye(4)
+        for i in range(n):
+            if i > 0:
+                T_world = T_world @ rel[i][0]
+                iters.append(rel[i][1])
+            poses.append(T_world.copy())
+        wall = time.perf_counter() - t0
         return poses, wall, iters
 
 
@@ -272,11 +299,11 @@ def run_synthetic(num_frames=20, pinned=False, **kw):
         "frames": num_frames,
         "scans_in_pinned_host_memory": bool(pinned),
         "points_per_scan": float(np.mean(sizes)),
-        "registration_ms_per_scan": float(np.mean(odom.reg_ms[skip:])),
-        "total_ms_per_scan": float(np.mean(odom.total_ms[skip:])),
+        "registration_ms_per_scan": float(np.mean(odom.reg_ms[skip:])) if len(odom.reg_ms) > skip else float("nan"),
+        "total_ms_per_scan": float(np.mean(odom.total_ms[skip:])) if len(odom.total_ms) > skip else float("nan"),
         "mean_iterations": float(np.mean(odom.iterations)) if odom.iterations else 0.0,
-        "rpe_trans_m_mean": float(np.mean(rpe_t)),
-        "rpe_rot_rad_mean": float(np.mean(rpe_r)),
+        "rpe_trans_m_mean": float(np.mean(rpe_t)) if rpe_t else 0.0,
+        "rpe_rot_rad_mean": float(np.mean(rpe_r)) if rpe_r else 0.0,
         "estimated": est,
         "ground_truth": gt,
     }
@@ -324,47 +351,95 @@ def run_synthetic_pipelined(num_frames=20, pinned=False, **kw):
     return {"frames": num_frames, "ms_per_scan": 1e3 * wall / num_frames, "estimated": poses, "mean_iterations": float(np.mean(iters)) if iters else 0.0}
 
 
+def _cpp_driver(source, workdir, num_frames):
+    """Write the synthetic sequence as KITTI .bin files under workdir/velodyne (once) and compile examples/<source> against the in-tree
+    library.  Returns (executable, dataset directory)."""
+    import os
+    import subprocess
+
+    from . import _lib, synthetic
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    data = os.path.join(workdir, "velodyne")
+    os.makedirs(data, exist_ok=True)
+    for f in range(num_frames):
+        name = os.path.join(data, "%06d.bin" % f)
+        if os.path.exists(name):
+            continue
+        pts, _ = synthetic.kitti_like_scan(f)
+        v = np.zeros((len(pts), 4), "<f4")
+        v[:, :3] = pts[:, :3]
+        v.tofile(name)
+    exe = os.path.join(workdir, os.path.splitext(source)[0])
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", source), "-o", exe, "-L" + libdir, "-lsmall_gicp_amd",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath-link,/opt/rocm/lib"])
+    return exe, data
+
+
+def _read_trajectory(path):
+    poses = []
+    for ln in open(path):
+        T = np.eye(4)
+        T[:3, :4] = np.array(ln.split(), dtype=np.float64).reshape(3, 4)
+        poses.append(T)
+    return poses
+
+
 def run_synthetic_cpp(num_frames=20, workdir=None, downsampling_resolution=0.25, num_neighbors=20):
     """The same sequence through the C++ driver examples/odometry_benchmark.cpp (the reference's benchmark protocol over
     include/small_gicp_amd.hpp): writes the scans as KITTI .bin files, compiles the driver with g++ against the in-tree library, runs it and
     parses its report and trajectory.  Returns registration / total ms per scan as the driver measured them and the poses."""
-    import os
     import re
     import shutil
     import subprocess
     import tempfile
 
-    from . import _lib, synthetic
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     own = workdir is None
     workdir = workdir or tempfile.mkdtemp(prefix="sga_odom_cpp_")
     try:
-        data = os.path.join(workdir, "velodyne")
-        os.makedirs(data, exist_ok=True)
-        for f in range(num_frames):
-            pts, _ = synthetic.kitti_like_scan(f)
-            v = np.zeros((len(pts), 4), "<f4")
-            v[:, :3] = pts[:, :3]
-            v.tofile(os.path.join(data, "%06d.bin" % f))
-        exe = os.path.join(workdir, "odometry_benchmark")
-        libdir = os.path.dirname(_lib.LIB_PATH)
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "odometry_benchmark.cpp"), "-o", exe, "-L" + libdir, "-lsmall_gicp_amd",
-                               "-Wl,-rpath," + libdir, "-Wl,-rpath-link,/opt/rocm/lib"])
+        exe, data = _cpp_driver("odometry_benchmark.cpp", workdir, num_frames)
         traj = os.path.join(workdir, "traj.txt")
-        p = subprocess.run([exe, data, traj, "--num_neighbors", str(num_neighbors), "--downsampling_resolution", str(downsampling_resolution)], capture_output=True, text=True, timeout=600)
+        p = subprocess.run([exe, data, traj, "--num_neighbors", str(num_neighbors), "--downsampling_resolution", str(downsampling_resolution), "--max_frames", str(num_frames)], capture_output=True, text=True, timeout=600)
         if p.returncode != 0:
             raise RuntimeError("odometry_benchmark failed: " + p.stdout[-1000:] + p.stderr[-1000:])
         m = re.search(r"registration_time_stats=([0-9.eE+-]+) \+- ([0-9.eE+-]+) \[msec/scan\]\s+total_throughput=([0-9.eE+-]+) \+- ([0-9.eE+-]+) \[msec/scan\]\s+mean_iterations=([0-9.eE+-]+)", p.stdout)
         if m is None:
             raise RuntimeError("no report in the driver's output: " + p.stdout[-1000:])
-        poses = []
-        for ln in open(traj):
-            T = np.eye(4)
-            T[:3, :4] = np.array(ln.split(), dtype=np.float64).reshape(3, 4)
-            poses.append(T)
         return {"frames": num_frames, "registration_ms_per_scan": float(m.group(1)), "registration_ms_std": float(m.group(2)), "total_ms_per_scan": float(m.group(3)), "mean_iterations": float(m.group(5)),
-                "estimated": poses, "driver": "examples/odometry_benchmark.cpp (C++ over include/small_gicp_amd.hpp), all scans read into host memory first"}
+                "estimated": _read_trajectory(traj), "driver": "examples/odometry_benchmark.cpp (C++ over include/small_gicp_amd.hpp), all scans read into host memory first"}
+    finally:
+        if own:
+            shutil.rmtree(workdir, ignore_errors=True)
+
+
+def run_synthetic_cpp_flow(num_frames=20, workdir=None, downsampling_resolution=0.25, num_neighbors=20, preprocess_workers=2, registration_workers=2, pinned=False, repeat=3, env=None):
+    """The same sequence through the C++ FLOW driver examples/odometry_benchmark_flow.cpp — the throughput protocol of the reference's TBB
+    flow-graph engine (odometry_benchmark_small_gicp_tbb_flow.cpp:50-141): preprocessing and registration stages on threads with a HIP
+    stream each, pairs registered side by side, poses multiplied up in frame order.  Returns the best total_throughput [ms/scan] of the runs
+    after the first (which carries code-object loads and first allocations), every run's figure and the trajectory of the last run."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+
+    own = workdir is None
+    workdir = workdir or tempfile.mkdtemp(prefix="sga_odom_flow_")
+    try:
+        exe, data = _cpp_driver("odometry_benchmark_flow.cpp", workdir, num_frames)
+        traj = os.path.join(workdir, "traj_flow.txt")
+        cmd = [exe, data, traj, "--num_neighbors", str(num_neighbors), "--downsampling_resolution", str(downsampling_resolution), "--max_frames", str(num_frames), "--preprocess_workers", str(preprocess_workers),
+               "--registration_workers", str(registration_workers), "--repeat", str(max(2, repeat))] + (["--pinned"] if pinned else [])
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, **(env or {})))
+        if p.returncode != 0:
+            raise RuntimeError("odometry_benchmark_flow failed: " + p.stdout[-1000:] + p.stderr[-1000:])
+        runs = [(float(a), float(b), float(c)) for a, b, c in re.findall(r"total_throughput=([0-9.eE+-]+) \[msec/scan\]\s+frame_latency=([0-9.eE+-]+) \[msec\]\s+mean_iterations=([0-9.eE+-]+)", p.stdout)]
+        if len(runs) < 2:
+            raise RuntimeError("no report in the driver's output: " + p.stdout[-1000:])
+        best = min(runs[1:])
+        return {"frames": num_frames, "ms_per_scan": best[0], "frame_latency_ms": best[1], "mean_iterations": best[2], "runs_ms_per_scan": [r[0] for r in runs], "preprocess_workers": preprocess_workers,
+                "registration_workers": registration_workers, "scans_in_pinned_host_memory": bool(pinned), "estimated": _read_trajectory(traj),
+                "driver": "examples/odometry_benchmark_flow.cpp (C++ threads over include/small_gicp_amd.hpp, a HIP stream per worker), all scans read into host memory first; best of the runs after the first"}
     finally:
         if own:
             shutil.rmtree(workdir, ignore_errors=True)

@@ -1062,6 +1062,38 @@ def test_pipelined_odometry_gives_the_same_poses():
         assert (a == b).all()
 
 
+@pytest.mark.parametrize("workers,reg_workers,frames", [(2, 2, 9), (3, 3, 10), (1, 4, 7), (2, 2, 1), (2, 3, 2)])
+def test_flow_odometry_registers_pairs_side_by_side_and_gives_the_same_poses(workers, reg_workers, frames):
+    """The flow form of the reference's TBB engine (odometry_benchmark_small_gicp_tbb_flow.cpp:55-141: preprocessing AND registration nodes with
+    unlimited concurrency, sequencers in between): pairs are registered from the identity, so several run at once on contexts of their own;
+    the products in frame order are bit-identical to the sequential driver's, whatever order the pairs finish in."""
+    from small_gicp_amd import odometry
+
+    seq = odometry.run_synthetic(frames)
+    pipe = odometry.run_synthetic_pipelined(frames, workers=workers, reg_workers=reg_workers)
+    assert len(pipe["estimated"]) == frames
+    for a, b in zip(seq["estimated"], pipe["estimated"]):
+        assert (a == b).all()
+    if frames > 1:
+        assert abs(pipe["mean_iterations"] - seq["mean_iterations"]) < 1e-12
+
+
+def test_cpp_flow_driver_matches_the_sequential_cpp_driver(tmp_path):
+    """examples/odometry_benchmark_flow.cpp — std::thread workers with a context (HIP stream) each over include/small_gicp_amd.hpp
+    (PointCloud on a named context, ParallelReductionHIP::context), pinned and pageable scans: the trajectory file equals the sequential
+    C++ driver's line for line, the iteration counts agree."""
+    from small_gicp_amd import odometry
+
+    cr = odometry.run_synthetic_cpp(10, workdir=str(tmp_path))
+    for pw, rw, pinned in ((2, 2, False), (3, 2, True), (1, 1, False)):
+        fr = odometry.run_synthetic_cpp_flow(10, workdir=str(tmp_path), preprocess_workers=pw, registration_workers=rw, pinned=pinned, repeat=2)
+        assert len(fr["estimated"]) == 10
+        worst = max(np.abs(a - b).max() for a, b in zip(cr["estimated"], fr["estimated"]))
+        assert worst == 0.0, (pw, rw, pinned, worst)  # the same numbers printed with the same format
+        assert abs(fr["mean_iterations"] - cr["mean_iterations"]) < 0.01
+        print("C++ flow driver %d x %d%s: %.3f ms/scan (sequential driver: %.3f total)" % (pw, rw, " pinned" if pinned else "", fr["ms_per_scan"], cr["total_ms_per_scan"]))
+
+
 # ---- §8f row 3: incremental GaussianVoxelMap (scan-to-model target) -----------------------------------------------------------------
 def test_incremental_voxelmap_matches_oracle(orc, c1_f32, gpu_c1):
     """The same sequence of insert(cloud, T) on the device (csrc/voxelmap.hip) and in the oracle (pinned to the reference's
