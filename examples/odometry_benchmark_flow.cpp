@@ -290,8 +290,11 @@ int main(int argc, char** argv) {
       const double t_begin = now_ms();
       traj = odom.estimate(scans, wall_ms, mean_iterations, latency_ms);
       // the reference's flow engine reports elapsed / frames (:113-114)
-      std::printf("run=%d total_throughput=%.4f [msec/scan]  frame_latency=%.4f [msec]  mean_iterations=%.2f  window_ns=%.0f,%.0f\n", rep, scans.empty() ? 0.0 : wall_ms / static_cast<double>(scans.size()), latency_ms,
-                  mean_iterations, 1e6 * t_begin, 1e6 * (t_begin + wall_ms));  // steady_clock = CLOCK_MONOTONIC: the clock of a rocprofv3 kernel trace
+      uint64_t al[5];
+      sga_allocator_stats(al);  // cumulative: hipMalloc calls / served by the stream's own list / the shared pool / completed deferred frees / frees deferred
+      std::printf("run=%d total_throughput=%.4f [msec/scan]  frame_latency=%.4f [msec]  mean_iterations=%.2f  window_ns=%.0f,%.0f  allocator=%llu,%llu,%llu,%llu,%llu\n", rep,
+                  scans.empty() ? 0.0 : wall_ms / static_cast<double>(scans.size()), latency_ms, mean_iterations, 1e6 * t_begin, 1e6 * (t_begin + wall_ms),  // steady_clock = CLOCK_MONOTONIC: the clock of a rocprofv3 kernel trace
+                  static_cast<unsigned long long>(al[0]), static_cast<unsigned long long>(al[1]), static_cast<unsigned long long>(al[2]), static_cast<unsigned long long>(al[3]), static_cast<unsigned long long>(al[4]));
     }
     std::ofstream ofs(output_path);
     char buf[64];
