@@ -116,14 +116,16 @@ __device__ __forceinline__ float grid_rho2(const GridView& g, float qx, float qy
 
 __device__ __forceinline__ float grid_rex_from_r2(float r2) { return sqrtf(r2) * 0.9999995f; }  // as linearize.hip: sqrt of the bound, rounded down
 
-// nn / nn2 / rex of a query whose block has been scanned.  Returns false if the block does not settle it.
-__device__ __forceinline__ bool grid_settle(const GridTop3& t, float rho2, float bound2, int& nn, int& nn2, float& rex) {
+// nn / nn2 / rex of a query whose block has been scanned.  Returns false if the block does not settle it.  by_face (optional): the
+// exclusion radius ends at the block's FACE, not at a third target point — a radius a tree walk could widen.
+__device__ __forceinline__ bool grid_settle(const GridTop3& t, float rho2, float bound2, int& nn, int& nn2, float& rex, bool* by_face = nullptr) {
   const float d1 = grid_key_dist(t.k1);
   const bool hit = d1 < bound2;
   const bool settled = d1 < rho2 || rho2 >= bound2;  // the nearest point lies inside the certified ball, or the ball covers the whole reach
   nn = hit ? grid_key_pos(t.k1) : -1;
   nn2 = (hit && t.k2 != kGridNoKey) ? grid_key_pos(t.k2) : -1;
   rex = grid_rex_from_r2(fminf(hit ? t.d3 : d1, rho2));
+  if (by_face != nullptr) *by_face = rho2 < (hit ? t.d3 : d1);
   return settled;
 }
 
@@ -132,7 +134,7 @@ __device__ __forceinline__ bool grid_settle(const GridTop3& t, float rho2, float
 // 27 cells settle the query (then nn / nn2 / rex are its exact neighbour, runner-up and exclusion radius); otherwise `seen` = the distance
 // of the nearest point the ring saw (+inf: none).  A chain of two dependent loads where the seeded kd walk has a dozen: this is what the
 // walkers of warm passes use (linearize.hip: certify_linearize_kernel).
-__device__ __forceinline__ bool grid_ring1_lane(const GridView& g, float qx, float qy, float qz, float bound2, int& nn, int& nn2, float& rex, float& seen) {
+__device__ __forceinline__ bool grid_ring1_lane(const GridView& g, float qx, float qy, float qz, float bound2, int& nn, int& nn2, float& rex, float& seen, bool* by_face = nullptr) {
   const int cx = grid_cell(qx, g.ox, g.inv_h, g.nx), cy = grid_cell(qy, g.oy, g.inv_h, g.ny), cz = grid_cell(qz, g.oz, g.inv_h, g.nz);
   uint32_t s[9], e[9];
 #pragma unroll
@@ -154,7 +156,7 @@ __device__ __forceinline__ bool grid_ring1_lane(const GridView& g, float qx, flo
     grid_scan_run(g, s[r] + 4u, e[r], qx, qy, qz, t);  // the rest of a run longer than four (wave-uniform loop; skipped when no lane has one)
   }
   seen = t.k1 != kGridNoKey ? sqrtf(grid_key_dist(t.k1)) : INFINITY;
-  return grid_settle(t, grid_rho2(g, qx, qy, qz, cx, cy, cz, 1), bound2, nn, nn2, rex);
+  return grid_settle(t, grid_rho2(g, qx, qy, qz, cx, cy, cz, 1), bound2, nn, nn2, rex, by_face);
 }
 
 __device__ __forceinline__ unsigned long long grid_wave_min_u64(unsigned long long v) {
@@ -233,7 +235,7 @@ __device__ __forceinline__ unsigned grid_settle_wave(const GridView& g, int lane
 // The lanes' three nearest are merged with minima over the group (shuffles on the 64-bit keys; every point lies in exactly one run, so no
 // key occurs twice).  All lanes of the wave must call this together (`has` = this lane's group has a query); the result is uniform
 // within a group.
-__device__ __forceinline__ bool grid_ring1_group(const GridView& g, int G, int gl, bool has, float qx, float qy, float qz, float bound2, int& nn, int& nn2, float& rex, float& seen) {
+__device__ __forceinline__ bool grid_ring1_group(const GridView& g, int G, int gl, bool has, float qx, float qy, float qz, float bound2, int& nn, int& nn2, float& rex, float& seen, bool* by_face = nullptr) {
   const int cx = grid_cell(qx, g.ox, g.inv_h, g.nx), cy = grid_cell(qy, g.oy, g.inv_h, g.ny), cz = grid_cell(qz, g.oz, g.inv_h, g.nz);
   uint32_t off[9], pre[10];  // off[r] = start of run r - candidates before it; pre[r] = candidates before run r
   pre[0] = 0u;
@@ -278,7 +280,7 @@ __device__ __forceinline__ bool grid_ring1_group(const GridView& g, int G, int g
   GridTop3 m;
   m.k1 = g1, m.k2 = g2, m.d3 = third;
   seen = g1 != kGridNoKey ? sqrtf(grid_key_dist(g1)) : INFINITY;
-  return grid_settle(m, grid_rho2(g, qx, qy, qz, cx, cy, cz, 1), bound2, nn, nn2, rex);
+  return grid_settle(m, grid_rho2(g, qx, qy, qz, cx, cy, cz, 1), bound2, nn, nn2, rex, by_face);
 }
 
 }  // namespace sga

@@ -301,7 +301,9 @@ __device__ __forceinline__ int search_lane(const NNParams<Real>& p, int tile, in
     if (p.grid_walk & 2) {
       int g_nn, g_nn2;
       float g_rex, g_seen;
-      if (grid_ring1_lane(p.grid, fx, fy, fz, p.bound2, g_nn, g_nn2, g_rex, g_seen)) {
+      bool g_face = false;
+      // (a radius that ends at the ring's face with less than the re-walk's slack to spare is left to the walk: see certify_linearize_kernel)
+      if (grid_ring1_lane(p.grid, fx, fy, fz, p.bound2, g_nn, g_nn2, g_rex, g_seen, &g_face) && !(g_face && g_nn >= 0 && (p.grid_walk & 32) && g_rex - g_seen < slack)) {
         p.nn[i] = g_nn;
         p.nn2[i] = g_nn2;
         p.rex[i] = g_rex;
@@ -503,7 +505,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 6))) void
             if (trying) {
               int g_nn, g_nn2;
               float g_rex, g_seen;
-              if (grid_ring1_lane(p.grid, qx, qy, qz, p.bound2, g_nn, g_nn2, g_rex, g_seen)) {
+              bool g_face = false;
+              // (a radius that ends at the ring's face with less than the walk's slack to spare is left to the walk: see certify_linearize_kernel)
+              if (grid_ring1_lane(p.grid, qx, qy, qz, p.bound2, g_nn, g_nn2, g_rex, g_seen, &g_face) && !(g_face && g_nn >= 0 && (p.grid_walk & 32) && g_rex - g_seen < s.slack)) {
                 p.nn[qi] = g_nn;
                 p.nn2[qi] = g_nn2;
                 p.rex[qi] = g_rex;
@@ -1078,6 +1082,7 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(4))) void
         bool g_settled = false;
         int g_nn = -1, g_nn2 = -1;
         float g_rex = 0.f, g_seen = INFINITY;
+        bool g_face = false;
         if (Gw > 1) {  // workgroup-uniform
           float gx = 0.f, gy = 0.f, gz = 0.f;
           if (has) {
@@ -1086,7 +1091,7 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(4))) void
             transform_point<Real>(p.T, Real(ps.x), Real(ps.y), Real(ps.z), t[0], t[1], t[2]);
             gx = static_cast<float>(t[0]), gy = static_cast<float>(t[1]), gz = static_cast<float>(t[2]);
           }
-          g_settled = grid_ring1_group(q.grid, Gw, gl, has, gx, gy, gz, q.bound2, g_nn, g_nn2, g_rex, g_seen);
+          g_settled = grid_ring1_group(q.grid, Gw, gl, has, gx, gy, gz, q.bound2, g_nn, g_nn2, g_rex, g_seen, &g_face);
         }
         if (mine) {
           const float4 ps = p.src_pts[i];
@@ -1099,7 +1104,16 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(4))) void
           // of at least a cell.  The rare walker ring 1 does not settle walks the tree.
           int j = -1;
           bool settled = g_settled;
-          if (Gw == 1 && (q.grid_walk & 1)) settled = grid_ring1_lane(q.grid, fx, fy, fz, q.bound2, g_nn, g_nn2, g_rex, g_seen);  // wave-uniform condition
+          if (Gw == 1 && (q.grid_walk & 1)) settled = grid_ring1_lane(q.grid, fx, fy, fz, q.bound2, g_nn, g_nn2, g_rex, g_seen, &g_face);  // wave-uniform condition
+          // The ring's certificate ends at the face of its 27 cells at the latest, with no exploration slack: a walker whose neighbour lies
+          // just inside that face would fail again in every later pass (the lone walker the last passes of a registration keep: ~5 us of
+          // tail each).  Such a walker — radius set by the face, less than the re-walk's slack beyond the neighbour — walks the tree
+          // once instead: the walk's radius ends at the third target point or the slack, whichever comes first.  (A radius that ends at
+          // a third point is all a walk would find too: those stay with the ring.)
+          if (settled && g_face && g_nn >= 0 && (q.grid_walk & 32)) {
+            const float need = -__hip_atomic_load(&q.rex[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // what the check left there: the re-walk's slack
+            if (g_rex - g_seen < need) settled = false;
+          }
           if (settled) {
             q.nn[i] = g_nn;
             q.nn2[i] = g_nn2;
@@ -1654,8 +1668,9 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
                  (grid_mode >= 4 || (!small_warm && (grid_mode == 3 || (!first_pass && pb->grid_open_frac <= grid_max_open))));
       // which walkers try ring 1 of the grid first (SGA_GRID_WALK, bits): 1 those of certify_linearize_kernel, 2 those of the
       // one-query-per-lane warm pass (search_linearize_kernel<CHECK>), 4 those of the queue-fed kernel, 8 certify_linearize_kernel scans ring 1
-      // with a group of lanes per walker when a workgroup has few of them (grid_ring1_group)
-      static const int grid_walk_bits = getenv("SGA_GRID_WALK") ? atoi(getenv("SGA_GRID_WALK")) : 15;
+      // with a group of lanes per walker when a workgroup has few of them (grid_ring1_group); 32: a ring certificate that ends at the ring's
+      // face with less than the re-walk's slack beyond the neighbour is left to the tree walk (the margin rule, certify_linearize_kernel)
+      static const int grid_walk_bits = getenv("SGA_GRID_WALK") ? atoi(getenv("SGA_GRID_WALK")) : 47;
       q.grid_walk = grid_walk_bits;
       q.grid = make_grid_view(idx);
       if (first_pass || (!use_grid && !warm)) pb->grid_open_frac = 0.0;  // a kd pass in between: the grid gets another chance afterwards

@@ -304,3 +304,31 @@ def test_certificate_headroom_changes_nothing_but_the_walkers():
         for (e, n, hm), (e0, n0, hm0) in zip(v["sums"], ref["sums"]):
             assert n == n0 and abs(e - e0) <= 1e-6 * abs(e0) and abs(hm - hm0) <= 1e-6 * hm0, (pad, e, e0, n, n0)
     assert out["5"]["walked"] > out["0"]["walked"], out  # (the large value does send more points into the walk)
+
+
+def test_ring_margin_rule_changes_nothing_but_the_walkers():
+    """SGA_GRID_WALK bit 32 (linearize.hip: the margin rule) only decides whether a walker whose ring-1 certificate ends at the ring's face,
+    with less than the re-walk's slack beyond its neighbour, keeps that certificate or walks the tree once for a wider one — the neighbour
+    is the exact one either way.  Same correspondences and sums on every pass of an LM-shaped pose chain with the rule on (the default)
+    and off; with it on, no more points walk in total (the late passes lose their repeat walkers).  One process per value."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for bits in ("15", "47"):
+        env = dict(os.environ, SGA_GRID_WALK=bits, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        r = subprocess.run([sys.executable, "-c", _HEADROOM_CHAIN], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (bits, r.stdout[-2000:], r.stderr[-2000:])
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1]
+        out[bits] = json.loads(line[len("RESULT "):])
+    print({k: (v["warm"], v["walked"]) for k, v in out.items()})
+    ref = out["15"]
+    assert ref["warm"] >= 4, ref
+    v = out["47"]
+    assert v["hash"] == ref["hash"], "correspondences differ"
+    assert v["warm"] == ref["warm"]
+    for (e, n, hm), (e0, n0, hm0) in zip(v["sums"], ref["sums"]):
+        assert n == n0 and abs(e - e0) <= 1e-6 * abs(e0) and abs(hm - hm0) <= 1e-6 * hm0, (e, e0, n, n0)
+    assert v["walked"] <= ref["walked"], out
