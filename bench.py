@@ -471,6 +471,7 @@ def main():
             out["scaled_scenes"] = scaled_scenes_leg(sga, ctx, target, source, args, value)
         if single and not args.no_preprocess:
             out["preprocess_rooflines"] = preprocess_rooflines(sga, ctx, target, args)
+            out["fresh_align_c3"] = fresh_align_leg(sga, ctx, target, source, args)
         if single and args.odom_frames > 1:
             out["kitti_odom"] = odometry_leg(sga, args, None)
         if single and not args.no_policy:
@@ -919,6 +920,61 @@ def preprocess_rooflines(sga, ctx, target_c3, args):
         out["note"] = ("gpu_us = HIP events around the stage's launches (the gaps between them included); best of 4 calls; covariances of <= 32768 points search with one wave per query (csrc/knn_wave.hpp), "
                        "larger clouds with one query per lane; index build of <= 32768 points: one launch per level (radix select + partition), larger ones per-level segmented sorts")
         return out
+    except Exception as ex:  # noqa: BLE001
+        return {"error": repr(ex)}
+
+
+def fresh_align_leg(sga, ctx, target, source, args):
+    """What a caller of align() on two NEW clouds waits for (registration_helper.hpp:28-44: preprocess both clouds, register): from two
+    host arrays (fp32, pageable) to the pose — upload, covariances k = 20 of both clouds, the target's kd-tree, the source sorted into
+    the problem, GICP from the identity with the default termination criteria.  Wall time of the whole chain on the context in
+    stream-ordered mode (one host wait, at the end) and, from a second run with a synchronisation after every stage, the stages.  Median of 5."""
+    try:
+        k = args.neighbors
+        tp = np.ascontiguousarray(target[:, :3], dtype=np.float32)
+        sp = np.ascontiguousarray(source[:, :3], dtype=np.float32)
+        st = sga.make_setting("GICP", max_correspondence_distance=1.0)
+
+        def chain(sync):
+            t = [time.perf_counter()]
+
+            def mark():
+                if sync:
+                    ctx.synchronize()
+                    t.append(time.perf_counter())
+
+            tgt, src = sga.PointCloud(tp, ctx=ctx), sga.PointCloud(sp, ctx=ctx)
+            mark()
+            tree = sga.KdTree(tgt)
+            mark()
+            sga.estimate_covariances(tgt, tree, k)
+            sga.estimate_covariances(src, None, k)
+            mark()
+            pb = sga.Problem(tree, src, np.eye(4))
+            mark()
+            res = pb.align(st, np.eye(4))
+            ctx.synchronize()
+            t.append(time.perf_counter())
+            return t, res
+
+        prev = ctx.set_stream_ordered(True)
+        try:
+            chain(False)  # first-touch allocations of these sizes
+            walls, stage_rows, res = [], [], None
+            for _ in range(5):
+                t, res = chain(False)
+                walls.append(1e3 * (t[-1] - t[0]))
+            for _ in range(3):
+                t, _ = chain(True)
+                stage_rows.append([1e3 * (b - a) for a, b in zip(t[:-1], t[1:])])
+        finally:
+            ctx.set_stream_ordered(prev)
+        stages = np.median(np.array(stage_rows), axis=0)
+        names = ["upload_2_clouds", "target_kdtree", "covariances_2_clouds", "problem_source_sort", "align_default_criteria"]
+        return {"ms": float(np.median(walls)), "runs_ms": walls, "stages_ms_synchronised": {n: float(v) for n, v in zip(names, stages)}, "iterations": int(res.iterations) + 1, "converged": bool(res.converged),
+                "points": [int(len(tp)), int(len(sp))],
+                "note": "host arrays (fp32, pageable) -> pose: 2 uploads (72 MB over PCIe), covariances k = %d of both clouds (the source's over a temporary tree of its own), the target's index, the source sorted by target leaf, "
+                        "GICP from the identity with the default termination criteria; the clouds and the index are released between runs" % k}
     except Exception as ex:  # noqa: BLE001
         return {"error": repr(ex)}
 
