@@ -494,9 +494,23 @@ def main():
                      "mode": "frame pairs are independent under the reference's protocol (identity initial guess per pair): contiguous blocks of frames per rank, every rank preprocesses its block + 1 scan, no collective"}
         except Exception as ex:  # noqa: BLE001
             pairs = {"error": repr(ex)}
+        # ... and each rank's block as a flow of stages (2 preprocessing x 2 registration workers per GPU)
+        pairs_flow = None
+        try:
+            pf = odometry.run_synthetic_pairs(args.odom_frames, rank, world, device=local_rank, flow=(2, 2))
+            t = torch.tensor([pf["seconds"]], dtype=torch.float64, device="cpu" if host_tensors else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            worst = 0.0
+            if "pr" in dir() and isinstance(pr, dict):
+                worst = max([float(np.abs(pf["relative_poses"][f] - pr["relative_poses"][f]).max()) for f in pf["relative_poses"] if f in pr["relative_poses"]] or [0.0])
+            pairs_flow = {"ms_per_scan": 1e3 * float(t.cpu()[0]) / args.odom_frames, "unit": "ms/scan (total)", "frames_per_rank": pf["frames"], "workers_per_rank": "2 preprocessing x 2 registration",
+                          "max_abs_relative_pose_difference_vs_frame_by_frame": worst}
+        except Exception as ex:  # noqa: BLE001
+            pairs_flow = {"error": repr(ex)}
         if rank == 0:
             out["kitti_odom"] = r
             out["kitti_odom_frame_pairs_per_rank"] = pairs
+            out["kitti_odom_frame_pairs_per_rank_flow"] = pairs_flow
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())

@@ -314,16 +314,25 @@ def run_synthetic_pairs(num_frames, rank, world, device=0, **kw):
     is registered from the identity (odometry_benchmark_small_gicp_omp.cpp:16-49), so the pairs are independent — rank r takes the
     contiguous block of frames [r F / W, (r + 1) F / W), preprocesses those scans plus the one before the block, and registers its pairs
     on a context of its own with no collective at all.  Returns this rank's wall time, its relative poses {f: T_(f-1) f} and frame count;
-    the job's ms/scan is max over ranks of the wall time / F."""
+    the job's ms/scan is max over ranks of the wall time / F.  flow=(P, R): the rank runs its block as a flow of stages (PipelinedOdometry: P
+    preprocessing and R registration workers with a stream each) instead of frame by frame."""
     import time as _time
 
     from . import synthetic
 
     lo, hi = rank * num_frames // world, (rank + 1) * num_frames // world
-    odom = OnlineOdometry(ctx=api.Context(device), **kw)
-    rel = {}
+    flow = kw.pop("flow", None)
     # generate the scans first: the generator is host work that a real stream would not pay
     scans = {f: synthetic.kitti_like_scan(f)[0] for f in range(max(lo - 1, 0), hi)}
+    if flow:  # (preprocessing workers, registration workers): the rank's block through the flow form (PipelinedOdometry) on its device
+        frames = sorted(scans)
+        pipe = PipelinedOdometry(device=device, workers=flow[0], reg_workers=flow[1], **kw)
+        pipe.run([scans[f] for f in frames[: min(4, len(frames))]])  # first-touch allocations, code objects
+        poses, el, _ = pipe.run([scans[f] for f in frames])
+        rel = {f: np.linalg.inv(poses[k - 1]) @ poses[k] for k, f in enumerate(frames) if k > 0 and f >= max(lo, 1)}
+        return {"seconds": el, "frames": hi - lo, "relative_poses": rel}
+    odom = OnlineOdometry(ctx=api.Context(device), **kw)
+    rel = {}
     odom.ctx.synchronize()
     t0 = _time.perf_counter()
     prev_T = None
