@@ -161,7 +161,8 @@ class PipelinedOdometry:
     A frame is a chain of ~30 dependent launches that leaves the GPU mostly idle, so several chains interleave almost for free.  Poses
     are identical to OnlineOdometry's (same kernels, same order of operations per frame and per pair; the products in frame order)."""
 
-    def __init__(self, downsampling_resolution=0.25, num_neighbors=20, max_correspondence_distance=1.0, device=0, workers=3, depth=None, reg_workers=1):
+    def __init__(self, downsampling_resolution=0.25, num_neighbors=20, max_correspondence_distance=1.0, device=0, workers=2, depth=None, reg_workers=2):
+        # defaults: 2 x 2 workers — the measured optimum on one MI355X (profiles/r06_flow_cpp_grid.txt); more streams make every kernel slower
         self.res = downsampling_resolution
         self.k = num_neighbors
         self.setting = api.make_setting("GICP", max_correspondence_distance=max_correspondence_distance)
