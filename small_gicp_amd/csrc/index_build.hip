@@ -482,6 +482,231 @@ __global__ __launch_bounds__(THREADS) void kd_split_level_kernel(const float4* _
   if (tid == 0) nodes[(1u << d) + seg] = make_float2(float_from_ordered(static_cast<int>(median ^ 0x80000000u)), __int_as_float(axis));
 }
 
+// ---- top levels of LARGE clouds: the same select + partition, a segment spread over many workgroups (round 6) -------------------------
+// A segment of more than kSplitMaxPoints points does not fit one workgroup's registers.  The sort-based level above orders ALL n (segment,
+// coordinate) keys to learn one median per segment: ~260 us per level at 1M points, 47 rocPRIM launches — most of a 1M-point build.  Here the
+// level is what kd_split_level_kernel does, with the segment cut into chunks of kTopChunk points (grid = chunks x segments) and the
+// histograms of the three select rounds accumulated in global memory (LDS first, the non-empty bins flushed with atomics):
+//   box   -> the segment's box (6 atomics per workgroup)                                           kd_top_box_kernel
+//   hist0 -> axis = longest extent; the keys (order-preserving coordinate) are stored once; top 11 bits   kd_top_hist_kernel<0>
+//   hist1, hist2 -> every workgroup re-derives the buckets chosen so far from the finished histograms (2048 bins: one scan), then counts
+//            the next 11 / 10 bits of the keys inside them                                          kd_top_hist_kernel<1>, <2>
+//   count -> the median is known: keys below / equal per chunk; chunk 0 writes the node                kd_top_count_kernel
+//   scatter -> [keys < median][`rank` of the equal ones] | [the other equal ones][keys > median], chunks in order, inside a chunk
+//            thread-major: a fixed order.  The POINTS move with the permutation (ping-pong copies), so that every pass of the next
+//            level streams instead of gathering through the permutation                               kd_top_scatter_kernel
+// Six passes over 4 - 20 bytes per point instead of a 64-bit key-value sort of the whole cloud.  The tree is another valid one over the
+// same points (like the split path's): the halves are the same SETS as the sort's whenever the median key is unique, the order inside
+// them is not the sorted one.
+constexpr uint32_t kTopItems = 8, kTopThreads = 1024, kTopChunk = kTopItems * kTopThreads;
+struct TopSel {
+  uint32_t median, below, rank, eq_total;  // the median key; keys below it; how many of the equal keys complete the left half; equal keys
+};
+
+__global__ __launch_bounds__(kTopThreads) void kd_top_box_kernel(const float4* __restrict__ pts, uint32_t n, int d, int* __restrict__ seg_box) {
+  __shared__ float sh_lo[kTopThreads / 64][3], sh_hi[kTopThreads / 64][3];
+  const uint32_t seg = blockIdx.y, tid = threadIdx.x;
+  const uint32_t first = kd_bound(n, d, seg), end = kd_bound(n, d, seg + 1);
+  const uint32_t i0 = first + blockIdx.x * kTopChunk;
+  if (i0 >= end) return;  // workgroup-uniform
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  float4 p[kTopItems];
+#pragma unroll
+  for (uint32_t j = 0; j < kTopItems; j++) p[j] = pts[min(i0 + j * kTopThreads + tid, end - 1u)];  // (a repeated last element changes nothing in a box)
+#pragma unroll
+  for (uint32_t j = 0; j < kTopItems; j++) {
+    lo[0] = fminf(lo[0], p[j].x), lo[1] = fminf(lo[1], p[j].y), lo[2] = fminf(lo[2], p[j].z);
+    hi[0] = fmaxf(hi[0], p[j].x), hi[1] = fmaxf(hi[1], p[j].y), hi[2] = fmaxf(hi[2], p[j].z);
+  }
+  for (int a = 0; a < 3; a++)
+    for (int off = 32; off > 0; off >>= 1) {
+      lo[a] = fminf(lo[a], __shfl_xor(lo[a], off));
+      hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off));
+    }
+  if ((tid & 63) == 0)
+    for (int a = 0; a < 3; a++) sh_lo[tid >> 6][a] = lo[a], sh_hi[tid >> 6][a] = hi[a];
+  __syncthreads();
+  if (tid < 3) {
+    float l = INFINITY, h = -INFINITY;
+    for (uint32_t w = 0; w < kTopThreads / 64; w++) l = fminf(l, sh_lo[w][tid]), h = fmaxf(h, sh_hi[w][tid]);
+    if (l <= h) {
+      atomicMin(&seg_box[6 * seg + tid], ordered_from_float(l));
+      atomicMax(&seg_box[6 * seg + 3 + tid], ordered_from_float(h));
+    }
+  }
+}
+
+// the bucket of `rank` in a finished histogram of kSplitBins bins: (bucket, keys in lower buckets, keys in it) -> sh_sel[0..2]; all threads call
+__device__ __forceinline__ void top_select(const uint32_t* __restrict__ hist, uint32_t rank, uint32_t* __restrict__ sh_wave, uint32_t* __restrict__ sh_sel) {
+  constexpr int kBinsPerThread = kSplitBins / kTopThreads;
+  const uint32_t tid = threadIdx.x;
+  uint32_t c[kBinsPerThread], mine = 0u;
+#pragma unroll
+  for (int b = 0; b < kBinsPerThread; b++) {
+    c[b] = hist[kBinsPerThread * tid + b];
+    mine += c[b];
+  }
+  uint32_t before = split_scan_exclusive<kTopThreads>(mine, sh_wave);
+  if (rank >= before && rank < before + mine) {  // exactly one thread
+#pragma unroll
+    for (int b = 0; b < kBinsPerThread; b++) {
+      if (rank >= before && rank < before + c[b]) {
+        sh_sel[0] = kBinsPerThread * tid + b;
+        sh_sel[1] = before;
+        sh_sel[2] = c[b];
+      }
+      before += c[b];
+    }
+  }
+  __syncthreads();
+}
+
+// hist: [segment][round][kSplitBins].  ROUND 0 also fixes the axis and stores the keys.
+template <int ROUND>
+__global__ __launch_bounds__(kTopThreads) void kd_top_hist_kernel(const float4* __restrict__ pts, uint32_t* __restrict__ keys, uint32_t n, int d, const int* __restrict__ seg_box, int* __restrict__ axis_of_seg, uint32_t* __restrict__ hist) {
+  __shared__ uint32_t sh_hist[kSplitBins];
+  __shared__ uint32_t sh_wave[2][kTopThreads / 64];
+  __shared__ uint32_t sh_sel[2][3];
+  const uint32_t seg = blockIdx.y, tid = threadIdx.x;
+  const uint32_t first = kd_bound(n, d, seg), end = kd_bound(n, d, seg + 1), mid = kd_bound(n, d + 1, 2 * seg + 1);
+  const uint32_t i0 = first + blockIdx.x * kTopChunk;
+  if (i0 >= end) return;  // workgroup-uniform
+  const uint32_t len = end - first;
+  uint32_t* __restrict__ seg_hist = hist + static_cast<size_t>(seg) * 3 * kSplitBins;
+  for (uint32_t b = tid; b < kSplitBins; b += kTopThreads) sh_hist[b] = 0u;
+  uint32_t key[kTopItems];
+  if constexpr (ROUND == 0) {
+    const int axis = kd_longest_axis(seg_box + 6 * seg);
+    if (blockIdx.x == 0 && tid == 0) axis_of_seg[seg] = axis;
+    const float* __restrict__ coord = reinterpret_cast<const float*>(pts) + axis;
+#pragma unroll
+    for (uint32_t j = 0; j < kTopItems; j++) {
+      const uint32_t i = i0 + j * kTopThreads + tid;
+      key[j] = ordered_u32(coord[4ull * min(i, end - 1u)]);
+      if (i < end) keys[i] = key[j];
+    }
+  } else {
+#pragma unroll
+    for (uint32_t j = 0; j < kTopItems; j++) key[j] = keys[min(i0 + j * kTopThreads + tid, end - 1u)];
+  }
+  uint32_t prefix = 0u, prefix_mask = 0u, rank = min(mid - first, len - 1u);
+  const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
+#pragma unroll
+  for (int r = 0; r < ROUND; r++) {  // the buckets the finished rounds chose (every workgroup of the segment derives the same)
+    top_select(seg_hist + r * kSplitBins, rank, sh_wave[r], sh_sel[r]);
+    prefix |= sh_sel[r][0] << shifts[r];
+    prefix_mask |= ((1u << bits[r]) - 1u) << shifts[r];
+    rank -= sh_sel[r][1];
+  }
+  __syncthreads();  // (ROUND 0: the cleared histogram)
+  const uint32_t bmask = (1u << bits[ROUND]) - 1u;
+#pragma unroll
+  for (uint32_t j = 0; j < kTopItems; j++)
+    if (i0 + j * kTopThreads + tid < end && (key[j] & prefix_mask) == prefix) atomicAdd(&sh_hist[(key[j] >> shifts[ROUND]) & bmask], 1u);
+  __syncthreads();
+  for (uint32_t b = tid; b < kSplitBins; b += kTopThreads) {
+    const uint32_t c = sh_hist[b];
+    if (c != 0u) atomicAdd(&seg_hist[ROUND * kSplitBins + b], c);
+  }
+}
+
+// cnt: [segment][chunk] x {keys below the median, keys equal to it}
+__global__ __launch_bounds__(kTopThreads) void kd_top_count_kernel(const uint32_t* __restrict__ keys, uint32_t n, int d, const int* __restrict__ axis_of_seg, const uint32_t* __restrict__ hist, uint32_t chunks, uint2* __restrict__ cnt,
+                                                                  TopSel* __restrict__ sel, float2* __restrict__ nodes) {
+  __shared__ uint32_t sh_wave[4][kTopThreads / 64];
+  __shared__ uint32_t sh_sel[3][3];
+  const uint32_t seg = blockIdx.y, tid = threadIdx.x;
+  const uint32_t first = kd_bound(n, d, seg), end = kd_bound(n, d, seg + 1), mid = kd_bound(n, d + 1, 2 * seg + 1);
+  const uint32_t i0 = first + blockIdx.x * kTopChunk;
+  if (i0 >= end) return;  // workgroup-uniform
+  const uint32_t len = end - first;
+  const uint32_t* __restrict__ seg_hist = hist + static_cast<size_t>(seg) * 3 * kSplitBins;
+  uint32_t key[kTopItems];
+#pragma unroll
+  for (uint32_t j = 0; j < kTopItems; j++) key[j] = keys[min(i0 + j * kTopThreads + tid, end - 1u)];
+  uint32_t median = 0u, rank = min(mid - first, len - 1u), below = 0u;
+  const int shifts[3] = {21, 10, 0};
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    top_select(seg_hist + r * kSplitBins, rank, sh_wave[r], sh_sel[r]);
+    median |= sh_sel[r][0] << shifts[r];
+    below += sh_sel[r][1];
+    rank -= sh_sel[r][1];
+  }
+  uint32_t my_less = 0u, my_eq = 0u;
+#pragma unroll
+  for (uint32_t j = 0; j < kTopItems; j++) {
+    const bool valid = i0 + j * kTopThreads + tid < end;
+    my_less += (valid && key[j] < median) ? 1u : 0u;
+    my_eq += (valid && key[j] == median) ? 1u : 0u;
+  }
+  const uint32_t packed = split_scan_exclusive<kTopThreads>(my_less | (my_eq << 16), sh_wave[3]);  // <= 8 per thread, <= 8192 in all: 16 bits each
+  if (tid == kTopThreads - 1) cnt[static_cast<size_t>(seg) * chunks + blockIdx.x] = make_uint2((packed & 0xffffu) + my_less, (packed >> 16) + my_eq);
+  if (blockIdx.x == 0 && tid == 0) {
+    sel[seg] = TopSel{median, below, rank, sh_sel[2][2]};
+    nodes[(1u << d) + seg] = make_float2(float_from_ordered(static_cast<int>(median ^ 0x80000000u)), __int_as_float(axis_of_seg[seg]));
+  }
+}
+
+__global__ __launch_bounds__(kTopThreads) void kd_top_scatter_kernel(const float4* __restrict__ pts_in, const uint32_t* __restrict__ perm_in /* null: the identity */, const uint32_t* __restrict__ keys, uint32_t n, int d, uint32_t chunks,
+                                                                    const uint2* __restrict__ cnt, const TopSel* __restrict__ sel, float4* __restrict__ pts_out, uint32_t* __restrict__ perm_out) {
+  __shared__ uint32_t sh_wave[3][kTopThreads / 64];
+  const uint32_t seg = blockIdx.y, tid = threadIdx.x, chunk = blockIdx.x;
+  const uint32_t first = kd_bound(n, d, seg), end = kd_bound(n, d, seg + 1), mid = kd_bound(n, d + 1, 2 * seg + 1);
+  const uint32_t i0 = first + chunk * kTopChunk;
+  if (i0 >= end) return;  // workgroup-uniform
+  const uint32_t m = mid - first;
+  const TopSel s = sel[seg];
+  // keys below / equal in the chunks before this one (<= 128 chunks: one value per thread, two block sums)
+  uint2 mine = make_uint2(0u, 0u);
+  for (uint32_t c = tid; c < chunk; c += kTopThreads) {
+    const uint2 v = cnt[static_cast<size_t>(seg) * chunks + c];
+    mine.x += v.x, mine.y += v.y;
+  }
+  uint32_t lt_before = mine.x, eq_before = mine.y;
+  for (int off = 32; off > 0; off >>= 1) lt_before += __shfl_xor(lt_before, off), eq_before += __shfl_xor(eq_before, off);
+  if ((tid & 63) == 0) sh_wave[0][tid >> 6] = lt_before, sh_wave[1][tid >> 6] = eq_before;
+  __syncthreads();
+  lt_before = eq_before = 0u;
+  for (uint32_t w = 0; w < kTopThreads / 64; w++) lt_before += sh_wave[0][w], eq_before += sh_wave[1][w];
+  uint32_t key[kTopItems];
+  float4 p[kTopItems];
+  uint32_t src[kTopItems];
+#pragma unroll
+  for (uint32_t j = 0; j < kTopItems; j++) {
+    const uint32_t i = min(i0 + j * kTopThreads + tid, end - 1u);
+    key[j] = keys[i];
+    p[j] = pts_in[i];
+    src[j] = perm_in != nullptr ? perm_in[i] : i;
+  }
+  uint32_t my_less = 0u, my_eq = 0u, my_all = 0u;
+#pragma unroll
+  for (uint32_t j = 0; j < kTopItems; j++) {
+    const bool valid = i0 + j * kTopThreads + tid < end;
+    my_less += (valid && key[j] < s.median) ? 1u : 0u;
+    my_eq += (valid && key[j] == s.median) ? 1u : 0u;
+    my_all += valid ? 1u : 0u;
+  }
+  const uint32_t packed = split_scan_exclusive<kTopThreads>(my_less | (my_eq << 16), sh_wave[2]);
+  __syncthreads();  // sh_wave[0] is reused below
+  const uint32_t all_before = split_scan_exclusive<kTopThreads>(my_all, sh_wave[0]);
+  uint32_t n_less = lt_before + (packed & 0xffffu), n_eq = eq_before + (packed >> 16);
+  uint32_t n_all = (i0 - first) + all_before;  // elements of the segment ahead of this thread's in the fixed order (chunks, then thread-major)
+#pragma unroll
+  for (uint32_t j = 0; j < kTopItems; j++) {
+    if (i0 + j * kTopThreads + tid < end) {
+      const bool less = key[j] < s.median, eq = key[j] == s.median;
+      const uint32_t n_greater = n_all - n_less - n_eq;
+      const uint32_t dest = first + (less ? n_less : (eq ? (n_eq < s.rank ? s.below + n_eq : m + (n_eq - s.rank)) : m + (s.eq_total - s.rank) + n_greater));
+      pts_out[dest] = p[j];
+      perm_out[dest] = src[j];
+      n_less += less ? 1u : 0u;
+      n_eq += eq ? 1u : 0u;
+      n_all += 1u;
+    }
+  }
+}
+
 // Tight bounding boxes of all nodes, bottom-up (kd_search.hpp: a pending far side is opened only if its box can hold a closer point).
 // One launch covers up to 8 levels: every workgroup takes 256 adjacent nodes of depth `base` — their boxes come from the points
 // (base = D, leaves) or from the previous launch — and merges them pairwise in LDS up to depth base - 8.
@@ -749,11 +974,46 @@ static int build_kdtree(sga_context* ctx, const sga_cloud* cloud, sga_index* idx
     if (!lds_finish || D - dS > 8) dS = D;
     dA = dS;
   }
+  // SGA_KD_TOP=0: the levels above the split kernel's reach through the key-value sort (rounds 1 - 5); default: select + partition over many workgroups
+  const bool top_levels = split_levels && dS > 0 && !(getenv("SGA_KD_TOP") && atoi(getenv("SGA_KD_TOP")) == 0);
   if (dS > 0 || dA == 0) {  // (otherwise the root split level below hands over the box and reads the identity permutation)
     SGA_TRY(cloud_bbox_enqueue(ctx, cloud->pts.p, n, box_seq));
-    hipLaunchKernelGGL(iota_kernel, grid, block, 0, ctx->stream, perm.p, n);
+    if (!top_levels) hipLaunchKernelGGL(iota_kernel, grid, block, 0, ctx->stream, perm.p, n);
   }
-  for (int d = 0; d < dS; d++) {
+  DevBuf<float4> top_pts[2];
+  DevBuf<uint32_t> top_keys, top_hist;
+  DevBuf<uint2> top_cnt;
+  DevBuf<TopSel> top_sel;
+  if (top_levels) {
+    const uint32_t max_seg = 1u << (dS - 1);
+    SGA_TRY(top_pts[0].alloc(n));
+    SGA_TRY(top_pts[1].alloc(n));
+    SGA_TRY(top_keys.alloc(n));
+    SGA_TRY(top_hist.alloc(static_cast<size_t>(max_seg) * 3 * kSplitBins));
+    SGA_TRY(top_cnt.alloc(static_cast<size_t>(n / kTopChunk) + 2 + 2 * static_cast<size_t>(max_seg)));  // segments x chunks of the longest segment <= n / chunk + 2 x segments
+    SGA_TRY(top_sel.alloc(max_seg));
+    const float4* pin = cloud->pts.p;
+    const uint32_t* permin = nullptr;  // level 0 reads the identity
+    for (int d = 0; d < dS; d++) {
+      const uint32_t nseg = 1u << d;
+      const uint32_t chunks = static_cast<uint32_t>((seg_max_at(d) + kTopChunk - 1) / kTopChunk);
+      const dim3 tgrid(chunks, nseg), tblock(kTopThreads);
+      float4* pout = top_pts[d & 1].p;
+      hipLaunchKernelGGL(kd_init_box_kernel, dim3((nseg + 255) / 256), block, 0, ctx->stream, seg_box.p, nseg);
+      SGA_HIP(hipMemsetAsync(top_hist.p, 0, static_cast<size_t>(nseg) * 3 * kSplitBins * sizeof(uint32_t), ctx->stream));
+      hipLaunchKernelGGL(kd_top_box_kernel, tgrid, tblock, 0, ctx->stream, pin, static_cast<uint32_t>(n), d, seg_box.p);
+      hipLaunchKernelGGL(kd_top_hist_kernel<0>, tgrid, tblock, 0, ctx->stream, pin, top_keys.p, static_cast<uint32_t>(n), d, seg_box.p, axis_of_seg.p, top_hist.p);
+      hipLaunchKernelGGL(kd_top_hist_kernel<1>, tgrid, tblock, 0, ctx->stream, pin, top_keys.p, static_cast<uint32_t>(n), d, seg_box.p, axis_of_seg.p, top_hist.p);
+      hipLaunchKernelGGL(kd_top_hist_kernel<2>, tgrid, tblock, 0, ctx->stream, pin, top_keys.p, static_cast<uint32_t>(n), d, seg_box.p, axis_of_seg.p, top_hist.p);
+      hipLaunchKernelGGL(kd_top_count_kernel, tgrid, tblock, 0, ctx->stream, top_keys.p, static_cast<uint32_t>(n), d, axis_of_seg.p, top_hist.p, chunks, top_cnt.p, top_sel.p, idx->kd_nodes.p);
+      hipLaunchKernelGGL(kd_top_scatter_kernel, tgrid, tblock, 0, ctx->stream, pin, permin, top_keys.p, static_cast<uint32_t>(n), d, chunks, top_cnt.p, top_sel.p, pout, nxt);
+      SGA_HIP(hipGetLastError());
+      pin = pout;
+      permin = nxt;
+      std::swap(cur, nxt);
+    }
+  }
+  for (int d = 0; d < dS && !top_levels; d++) {
     const uint32_t nseg = 1u << d;
     const dim3 sgrid((nseg + 255) / 256);
     const unsigned end_bit = 32 + (d > 0 ? d : 1);

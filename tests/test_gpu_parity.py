@@ -931,6 +931,42 @@ def test_kd_split_path_on_degenerate_clouds(monkeypatch):
         assert np.abs(res[0] - brute).max() <= 1e-5 * max(1.0, float(brute.max())), name
 
 
+def test_kd_top_levels_on_degenerate_clouds(monkeypatch):
+    """The levels above the split kernel's reach (segments of more than 32768 points: kd_top_*_kernel — select + partition with a segment
+    spread over many workgroups, the points moving with the permutation) on inputs that stress the select across chunks: all points
+    identical, a line, two distinct points, a lattice with many copies (median keys shared by thousands of points in several chunks),
+    large coordinates with ties, and sizes around the chunk (8192) and segment boundaries.  The kNN DISTANCES must equal those of the
+    sort-based levels (SGA_KD_TOP=0: another valid tree over the same points) and brute force."""
+    rng = np.random.default_rng(33)
+    g = np.arange(16, dtype=np.float32)
+    lattice = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    clouds = {
+        "identical": np.tile(np.array([[1.5, -2.0, 0.25]], np.float32), (70001, 1)),
+        "line": np.c_[rng.uniform(-100, 100, 90000), np.zeros(90000), np.zeros(90000)].astype(np.float32),
+        "two points": np.array([[0, 0, 0], [1, 1, 1]], np.float32)[rng.integers(0, 2, 66000)],
+        "lattice x20": np.concatenate([lattice] * 20),
+        "large range with ties": (rng.integers(-1000, 1000, (150000, 3)) * 1000.0).astype(np.float32),
+    }
+    for n in (32769, 40961, 65535, 65537, 131073, 270001):
+        clouds["uniform %d" % n] = rng.uniform(-10, 10, (n, 3)).astype(np.float32)
+    for name, pts in clouds.items():
+        q = np.concatenate([pts[rng.choice(len(pts), 150, replace=False)] + rng.normal(0, 0.3, (150, 3)).astype(np.float32), rng.uniform(-20, 20, (50, 3)).astype(np.float32)])
+        k = 5
+        res = []
+        for top in ("1", "0"):
+            monkeypatch.setenv("SGA_KD_TOP", top)
+            tree = sga.KdTree(sga.PointCloud(pts))
+            res.append(tree.batch_knn_search(q, k)[1])
+        monkeypatch.delenv("SGA_KD_TOP")
+        assert np.array_equal(res[0], res[1]), name
+        brute = np.empty((len(q), k))
+        p64 = pts.astype(np.float64)
+        for a in range(0, len(q), 20):  # (chunks of queries: 270k x 20 x 3 doubles at a time)
+            d = ((q[a : a + 20, None, :].astype(np.float64) - p64[None, :, :]) ** 2).sum(-1)
+            brute[a : a + 20] = np.sort(np.partition(d, k, axis=1)[:, :k], axis=1)
+        assert np.abs(res[0] - brute).max() <= 1e-5 * max(1.0, float(brute.max())), name
+
+
 def test_nearest_neighbour_exact_at_scale_and_seed_independent(c3):
     """The registration search (pair records + plane and box pruning + seeds from the previous pose) returns the exact nearest
     neighbour at the C3 size: checked against brute force on a sample, and seeded == unseeded on all 1M correspondences."""
