@@ -987,7 +987,7 @@ def fresh_align_leg(sga, ctx, target, source, args):
         names = ["upload_2_clouds", "target_kdtree", "covariances_2_clouds", "problem_source_sort", "align_default_criteria"]
         return {"ms": float(np.median(walls)), "runs_ms": walls, "stages_ms_synchronised": {n: float(v) for n, v in zip(names, stages)}, "iterations": int(res.iterations) + 1, "converged": bool(res.converged),
                 "points": [int(len(tp)), int(len(sp))],
-                "note": "host arrays (fp32, pageable) -> pose: 2 uploads (72 MB over PCIe), covariances k = %d of both clouds (the source's over a temporary tree of its own), the target's index, the source sorted by target leaf, "
+                "note": "host arrays (fp32, pageable) -> pose: 2 uploads (2 x 12 MB: one staging pass on the host each, then PCIe), covariances k = %d of both clouds (the source's over a temporary tree of its own), the target's index, the source sorted by target leaf, "
                         "GICP from the identity with the default termination criteria; the clouds and the index are released between runs" % k}
     except Exception as ex:  # noqa: BLE001
         return {"error": repr(ex)}

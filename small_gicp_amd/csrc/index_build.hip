@@ -966,7 +966,12 @@ static int build_kdtree(sga_context* ctx, const sga_cloud* cloud, sga_index* idx
   const int cap = n >= 400000 ? kFinishCap : kFinishCap / 2;
   int dS = 0, dA = 0;
   if (split_levels) {
-    while (dS < D && seg_max_at(dS) > static_cast<size_t>(kSplitMaxPoints)) dS++;
+    // the many-workgroup levels (kd_top_*_kernel, ~55 us per level at 1M whatever the number of segments) also take the first levels the split
+    // kernel could hold: its 32-key form runs 136 us for 32 segments of 31k points (32 workgroups on 256 CUs), its 16-key form 53 us
+    static const size_t top_min = getenv("SGA_KD_TOP_MIN") ? static_cast<size_t>(atoll(getenv("SGA_KD_TOP_MIN"))) : 16384;
+    const bool top_on = !(getenv("SGA_KD_TOP") && atoi(getenv("SGA_KD_TOP")) == 0);
+    const size_t reach = (top_on && n > kSplitMaxPoints) ? std::min<size_t>(top_min, kSplitMaxPoints) : kSplitMaxPoints;  // (clouds the split kernel holds whole stay with it)
+    while (dS < D && seg_max_at(dS) > reach) dS++;
     dA = dS;
     while (dA < D && seg_max_at(dA) > static_cast<size_t>(kSplitFinish)) dA++;
   } else {
