@@ -213,8 +213,9 @@ constexpr int kFinishMaxSub = 256;    // sub-segments at the last level: kFinish
 
 __device__ __forceinline__ uint32_t ordered_u32(float c) { return static_cast<uint32_t>(ordered_from_float(c)) ^ 0x80000000u; }
 
-template <int CAP>
-__global__ __launch_bounds__(kFinishThreads) void kd_finish_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ perm_in, uint32_t* __restrict__ perm_out, uint32_t n, int dA, int D, float2* __restrict__ nodes) {
+// THREADS: workgroup size (a sub-tree of <= 256 points keeps 256 threads busy, not 512: twice the workgroups per CU)
+template <int CAP, int THREADS = kFinishThreads>
+__global__ __launch_bounds__(THREADS) void kd_finish_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ perm_in, uint32_t* __restrict__ perm_out, uint32_t n, int dA, int D, float2* __restrict__ nodes) {
   __shared__ float cx[CAP], cy[CAP], cz[CAP];
   __shared__ uint32_t gidx[CAP];
   __shared__ unsigned long long key[CAP];
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(kFinishThreads) void kd_finish_kernel(const float4*
   const uint32_t B0 = kd_bound(n, dA, seg), B1 = kd_bound(n, dA, seg + 1);
   const uint32_t m = B1 - B0;
   const int tid = threadIdx.x;
-  for (uint32_t i = tid; i < m; i += kFinishThreads) {
+  for (uint32_t i = tid; i < m; i += THREADS) {
     const uint32_t g = perm_in[B0 + i];
     const float4 p = pts[g];
     cx[i] = p.x;
@@ -237,9 +238,9 @@ __global__ __launch_bounds__(kFinishThreads) void kd_finish_kernel(const float4*
   __syncthreads();
   for (int d = dA; d < D; d++) {
     const uint32_t nsub = 1u << (d - dA), sub0 = seg << (d - dA);
-    for (uint32_t j = tid; j < nsub * 6; j += kFinishThreads) box[j / 6][j % 6] = (j % 6) < 3 ? 0x7f800000 : (static_cast<int>(0xff800000u) ^ 0x7fffffff);
+    for (uint32_t j = tid; j < nsub * 6; j += THREADS) box[j / 6][j % 6] = (j % 6) < 3 ? 0x7f800000 : (static_cast<int>(0xff800000u) ^ 0x7fffffff);
     __syncthreads();
-    for (uint32_t base = 0; base < m; base += kFinishThreads) {  // whole waves take part in the shuffles below
+    for (uint32_t base = 0; base < m; base += THREADS) {  // whole waves take part in the shuffles below
       const uint32_t pos = base + tid;
       const bool valid = pos < m;
       const uint32_t e = ord[valid ? pos : m - 1], j = kd_segment_of(B0 + (valid ? pos : m - 1), n, d) - sub0;
@@ -264,13 +265,13 @@ __global__ __launch_bounds__(kFinishThreads) void kd_finish_kernel(const float4*
       }
     }
     __syncthreads();
-    for (uint32_t j = tid; j < nsub; j += kFinishThreads) {
+    for (uint32_t j = tid; j < nsub; j += THREADS) {
       float v[3];
       for (int a = 0; a < 3; a++) v[a] = float_from_ordered(box[j][3 + a]) - float_from_ordered(box[j][a]);
       axis_of[j] = v[0] >= v[1] ? (v[0] >= v[2] ? 0 : 2) : (v[1] >= v[2] ? 1 : 2);  // same rule as kd_longest_axis
     }
     __syncthreads();
-    for (uint32_t pos = tid; pos < m; pos += kFinishThreads) {
+    for (uint32_t pos = tid; pos < m; pos += THREADS) {
       const uint32_t e = ord[pos], j = kd_segment_of(B0 + pos, n, d) - sub0;
       const int a = axis_of[j];
       const float c = a == 0 ? cx[e] : (a == 1 ? cy[e] : cz[e]);
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(kFinishThreads) void kd_finish_kernel(const float4*
     // rank sort inside every sub-segment: the new position of an element is the sub-segment's first position + the number of
     // its keys that are smaller (keys are distinct: they end with the current position).  All lanes of a wave read the same
     // key[i] (LDS broadcast), and the total work halves with every level — far cheaper than a sorting network here.
-    for (uint32_t pos = tid; pos < m; pos += kFinishThreads) {
+    for (uint32_t pos = tid; pos < m; pos += THREADS) {
       const unsigned long long mine = key[pos];
       const uint32_t gs = sub0 + static_cast<uint32_t>(mine >> 43);
       const uint32_t first = kd_bound(n, d, gs) - B0, end = kd_bound(n, d, gs + 1) - B0;
@@ -297,9 +298,9 @@ __global__ __launch_bounds__(kFinishThreads) void kd_finish_kernel(const float4*
       ord2[first + smaller] = ord[pos];
     }
     __syncthreads();
-    for (uint32_t pos = tid; pos < m; pos += kFinishThreads) ord[pos] = ord2[pos];
+    for (uint32_t pos = tid; pos < m; pos += THREADS) ord[pos] = ord2[pos];
     __syncthreads();
-    for (uint32_t j = tid; j < nsub; j += kFinishThreads) {
+    for (uint32_t j = tid; j < nsub; j += THREADS) {
       const uint32_t gs = sub0 + j;
       const uint32_t first = kd_bound(n, d, gs), end = kd_bound(n, d, gs + 1), mid = kd_bound(n, d + 1, 2 * gs + 1);
       const int a = axis_of[j];
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(kFinishThreads) void kd_finish_kernel(const float4*
     }
     __syncthreads();
   }
-  for (uint32_t pos = tid; pos < m; pos += kFinishThreads) perm_out[B0 + pos] = gidx[ord[pos]];
+  for (uint32_t pos = tid; pos < m; pos += THREADS) perm_out[B0 + pos] = gidx[ord[pos]];
 }
 
 // ---- top levels of SMALL clouds: one launch per level, one workgroup per segment --------------------------------------------------
@@ -916,6 +917,11 @@ __global__ __launch_bounds__(256) void kd_tail_kernel(const uint32_t* __restrict
   }
 }
 
+__global__ void compose_perm_kernel(const uint32_t* __restrict__ inner, const uint32_t* __restrict__ outer, uint32_t* __restrict__ out, size_t n) {
+  const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
+  if (i < n) out[i] = outer[inner[i]];
+}
+
 __global__ void iota_kernel(uint32_t* __restrict__ v, size_t n) {
   const size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x;
   if (i < n) v[i] = static_cast<uint32_t>(i);
@@ -986,7 +992,8 @@ static int build_kdtree(sga_context* ctx, const sga_cloud* cloud, sga_index* idx
     if (!top_levels) hipLaunchKernelGGL(iota_kernel, grid, block, 0, ctx->stream, perm.p, n);
   }
   DevBuf<float4> top_pts[2];
-  DevBuf<uint32_t> top_keys, top_hist;
+  DevBuf<uint32_t> top_keys, top_hist, top_perm;
+  const float4* base_pts = cloud->pts.p;  // what the levels below gather from: the cloud, or its copy in the order the top levels left (see below)
   DevBuf<uint2> top_cnt;
   DevBuf<TopSel> top_sel;
   if (top_levels) {
@@ -997,6 +1004,7 @@ static int build_kdtree(sga_context* ctx, const sga_cloud* cloud, sga_index* idx
     SGA_TRY(top_hist.alloc(static_cast<size_t>(max_seg) * 3 * kSplitBins));
     SGA_TRY(top_cnt.alloc(static_cast<size_t>(n / kTopChunk) + 2 + 2 * static_cast<size_t>(max_seg)));  // segments x chunks of the longest segment <= n / chunk + 2 x segments
     SGA_TRY(top_sel.alloc(max_seg));
+    SGA_TRY(top_perm.alloc(n));
     const float4* pin = cloud->pts.p;
     const uint32_t* permin = nullptr;  // level 0 reads the identity
     for (int d = 0; d < dS; d++) {
@@ -1011,12 +1019,17 @@ static int build_kdtree(sga_context* ctx, const sga_cloud* cloud, sga_index* idx
       hipLaunchKernelGGL(kd_top_hist_kernel<1>, tgrid, tblock, 0, ctx->stream, pin, top_keys.p, static_cast<uint32_t>(n), d, seg_box.p, axis_of_seg.p, top_hist.p);
       hipLaunchKernelGGL(kd_top_hist_kernel<2>, tgrid, tblock, 0, ctx->stream, pin, top_keys.p, static_cast<uint32_t>(n), d, seg_box.p, axis_of_seg.p, top_hist.p);
       hipLaunchKernelGGL(kd_top_count_kernel, tgrid, tblock, 0, ctx->stream, top_keys.p, static_cast<uint32_t>(n), d, axis_of_seg.p, top_hist.p, chunks, top_cnt.p, top_sel.p, idx->kd_nodes.p);
-      hipLaunchKernelGGL(kd_top_scatter_kernel, tgrid, tblock, 0, ctx->stream, pin, permin, top_keys.p, static_cast<uint32_t>(n), d, chunks, top_cnt.p, top_sel.p, pout, nxt);
+      uint32_t* perm_out = d + 1 == dS ? top_perm.p : nxt;  // the last of these levels keeps its permutation in a buffer of its own
+      hipLaunchKernelGGL(kd_top_scatter_kernel, tgrid, tblock, 0, ctx->stream, pin, permin, top_keys.p, static_cast<uint32_t>(n), d, chunks, top_cnt.p, top_sel.p, pout, perm_out);
       SGA_HIP(hipGetLastError());
       pin = pout;
-      permin = nxt;
-      std::swap(cur, nxt);
+      permin = perm_out;
+      if (d + 1 < dS) std::swap(cur, nxt);
     }
+    // The levels below work on the MOVED copy of the points with the identity as their input permutation: a segment of <= 16 384
+    // points is a contiguous 256 KB of it, so all their gathers stay inside one L2 (through the permutation of the whole cloud they touched a
+    // 64-byte sector of a 16 MB array per point).  Their result — positions in the moved copy — is composed with top_perm at the end.
+    base_pts = pin;
   }
   for (int d = 0; d < dS && !top_levels; d++) {
     const uint32_t nseg = 1u << d;
@@ -1040,8 +1053,8 @@ static int build_kdtree(sga_context* ctx, const sga_cloud* cloud, sga_index* idx
     if (d == 0) {  // the root level reads the identity permutation and hands the cloud's box to the host
       *box_seq = note_begin(ctx, &note_slot);
     }
-    const uint32_t* level_in = d == 0 ? nullptr : cur;
-#define SGA_SPLIT(THREADS, KEYS) hipLaunchKernelGGL((kd_split_level_kernel<THREADS, KEYS>), dim3(1u << d), dim3(THREADS), 0, ctx->stream, cloud->pts.p, level_in, nxt, static_cast<uint32_t>(n), d, idx->kd_nodes.p, note_slot, *box_seq)
+    const uint32_t* level_in = (d == 0 || (top_levels && d == dS)) ? nullptr : cur;
+#define SGA_SPLIT(THREADS, KEYS) hipLaunchKernelGGL((kd_split_level_kernel<THREADS, KEYS>), dim3(1u << d), dim3(THREADS), 0, ctx->stream, base_pts, level_in, nxt, static_cast<uint32_t>(n), d, idx->kd_nodes.p, note_slot, *box_seq)
     if (seg_max <= 256 * 2) SGA_SPLIT(256, 2);
     else if (seg_max <= 256 * 4) SGA_SPLIT(256, 4);
     else if (seg_max <= 256 * 8) SGA_SPLIT(256, 8);
@@ -1052,14 +1065,19 @@ static int build_kdtree(sga_context* ctx, const sga_cloud* cloud, sga_index* idx
 #undef SGA_SPLIT
     std::swap(cur, nxt);
   }
+  if (top_levels && dA == dS) hipLaunchKernelGGL(iota_kernel, grid, block, 0, ctx->stream, cur, n);  // (no split level ran: the finish reads the identity)
   if (dA < D && split_levels) {
-    hipLaunchKernelGGL(kd_finish_kernel<kSplitFinish>, dim3(1u << dA), dim3(kFinishThreads), 0, ctx->stream, cloud->pts.p, cur, nxt, static_cast<uint32_t>(n), dA, D, idx->kd_nodes.p);
+    hipLaunchKernelGGL((kd_finish_kernel<kSplitFinish, kSplitFinish>), dim3(1u << dA), dim3(kSplitFinish), 0, ctx->stream, base_pts, cur, nxt, static_cast<uint32_t>(n), dA, D, idx->kd_nodes.p);
     std::swap(cur, nxt);
   } else if (dA < D) {
     if (cap == kFinishCap)
       hipLaunchKernelGGL(kd_finish_kernel<kFinishCap>, dim3(1u << dA), dim3(kFinishThreads), 0, ctx->stream, cloud->pts.p, cur, nxt, static_cast<uint32_t>(n), dA, D, idx->kd_nodes.p);
     else
       hipLaunchKernelGGL(kd_finish_kernel<kFinishCap / 2>, dim3(1u << dA), dim3(kFinishThreads), 0, ctx->stream, cloud->pts.p, cur, nxt, static_cast<uint32_t>(n), dA, D, idx->kd_nodes.p);
+    std::swap(cur, nxt);
+  }
+  if (top_levels) {  // positions in the moved copy -> indices of the cloud
+    hipLaunchKernelGGL(compose_perm_kernel, grid, block, 0, ctx->stream, cur, top_perm.p, nxt, n);
     std::swap(cur, nxt);
   }
   SGA_HIP(hipGetLastError());
