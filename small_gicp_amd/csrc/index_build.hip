@@ -650,8 +650,10 @@ __global__ __launch_bounds__(kTopThreads) void kd_top_count_kernel(const uint32_
 }
 
 __global__ __launch_bounds__(kTopThreads) void kd_top_scatter_kernel(const float4* __restrict__ pts_in, const uint32_t* __restrict__ perm_in /* null: the identity */, const uint32_t* __restrict__ keys, uint32_t n, int d, uint32_t chunks,
-                                                                    const uint2* __restrict__ cnt, const TopSel* __restrict__ sel, float4* __restrict__ pts_out, uint32_t* __restrict__ perm_out) {
+                                                                    const uint2* __restrict__ cnt, const TopSel* __restrict__ sel, float4* __restrict__ pts_out, uint32_t* __restrict__ perm_out,
+                                                                    int* __restrict__ child_box /* the boxes of the next level's segments (6 ints each, this level's segment s -> 2 s, 2 s + 1), or null */) {
   __shared__ uint32_t sh_wave[3][kTopThreads / 64];
+  __shared__ float sh_box[kTopThreads / 64][12];
   const uint32_t seg = blockIdx.y, tid = threadIdx.x, chunk = blockIdx.x;
   const uint32_t first = kd_bound(n, d, seg), end = kd_bound(n, d, seg + 1), mid = kd_bound(n, d + 1, 2 * seg + 1);
   const uint32_t i0 = first + chunk * kTopChunk;
@@ -693,17 +695,49 @@ __global__ __launch_bounds__(kTopThreads) void kd_top_scatter_kernel(const float
   const uint32_t all_before = split_scan_exclusive<kTopThreads>(my_all, sh_wave[0]);
   uint32_t n_less = lt_before + (packed & 0xffffu), n_eq = eq_before + (packed >> 16);
   uint32_t n_all = (i0 - first) + all_before;  // elements of the segment ahead of this thread's in the fixed order (chunks, then thread-major)
+  float bx[12] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY, INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};  // left child's lo, hi; right child's
 #pragma unroll
   for (uint32_t j = 0; j < kTopItems; j++) {
     if (i0 + j * kTopThreads + tid < end) {
       const bool less = key[j] < s.median, eq = key[j] == s.median;
       const uint32_t n_greater = n_all - n_less - n_eq;
-      const uint32_t dest = first + (less ? n_less : (eq ? (n_eq < s.rank ? s.below + n_eq : m + (n_eq - s.rank)) : m + (s.eq_total - s.rank) + n_greater));
-      pts_out[dest] = p[j];
-      perm_out[dest] = src[j];
+      const uint32_t off = less ? n_less : (eq ? (n_eq < s.rank ? s.below + n_eq : m + (n_eq - s.rank)) : m + (s.eq_total - s.rank) + n_greater);
+      pts_out[first + off] = p[j];
+      perm_out[first + off] = src[j];
       n_less += less ? 1u : 0u;
       n_eq += eq ? 1u : 0u;
       n_all += 1u;
+      // the box of the child the element goes to: the next level's box pass, taken on the way
+      const bool right = off >= m;
+      const float c[3] = {p[j].x, p[j].y, p[j].z};
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        bx[a] = fminf(bx[a], right ? INFINITY : c[a]);
+        bx[3 + a] = fmaxf(bx[3 + a], right ? -INFINITY : c[a]);
+        bx[6 + a] = fminf(bx[6 + a], right ? c[a] : INFINITY);
+        bx[9 + a] = fmaxf(bx[9 + a], right ? c[a] : -INFINITY);
+      }
+    }
+  }
+  if (child_box != nullptr) {  // kernel-uniform
+#pragma unroll
+    for (int v = 0; v < 12; v++) {
+      const bool is_lo = (v % 6) < 3;
+      for (int off = 32; off > 0; off >>= 1) bx[v] = is_lo ? fminf(bx[v], __shfl_xor(bx[v], off)) : fmaxf(bx[v], __shfl_xor(bx[v], off));
+    }
+    if ((tid & 63) == 0)
+      for (int v = 0; v < 12; v++) sh_box[tid >> 6][v] = bx[v];
+    __syncthreads();
+    if (tid < 12) {
+      const bool is_lo = (tid % 6) < 3;
+      float r = is_lo ? INFINITY : -INFINITY;
+      for (uint32_t w = 0; w < kTopThreads / 64; w++) r = is_lo ? fminf(r, sh_box[w][tid]) : fmaxf(r, sh_box[w][tid]);
+      int* dst = child_box + 6 * (2 * seg + tid / 6) + tid % 6;
+      if (is_lo) {
+        if (r < INFINITY) atomicMin(dst, ordered_from_float(r));
+      } else {
+        if (r > -INFINITY) atomicMax(dst, ordered_from_float(r));
+      }
     }
   }
 }
@@ -1001,26 +1035,32 @@ static int build_kdtree(sga_context* ctx, const sga_cloud* cloud, sga_index* idx
     SGA_TRY(top_pts[0].alloc(n));
     SGA_TRY(top_pts[1].alloc(n));
     SGA_TRY(top_keys.alloc(n));
-    SGA_TRY(top_hist.alloc(static_cast<size_t>(max_seg) * 3 * kSplitBins));
+    const uint32_t all_seg = (1u << dS) - 1u;  // the segments of all these levels: level d's start at 2^d - 1
+    SGA_TRY(top_hist.alloc(static_cast<size_t>(all_seg) * 3 * kSplitBins));
     SGA_TRY(top_cnt.alloc(static_cast<size_t>(n / kTopChunk) + 2 + 2 * static_cast<size_t>(max_seg)));  // segments x chunks of the longest segment <= n / chunk + 2 x segments
     SGA_TRY(top_sel.alloc(max_seg));
     SGA_TRY(top_perm.alloc(n));
     const float4* pin = cloud->pts.p;
     const uint32_t* permin = nullptr;  // level 0 reads the identity
+    // boxes and histograms of ALL these levels are cleared once (level d's segments at offset 2^d - 1); the box pass runs for the root only:
+    // every scatter takes the boxes of its segments' children on the way
+    hipLaunchKernelGGL(kd_init_box_kernel, dim3((all_seg + 255) / 256), block, 0, ctx->stream, seg_box.p, all_seg);
+    SGA_HIP(hipMemsetAsync(top_hist.p, 0, static_cast<size_t>(all_seg) * 3 * kSplitBins * sizeof(uint32_t), ctx->stream));
     for (int d = 0; d < dS; d++) {
       const uint32_t nseg = 1u << d;
       const uint32_t chunks = static_cast<uint32_t>((seg_max_at(d) + kTopChunk - 1) / kTopChunk);
       const dim3 tgrid(chunks, nseg), tblock(kTopThreads);
       float4* pout = top_pts[d & 1].p;
-      hipLaunchKernelGGL(kd_init_box_kernel, dim3((nseg + 255) / 256), block, 0, ctx->stream, seg_box.p, nseg);
-      SGA_HIP(hipMemsetAsync(top_hist.p, 0, static_cast<size_t>(nseg) * 3 * kSplitBins * sizeof(uint32_t), ctx->stream));
-      hipLaunchKernelGGL(kd_top_box_kernel, tgrid, tblock, 0, ctx->stream, pin, static_cast<uint32_t>(n), d, seg_box.p);
-      hipLaunchKernelGGL(kd_top_hist_kernel<0>, tgrid, tblock, 0, ctx->stream, pin, top_keys.p, static_cast<uint32_t>(n), d, seg_box.p, axis_of_seg.p, top_hist.p);
-      hipLaunchKernelGGL(kd_top_hist_kernel<1>, tgrid, tblock, 0, ctx->stream, pin, top_keys.p, static_cast<uint32_t>(n), d, seg_box.p, axis_of_seg.p, top_hist.p);
-      hipLaunchKernelGGL(kd_top_hist_kernel<2>, tgrid, tblock, 0, ctx->stream, pin, top_keys.p, static_cast<uint32_t>(n), d, seg_box.p, axis_of_seg.p, top_hist.p);
-      hipLaunchKernelGGL(kd_top_count_kernel, tgrid, tblock, 0, ctx->stream, top_keys.p, static_cast<uint32_t>(n), d, axis_of_seg.p, top_hist.p, chunks, top_cnt.p, top_sel.p, idx->kd_nodes.p);
+      int* box_d = seg_box.p + 6 * static_cast<size_t>(nseg - 1u);
+      uint32_t* hist_d = top_hist.p + static_cast<size_t>(nseg - 1u) * 3 * kSplitBins;
+      if (d == 0) hipLaunchKernelGGL(kd_top_box_kernel, tgrid, tblock, 0, ctx->stream, pin, static_cast<uint32_t>(n), d, box_d);
+      hipLaunchKernelGGL(kd_top_hist_kernel<0>, tgrid, tblock, 0, ctx->stream, pin, top_keys.p, static_cast<uint32_t>(n), d, box_d, axis_of_seg.p, hist_d);
+      hipLaunchKernelGGL(kd_top_hist_kernel<1>, tgrid, tblock, 0, ctx->stream, pin, top_keys.p, static_cast<uint32_t>(n), d, box_d, axis_of_seg.p, hist_d);
+      hipLaunchKernelGGL(kd_top_hist_kernel<2>, tgrid, tblock, 0, ctx->stream, pin, top_keys.p, static_cast<uint32_t>(n), d, box_d, axis_of_seg.p, hist_d);
+      hipLaunchKernelGGL(kd_top_count_kernel, tgrid, tblock, 0, ctx->stream, top_keys.p, static_cast<uint32_t>(n), d, axis_of_seg.p, hist_d, chunks, top_cnt.p, top_sel.p, idx->kd_nodes.p);
       uint32_t* perm_out = d + 1 == dS ? top_perm.p : nxt;  // the last of these levels keeps its permutation in a buffer of its own
-      hipLaunchKernelGGL(kd_top_scatter_kernel, tgrid, tblock, 0, ctx->stream, pin, permin, top_keys.p, static_cast<uint32_t>(n), d, chunks, top_cnt.p, top_sel.p, pout, perm_out);
+      int* child_box = d + 1 < dS ? seg_box.p + 6 * static_cast<size_t>(2u * nseg - 1u) : static_cast<int*>(nullptr);
+      hipLaunchKernelGGL(kd_top_scatter_kernel, tgrid, tblock, 0, ctx->stream, pin, permin, top_keys.p, static_cast<uint32_t>(n), d, chunks, top_cnt.p, top_sel.p, pout, perm_out, child_box);
       SGA_HIP(hipGetLastError());
       pin = pout;
       permin = perm_out;
