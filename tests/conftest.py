@@ -18,7 +18,10 @@ def pytest_configure(config):
 def pose_error(T, T_ref):
     E = np.linalg.inv(T) @ T_ref
     dt = float(np.linalg.norm(E[:3, 3]))
-    dr = float(np.arccos(min(1.0, max(-1.0, (np.trace(E[:3, :3]) - 1.0) / 2.0))))
+    # the rotation angle from sine AND cosine: arccos alone resolves no angle below sqrt(2 eps) = 2.1e-8 rad (one ulp of the trace)
+    R = E[:3, :3]
+    s = 0.5 * float(np.linalg.norm([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]]))
+    dr = float(np.arctan2(s, (np.trace(R) - 1.0) / 2.0))
     return dt, dr
 
 
