@@ -994,12 +994,14 @@ static int build_kdtree(sga_context* ctx, const sga_cloud* cloud, sga_index* idx
   uint32_t* nxt = perm2.p;
   DevBuf<int> axis_of_seg;
   SGA_TRY(axis_of_seg.alloc(1ull << (D > 0 ? D - 1 : 0)));
-  // Three regimes, top down (round 6: large clouds now leave the sort-based levels as soon as a segment fits one workgroup of the split
-  // kernel — five levels instead of nine at 1M — and finish through the same per-level partition and small LDS finish as a scan):
-  //   [0, dS)   segments of more than kSplitMaxPoints points: per level a box pass, a key pass, a key-value sort and a node pass;
-  //   [dS, dA)  one launch per level (kd_split_level_kernel: radix select + partition, one workgroup per segment);
+  // Three regimes, top down — every level a median select + partition, nothing is sorted (round 6):
+  //   [0, dS)   segments of more than 16 384 points (clouds of more than kSplitMaxPoints): the segment spread over many workgroups, six
+  //             launches per level, the points moving with the permutation (kd_top_*_kernel);
+  //   [dS, dA)  one launch per level, one workgroup per segment (kd_split_level_kernel), gathering from the copy the levels above left;
   //   [dA, D)   the rest of every sub-tree in LDS (kd_finish_kernel<kSplitFinish>).
-  // SGA_KD_SPLIT=0: no split levels (sort-based down to kFinishCap, then the large LDS finish); SGA_KD_FINISH=0: sort-based throughout.
+  // The older paths stay for the tests that compare them: SGA_KD_TOP=0: [0, dS) (then: segments of more than kSplitMaxPoints points) by a
+  // box pass, a key pass, a key-value sort of the whole cloud and a node pass per level; SGA_KD_SPLIT=0: no split levels (sort-based down to
+  // kFinishCap, then the large LDS finish); SGA_KD_FINISH=0: sort-based throughout.
   const bool lds_finish = !(getenv("SGA_KD_FINISH") && atoi(getenv("SGA_KD_FINISH")) == 0);  // read per build: the tests compare the paths
   const bool split_levels = lds_finish && !(getenv("SGA_KD_SPLIT") && atoi(getenv("SGA_KD_SPLIT")) == 0);
   auto seg_max_at = [&](int d) { return (n + (1ull << d) - 1) >> d; };
