@@ -1712,7 +1712,9 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
       LinParams<Real>& pc = p;
       pc.num_tiles = (p.n + kTile * spts - 1) / (kTile * spts);
       const int cblocks = grid_blocks(pc.num_tiles);
-      const bool cfuse = cblocks <= g_fuse_max;
+      // (this kernel's workgroups finish their streaming step together: 128 - 256 of them taking the tail's ticket one after the other — each
+      // an agent-scope acquire / release — cost the late passes of a 250k-point source 28 us, 59 against 31: scripts/diag_shards.py, N = 4)
+      const bool cfuse = cblocks <= std::min(g_fuse_max, 64);
       pc.tail = FusedTail{cfuse ? 1 : 0, ctx->d_ticket.p, d_out30, out_n, host, seq};
       split_fused_tail = cfuse;
       p.cert_nn = pb->hint.p;
