@@ -472,7 +472,9 @@ __global__ void refresh_attributes_kernel(const float4* __restrict__ idx_pts, si
 using namespace sga;
 
 // clouds of at most this many points estimate their normals / covariances with one wave per query (knn_wave.hpp); SGA_KNN_WAVE_MAX, sga_set_knn_wave_max
-static long long g_knn_wave_max = getenv("SGA_KNN_WAVE_MAX") ? atoll(getenv("SGA_KNN_WAVE_MAX")) : 32768;
+// (81 920: the measured crossover with the one-query-per-lane kernel, whose time is flat ~200 us while it under-fills the chip — 33k points 194
+// against 98 us, 60k 182 against 138, 80k 230 against 196, 100k 215 against 240 us for k = 20)
+static long long g_knn_wave_max = getenv("SGA_KNN_WAVE_MAX") ? atoll(getenv("SGA_KNN_WAVE_MAX")) : 81920;
 
 extern "C" {
 

@@ -19,7 +19,7 @@ def _features(pts, k, wave):
         sga.estimate_normals_covariances(c, None, k)
         return c.normals()[:, :3], c.covs()[:, :3, :3]
     finally:
-        lib.sga_set_knn_wave_max(32768)
+        lib.sga_set_knn_wave_max(81920)
 
 
 def _brute_features(pts, k):
@@ -48,6 +48,20 @@ def test_wave_search_equals_lane_search(k, c1_raw):
         bad = (dn > 1e-3) | (dc > 1e-3)  # a different neighbour set (equidistant k-th candidates) or a near-degenerate spectrum
         print("k=%d n=%d: %d points differ between the two searches, the rest to %.1e / %.1e" % (k, len(pts), bad.sum(), dn[~bad].max(), dc[~bad].max()))
         assert bad.sum() <= 2 and dn[~bad].max() < 1e-5 and dc[~bad].max() < 1e-5
+
+
+@pytest.mark.parametrize("n,k", [(33000, 20), (70000, 10), (81920, 20)])
+def test_wave_search_equals_lane_search_at_the_upper_sizes(n, k):
+    """The sizes the one-wave-per-query search took over late in round 6 (32 768 < n <= 81 920): the same neighbour sets as the
+    one-query-per-lane search on the synthetic scene."""
+    pts = synthetic.scene(n, 4)[:, :3].astype(np.float32)
+    nw, cw = _features(pts, k, True)
+    nl, cl = _features(pts, k, False)
+    dn = np.abs(nw - nl).max(axis=1)
+    dc = np.abs(cw - cl).reshape(len(pts), -1).max(axis=1)
+    bad = (dn > 1e-3) | (dc > 1e-3)
+    print("n=%d k=%d: %d points differ between the two searches, the rest to %.1e / %.1e" % (n, k, bad.sum(), dn[~bad].max(), dc[~bad].max()))
+    assert bad.sum() <= max(2, n // 20000) and dn[~bad].max() < 1e-5 and dc[~bad].max() < 1e-5
 
 
 @pytest.mark.parametrize("n", [1, 4, 5, 8, 9, 63, 64, 65, 127, 500, 513, 4097])
