@@ -52,8 +52,11 @@ constexpr int kMaxBlocks = 2048;     // linearize_kernel / error_kernel: 8 workg
 // Small grids (a 15k-point scan is 60 workgroups) fold the final reduction into the producer kernel: every workgroup publishes its
 // partial row (agent-scope write-through stores), takes a ticket, and the workgroup that arrives last adds the rows in fixed order
 // and hands the result over — one launch and one dependent-launch gap less per pass.  (With the 2048 workgroups of a 1M-point pass
-// the ticket contention costs more than the launch: those keep the separate reduce_rows_kernel.)
-constexpr int kFuseMaxBlocks = 256;
+// the ticket contention costs more than the launch: those keep the separate reduce_rows_kernel.)  Where the gain ends, measured late in
+// round 6 on VGICP iterations of 3k ... 400k points (the workgroups of a streaming kernel finish together and take the ticket one after
+// the other, an agent-scope acquire / release each): 12 workgroups -1.6 us per pass, 24 -0.6, 40 +1.1, 63 +3.4, 120 (30k points) +10,
+// 235 (60k) +25, 245 (250k points at four per lane) +30 us — the limit was 256 since round 3.
+constexpr int kFuseMaxBlocks = 32;
 constexpr int kSeqWord = 128;  // h_accum: [0, 128) a result, word 128 the sequence number of the last published one
 struct FusedTail {
   int enabled;
@@ -1712,9 +1715,9 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
       LinParams<Real>& pc = p;
       pc.num_tiles = (p.n + kTile * spts - 1) / (kTile * spts);
       const int cblocks = grid_blocks(pc.num_tiles);
-      // (this kernel's workgroups finish their streaming step together: 128 - 256 of them taking the tail's ticket one after the other — each
-      // an agent-scope acquire / release — cost the late passes of a 250k-point source 28 us, 59 against 31: scripts/diag_shards.py, N = 4)
-      const bool cfuse = cblocks <= std::min(g_fuse_max, 64);
+      // (never at its sizes since kFuseMaxBlocks is 32: 128 - 256 workgroups taking the tail's ticket one after the other cost the late passes
+      // of a 250k-point source 28 us, 59 against 31: scripts/diag_shards.py, N = 4)
+      const bool cfuse = cblocks <= g_fuse_max;
       pc.tail = FusedTail{cfuse ? 1 : 0, ctx->d_ticket.p, d_out30, out_n, host, seq};
       split_fused_tail = cfuse;
       p.cert_nn = pb->hint.p;
