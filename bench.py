@@ -558,7 +558,7 @@ def scaling_model(world, per_rank):
     doing the work of one rank of N): K1 per pass of a 1 / N source slice + 6.5 us of host work + the all-reduce.  Printed beside the
     measurement so that the first real multi-GPU run is a one-line comparison; `with_measured_collective` replaces the assumed 20 us by
     this run's own per_rank.collective_avg_us."""
-    k1 = {1: 118.0, 2: 83.2, 4: 63.0, 8: 52.2}  # us per pass, measured on the round's final build (scripts/diag_shards.py)
+    k1 = {1: 118.0, 2: 83.2, 4: 60.7, 8: 52.2}  # us per pass, measured on the round's final build (scripts/diag_shards.py)
     host_us, assumed = 6.5, 20.0
     n = min(k1, key=lambda g: abs(g - world))
     out = {"shard_k1_us": k1, "host_us": host_us, "assumed_allreduce_us": assumed,

@@ -1698,11 +1698,13 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
     // against 44 - 66) and loses where many do (the walkers of a pass sit where the points moved most, i.e. in a few workgroups, which
     // then walk alone: 121 against 99 us after a 1 cm motion), hence the second, smaller limit SGA_SPLIT_DELTA.
     static const double split_delta = getenv("SGA_SPLIT_DELTA") ? atof(getenv("SGA_SPLIT_DELTA")) : 0.002;
-    // Only from SGA_SPLIT_MIN_POINTS source points on (default 131072 = SGA_LIN_PTS_MIN): measured on C2 (100k points) and C5 (12k-point
+    // Only from SGA_SPLIT_MIN_POINTS source points on (default 262144; 131072 until the size sweep late in round 6: late passes of 135k / 200k /
+    // 300k / 400k / 600k-point pairs 27.3 / 29.1 / 33.8 / 35.0 / 41.0 us with this kernel against 24.6 / 26.6 / 34.2 / 38.5 / 43.2 us with the
+    // queue-fed one: the crossover is near 300k): measured on C2 (100k points) and C5 (12k-point
     // scans) the kernel — one point per lane there, the row reduction folded into it (fused_tail) when the grid is small — is no faster
     // than the queue-fed one (C2 warm pass 39.9 against 40.3 us, C5 registration 0.51 against 0.48 ms/scan; with 4 points per lane 53.9 us):
     // at those sizes a pass is a chain of launch, a few dependent loads and the hand-off, whichever kernel runs it.
-    static const size_t split_min_points = getenv("SGA_SPLIT_MIN_POINTS") ? static_cast<size_t>(atoll(getenv("SGA_SPLIT_MIN_POINTS"))) : 131072;
+    static const size_t split_min_points = getenv("SGA_SPLIT_MIN_POINTS") ? static_cast<size_t>(atoll(getenv("SGA_SPLIT_MIN_POINTS"))) : 262144;
     static const int split_pts_env = getenv("SGA_SPLIT_PTS") ? atoi(getenv("SGA_SPLIT_PTS")) : 0;
     const bool split = warm_split && queue && warm && displacement <= split_delta * unit && g_search_queue == 2 && g_fuse_search && !host_rejector && sizeof(Real) == 4 && pb->n >= split_min_points && q.leaves == nullptr;
     fused_search = !use_grid && g_fuse_search && !host_rejector && !queue && sizeof(Real) == 4;  // fp64 math: the fused kernel would spill

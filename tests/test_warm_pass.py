@@ -135,7 +135,7 @@ def test_warm_registration_matches_cold_registration_100k():
 
 
 def test_streaming_warm_kernel_walks_the_tree_on_a_deep_index():
-    """certify_linearize_kernel (>= 131072 source points, millimetre motions) with its walkers sent through the kd walk (no cell grid:
+    """certify_linearize_kernel (>= 262144 source points, millimetre motions) with its walkers sent through the kd walk (no cell grid:
     SGA_GRID = 0) over a 1M-point target — a tree of depth 17, where each of the workgroup's four waves needs its own full-depth
     traversal stack (the stacks were indexed by threadIdx.x instead of the lane, so wave w worked w rows further down and
     wave 3 could reach past the allocation).  Warm == cold on a chain of millimetre steps, rejector tight and wide."""
@@ -259,7 +259,7 @@ import numpy as np
 from scipy.spatial.transform import Rotation
 import small_gicp_amd as sga
 
-target, source, T_gt = sga.synthetic.registration_pair(150_000)  # >= 131 072 source points: the streaming warm kernel takes the millimetre passes
+target, source, T_gt = sga.synthetic.registration_pair(280_000)  # >= 262 144 source points: the streaming warm kernel takes the millimetre passes
 tgt, src = sga.PointCloud(target), sga.PointCloud(source)
 sga.estimate_covariances(tgt, None, 10)
 sga.estimate_covariances(src, None, 10)
