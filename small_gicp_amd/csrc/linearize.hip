@@ -1453,7 +1453,10 @@ static void launch_reduce(sga_context* ctx, const double* partials, int nrows, i
 
 static bool g_lazy_maha = getenv("SGA_LAZY_MAHA") ? atoi(getenv("SGA_LAZY_MAHA")) != 0 : true;
 static int g_fuse_max = getenv("SGA_FUSE_MAX") ? atoi(getenv("SGA_FUSE_MAX")) : kFuseMaxBlocks;
-static int g_lin_pts_min = getenv("SGA_LIN_PTS_MIN") ? atoi(getenv("SGA_LIN_PTS_MIN")) : 131072;
+// four points per lane in the standalone factor kernel from this many points on (VGICP iterations of 140k / 200k / 300k / 500k / 1M points:
+// 32.5 / 32.7 / 36.4 / 39.0 / 45.1 us at four per lane against 25.5 / 27.0 / 30.4 / 37.0 / 45.4 us at one: the size sweep late in round 6;
+// 131072 before)
+static int g_lin_pts_min = getenv("SGA_LIN_PTS_MIN") ? atoi(getenv("SGA_LIN_PTS_MIN")) : 750000;
 static int grid_blocks(int num_tiles) { return num_tiles < kMaxBlocks ? (num_tiles < 1 ? 1 : num_tiles) : kMaxBlocks; }
 
 // nearest neighbour (caller's target order) and squared distance of every source point in the caller's source order: the input of a
@@ -1713,7 +1716,9 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
     if (use_grid) {
       // searched above; the factors follow as linearize_kernel over nn[]
     } else if (split) {
-      const int spts = split_pts_env == 1 || split_pts_env == 4 ? split_pts_env : pts;
+      // one point per lane unless told otherwise (SGA_SPLIT_PTS=4): the size sweep late in round 6 — late passes of 300k / 600k / 700k-point pairs
+      // 34.0 / 40.4 / 42.3 us at four per lane against 31.2 / 38.8 / 40.6 us at one, C3's warm passes 83.8 -> 81.2 us on average (+1.2 % on the headline)
+      const int spts = split_pts_env == 1 || split_pts_env == 4 ? split_pts_env : 1;
       LinParams<Real>& pc = p;
       pc.num_tiles = (p.n + kTile * spts - 1) / (kTile * spts);
       const int cblocks = grid_blocks(pc.num_tiles);
@@ -2502,6 +2507,7 @@ void preload_hot_kernels() {
   SGA_PRELOAD(search_linearize_kernel<float, F, true>);             \
   SGA_PRELOAD(nn_search_queue_kernel<float, true, F>);              \
   SGA_PRELOAD(certify_linearize_kernel<float, F, kLinPts>);         \
+  SGA_PRELOAD(certify_linearize_kernel<float, F, 1>);               \
   SGA_PRELOAD(linearize_kernel<float, F, 0, kLinPts>);              \
   SGA_PRELOAD(linearize_kernel<float, F, 0, 1>)
   SGA_PRELOAD_FACTOR(SGA_GICP);
