@@ -47,7 +47,10 @@ constexpr int kModelOff = 32;        // error model: [32, 41) sum p_a g_j, [41, 
 constexpr int kModelCols = 95;
 constexpr int kStatsCol = 30;        // spare columns 30, 31: search statistics of a grid pass (cell_grid.hip), not sums over points
 constexpr int kSearchBlock = 64;      // search kernels: one wave per workgroup
-constexpr int kMaxBlocks = 2048;     // linearize_kernel / error_kernel: 8 workgroups per CU, the whole grid is resident
+#ifndef SGA_MAX_BLOCKS
+#define SGA_MAX_BLOCKS 2048
+#endif
+constexpr int kMaxBlocks = SGA_MAX_BLOCKS;  // linearize_kernel / error_kernel / certify_linearize_kernel: 8 workgroups per CU
 
 // Small grids (a 15k-point scan is 60 workgroups) fold the final reduction into the producer kernel: every workgroup publishes its
 // partial row (agent-scope write-through stores), takes a ticket, and the workgroup that arrives last adds the rows in fixed order
