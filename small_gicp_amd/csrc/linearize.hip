@@ -1029,8 +1029,11 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(4))) void
 // workgroup then walks them, 64 at a time (seeded top-down walk with exploration slack, walk_lane), and adds their factors to its row —
 // while the other workgroups stream on.  One launch, one partial row per workgroup; the old form (nn_search_queue_kernel: certificate
 // check, queue-fed walks and factors per chunk of 4 tiles in one wave) streams at half this rate and stays for small clouds.
+#ifndef SGA_CERT_WAVES
+#define SGA_CERT_WAVES 4
+#endif
 template <typename Real, int FACTOR, int PTS>
-__global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(4))) void certify_linearize_kernel(const LinParams<Real> p, const NNParams<Real> q_arg) {
+__global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(SGA_CERT_WAVES))) void certify_linearize_kernel(const LinParams<Real> p, const NNParams<Real> q_arg) {
   extern __shared__ uint32_t kd_stack[];  // 4 x tree depth x 64 words: the traversal stacks of the waves' walks
   __shared__ double sh_acc[kTile / 64][kRow];
   __shared__ unsigned long long sh_failed[kTile / 64][PTS];
