@@ -486,7 +486,7 @@ __global__ __launch_bounds__(THREADS) void kd_split_level_kernel(const float4* _
 // ---- top levels of LARGE clouds: the same select + partition, a segment spread over many workgroups (round 6) -------------------------
 // A segment of more than kSplitMaxPoints points does not fit one workgroup's registers.  The sort-based level above orders ALL n (segment,
 // coordinate) keys to learn one median per segment: ~260 us per level at 1M points, 47 rocPRIM launches — most of a 1M-point build.  Here the
-// level is what kd_split_level_kernel does, with the segment cut into chunks of kTopChunk points (grid = chunks x segments) and the
+// level is what kd_split_level_kernel does, with the segment cut into chunks of kTopChunk (4096) points (grid = chunks x segments) and the
 // histograms of the three select rounds accumulated in global memory (LDS first, the non-empty bins flushed with atomics):
 //   box   -> the segment's box (6 atomics per workgroup)                                           kd_top_box_kernel
 //   hist0 -> axis = longest extent; the keys (order-preserving coordinate) are stored once; top 11 bits   kd_top_hist_kernel<0>
@@ -499,7 +499,10 @@ __global__ __launch_bounds__(THREADS) void kd_split_level_kernel(const float4* _
 // Six passes over 4 - 20 bytes per point instead of a 64-bit key-value sort of the whole cloud.  The tree is another valid one over the
 // same points (like the split path's): the halves are the same SETS as the sort's whenever the median key is unique, the order inside
 // them is not the sorted one.
-constexpr uint32_t kTopItems = 8, kTopThreads = 1024, kTopChunk = kTopItems * kTopThreads;
+#ifndef SGA_TOP_ITEMS
+#define SGA_TOP_ITEMS 4  // items per thread: chunks of 4096 points (measured: 2 / 4 / 8 / 16 items -> 1M-point build 1.29 / 1.23 / 1.26 / 1.42 ms, 400k 0.80 / 0.80 / 0.85 / 0.98)
+#endif
+constexpr uint32_t kTopItems = SGA_TOP_ITEMS, kTopThreads = 1024, kTopChunk = kTopItems * kTopThreads;
 struct TopSel {
   uint32_t median, below, rank, eq_total;  // the median key; keys below it; how many of the equal keys complete the left half; equal keys
 };

@@ -935,7 +935,7 @@ def test_kd_top_levels_on_degenerate_clouds(monkeypatch):
     """The levels above the split kernel's reach (segments of more than 32768 points: kd_top_*_kernel — select + partition with a segment
     spread over many workgroups, the points moving with the permutation) on inputs that stress the select across chunks: all points
     identical, a line, two distinct points, a lattice with many copies (median keys shared by thousands of points in several chunks),
-    large coordinates with ties, and sizes around the chunk (8192) and segment boundaries.  The kNN DISTANCES must equal those of the
+    large coordinates with ties, and sizes around the chunk (4096) and segment boundaries.  The kNN DISTANCES must equal those of the
     sort-based levels (SGA_KD_TOP=0: another valid tree over the same points) and brute force."""
     rng = np.random.default_rng(33)
     g = np.arange(16, dtype=np.float32)
