@@ -1059,6 +1059,21 @@ def odometry_leg(sga, args, shard):
                 shutil.rmtree(work, ignore_errors=True)
         except Exception as ex:  # noqa: BLE001
             out["flow_cpp_driver"] = {"error": repr(ex)}
+        gc.collect()
+        try:  # the reference's scan-to-MODEL engines (odometry_benchmark_small_vgicp_model_omp.cpp:12-57, ..._small_gicp_model_omp.cpp): one voxel map accumulating
+            # every registered scan (incremental insert with the estimated pose, LRU removal), each scan registered against it from the previous pose
+            frames_m = min(args.odom_frames, 60)
+            sm = {}
+            for model in ("gaussian", "flat"):
+                mr = odometry.run_synthetic_model(frames_m, model=model)
+                sm[model] = {k: mr[k] for k in ("registration_ms_per_scan", "total_ms_per_scan", "mean_iterations", "ate_trans_m_max", "num_voxels")}
+            sm["frames"] = frames_m
+            sm["protocol"] = ("gaussian: GaussianVoxelMap 1.0 m + VGICP (small_vgicp_model); flat: IncrementalVoxelMap<FlatContainerCov> + GICP (small_gicp_model); registration = covariances + align + "
+                              "insert into the map; total adds the 0.25 m voxel grid; ate = largest drift of the trajectory against the generator's ground truth")
+            out["scan_to_model"] = sm
+        except Exception as ex:  # noqa: BLE001
+            out["scan_to_model"] = {"error": repr(ex)}
+        gc.collect()
         out["protocol"] = "src/benchmark/odometry_benchmark_small_gicp_omp.cpp:16-49: registration = index build + covariances + align; total adds the 0.25 m voxel grid"
         try:  # the same scans through the C++ driver (examples/odometry_benchmark.cpp): the reference's benchmark is a C++ program too
             cr = odometry.run_synthetic_cpp(args.odom_frames)
