@@ -1490,7 +1490,10 @@ __global__ void export_neighbours_kernel(const float4* __restrict__ src_pts, con
 // Points per lane and reduction (linearize_kernel's PTS): large clouds amortise the wave reductions over 4 points; small ones (a
 // 15k-point scan) keep one point per lane — they are bound by latency and want every workgroup they can get.
 constexpr int kLinPts = 4;
-static int linearize_pts(int n) { return n >= g_lin_pts_min ? kLinPts : 1; }
+// (fp64 per-pair arithmetic keeps four per lane from 131 072 points on: its factor kernel is arithmetic-bound and loses a quarter of its rate at one —
+// 200k / 400k / 700k / 1M points 11 047 / 9 236 / 6 768 / 5 389 against 9 632 / 7 069 / 4 921 / 3 673 iterations/s)
+static int g_lin_pts_min_f64 = getenv("SGA_LIN_PTS_MIN_F64") ? atoi(getenv("SGA_LIN_PTS_MIN_F64")) : 131072;
+static int linearize_pts(int n, bool fp64) { return n >= (fp64 ? g_lin_pts_min_f64 : g_lin_pts_min) ? kLinPts : 1; }
 
 template <typename Real, int FACTOR, int TARGET>
 static void launch_linearize(hipStream_t st, const LinParams<Real>& p, int blocks, int pts) {
@@ -1575,7 +1578,7 @@ static int linearize_dispatch(sga_context* ctx, sga_problem* pb, const sga_facto
   p.src_pts = pb->src_pts();
   p.src_cov = pb->src_cov();
   p.n = static_cast<int>(pb->n);
-  const int pts = linearize_pts(p.n);
+  const int pts = linearize_pts(p.n, sizeof(Real) == 8);
   p.num_tiles = (p.n + kTile * pts - 1) / (kTile * pts);  // steps of kTile * pts points
   p.tgt_pts = voxel ? idx->pts.p : idx->kd_pts.p;
   p.tgt_nrm = idx->nrm.p;
